@@ -1,0 +1,1039 @@
+/*
+ * lcqp_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See lcqp_oracle.h.
+ * Every function cites the reference file:line (under /root/reference) it restates.
+ */
+#include "lcqp_oracle.h"
+#include "../include/lcqp_synth.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+#define ORC_EPS 2.221e-16 /* include/Utilities.hpp:350 */
+
+/* ------------------------------------------------------------------------------------------------
+ * Options defaults: src/Options.cpp:296-333
+ * ---------------------------------------------------------------------------------------------- */
+void orc_options_default(orc_options_t* o)
+{
+    memset(o, 0, sizeof(*o));
+    o->complementarityTolerance = 1.0e3 * ORC_EPS;
+    o->stationarityTolerance = 1.0e6 * ORC_EPS;
+    o->initialPenaltyParameter = 0.01;
+    o->penaltyUpdateFactor = 2.0;
+    o->maxPenaltyParameter = 1e8;
+    o->etaDynamicPenalty = 0.9;
+    o->solveZeroPenaltyFirst = 1;
+    o->perturbStep = 1;
+    o->maxIterations = 1000;
+    o->nDynamicPenalty = 3;
+    o->printLevel = 2;
+    o->storeSteps = 0;
+    o->perturbSeed = 0x5EEDULL;
+    o->admmRho = 0.1;
+    o->admmSigma = 1e-6;
+    o->admmAlpha = 1.6;
+    o->rhoEqMult = 1e3;
+    o->proxSmall = 1e-12;
+    o->proxBig = 1e-8;
+    o->pivotThreshold = 1e-7;
+    o->depTau = 1e-12;
+    o->feasTol = 1e-9;
+    o->resTol = 1e-12;
+    o->admmFirst = 10;
+    o->admmHot = 0;
+    o->maxTrials = 12;
+    o->maxRounds = 40;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Utilities restated loop-for-loop (row-major dense): src/Utilities.cpp
+ * ---------------------------------------------------------------------------------------------- */
+void orc_util_matmul(const double* A, const double* B, double* C, int m, int n, int p)
+{ /* :38-47 */
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < p; j++) {
+            C[i * p + j] = 0;
+            for (int k = 0; k < n; k++) C[i * p + j] += A[i * n + k] * B[k * p + j];
+        }
+}
+
+void orc_util_matmul_t(const double* A, const double* B, double* C, int m, int n, int p)
+{ /* :62-72  C = A' * B, A is m x n */
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < p; j++) {
+            C[i * p + j] = 0;
+            for (int k = 0; k < m; k++) C[i * p + j] += A[k * n + i] * B[k * p + j];
+        }
+}
+
+void orc_util_add_matmul_t(const double* A, const double* B, double* C, int m, int n, int p)
+{ /* :85-93  C += A' * B */
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < p; j++)
+            for (int k = 0; k < m; k++) C[i * p + j] += A[k * n + i] * B[k * p + j];
+}
+
+void orc_util_symm_product(const double* A, const double* B, double* C, int m, int n)
+{ /* :104-116  C = A'B + B'A */
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j <= i; j++) {
+            C[i * n + j] = 0;
+            for (int k = 0; k < m; k++) C[i * n + j] += A[k * n + i] * B[k * n + j] + B[k * n + i] * A[k * n + j];
+            C[j * n + i] = C[i * n + j];
+        }
+}
+
+void orc_util_affine(double alpha, const double* A, const double* b, const double* c, double* d, int m, int n)
+{ /* :176-186  d = alpha*A*b + c */
+    for (int i = 0; i < m; i++) {
+        double tmp = 0;
+        for (int k = 0; k < n; k++) tmp += A[i * n + k] * b[k];
+        d[i] = alpha * tmp + c[i];
+    }
+}
+
+void orc_util_weighted_matadd(double alpha, const double* A, double beta, const double* B, double* C, int m, int n)
+{ /* :202-206 */
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < n; j++) C[i * n + j] = alpha * A[i * n + j] + beta * B[i * n + j];
+}
+
+void orc_util_weighted_vecadd(double alpha, const double* a, double beta, const double* b, double* c, int m)
+{ /* :209-211 */
+    orc_util_weighted_matadd(alpha, a, beta, b, c, m, 1);
+}
+
+double orc_util_quadform(const double* Q, const double* p, int m)
+{ /* :214-225 */
+    double ret = 0;
+    for (int i = 0; i < m; i++) {
+        double tmp = 0;
+        for (int j = 0; j < m; j++) tmp += Q[i * m + j] * p[j];
+        ret += tmp * p[i];
+    }
+    return ret;
+}
+
+double orc_util_dot(const double* a, const double* b, int m)
+{ /* :244-250 */
+    double ret = 0;
+    for (int i = 0; i < m; i++) ret += a[i] * b[i];
+    return ret;
+}
+
+double orc_util_maxabs(const double* a, int m)
+{ /* :253-265 */
+    double mx = 0, mn = 0;
+    for (int i = 0; i < m; i++) {
+        if (a[i] > mx) mx = a[i];
+        else if (a[i] < mn) mn = a[i];
+    }
+    return mx > -mn ? mx : -mn;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Small dense kernels for the QP subsolver (no reference counterpart: this arithmetic lives in
+ * qpOASES in the reference and is replaced, not ported).
+ * ---------------------------------------------------------------------------------------------- */
+static double* dalloc(size_t n) { return (double*)calloc(n ? n : 1, sizeof(double)); }
+
+/* in-place lower Cholesky of the n x n row-major matrix M (ld = n); reports the smallest pivot
+ * (before sqrt). Returns -1 when a pivot is not positive. The strict upper triangle is zeroed. */
+static int chol_lower(double* M, int n, double* minpiv)
+{
+    double mp = INFINITY;
+    for (int j = 0; j < n; j++) {
+        double d = M[j * n + j];
+        for (int k = 0; k < j; k++) d -= M[j * n + k] * M[j * n + k];
+        if (d < mp) mp = d;
+        if (!(d > 0)) { if (minpiv) *minpiv = mp; return -1; }
+        double ljj = sqrt(d);
+        M[j * n + j] = ljj;
+        for (int i = j + 1; i < n; i++) {
+            double s = M[i * n + j];
+            const double* ri = M + (size_t)i * n;
+            const double* rj = M + (size_t)j * n;
+            for (int k = 0; k < j; k++) s -= ri[k] * rj[k];
+            M[i * n + j] = s / ljj;
+        }
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = i + 1; j < n; j++) M[i * n + j] = 0.0;
+    if (minpiv) *minpiv = mp;
+    return 0;
+}
+
+/* Cholesky of the Gram matrix of active rows; a pivot <= tau * (original diagonal) marks the row as
+ * linearly dependent: its pivot is set to 1e150 and its column to 0, so its multiplier stays ~0. */
+static int safe_chol(double* S, int n, double tau)
+{
+    int ndep = 0;
+    for (int j = 0; j < n; j++) {
+        double d0 = S[j * n + j];
+        double d = d0;
+        for (int k = 0; k < j; k++) d -= S[j * n + k] * S[j * n + k];
+        if (!(d > tau * d0) || !(d > 0)) {
+            S[j * n + j] = 1e150;
+            for (int i = j + 1; i < n; i++) S[i * n + j] = 0.0;
+            ndep++;
+            continue;
+        }
+        double ljj = sqrt(d);
+        S[j * n + j] = ljj;
+        for (int i = j + 1; i < n; i++) {
+            double s = S[i * n + j];
+            const double* ri = S + (size_t)i * n;
+            const double* rj = S + (size_t)j * n;
+            for (int k = 0; k < j; k++) s -= ri[k] * rj[k];
+            S[i * n + j] = s / ljj;
+        }
+    }
+    return ndep;
+}
+
+static void trsv_lower(const double* L, int n, double* b) /* solves L y = b in place */
+{
+    for (int i = 0; i < n; i++) {
+        double s = b[i];
+        const double* r = L + (size_t)i * n;
+        for (int k = 0; k < i; k++) s -= r[k] * b[k];
+        b[i] = s / r[i];
+    }
+}
+
+static void trsv_lower_t(const double* L, int n, double* b) /* solves L' x = b in place */
+{
+    for (int i = n - 1; i >= 0; i--) {
+        double xi = b[i] / L[(size_t)i * n + i];
+        b[i] = xi;
+        const double* r = L + (size_t)i * n;
+        for (int k = 0; k < i; k++) b[k] -= r[k] * xi;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * QP subsolver:  min 1/2 x'Qx + g'x  s.t.  lbA <= A x <= ubA,  lb <= x <= ub
+ * in the place of qpOASES behind SubsolverQPOASES (src/SubsolverQPOASES.cpp:32-46,134-181).
+ * Internally E = [A ; rows of I for variables with a finite bound], duals in OSQP sign
+ * (Qx + g + E'y = 0); getSolution converts to the qpOASES layout/sign:
+ * y[0:nV] box duals, y[nV:] row duals, Qx + g - A'y_A - y_box = 0.
+ * ---------------------------------------------------------------------------------------------- */
+enum { ST_INACT = 0, ST_LOWER = 1, ST_UPPER = 2, ST_EQ = 3 };
+
+struct orc_qp {
+    int nV, nC;
+    double *Q, *A;
+    orc_options_t opt;
+    /* setup */
+    int is_setup, mE, nfin;
+    int* boxidx;
+    double *E, *Et, *l, *u, *rhov;
+    double scale, sigma, spv, rho;
+    double *L1, *LK;
+    /* persistent solver state (hot start) */
+    double *x, *y; /* last solution (y: OSQP sign, length mE) */
+    int* st;       /* last active set */
+    int have_solution;
+    /* ADMM state */
+    double *xa, *ya, *za;
+    /* scratch */
+    double *w_n1, *w_n2, *w_n3, *w_m1, *T, *S, *w_a1, *w_a2;
+    int *idx, *newst;
+    int cap_na;
+    /* outputs */
+    double *xsol, *ysol;
+    /* counters */
+    int c_admm, c_trials, c_fact, c_corr;
+};
+
+orc_qp_t* orc_qp_create(int nV, int nC, const double* Q, const double* A, const orc_options_t* opt)
+{
+    orc_qp_t* q = (orc_qp_t*)calloc(1, sizeof(*q));
+    q->nV = nV; q->nC = nC;
+    q->Q = dalloc((size_t)nV * nV);
+    q->A = dalloc((size_t)nC * nV);
+    memcpy(q->Q, Q, sizeof(double) * nV * nV);           /* deep copy: SubsolverQPOASES.cpp:41-45 */
+    if (nC > 0) memcpy(q->A, A, sizeof(double) * nC * nV);
+    if (opt) q->opt = *opt; else orc_options_default(&q->opt);
+    q->xsol = dalloc(nV);
+    q->ysol = dalloc((size_t)nV + nC);
+    return q;
+}
+
+static void qp_free_setup(orc_qp_t* q)
+{
+    free(q->boxidx); free(q->E); free(q->Et); free(q->l); free(q->u); free(q->rhov);
+    free(q->L1); free(q->LK); free(q->x); free(q->y); free(q->st); free(q->xa); free(q->ya); free(q->za);
+    free(q->w_n1); free(q->w_n2); free(q->w_n3); free(q->w_m1); free(q->T); free(q->S); free(q->w_a1); free(q->w_a2);
+    free(q->idx); free(q->newst);
+    q->boxidx = NULL; q->E = q->Et = q->l = q->u = q->rhov = q->L1 = q->LK = q->x = q->y = NULL;
+    q->st = NULL; q->xa = q->ya = q->za = q->w_n1 = q->w_n2 = q->w_n3 = q->w_m1 = q->T = q->S = q->w_a1 = q->w_a2 = NULL;
+    q->idx = q->newst = NULL;
+    q->is_setup = 0;
+}
+
+void orc_qp_destroy(orc_qp_t* q)
+{
+    if (!q) return;
+    qp_free_setup(q);
+    free(q->Q); free(q->A); free(q->xsol); free(q->ysol);
+    free(q);
+}
+
+void orc_qp_get_counters(orc_qp_t* q, int* admm, int* trials, int* facts, int* corrections)
+{
+    if (admm) *admm = q->c_admm;
+    if (trials) *trials = q->c_trials;
+    if (facts) *facts = q->c_fact;
+    if (corrections) *corrections = q->c_corr;
+}
+
+static double bound_or(const double* b, int i, double dflt) { return b ? b[i] : dflt; }
+
+/* One-time setup for a bound pattern: E, rho vector, the two constant factorisations
+ * (L1 of Q + sp I for the polish, LK of Q + sigma I + E' diag(rho) E for ADMM), Et = E L1^-T.
+ * Returns 0, or 3 when Q + sp I is not positive definite (non-convex QP). */
+static int qp_setup(orc_qp_t* q, const double* lbA, const double* ubA, const double* lb, const double* ub)
+{
+    const int n = q->nV, nC = q->nC;
+    const orc_options_t* o = &q->opt;
+    qp_free_setup(q);
+    q->boxidx = (int*)calloc(n ? n : 1, sizeof(int));
+    int nfin = 0;
+    for (int i = 0; i < n; i++) {
+        double lo = bound_or(lb, i, -INFINITY), hi = bound_or(ub, i, INFINITY);
+        if (isfinite(lo) || isfinite(hi)) q->boxidx[nfin++] = i;
+    }
+    q->nfin = nfin;
+    const int mE = nC + nfin;
+    q->mE = mE;
+    q->E = dalloc((size_t)mE * n);
+    q->Et = dalloc((size_t)mE * n);
+    q->l = dalloc(mE); q->u = dalloc(mE); q->rhov = dalloc(mE);
+    if (nC > 0) memcpy(q->E, q->A, sizeof(double) * nC * n);
+    for (int k = 0; k < nfin; k++) q->E[(size_t)(nC + k) * n + q->boxidx[k]] = 1.0;
+    for (int i = 0; i < nC; i++) { q->l[i] = bound_or(lbA, i, -INFINITY); q->u[i] = bound_or(ubA, i, INFINITY); }
+    for (int k = 0; k < nfin; k++) {
+        q->l[nC + k] = bound_or(lb, q->boxidx[k], -INFINITY);
+        q->u[nC + k] = bound_or(ub, q->boxidx[k], INFINITY);
+    }
+    double scale = 0;
+    for (int i = 0; i < n; i++) { double d = fabs(q->Q[(size_t)i * n + i]); if (d > scale) scale = d; }
+    if (!(scale > 1e-300)) scale = 1.0;
+    q->scale = scale;
+    q->sigma = o->admmSigma * scale;
+    q->rho = o->admmRho * scale;
+    for (int i = 0; i < mE; i++) {
+        if (isinf(q->l[i]) && isinf(q->u[i])) q->rhov[i] = 0.0;
+        else if (q->l[i] == q->u[i]) q->rhov[i] = q->rho * o->rhoEqMult;
+        else q->rhov[i] = q->rho;
+    }
+    /* L1 = chol(Q + sp I): try the small prox weight, fall back to the big one for PSD Hessians */
+    q->L1 = dalloc((size_t)n * n);
+    for (int pass = 0; pass < 2; pass++) {
+        q->spv = (pass == 0 ? o->proxSmall : o->proxBig) * scale;
+        memcpy(q->L1, q->Q, sizeof(double) * n * n);
+        for (int i = 0; i < n; i++) q->L1[(size_t)i * n + i] += q->spv;
+        double minpiv;
+        int rc = chol_lower(q->L1, n, &minpiv);
+        if (rc == 0 && (pass == 1 || minpiv >= o->pivotThreshold * scale)) break;
+        if (pass == 1) return 3;
+    }
+    /* Et = E L1^-T : row r solves L1 t = e_r' */
+    for (int r = 0; r < mE; r++) {
+        double* t = q->Et + (size_t)r * n;
+        memcpy(t, q->E + (size_t)r * n, sizeof(double) * n);
+        trsv_lower(q->L1, n, t);
+    }
+    /* LK = chol(Q + sigma I + E' diag(rhov) E) */
+    q->LK = dalloc((size_t)n * n);
+    memcpy(q->LK, q->Q, sizeof(double) * n * n);
+    for (int i = 0; i < n; i++) q->LK[(size_t)i * n + i] += q->sigma;
+    for (int r = 0; r < mE; r++) {
+        double rv = q->rhov[r];
+        if (rv == 0.0) continue;
+        const double* e = q->E + (size_t)r * n;
+        for (int i = 0; i < n; i++) {
+            double ei = rv * e[i];
+            if (ei == 0.0) continue;
+            double* row = q->LK + (size_t)i * n;
+            for (int j = 0; j < n; j++) row[j] += ei * e[j];
+        }
+    }
+    if (chol_lower(q->LK, n, NULL) != 0) return 3;
+
+    q->x = dalloc(n); q->y = dalloc(mE); q->st = (int*)calloc(mE ? mE : 1, sizeof(int));
+    q->xa = dalloc(n); q->ya = dalloc(mE); q->za = dalloc(mE);
+    q->w_n1 = dalloc(n); q->w_n2 = dalloc(n); q->w_n3 = dalloc(n); q->w_m1 = dalloc(mE);
+    q->cap_na = (2 * n < mE) ? 2 * n : mE;
+    q->T = dalloc((size_t)q->cap_na * n);
+    q->S = dalloc((size_t)q->cap_na * q->cap_na);
+    q->w_a1 = dalloc(q->cap_na); q->w_a2 = dalloc(q->cap_na);
+    q->idx = (int*)calloc(q->cap_na ? q->cap_na : 1, sizeof(int));
+    q->newst = (int*)calloc(mE ? mE : 1, sizeof(int));
+    q->have_solution = 0;
+    q->is_setup = 1;
+    return 0;
+}
+
+/* true when the new bounds keep the finite/equality pattern the factorisations were built for */
+static int qp_bounds_compatible(orc_qp_t* q, const double* lbA, const double* ubA, const double* lb, const double* ub)
+{
+    const int n = q->nV, nC = q->nC;
+    int k = 0;
+    for (int i = 0; i < n; i++) {
+        double lo = bound_or(lb, i, -INFINITY), hi = bound_or(ub, i, INFINITY);
+        int fin = isfinite(lo) || isfinite(hi);
+        int was = (k < q->nfin && q->boxidx[k] == i);
+        if (fin != was) return 0;
+        if (was) k++;
+    }
+    for (int i = 0; i < q->mE; i++) {
+        double lo, hi;
+        if (i < nC) { lo = bound_or(lbA, i, -INFINITY); hi = bound_or(ubA, i, INFINITY); }
+        else { lo = bound_or(lb, q->boxidx[i - nC], -INFINITY); hi = bound_or(ub, q->boxidx[i - nC], INFINITY); }
+        int free_new = isinf(lo) && isinf(hi), free_old = (q->rhov[i] == 0.0);
+        int eq_new = (lo == hi), eq_old = (q->l[i] == q->u[i]);
+        if (free_new != free_old || eq_new != eq_old) return 0;
+    }
+    return 1;
+}
+
+static void qp_update_bounds(orc_qp_t* q, const double* lbA, const double* ubA, const double* lb, const double* ub)
+{
+    const int nC = q->nC;
+    for (int i = 0; i < q->mE; i++) {
+        if (i < nC) { q->l[i] = bound_or(lbA, i, -INFINITY); q->u[i] = bound_or(ubA, i, INFINITY); }
+        else { q->l[i] = bound_or(lb, q->boxidx[i - nC], -INFINITY); q->u[i] = bound_or(ub, q->boxidx[i - nC], INFINITY); }
+    }
+}
+
+static double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* n_it ADMM iterations on (xa, za, ya) with the constant factor LK (OSQP iteration, reduced KKT form):
+ *   xt = K^-1 (sigma x - g + E'(rho.z - y));  zt = E xt;  relaxation alpha;  z = clip;  y += rho (zr - z). */
+static void qp_admm(orc_qp_t* q, const double* g, int n_it)
+{
+    const int n = q->nV, mE = q->mE;
+    const double alpha = q->opt.admmAlpha, sigma = q->sigma;
+    double* rhs = q->w_n1;
+    for (int it = 0; it < n_it; it++) {
+        for (int i = 0; i < n; i++) rhs[i] = sigma * q->xa[i] - g[i];
+        for (int r = 0; r < mE; r++) {
+            double v = q->rhov[r] * q->za[r] - q->ya[r];
+            if (v == 0.0) continue;
+            const double* e = q->E + (size_t)r * n;
+            for (int i = 0; i < n; i++) rhs[i] += e[i] * v;
+        }
+        trsv_lower(q->LK, n, rhs);
+        trsv_lower_t(q->LK, n, rhs); /* rhs = xt */
+        for (int r = 0; r < mE; r++) {
+            const double* e = q->E + (size_t)r * n;
+            double zt = 0;
+            for (int i = 0; i < n; i++) zt += e[i] * rhs[i];
+            double zr = alpha * zt + (1.0 - alpha) * q->za[r];
+            double rv = q->rhov[r];
+            if (rv > 0.0) {
+                double zn = clipd(zr + q->ya[r] / rv, q->l[r], q->u[r]);
+                q->ya[r] += rv * (zr - zn);
+                q->za[r] = zn;
+            } else {
+                q->za[r] = zr;
+                q->ya[r] = 0.0;
+            }
+        }
+        for (int i = 0; i < n; i++) q->xa[i] = alpha * rhs[i] + (1.0 - alpha) * q->xa[i];
+        q->c_admm++;
+    }
+}
+
+/* active-set guess from an ADMM iterate (the rule OSQP's polish uses) */
+static void qp_guess_from_admm(orc_qp_t* q, int* st)
+{
+    for (int r = 0; r < q->mE; r++) {
+        double l = q->l[r], u = q->u[r], z = q->za[r], y = q->ya[r];
+        int s = ST_INACT;
+        if (isfinite(l) && (z - l < -y)) s = ST_LOWER;
+        if (isfinite(u) && (u - z < y)) s = ST_UPPER;
+        if (l == u) s = ST_EQ;
+        st[r] = s;
+    }
+}
+
+/* Primal-dual active-set polish in correction (iterative refinement) form.
+ * Start: x, yfull (OSQP sign, zero on inactive rows), active set st.  Each trial evaluates the true KKT
+ * residuals (one pass over Q and E), tests optimality, else updates the active set (all violated rows
+ * enter, all wrong-signed multipliers leave) and solves one correction with the constant factor L1 and
+ * the Cholesky factor of S = Et_act Et_act'.   Returns 1 on a verified KKT point. */
+static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int* st)
+{
+    const int n = q->nV, mE = q->mE;
+    const orc_options_t* o = &q->opt;
+    double gmax = 0;
+    for (int i = 0; i < n; i++) { double a = fabs(g[i]); if (a > gmax) gmax = a; }
+    const double gs = 1.0 + gmax;
+    double *r1 = q->w_n1, *c = q->w_n2, *du = q->w_n3, *Ex = q->w_m1, *r2 = q->w_a1, *dy = q->w_a2;
+    int na = 0, fact_valid = 0;
+
+    for (int trial = 0; trial < o->maxTrials; trial++) {
+        q->c_trials++;
+        /* residual evaluation */
+        for (int i = 0; i < n; i++) {
+            const double* qr = q->Q + (size_t)i * n;
+            double s = 0;
+            for (int k = 0; k < n; k++) s += qr[k] * x[k];
+            r1[i] = -g[i] - s;
+        }
+        for (int r = 0; r < mE; r++) {
+            const double* e = q->E + (size_t)r * n;
+            double s = 0;
+            for (int k = 0; k < n; k++) s += e[k] * x[k];
+            Ex[r] = s;
+            double yr = yfull[r];
+            if (yr != 0.0)
+                for (int k = 0; k < n; k++) r1[k] -= e[k] * yr;
+        }
+        double res_stat = 0, res_eq = 0, bmax = 0;
+        for (int i = 0; i < n; i++) { double a = fabs(r1[i]); if (a > res_stat) res_stat = a; }
+        int changed = 0;
+        for (int r = 0; r < mE; r++) {
+            int s = st[r], ns = s;
+            if (s == ST_INACT) {
+                double ftol = o->feasTol * (1.0 + fabs(Ex[r]));
+                if (Ex[r] < q->l[r] - ftol) ns = ST_LOWER;
+                else if (Ex[r] > q->u[r] + ftol) ns = ST_UPPER;
+            } else {
+                double b = (s == ST_UPPER) ? q->u[r] : q->l[r];
+                double a = fabs(b - Ex[r]);
+                if (a > res_eq) res_eq = a;
+                if (fabs(b) > bmax) bmax = fabs(b);
+                double ytol = o->feasTol * gs;
+                if (s == ST_LOWER && yfull[r] > ytol) ns = ST_INACT;
+                if (s == ST_UPPER && yfull[r] < -ytol) ns = ST_INACT;
+            }
+            q->newst[r] = ns;
+            if (ns != s) changed = 1;
+        }
+        if (trial > 0 && !changed && res_stat <= o->resTol * gs && res_eq <= o->resTol * (1.0 + bmax))
+            return 1;
+        if (changed && trial > 0) {
+            for (int r = 0; r < mE; r++) {
+                int ns = q->newst[r];
+                if (ns == ST_INACT && st[r] != ST_INACT) {
+                    /* leaving row: remove its multiplier from the stationarity residual */
+                    double yr = yfull[r];
+                    if (yr != 0.0) {
+                        const double* e = q->E + (size_t)r * n;
+                        for (int k = 0; k < n; k++) r1[k] += e[k] * yr;
+                    }
+                    yfull[r] = 0.0;
+                }
+                st[r] = ns;
+            }
+            fact_valid = 0;
+        }
+        if (!fact_valid) {
+            na = 0;
+            for (int r = 0; r < mE; r++)
+                if (st[r] != ST_INACT) {
+                    if (na >= q->cap_na) return 0;
+                    q->idx[na++] = r;
+                }
+            for (int a = 0; a < na; a++) memcpy(q->T + (size_t)a * n, q->Et + (size_t)q->idx[a] * n, sizeof(double) * n);
+            for (int a = 0; a < na; a++)
+                for (int b2 = 0; b2 <= a; b2++) {
+                    const double *ta = q->T + (size_t)a * n, *tb = q->T + (size_t)b2 * n;
+                    double s = 0;
+                    for (int k = 0; k < n; k++) s += ta[k] * tb[k];
+                    q->S[(size_t)a * na + b2] = s;
+                }
+            safe_chol(q->S, na, o->depTau);
+            q->c_fact++;
+            fact_valid = 1;
+        }
+        /* correction:  c = L1^-1 r1 ;  S dy = T c - r2 ;  dx = L1^-T (c - T' dy) */
+        for (int a = 0; a < na; a++) {
+            int r = q->idx[a];
+            double b = (st[r] == ST_UPPER) ? q->u[r] : q->l[r];
+            r2[a] = b - Ex[r];
+        }
+        memcpy(c, r1, sizeof(double) * n);
+        trsv_lower(q->L1, n, c);
+        for (int a = 0; a < na; a++) {
+            const double* ta = q->T + (size_t)a * n;
+            double s = 0;
+            for (int k = 0; k < n; k++) s += ta[k] * c[k];
+            dy[a] = s - r2[a];
+        }
+        if (na > 0) { trsv_lower(q->S, na, dy); trsv_lower_t(q->S, na, dy); }
+        memcpy(du, c, sizeof(double) * n);
+        for (int a = 0; a < na; a++) {
+            const double* ta = q->T + (size_t)a * n;
+            double v = dy[a];
+            if (v == 0.0) continue;
+            for (int k = 0; k < n; k++) du[k] -= ta[k] * v;
+        }
+        trsv_lower_t(q->L1, n, du);
+        for (int i = 0; i < n; i++) x[i] += du[i];
+        for (int a = 0; a < na; a++) yfull[q->idx[a]] += dy[a];
+        q->c_corr++;
+    }
+    return 0;
+}
+
+int orc_qp_solve(orc_qp_t* q, int initialSolve, int* iterations, int* exit_flag, const double* g,
+                 const double* lbA, const double* ubA, const double* x0, const double* y0,
+                 const double* lb, const double* ub)
+{
+    const int n = q->nV, nC = q->nC;
+    const orc_options_t* o = &q->opt;
+    int trials0 = q->c_trials, admm0 = q->c_admm;
+    *iterations = 0;
+    *exit_flag = 0;
+    if (initialSolve || !q->is_setup || !qp_bounds_compatible(q, lbA, ubA, lb, ub)) {
+        double *xkeep = NULL, *ykeep = NULL; /* (a pattern change on a hot start restarts cold) */
+        (void)xkeep; (void)ykeep;
+        int rc = qp_setup(q, lbA, ubA, lb, ub);
+        if (rc != 0) { *exit_flag = rc; return ORC_SUBPROBLEM_SOLVER_ERROR; }
+        initialSolve = 1;
+    } else {
+        qp_update_bounds(q, lbA, ubA, lb, ub);
+    }
+    const int mE = q->mE;
+    for (int r = 0; r < mE; r++)
+        if (q->l[r] > q->u[r]) { *exit_flag = 2; return ORC_SUBPROBLEM_SOLVER_ERROR; } /* infeasible bounds */
+
+    /* starting point: initial solve uses (x0, y0) like qp.init (SubsolverQPOASES.cpp:152); a hot start
+     * continues from the previous solution and working set like qp.hotstart (:158) */
+    if (initialSolve) {
+        for (int i = 0; i < n; i++) q->x[i] = x0 ? x0[i] : 0.0;
+        for (int r = 0; r < mE; r++) {
+            double yr = 0.0;
+            if (y0) yr = (r < nC) ? -y0[n + r] : -y0[q->boxidx[r - nC]];
+            q->y[r] = yr;
+        }
+    }
+    memcpy(q->xa, q->x, sizeof(double) * n);
+    memcpy(q->ya, q->y, sizeof(double) * mE);
+    for (int r = 0; r < mE; r++) {
+        const double* e = q->E + (size_t)r * n;
+        double s = 0;
+        for (int k = 0; k < n; k++) s += e[k] * q->xa[k];
+        q->za[r] = clipd(s, q->l[r], q->u[r]);
+        if (q->rhov[r] == 0.0) q->ya[r] = 0.0;
+    }
+    int n_admm = initialSolve ? o->admmFirst : o->admmHot;
+    int use_stored_set = (!initialSolve && q->have_solution && n_admm == 0);
+    double* xt = (double*)malloc(sizeof(double) * (n ? n : 1));
+    double* yt = (double*)malloc(sizeof(double) * (mE ? mE : 1));
+    int* stt = (int*)malloc(sizeof(int) * (mE ? mE : 1));
+    int solved = 0;
+    for (int round = 0; round < o->maxRounds && !solved; round++) {
+        if (n_admm > 0) qp_admm(q, g, n_admm);
+        if (round == 0 && use_stored_set) {
+            memcpy(stt, q->st, sizeof(int) * mE);
+            for (int r = 0; r < mE; r++) if (q->l[r] == q->u[r]) stt[r] = ST_EQ;
+        } else {
+            qp_guess_from_admm(q, stt);
+        }
+        memcpy(xt, q->xa, sizeof(double) * n);
+        for (int r = 0; r < mE; r++) yt[r] = (stt[r] != ST_INACT) ? q->ya[r] : 0.0;
+        if (qp_polish(q, g, xt, yt, stt)) { solved = 1; break; }
+        n_admm = 2 * n_admm;
+        if (n_admm < 10) n_admm = 10;
+        if (n_admm > 400) n_admm = 400;
+    }
+    *iterations = (q->c_trials - trials0) + (q->c_admm - admm0);
+    if (!solved) { free(xt); free(yt); free(stt); *exit_flag = 1; return ORC_SUBPROBLEM_SOLVER_ERROR; }
+    memcpy(q->x, xt, sizeof(double) * n);
+    memcpy(q->y, yt, sizeof(double) * mE);
+    memcpy(q->st, stt, sizeof(int) * mE);
+    q->have_solution = 1;
+    free(xt); free(yt); free(stt);
+    /* qpOASES layout/sign */
+    memcpy(q->xsol, q->x, sizeof(double) * n);
+    for (int i = 0; i < n + nC; i++) q->ysol[i] = 0.0;
+    for (int r = 0; r < nC; r++) q->ysol[n + r] = -q->y[r];
+    for (int k = 0; k < q->nfin; k++) q->ysol[q->boxidx[k]] = -q->y[nC + k];
+    return ORC_SUCCESSFUL_RETURN;
+}
+
+void orc_qp_get_solution(orc_qp_t* q, double* x, double* y)
+{ /* SubsolverQPOASES.cpp:172-181 */
+    memcpy(x, q->xsol, sizeof(double) * q->nV);
+    memcpy(y, q->ysol, sizeof(double) * ((size_t)q->nV + q->nC));
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * LCQP: loadLCQP (dense) + runSolver.   src/LCQProblem.cpp
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int nV, nC, nComp, nDuals, boxDualOffset;
+    double *Q, *g, *L, *R, *A, *lbA, *ubA, *lb, *ub, *C, *Qk;
+    double *lbL, *lbR; /* NULL when not given */
+    double *g_tilde, *g_phi;
+    double phi_const;
+    double *xk, *yk, *yk_A, *gk, *xnew, *pk, *statk, *constr_statk, *lk_tmp;
+    int have_yk;
+    double alphak, rho;
+    int outerIter, innerIter, totalIter, algoStat;
+    double* hist; int histLen;
+    const orc_options_t* opt;
+    orc_stats_t* stats;
+    orc_qp_t* qp;
+    int qpIterk, qpExit;
+    uint64_t perturbCounter;
+} lcqp_t;
+
+static double lcqp_getPhi(lcqp_t* p)
+{ /* :1172-1185 */
+    double phi_lin = 0;
+    if (p->g_phi) phi_lin += orc_util_dot(p->g_phi, p->xk, p->nV);
+    return p->phi_const + phi_lin + orc_util_quadform(p->C, p->xk, p->nV) / 2.0;
+}
+
+static void lcqp_updateLinearization(lcqp_t* p)
+{ /* :1105-1112  gk = rho*C*xk + g_tilde */
+    orc_util_affine(p->rho, p->C, p->xk, p->g_tilde, p->gk, p->nV, p->nV);
+}
+
+static int lcqp_solveQPSubproblem(lcqp_t* p, int initialSolve)
+{ /* :1115-1148 */
+    int ret = orc_qp_solve(p->qp, initialSolve, &p->qpIterk, &p->qpExit, p->gk, p->lbA, p->ubA, p->xk,
+                           p->have_yk ? p->yk : NULL, p->lb, p->ub);
+    p->stats->subproblemIter += p->qpIterk;
+    p->stats->qpSolverExitFlag = p->qpExit;
+    p->stats->qpSolves++;
+    p->have_yk = 1; /* :1129-1131 allocates yk when it was NULL */
+    if (ret != ORC_SUCCESSFUL_RETURN) return ret;
+    orc_qp_get_solution(p->qp, p->xnew, p->yk);
+    for (int i = 0; i < p->nC + 2 * p->nComp; i++) p->yk_A[i] = p->yk[p->boxDualOffset + i];
+    orc_util_weighted_vecadd(1, p->xnew, -1, p->xk, p->pk, p->nV);
+    return ORC_SUCCESSFUL_RETURN;
+}
+
+static void lcqp_updateStationarity(lcqp_t* p)
+{ /* :1246-1272  statk = Qk*xk + g_tilde - A'*yk_A - yk[0:nV] */
+    const int nV = p->nV, m = p->nC + 2 * p->nComp;
+    orc_util_affine(1, p->Qk, p->xk, p->g_tilde, p->statk, nV, nV);
+    orc_util_matmul_t(p->A, p->yk_A, p->constr_statk, m, nV, 1);
+    orc_util_weighted_vecadd(1, p->statk, -1, p->constr_statk, p->statk, nV);
+    /* box term: lb/ub are always allocated on the dense arm (:896-904), so it is always applied */
+    orc_util_weighted_vecadd(1, p->statk, -1, p->yk, p->statk, nV);
+}
+
+static void lcqp_updatePenalty(lcqp_t* p)
+{ /* :1199-1214 */
+    if (p->opt->nDynamicPenalty > 0) p->histLen = 0;
+    p->rho *= p->opt->penaltyUpdateFactor;
+    p->stats->rhoOpt = p->rho;
+    orc_util_weighted_matadd(1, p->Q, p->rho, p->C, p->Qk, p->nV, p->nV); /* updateQk :1316-1326 */
+    if (p->g_phi) orc_util_weighted_vecadd(1.0, p->g, p->rho, p->g_phi, p->g_tilde, p->nV);
+}
+
+static int lcqp_leyfferCheckPositive(lcqp_t* p)
+{ /* :1275-1313 */
+    int n = p->opt->nDynamicPenalty;
+    if (n <= 0) return 0;
+    double complCur = lcqp_getPhi(p);
+    if (p->histLen < n) { p->hist[p->histLen++] = complCur; return 0; }
+    if (lcqp_getPhi(p) < p->opt->complementarityTolerance) { /* complementarityCheck :1156-1158 */
+        memmove(p->hist, p->hist + 1, sizeof(double) * (n - 1));
+        p->hist[n - 1] = complCur;
+        return 0;
+    }
+    int retFlag = 1;
+    for (int i = 0; i < n; i++)
+        if (complCur < p->opt->etaDynamicPenalty * p->hist[i]) { retFlag = 0; break; }
+    memmove(p->hist, p->hist + 1, sizeof(double) * (n - 1));
+    p->hist[n - 1] = complCur;
+    return retFlag;
+}
+
+static void lcqp_getOptimalStepLength(lcqp_t* p)
+{ /* :1217-1237 */
+    double qk = orc_util_quadform(p->Qk, p->pk, p->nV);
+    orc_util_affine(1, p->Qk, p->xk, p->g_tilde, p->lk_tmp, p->nV, p->nV);
+    double lk = orc_util_dot(p->pk, p->lk_tmp, p->nV);
+    p->alphak = 1;
+    if (qk > 0 && lk < 0) { double a = -lk / qk; p->alphak = a < 1.0 ? a : 1.0; }
+}
+
+static void lcqp_perturbStep(lcqp_t* p)
+{ /* :1353-1362; the reference draws rand()%3-1 from a time-seeded generator, here a seeded SplitMix64 */
+    for (int i = 0; i < p->nV; i++) {
+        int randNum = (int)(lcqp_sm64(p->opt->perturbSeed, p->perturbCounter++) % 3ULL) - 1;
+        p->xk[i] += randNum * ORC_EPS;
+    }
+}
+
+static void lcqp_transformDuals(lcqp_t* p)
+{ /* :1381-1409 */
+    const int nV = p->nV, nC = p->nC, nComp = p->nComp, off = p->boxDualOffset;
+    double* tmp = dalloc(nComp);
+    orc_util_matmul(p->R, p->xk, tmp, nComp, nV, 1);
+    for (int i = 0; i < nComp; i++) p->yk[off + nC + i] = p->yk[off + nC + i] - p->rho * tmp[i];
+    orc_util_matmul(p->L, p->xk, tmp, nComp, nV, 1);
+    for (int i = 0; i < nComp; i++) p->yk[off + nC + nComp + i] = p->yk[off + nC + nComp + i] - p->rho * tmp[i];
+    free(tmp);
+}
+
+static void lcqp_determineStationarityType(lcqp_t* p)
+{ /* :1412-1453 with getWeakComplementarities :1456-1482 */
+    const int nV = p->nV, nC = p->nC, nComp = p->nComp;
+    const double ctol = p->opt->complementarityTolerance;
+    double *Lx = dalloc(nComp), *Rx = dalloc(nComp);
+    orc_util_matmul(p->L, p->xk, Lx, nComp, nV, 1);
+    orc_util_matmul(p->R, p->xk, Rx, nComp, nV, 1);
+    int s_stat = 1, m_stat = 1, done = 0;
+    for (int i = 0; i < nComp && !done; i++) {
+        if (!(Lx[i] <= ctol && Rx[i] <= ctol)) continue;
+        double a = p->yk_A[nC + i], b = p->yk_A[nC + nComp + i];
+        double dualProd = a * b, dualMin = a < b ? a : b;
+        if (dualMin < 0) s_stat = 0;
+        if (fabs(dualProd) >= ctol && dualMin <= 0) {
+            if (dualProd <= ctol) { p->algoStat = ORC_W_STATIONARY; done = 1; break; }
+            m_stat = 0;
+        }
+    }
+    free(Lx); free(Rx);
+    if (done) return;
+    if (s_stat) { p->algoStat = ORC_S_STATIONARY; return; }
+    if (m_stat) { p->algoStat = ORC_M_STATIONARY; return; }
+    p->algoStat = ORC_C_STATIONARY;
+}
+
+int orc_lcqp_solve(int nV, int nC, int nComp,
+                   const double* Q, const double* g, const double* L, const double* R,
+                   const double* lbL, const double* ubL, const double* lbR, const double* ubR,
+                   const double* A, const double* lbA, const double* ubA,
+                   const double* lb, const double* ub, const double* x0, const double* y0,
+                   const orc_options_t* opt, double* xOpt, double* yOpt, orc_stats_t* stats,
+                   int traceCap, double* traceScalars, double* traceX, int* traceLen)
+{
+    orc_options_t dflt;
+    orc_stats_t lstats;
+    if (!opt) { orc_options_default(&dflt); opt = &dflt; }
+    if (!stats) stats = &lstats;
+    memset(stats, 0, sizeof(*stats));
+    if (traceLen) *traceLen = 0;
+    if (nV <= 0 || nComp <= 0) return (stats->returnValue = ORC_LCQPOBJECT_NOT_SETUP);   /* :98-99 */
+    if (!g) return (stats->returnValue = ORC_INVALID_OBJECTIVE_LINEAR_TERM);               /* .ipp:44-45 */
+    if (!A && nC > 0) return (stats->returnValue = ORC_INVALID_CONSTRAINT_MATRIX);         /* :569-570 */
+    if (!L || !R) return (stats->returnValue = ORC_INVALID_COMPLEMENTARITY_MATRIX);        /* :611-612 */
+    if (nC < 0) nC = 0;
+
+    lcqp_t P; memset(&P, 0, sizeof(P));
+    lcqp_t* p = &P;
+    const int m = nC + 2 * nComp;
+    p->nV = nV; p->nC = nC; p->nComp = nComp; p->opt = opt; p->stats = stats;
+    p->Q = dalloc((size_t)nV * nV); memcpy(p->Q, Q, sizeof(double) * nV * nV);   /* setQ .ipp:27-36 */
+    p->g = dalloc(nV); memcpy(p->g, g, sizeof(double) * nV);
+    /* setConstraints :563-626: stack [A; L; R], default bounds */
+    p->A = dalloc((size_t)m * nV);
+    for (int i = 0; i < nC * nV; i++) p->A[i] = A[i];
+    for (int i = 0; i < nComp * nV; i++) p->A[i + nC * nV] = L[i];
+    for (int i = 0; i < nComp * nV; i++) p->A[i + nC * nV + nComp * nV] = R[i];
+    p->lbA = dalloc(m); p->ubA = dalloc(m);
+    for (int i = 0; i < nC; i++) { p->lbA[i] = lbA ? lbA[i] : -INFINITY; p->ubA[i] = ubA ? ubA[i] : INFINITY; }
+    p->L = dalloc((size_t)nComp * nV); p->R = dalloc((size_t)nComp * nV);
+    memcpy(p->L, L, sizeof(double) * nComp * nV); memcpy(p->R, R, sizeof(double) * nComp * nV);
+    p->C = dalloc((size_t)nV * nV);
+    orc_util_symm_product(p->L, p->R, p->C, nComp, nV);
+    int rc = ORC_SUCCESSFUL_RETURN;
+    /* setComplementarityBounds :726-785 */
+    if (lbL) { p->lbL = dalloc(nComp); }
+    if (lbR) { p->lbR = dalloc(nComp); }
+    for (int i = 0; i < nComp && rc == 0; i++) {
+        if (lbL) { if (lbL[i] <= -INFINITY) { rc = ORC_INVALID_LOWER_COMPLEMENTARITY_BOUND; break; } p->lbL[i] = lbL[i]; p->lbA[nC + i] = lbL[i]; }
+        else p->lbA[nC + i] = 0;
+        p->ubA[nC + i] = ubL ? ubL[i] : INFINITY;
+    }
+    for (int i = 0; i < nComp && rc == 0; i++) {
+        if (lbR) { if (lbR[i] <= -INFINITY) { rc = ORC_INVALID_LOWER_COMPLEMENTARITY_BOUND; break; } p->lbR[i] = lbR[i]; p->lbA[nC + nComp + i] = lbR[i]; }
+        else p->lbA[nC + nComp + i] = 0;
+        p->ubA[nC + nComp + i] = ubR ? ubR[i] : INFINITY;
+    }
+    /* setInitialGuess .ipp:133-158 */
+    p->nDuals = nV + m; p->boxDualOffset = nV;                                   /* :889-890 */
+    p->xk = dalloc(nV); if (x0) memcpy(p->xk, x0, sizeof(double) * nV);
+    p->yk = dalloc(p->nDuals);
+    if (y0) { memcpy(p->yk, y0, sizeof(double) * p->nDuals); p->have_yk = 1; }
+    /* initializeSolver :885-1034 (dense arm) */
+    p->lb = dalloc(nV); p->ub = dalloc(nV);
+    for (int i = 0; i < nV; i++) { p->lb[i] = lb ? lb[i] : -INFINITY; p->ub[i] = ub ? ub[i] : INFINITY; }  /* setLB/setUB .ipp:54-112 */
+    p->Qk = dalloc((size_t)nV * nV); p->gk = dalloc(nV); p->xnew = dalloc(nV); p->yk_A = dalloc(m);
+    p->pk = dalloc(nV); p->statk = dalloc(nV); p->constr_statk = dalloc(nV); p->lk_tmp = dalloc(nV);
+    p->g_tilde = dalloc(nV); memcpy(p->g_tilde, p->g, sizeof(double) * nV);     /* :966-967 */
+    p->hist = dalloc(opt->nDynamicPenalty > 0 ? opt->nDynamicPenalty : 1);
+    if (rc == 0) {
+        /* phi expressions :969-996.  (The reference dereferences both lbL and lbR when either is given;
+         * a missing one is treated as zeros here.) */
+        if (p->lbL || p->lbR) {
+            double* zero = dalloc(nComp);
+            const double* a = p->lbL ? p->lbL : zero; const double* b = p->lbR ? p->lbR : zero;
+            p->phi_const = orc_util_dot(a, b, nComp);
+            p->g_phi = dalloc(nV);
+            if (p->lbL) orc_util_add_matmul_t(p->R, p->lbL, p->g_phi, nComp, nV, 1);
+            if (p->lbR) orc_util_add_matmul_t(p->L, p->lbR, p->g_phi, nComp, nV, 1);
+            for (int i = 0; i < nV; i++) p->g_phi[i] = -p->g_phi[i];
+            free(zero);
+        }
+        p->alphak = 1; p->rho = opt->initialPenaltyParameter;                  /* :999-1004 */
+        p->algoStat = ORC_PROBLEM_NOT_SOLVED;
+        p->qp = orc_qp_create(nV, m, p->Q, p->A, opt);                          /* :906-907 */
+
+        /* runSolver :444-560 */
+        if (opt->solveZeroPenaltyFirst) memcpy(p->gk, p->g, sizeof(double) * nV);
+        else lcqp_updateLinearization(p);
+        rc = lcqp_solveQPSubproblem(p, 1);
+        if (rc == 0) {
+            orc_util_weighted_matadd(1, p->Q, p->rho, p->C, p->Qk, nV, nV);     /* setQk :880 */
+            stats->rhoOpt = p->rho;
+            for (;;) {
+                orc_util_weighted_vecadd(1, p->xk, p->alphak, p->pk, p->xk, nV); /* updateStep :1240-1243 */
+                lcqp_updateStationarity(p);
+                if (traceCap > 0 && traceLen && *traceLen < traceCap) {
+                    int t = *traceLen;
+                    if (traceScalars) {
+                        traceScalars[4 * t + 0] = orc_util_maxabs(p->statk, nV);
+                        traceScalars[4 * t + 1] = lcqp_getPhi(p);
+                        traceScalars[4 * t + 2] = p->rho;
+                        traceScalars[4 * t + 3] = p->alphak;
+                    }
+                    if (traceX) memcpy(traceX + (size_t)t * nV, p->xk, sizeof(double) * nV);
+                    *traceLen = t + 1;
+                }
+                p->totalIter++; stats->iterTotal++;                             /* :1335-1338 */
+                p->innerIter++;
+                if (lcqp_leyfferCheckPositive(p)) {
+                    lcqp_updatePenalty(p);
+                    p->outerIter++; stats->iterOuter++; p->innerIter = 0;
+                }
+                lcqp_updateLinearization(p);
+                if (orc_util_maxabs(p->statk, nV) < opt->stationarityTolerance) {      /* :1151-1153 */
+                    if (lcqp_getPhi(p) < opt->complementarityTolerance) {               /* :1156-1158 */
+                        lcqp_transformDuals(p);
+                        lcqp_determineStationarityType(p);
+                        stats->status = p->algoStat;
+                        rc = ORC_SUCCESSFUL_RETURN;
+                        break;
+                    } else {
+                        lcqp_updatePenalty(p);
+                        p->outerIter++; stats->iterOuter++; p->innerIter = 0;
+                    }
+                }
+                if (p->totalIter > opt->maxIterations) { rc = ORC_MAX_ITERATIONS_REACHED; break; }
+                if (p->rho > opt->maxPenaltyParameter) { rc = ORC_MAX_PENALTY_REACHED; break; }
+                lcqp_updateLinearization(p);
+                rc = lcqp_solveQPSubproblem(p, 0);
+                if (rc != 0) break;
+                if (opt->perturbStep) lcqp_perturbStep(p);
+                lcqp_getOptimalStepLength(p);
+            }
+        }
+    }
+    if (xOpt) memcpy(xOpt, p->xk, sizeof(double) * nV);                           /* :1485-1493 */
+    if (yOpt) memcpy(yOpt, p->yk, sizeof(double) * p->nDuals);                    /* :1496-1504 */
+    stats->status = p->algoStat;
+    stats->returnValue = rc;
+    if (p->qp) {
+        orc_qp_get_counters(p->qp, &stats->admmIter, &stats->trials, &stats->factorizations, &stats->corrections);
+        orc_qp_destroy(p->qp);
+    }
+    free(p->Q); free(p->g); free(p->A); free(p->lbA); free(p->ubA); free(p->L); free(p->R); free(p->C);
+    free(p->lbL); free(p->lbR); free(p->xk); free(p->yk); free(p->lb); free(p->ub); free(p->Qk); free(p->gk);
+    free(p->xnew); free(p->yk_A); free(p->pk); free(p->statk); free(p->constr_statk); free(p->lk_tmp);
+    free(p->g_tilde); free(p->g_phi); free(p->hist);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Synthetic instances (include/lcqp_synth.h) and the threaded CPU-baseline driver.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_synth_generate(uint64_t seed0, uint64_t instance, int n, int nC, int nComp,
+                        double* Q, double* g, double* L, double* R, double* A, double* lbA, double* ubA)
+{
+    const uint64_t st = lcqp_synth_state(seed0, instance);
+    double* M = dalloc((size_t)n * n);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) M[(size_t)i * n + j] = lcqp_synth_M(st, n, i, j);
+    /* Q = M'M/n + I, summed over k ascending (the device generator uses the same order) */
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) Q[(size_t)i * n + j] = 0.0;
+    for (int k = 0; k < n; k++) {
+        const double* mk = M + (size_t)k * n;
+        for (int i = 0; i < n; i++) {
+            double a = mk[i];
+            double* qi = Q + (size_t)i * n;
+            for (int j = 0; j < n; j++) qi[j] += a * mk[j];
+        }
+    }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) Q[(size_t)i * n + j] = Q[(size_t)i * n + j] / (double)n + (i == j ? 1.0 : 0.0);
+    free(M);
+    for (int i = 0; i < n; i++) g[i] = lcqp_synth_g(st, n, nC, nComp, i);
+    memset(L, 0, sizeof(double) * nComp * n);
+    memset(R, 0, sizeof(double) * nComp * n);
+    for (int i = 0; i < nComp; i++) { L[(size_t)i * n + i] = 1.0; R[(size_t)i * n + nComp + i] = 1.0; }
+    const double sn = sqrt((double)n);
+    for (int r = 0; r < nC; r++) {
+        double ax = 0;
+        for (int c = 0; c < n; c++) {
+            double a = lcqp_synth_Araw(st, n, nC, nComp, r, c) / sn;
+            A[(size_t)r * n + c] = a;
+            ax += a * lcqp_synth_xstar(st, n, nC, nComp, c);
+        }
+        lbA[r] = ax - lcqp_synth_slo(st, n, nC, nComp, r);
+        ubA[r] = ax + lcqp_synth_shi(st, n, nC, nComp, r);
+    }
+}
+
+typedef struct {
+    uint64_t seed0; int first, count, n, nC, nComp; const orc_options_t* opt;
+    double *xOut, *yOut; orc_stats_t* statsOut;
+    int next; int ok; pthread_mutex_t mu;
+} batch_ctx_t;
+
+static void* batch_worker(void* arg)
+{
+    batch_ctx_t* c = (batch_ctx_t*)arg;
+    const int n = c->n, nC = c->nC, nComp = c->nComp, nd = n + nC + 2 * nComp;
+    double *Q = dalloc((size_t)n * n), *g = dalloc(n), *L = dalloc((size_t)nComp * n), *R = dalloc((size_t)nComp * n);
+    double *A = dalloc((size_t)nC * n), *lbA = dalloc(nC), *ubA = dalloc(nC), *x = dalloc(n), *y = dalloc(nd);
+    for (;;) {
+        pthread_mutex_lock(&c->mu);
+        int k = c->next++;
+        pthread_mutex_unlock(&c->mu);
+        if (k >= c->count) break;
+        orc_stats_t st;
+        orc_synth_generate(c->seed0, (uint64_t)(c->first + k), n, nC, nComp, Q, g, L, R, A, lbA, ubA);
+        int rc = orc_lcqp_solve(n, nC, nComp, Q, g, L, R, NULL, NULL, NULL, NULL, A, lbA, ubA, NULL, NULL, NULL, NULL,
+                                c->opt, x, y, &st, 0, NULL, NULL, NULL);
+        if (c->xOut) memcpy(c->xOut + (size_t)k * n, x, sizeof(double) * n);
+        if (c->yOut) memcpy(c->yOut + (size_t)k * nd, y, sizeof(double) * nd);
+        if (c->statsOut) c->statsOut[k] = st;
+        if (rc == 0) { pthread_mutex_lock(&c->mu); c->ok++; pthread_mutex_unlock(&c->mu); }
+    }
+    free(Q); free(g); free(L); free(R); free(A); free(lbA); free(ubA); free(x); free(y);
+    return NULL;
+}
+
+int orc_synth_batch_solve(uint64_t seed0, int first, int count, int n, int nC, int nComp, const orc_options_t* opt,
+                          int threads, double* xOut, double* yOut, orc_stats_t* statsOut)
+{
+    batch_ctx_t c;
+    memset(&c, 0, sizeof(c));
+    c.seed0 = seed0; c.first = first; c.count = count; c.n = n; c.nC = nC; c.nComp = nComp; c.opt = opt;
+    c.xOut = xOut; c.yOut = yOut; c.statsOut = statsOut;
+    pthread_mutex_init(&c.mu, NULL);
+    if (threads < 1) threads = 1;
+    pthread_t* th = (pthread_t*)calloc(threads, sizeof(pthread_t));
+    for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, batch_worker, &c);
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    free(th);
+    pthread_mutex_destroy(&c.mu);
+    return c.ok;
+}

@@ -1,0 +1,196 @@
+"""ctypes binding of the CPU oracle (oracle/liblcqp_oracle.so).
+
+Test infrastructure only: imported by tests/, bench.py's cpu_baseline leg and
+__graft_entry__.smoke(); never by the product package lcqpow_amd.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+_SO = os.path.join(ROOT, "oracle", "liblcqp_oracle.so")
+
+c_double_p = C.POINTER(C.c_double)
+
+
+class Options(C.Structure):
+    """Mirrors orc_options_t / lcqp_options_t (identical field order)."""
+    _fields_ = [
+        ("complementarityTolerance", C.c_double),
+        ("stationarityTolerance", C.c_double),
+        ("initialPenaltyParameter", C.c_double),
+        ("penaltyUpdateFactor", C.c_double),
+        ("maxPenaltyParameter", C.c_double),
+        ("etaDynamicPenalty", C.c_double),
+        ("solveZeroPenaltyFirst", C.c_int),
+        ("perturbStep", C.c_int),
+        ("maxIterations", C.c_int),
+        ("nDynamicPenalty", C.c_int),
+        ("printLevel", C.c_int),
+        ("storeSteps", C.c_int),
+        ("perturbSeed", C.c_uint64),
+        ("admmRho", C.c_double),
+        ("admmSigma", C.c_double),
+        ("admmAlpha", C.c_double),
+        ("rhoEqMult", C.c_double),
+        ("proxSmall", C.c_double),
+        ("proxBig", C.c_double),
+        ("pivotThreshold", C.c_double),
+        ("depTau", C.c_double),
+        ("feasTol", C.c_double),
+        ("resTol", C.c_double),
+        ("admmFirst", C.c_int),
+        ("admmHot", C.c_int),
+        ("maxTrials", C.c_int),
+        ("maxRounds", C.c_int),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("iterTotal", C.c_int), ("iterOuter", C.c_int), ("subproblemIter", C.c_int),
+        ("status", C.c_int), ("qpSolverExitFlag", C.c_int), ("returnValue", C.c_int),
+        ("rhoOpt", C.c_double),
+        ("admmIter", C.c_int), ("trials", C.c_int), ("factorizations", C.c_int),
+        ("corrections", C.c_int), ("qpSolves", C.c_int), ("reserved", C.c_int),
+    ]
+
+    def asdict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or any(
+            os.path.getmtime(os.path.join(ROOT, p)) > os.path.getmtime(_SO)
+            for p in ("oracle/lcqp_oracle.c", "oracle/lcqp_oracle.h", "include/lcqp_synth.h")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.orc_options_default.argtypes = [C.POINTER(Options)]
+        L.orc_util_quadform.restype = C.c_double
+        L.orc_util_dot.restype = C.c_double
+        L.orc_util_maxabs.restype = C.c_double
+        L.orc_qp_create.restype = C.c_void_p
+        L.orc_qp_create.argtypes = [C.c_int, C.c_int, c_double_p, c_double_p, C.POINTER(Options)]
+        L.orc_qp_destroy.argtypes = [C.c_void_p]
+        L.orc_qp_solve.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)] + [c_double_p] * 7
+        L.orc_qp_get_solution.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        L.orc_qp_get_counters.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+        L.orc_lcqp_solve.argtypes = ([C.c_int] * 3 + [c_double_p] * 15 + [C.POINTER(Options), c_double_p, c_double_p,
+                                     C.POINTER(Stats), C.c_int, c_double_p, c_double_p, C.POINTER(C.c_int)])
+        L.orc_synth_generate.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int] + [c_double_p] * 7
+        L.orc_synth_batch_solve.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Options),
+                                            C.c_int, c_double_p, c_double_p, C.POINTER(Stats)]
+        _lib = L
+    return _lib
+
+
+def default_options(**kw):
+    o = Options()
+    lib().orc_options_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def _p(a):
+    if a is None:
+        return None
+    return a.ctypes.data_as(c_double_p)
+
+
+def _arr(a):
+    if a is None:
+        return None
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+SEED0 = 0x4C43515000000001
+
+
+def synth_generate(instance, n=256, nC=512, nComp=64, seed0=SEED0):
+    Q = np.empty((n, n)); g = np.empty(n); L = np.empty((nComp, n)); R = np.empty((nComp, n))
+    A = np.empty((nC, n)); lbA = np.empty(nC); ubA = np.empty(nC)
+    lib().orc_synth_generate(seed0, instance, n, nC, nComp, _p(Q), _p(g), _p(L), _p(R), _p(A), _p(lbA), _p(ubA))
+    return dict(Q=Q, g=g, L=L, R=R, A=A, lbA=lbA, ubA=ubA, nV=n, nC=nC, nComp=nComp)
+
+
+def lcqp_solve(Q, g, L, R, lbL=None, ubL=None, lbR=None, ubR=None, A=None, lbA=None, ubA=None, lb=None, ub=None,
+               x0=None, y0=None, opt=None, trace=0, nV=None, nC=None, nComp=None):
+    """Dense loadLCQP + runSolver on the oracle. Returns dict(ret, x, y, stats, trace?)."""
+    Q = _arr(Q); g = _arr(g); L = _arr(L); R = _arr(R); A = _arr(A)
+    nV = nV or g.shape[0]
+    nComp = nComp or (L.size // nV)
+    nC = nC if nC is not None else (0 if A is None else A.size // nV)
+    arrs = [_arr(v) for v in (lbL, ubL, lbR, ubR)]
+    lbA = _arr(lbA); ubA = _arr(ubA); lb = _arr(lb); ub = _arr(ub); x0 = _arr(x0); y0 = _arr(y0)
+    opt = opt or default_options()
+    x = np.zeros(nV); y = np.zeros(nV + nC + 2 * nComp)
+    st = Stats()
+    ts = np.zeros((max(trace, 1), 4)); tx = np.zeros((max(trace, 1), nV)); tl = C.c_int(0)
+    ret = lib().orc_lcqp_solve(nV, nC, nComp, _p(Q), _p(g), _p(L), _p(R), _p(arrs[0]), _p(arrs[1]), _p(arrs[2]),
+                               _p(arrs[3]), _p(A), _p(lbA), _p(ubA), _p(lb), _p(ub), _p(x0), _p(y0), C.byref(opt),
+                               _p(x), _p(y), C.byref(st), trace, _p(ts), _p(tx), C.byref(tl))
+    out = dict(ret=ret, x=x, y=y, stats=st.asdict())
+    if trace:
+        out["trace_scalars"] = ts[:tl.value].copy()
+        out["trace_x"] = tx[:tl.value].copy()
+    return out
+
+
+class QP:
+    """SubsolverBase-shaped handle on the oracle QP solver."""
+
+    def __init__(self, Q, A, opt=None):
+        Q = _arr(Q); self.nV = Q.shape[0]
+        A = _arr(A) if A is not None else np.zeros((0, self.nV))
+        self.nC = A.size // self.nV
+        self.opt = opt or default_options()
+        self.h = lib().orc_qp_create(self.nV, self.nC, _p(Q), _p(A), C.byref(self.opt))
+
+    def solve(self, initial, g, lbA=None, ubA=None, x0=None, y0=None, lb=None, ub=None):
+        it = C.c_int(0); ef = C.c_int(0)
+        a = [_arr(v) for v in (g, lbA, ubA, x0, y0, lb, ub)]
+        ret = lib().orc_qp_solve(self.h, int(initial), C.byref(it), C.byref(ef), *[_p(v) for v in a])
+        return ret, it.value, ef.value
+
+    def solution(self):
+        x = np.zeros(self.nV); y = np.zeros(self.nV + self.nC)
+        lib().orc_qp_get_solution(self.h, _p(x), _p(y))
+        return x, y
+
+    def counters(self):
+        v = [C.c_int(0) for _ in range(4)]
+        lib().orc_qp_get_counters(self.h, *[C.byref(t) for t in v])
+        return dict(admm=v[0].value, trials=v[1].value, factorizations=v[2].value, corrections=v[3].value)
+
+    def __del__(self):
+        try:
+            lib().orc_qp_destroy(self.h)
+        except Exception:
+            pass
+
+
+def synth_batch_solve(first, count, n=256, nC=512, nComp=64, opt=None, threads=1, seed0=SEED0, want_xy=True):
+    opt = opt or default_options()
+    nd = n + nC + 2 * nComp
+    x = np.zeros((count, n)) if want_xy else None
+    y = np.zeros((count, nd)) if want_xy else None
+    st = (Stats * count)()
+    ok = lib().orc_synth_batch_solve(seed0, first, count, n, nC, nComp, C.byref(opt), threads, _p(x), _p(y), st)
+    return ok, x, y, [s.asdict() for s in st]
