@@ -1,0 +1,162 @@
+/*
+ * lcqp_hip.h -- C ABI of the MI355X-native LCQPow hot path (liblcqpow_hip.so).
+ *
+ * This is the drop-in boundary of SURVEY.md §8(b): plain C types, caller-owned buffers, integer
+ * return codes, no exceptions.  Each entry point cites the reference interface it replaces
+ * (file:line under the LCQPow tree).  A reference-side binding (a SubsolverHIP class derived from
+ * SubsolverBase) is shown in INTEGRATION.md.
+ *
+ * Two groups:
+ *   lcqp_hip_qp_*     one convex QP object with the SubsolverBase semantics
+ *                     (include/SubsolverBase.hpp:37,52-56; src/SubsolverQPOASES.cpp:32-46,134-181).
+ *   lcqp_hip_batch_*  B independent LCQPs solved by the penalty homotopy entirely on the device
+ *                     (LCQProblem::loadLCQP + runSolver, src/LCQProblem.cpp:87-144,444-560), one
+ *                     persistent workgroup per instance.  The reference has no batched API; this is
+ *                     the throughput path that BASELINE.json's metric is measured on.
+ *
+ * All matrices are dense row-major doubles exactly as the reference takes them
+ * (src/Utilities.cpp:43).  Infinite bounds are IEEE +-INFINITY (src/LCQProblem.cpp:596,607).
+ */
+#ifndef LCQP_HIP_H
+#define LCQP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ReturnValue subset used across the boundary: include/Utilities.hpp:37-87 */
+#define LCQP_SUCCESSFUL_RETURN 0
+#define LCQP_INVALID_ARGUMENT 100
+#define LCQP_INVALID_OBJECTIVE_LINEAR_TERM 116
+#define LCQP_INVALID_CONSTRAINT_MATRIX 117
+#define LCQP_INVALID_COMPLEMENTARITY_MATRIX 118
+#define LCQP_INVALID_LOWER_COMPLEMENTARITY_BOUND 120
+#define LCQP_MAX_ITERATIONS_REACHED 200
+#define LCQP_MAX_PENALTY_REACHED 201
+#define LCQP_SUBPROBLEM_SOLVER_ERROR 203
+#define LCQP_LCQPOBJECT_NOT_SETUP 300
+/* backend errors (new) */
+#define LCQP_HIP_ERROR 900          /* a HIP runtime call failed; see lcqp_hip_last_error() */
+#define LCQP_HIP_UNSUPPORTED 901    /* dimensions outside what the kernels are built for */
+
+/* Options: the 13 algorithm options of include/Options.hpp with the defaults of
+ * src/Options.cpp:296-333, followed by the subsolver knobs that take the place of
+ * qpOASES::Options (src/Options.cpp:320-321). */
+typedef struct {
+    double complementarityTolerance; /* 1e3*EPS */
+    double stationarityTolerance;    /* 1e6*EPS */
+    double initialPenaltyParameter;  /* 0.01 */
+    double penaltyUpdateFactor;      /* 2 */
+    double maxPenaltyParameter;      /* 1e8 */
+    double etaDynamicPenalty;        /* 0.9 */
+    int    solveZeroPenaltyFirst;    /* 1 */
+    int    perturbStep;              /* 1 */
+    int    maxIterations;            /* 1000 */
+    int    nDynamicPenalty;          /* 3 */
+    int    printLevel;               /* 2; the device path never prints */
+    int    storeSteps;               /* 0 */
+    uint64_t perturbSeed;            /* deterministic stand-in for srand(time(NULL)), src/LCQProblem.cpp:1016 */
+    double admmRho, admmSigma, admmAlpha, rhoEqMult;
+    double proxSmall, proxBig, pivotThreshold, depTau, feasTol, resTol;
+    int    admmFirst, admmHot, maxTrials, maxRounds;
+} lcqp_options_t;
+
+/* OutputStatistics counters (src/OutputStatistics.cpp:81-128) + work counters of the subsolver. */
+typedef struct {
+    int    iterTotal, iterOuter, subproblemIter, status, qpSolverExitFlag, returnValue;
+    double rhoOpt;
+    int    admmIter, trials, factorizations, corrections, qpSolves, reserved;
+} lcqp_stats_t;
+
+void lcqp_hip_options_default(lcqp_options_t* opt);               /* Options::setToDefault, src/Options.cpp:296 */
+const char* lcqp_hip_last_error(void);
+int  lcqp_hip_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * QP object == SubsolverBase implementation state.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lcqp_hip_qp lcqp_hip_qp_t;
+
+/* SubsolverQPOASES(int nV,int nC,double* Q,double* A): src/SubsolverQPOASES.cpp:32-46 (deep copy of Q, A).
+ * nC is the number of stacked rows (nC + 2*nComp).  Host pointers.  Returns NULL on failure. */
+lcqp_hip_qp_t* lcqp_hip_qp_create(int nV, int nC, const double* Q, const double* A,
+                                  const lcqp_options_t* opt, int device);
+/* copy-ctor / operator= of the reference (src/SubsolverQPOASES.cpp:184-230): shares the immutable
+ * device copies of Q, A by reference count, duplicates solver state. */
+lcqp_hip_qp_t* lcqp_hip_qp_clone(const lcqp_hip_qp_t* src);
+void lcqp_hip_qp_destroy(lcqp_hip_qp_t* qp);
+/* SubsolverBase::solve, include/SubsolverBase.hpp:52-56 / src/SubsolverQPOASES.cpp:134-169.
+ * Returns LCQP_SUCCESSFUL_RETURN or LCQP_SUBPROBLEM_SOLVER_ERROR; *exit_flag != 0 on failure.
+ * lbA/ubA/lb/ub/x0/y0 may be NULL as in the reference. */
+int  lcqp_hip_qp_solve(lcqp_hip_qp_t* qp, int initialSolve, int* iterations, int* exit_flag,
+                       const double* g, const double* lbA, const double* ubA,
+                       const double* x0, const double* y0, const double* lb, const double* ub);
+/* SubsolverBase::getSolution, include/SubsolverBase.hpp:37 / src/SubsolverQPOASES.cpp:172-181:
+ * x[nV], y[nV + nC]: box duals first, then one dual per stacked row; Qx + g - A'y_A - y_box = 0. */
+void lcqp_hip_qp_get_solution(lcqp_hip_qp_t* qp, double* x, double* y);
+void lcqp_hip_qp_get_counters(lcqp_hip_qp_t* qp, int* admm, int* trials, int* factorizations, int* corrections);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch of B independent dense LCQPs of one shape (nV, nC, nComp).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lcqp_hip_batch lcqp_hip_batch_t;
+
+/* LCQProblem(nV,nC,nComp) x B: src/LCQProblem.cpp:43-79.  withBox != 0 reserves rows for lb/ub. */
+lcqp_hip_batch_t* lcqp_hip_batch_create(int batch, int nV, int nC, int nComp, int withBox, int device);
+void lcqp_hip_batch_destroy(lcqp_hip_batch_t* b);
+/* LCQProblem::setOptions, include/LCQProblem.ipp:160-163 */
+int  lcqp_hip_batch_set_options(lcqp_hip_batch_t* b, const lcqp_options_t* opt);
+/* LCQProblem::loadLCQP (dense), src/LCQProblem.cpp:87-144, for instances [first, first+count):
+ * arrays are host pointers, packed instance after instance ([count][...]); NULL as in the reference. */
+int  lcqp_hip_batch_load(lcqp_hip_batch_t* b, int first, int count,
+                         const double* Q, const double* g, const double* L, const double* R,
+                         const double* lbL, const double* ubL, const double* lbR, const double* ubR,
+                         const double* A, const double* lbA, const double* ubA,
+                         const double* lb, const double* ub, const double* x0, const double* y0);
+/* Fill instances [0,B) with the synthetic generator of include/lcqp_synth.h directly in HBM
+ * (instance id = firstInstance + b). */
+int  lcqp_hip_batch_generate_synthetic(lcqp_hip_batch_t* b, uint64_t seed0, uint64_t firstInstance);
+/* read one instance's problem data back (any pointer may be NULL) -- used by parity tests / cpu_baseline */
+int  lcqp_hip_batch_read_problem(lcqp_hip_batch_t* b, int instance, double* Q, double* g, double* L, double* R,
+                                 double* A, double* lbA, double* ubA);
+/* Constant-matrix setup: C = L'R + R'L (src/LCQProblem.cpp:622-623), phi expressions (:969-996) and the
+ * two factorisations the subsolver reuses across every iterate (replaces qp.init's setup,
+ * src/SubsolverQPOASES.cpp:152).  Asynchronous on the batch stream. */
+int  lcqp_hip_batch_setup(lcqp_hip_batch_t* b);
+/* LCQProblem::runSolver for all instances, src/LCQProblem.cpp:444-560.  Asynchronous on the batch
+ * stream; includes setup if it has not run since the last load. */
+int  lcqp_hip_batch_run(lcqp_hip_batch_t* b);
+int  lcqp_hip_batch_synchronize(lcqp_hip_batch_t* b);
+/* time of the last run (setup + homotopy kernel) measured with HIP events on the batch stream, ms */
+int  lcqp_hip_batch_last_timing(lcqp_hip_batch_t* b, float* setup_ms, float* solve_ms);
+/* getPrimalSolution / getDualSolution / getOutputStatistics, src/LCQProblem.cpp:1485-1504,1519:
+ * x[B][nV], y[B][nV+nC+2nComp], stats[B]; returnValue of runSolver is stats[i].returnValue. */
+int  lcqp_hip_batch_get_solution(lcqp_hip_batch_t* b, double* x, double* y, lcqp_stats_t* stats);
+/* raw HIP stream (hipStream_t) the batch launches on, for event timing by the caller */
+void* lcqp_hip_batch_stream(lcqp_hip_batch_t* b);
+/* algorithmic HBM bytes of the last run, from the work counters the kernels keep */
+double lcqp_hip_batch_algorithmic_bytes(lcqp_hip_batch_t* b);
+
+/* ------------------------------------------------------------------------------------------------
+ * Building blocks exposed for parity tests and micro-benchmarks (each is one kernel launch over a
+ * batch of independent instances; host pointers, synchronous).
+ * ---------------------------------------------------------------------------------------------- */
+/* Utilities::AffineLinearTransformation for symmetric A, src/Utilities.cpp:176-186: d = alpha*A*b + c */
+int lcqp_hip_util_symv(int batch, int n, double alpha, const double* A, const double* b, const double* c, double* d);
+/* Utilities::TransponsedMatrixMultiplication with p = 1, src/Utilities.cpp:62-72: c = A' * b (A is m x n) */
+int lcqp_hip_util_gemv_t(int batch, int m, int n, const double* A, const double* b, double* c);
+/* Utilities::MatrixMultiplication with p = 1, src/Utilities.cpp:38-47: c = A * b */
+int lcqp_hip_util_gemv(int batch, int m, int n, const double* A, const double* b, double* c);
+/* Utilities::MatrixSymmetrizationProduct, src/Utilities.cpp:104-116: C = A'B + B'A (A, B are m x n) */
+int lcqp_hip_util_symm_product(int batch, int m, int n, const double* A, const double* B, double* C);
+/* Cholesky factorisation + nrhs back-solves of an SPD n x n matrix: x = K^-1 b (the factor-once /
+ * back-solve-many kernel pair).  repeat > 1 re-runs the back-solve for timing; *ms gets the
+ * per-back-solve kernel time. */
+int lcqp_hip_chol_solve(int batch, int n, const double* K, const double* b, double* x, int repeat, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCQP_HIP_H */

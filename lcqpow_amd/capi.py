@@ -1,0 +1,271 @@
+"""ctypes binding of the C ABI in include/lcqp_hip.h (liblcqpow_hip.so).  No CPU fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblcqpow_hip.so")
+c_double_p = C.POINTER(C.c_double)
+
+SEED0 = 0x4C43515000000001
+SUCCESSFUL_RETURN = 0
+SUBPROBLEM_SOLVER_ERROR = 203
+MAX_ITERATIONS_REACHED = 200
+MAX_PENALTY_REACHED = 201
+
+
+class Options(C.Structure):
+    """lcqp_options_t (include/lcqp_hip.h); same field order as the oracle's orc_options_t."""
+    _fields_ = [
+        ("complementarityTolerance", C.c_double), ("stationarityTolerance", C.c_double),
+        ("initialPenaltyParameter", C.c_double), ("penaltyUpdateFactor", C.c_double),
+        ("maxPenaltyParameter", C.c_double), ("etaDynamicPenalty", C.c_double),
+        ("solveZeroPenaltyFirst", C.c_int), ("perturbStep", C.c_int), ("maxIterations", C.c_int),
+        ("nDynamicPenalty", C.c_int), ("printLevel", C.c_int), ("storeSteps", C.c_int),
+        ("perturbSeed", C.c_uint64),
+        ("admmRho", C.c_double), ("admmSigma", C.c_double), ("admmAlpha", C.c_double), ("rhoEqMult", C.c_double),
+        ("proxSmall", C.c_double), ("proxBig", C.c_double), ("pivotThreshold", C.c_double), ("depTau", C.c_double),
+        ("feasTol", C.c_double), ("resTol", C.c_double),
+        ("admmFirst", C.c_int), ("admmHot", C.c_int), ("maxTrials", C.c_int), ("maxRounds", C.c_int),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("iterTotal", C.c_int), ("iterOuter", C.c_int), ("subproblemIter", C.c_int), ("status", C.c_int),
+        ("qpSolverExitFlag", C.c_int), ("returnValue", C.c_int), ("rhoOpt", C.c_double),
+        ("admmIter", C.c_int), ("trials", C.c_int), ("factorizations", C.c_int), ("corrections", C.c_int),
+        ("qpSolves", C.c_int), ("reserved", C.c_int),
+    ]
+
+    def asdict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+_lib = None
+
+
+def library_path():
+    return _SO
+
+
+def lib():
+    """Load liblcqpow_hip.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise RuntimeError(f"{_SO} is missing: the HIP extension must be built (see __graft_entry__.build); "
+                               "there is no CPU fallback for the product path")
+        L = C.CDLL(_SO)
+        L.lcqp_hip_last_error.restype = C.c_char_p
+        L.lcqp_hip_options_default.argtypes = [C.POINTER(Options)]
+        L.lcqp_hip_qp_create.restype = C.c_void_p
+        L.lcqp_hip_qp_create.argtypes = [C.c_int, C.c_int, c_double_p, c_double_p, C.POINTER(Options), C.c_int]
+        L.lcqp_hip_qp_clone.restype = C.c_void_p
+        L.lcqp_hip_qp_clone.argtypes = [C.c_void_p]
+        L.lcqp_hip_qp_destroy.argtypes = [C.c_void_p]
+        L.lcqp_hip_qp_solve.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)] + [c_double_p] * 7
+        L.lcqp_hip_qp_get_solution.argtypes = [C.c_void_p, c_double_p, c_double_p]
+        L.lcqp_hip_qp_get_counters.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+        L.lcqp_hip_batch_create.restype = C.c_void_p
+        L.lcqp_hip_batch_create.argtypes = [C.c_int] * 6
+        L.lcqp_hip_batch_destroy.argtypes = [C.c_void_p]
+        L.lcqp_hip_batch_set_options.argtypes = [C.c_void_p, C.POINTER(Options)]
+        L.lcqp_hip_batch_load.argtypes = [C.c_void_p, C.c_int, C.c_int] + [c_double_p] * 15
+        L.lcqp_hip_batch_generate_synthetic.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.lcqp_hip_batch_read_problem.argtypes = [C.c_void_p, C.c_int] + [c_double_p] * 7
+        L.lcqp_hip_batch_setup.argtypes = [C.c_void_p]
+        L.lcqp_hip_batch_run.argtypes = [C.c_void_p]
+        L.lcqp_hip_batch_synchronize.argtypes = [C.c_void_p]
+        L.lcqp_hip_batch_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.lcqp_hip_batch_get_solution.argtypes = [C.c_void_p, c_double_p, c_double_p, C.POINTER(Stats)]
+        L.lcqp_hip_batch_stream.restype = C.c_void_p
+        L.lcqp_hip_batch_stream.argtypes = [C.c_void_p]
+        L.lcqp_hip_batch_algorithmic_bytes.restype = C.c_double
+        L.lcqp_hip_batch_algorithmic_bytes.argtypes = [C.c_void_p]
+        L.lcqp_hip_util_symv.argtypes = [C.c_int, C.c_int, C.c_double] + [c_double_p] * 4
+        L.lcqp_hip_util_gemv.argtypes = [C.c_int, C.c_int, C.c_int] + [c_double_p] * 3
+        L.lcqp_hip_util_gemv_t.argtypes = [C.c_int, C.c_int, C.c_int] + [c_double_p] * 3
+        L.lcqp_hip_util_symm_product.argtypes = [C.c_int, C.c_int, C.c_int] + [c_double_p] * 3
+        L.lcqp_hip_chol_solve.argtypes = [C.c_int, C.c_int] + [c_double_p] * 3 + [C.c_int, C.POINTER(C.c_float)]
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().lcqp_hip_last_error().decode()
+
+
+def device_count():
+    return lib().lcqp_hip_device_count()
+
+
+def default_options(**kw):
+    o = Options()
+    lib().lcqp_hip_options_default(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def _arr(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}: {last_error()}")
+
+
+class SubsolverHIP:
+    """Python view of the SubsolverBase-shaped QP object (include/SubsolverBase.hpp:28-58)."""
+
+    def __init__(self, nV, nC, Q, A, opt=None, device=0):
+        Q = _arr(Q); A = _arr(A)
+        self.nV, self.nC = nV, nC
+        self.opt = opt or default_options()
+        self.h = lib().lcqp_hip_qp_create(nV, nC, _p(Q), _p(A), C.byref(self.opt), device)
+        if not self.h:
+            raise RuntimeError("lcqp_hip_qp_create failed: " + last_error())
+
+    def solve(self, initialSolve, g, lbA=None, ubA=None, x0=None, y0=None, lb=None, ub=None):
+        it = C.c_int(0); ef = C.c_int(0)
+        a = [_arr(v) for v in (g, lbA, ubA, x0, y0, lb, ub)]
+        ret = lib().lcqp_hip_qp_solve(self.h, int(bool(initialSolve)), C.byref(it), C.byref(ef), *[_p(v) for v in a])
+        return ret, it.value, ef.value
+
+    def getSolution(self):
+        x = np.zeros(self.nV); y = np.zeros(self.nV + self.nC)
+        lib().lcqp_hip_qp_get_solution(self.h, _p(x), _p(y))
+        return x, y
+
+    def counters(self):
+        v = [C.c_int(0) for _ in range(4)]
+        lib().lcqp_hip_qp_get_counters(self.h, *[C.byref(t) for t in v])
+        return dict(admm=v[0].value, trials=v[1].value, factorizations=v[2].value, corrections=v[3].value)
+
+    def close(self):
+        if self.h:
+            lib().lcqp_hip_qp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchLCQP:
+    """B independent dense LCQPs of one shape solved on one GPU (lcqp_hip_batch_*)."""
+
+    def __init__(self, batch, nV, nC, nComp, with_box=False, device=0, opt=None):
+        self.B, self.nV, self.nC, self.nComp = batch, nV, nC, nComp
+        self.nd = nV + nC + 2 * nComp
+        self.h = lib().lcqp_hip_batch_create(batch, nV, nC, nComp, int(with_box), device)
+        if not self.h:
+            raise RuntimeError("lcqp_hip_batch_create failed: " + last_error())
+        if opt is not None:
+            self.set_options(opt)
+
+    def set_options(self, opt):
+        _check(lib().lcqp_hip_batch_set_options(self.h, C.byref(opt)), "set_options")
+
+    def load(self, first, count, Q, g, L, R, lbL=None, ubL=None, lbR=None, ubR=None, A=None, lbA=None, ubA=None,
+             lb=None, ub=None, x0=None, y0=None):
+        a = [_arr(v) for v in (Q, g, L, R, lbL, ubL, lbR, ubR, A, lbA, ubA, lb, ub, x0, y0)]
+        return lib().lcqp_hip_batch_load(self.h, first, count, *[_p(v) for v in a])
+
+    def generate_synthetic(self, first_instance=0, seed0=SEED0):
+        _check(lib().lcqp_hip_batch_generate_synthetic(self.h, seed0, first_instance), "generate_synthetic")
+
+    def read_problem(self, b):
+        n, nC, nComp = self.nV, self.nC, self.nComp
+        Q = np.zeros((n, n)); g = np.zeros(n); L = np.zeros((nComp, n)); R = np.zeros((nComp, n))
+        A = np.zeros((nC, n)); lbA = np.zeros(nC); ubA = np.zeros(nC)
+        _check(lib().lcqp_hip_batch_read_problem(self.h, b, _p(Q), _p(g), _p(L), _p(R), _p(A), _p(lbA), _p(ubA)), "read_problem")
+        return dict(Q=Q, g=g, L=L, R=R, A=A, lbA=lbA, ubA=ubA)
+
+    def setup(self):
+        _check(lib().lcqp_hip_batch_setup(self.h), "setup")
+
+    def run(self):
+        _check(lib().lcqp_hip_batch_run(self.h), "run")
+
+    def synchronize(self):
+        _check(lib().lcqp_hip_batch_synchronize(self.h), "synchronize")
+
+    def last_timing(self):
+        a = C.c_float(0); b = C.c_float(0)
+        _check(lib().lcqp_hip_batch_last_timing(self.h, C.byref(a), C.byref(b)), "last_timing")
+        return a.value, b.value
+
+    def solution(self):
+        x = np.zeros((self.B, self.nV)); y = np.zeros((self.B, self.nd))
+        st = (Stats * self.B)()
+        _check(lib().lcqp_hip_batch_get_solution(self.h, _p(x), _p(y), st), "get_solution")
+        return x, y, [s.asdict() for s in st]
+
+    def algorithmic_bytes(self):
+        return lib().lcqp_hip_batch_algorithmic_bytes(self.h)
+
+    def stream(self):
+        return lib().lcqp_hip_batch_stream(self.h)
+
+    def close(self):
+        if self.h:
+            lib().lcqp_hip_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def util_symv(alpha, A, b, c):
+    A = _arr(A); b = _arr(b); c = _arr(c)
+    batch, n = A.shape[0], A.shape[1]
+    d = np.zeros((batch, n))
+    _check(lib().lcqp_hip_util_symv(batch, n, alpha, _p(A), _p(b), _p(c), _p(d)), "util_symv")
+    return d
+
+
+def util_gemv(A, b):
+    A = _arr(A); b = _arr(b)
+    batch, m, n = A.shape
+    c = np.zeros((batch, m))
+    _check(lib().lcqp_hip_util_gemv(batch, m, n, _p(A), _p(b), _p(c)), "util_gemv")
+    return c
+
+
+def util_gemv_t(A, b):
+    A = _arr(A); b = _arr(b)
+    batch, m, n = A.shape
+    c = np.zeros((batch, n))
+    _check(lib().lcqp_hip_util_gemv_t(batch, m, n, _p(A), _p(b), _p(c)), "util_gemv_t")
+    return c
+
+
+def util_symm_product(A, B):
+    A = _arr(A); B = _arr(B)
+    batch, m, n = A.shape
+    Cm = np.zeros((batch, n, n))
+    _check(lib().lcqp_hip_util_symm_product(batch, m, n, _p(A), _p(B), _p(Cm)), "util_symm_product")
+    return Cm
+
+
+def chol_solve(K, b, repeat=1):
+    K = _arr(K); b = _arr(b)
+    batch, n = K.shape[0], K.shape[1]
+    x = np.zeros((batch, n)); ms = C.c_float(0)
+    _check(lib().lcqp_hip_chol_solve(batch, n, _p(K), _p(b), _p(x), repeat, C.byref(ms)), "chol_solve")
+    return x, ms.value

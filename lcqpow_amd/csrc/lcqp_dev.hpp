@@ -1,0 +1,519 @@
+// lcqp_dev.hpp -- device-side data layout and the per-instance solver logic (one workgroup = one LCQP).
+//
+// Restates, on top of the workgroup routines of lcqp_wg.hpp:
+//   * the QP subsolver that stands where the reference calls qpOASES
+//     (src/SubsolverQPOASES.cpp:134-181; algorithm: DESIGN.md §Subsolver), and
+//   * LCQProblem::runSolver and its helpers (src/LCQProblem.cpp:444-560, 1105-1326, 1353-1482).
+// The CPU oracle (oracle/lcqp_oracle.c) is the same algorithm in scalar C; tests compare the two.
+#pragma once
+#include "lcqp_wg.hpp"
+#include "../../include/lcqp_hip.h"
+
+namespace lcqp {
+
+// per-instance vectors of length np (padded nV)
+enum { V_G, V_GPHI, V_GTIL, V_XK, V_PK, V_XNEW, V_GK, V_QX, V_CX, V_QP, V_CP, V_STATK, V_TMP,
+       V_XQ, V_XA, V_XT, V_R1, V_C, V_DU, V_W, V_RHS, V_LB, V_UB, V_X0, V_NUM };
+// per-instance vectors of length mEcap (rows of E = [A; L; R; box rows])
+enum { M_L, M_U, M_RHOV, M_YQ, M_YA, M_ZA, M_YT, M_EX, M_COEF, M_NUM };
+enum { I_ST, I_STT, I_NUM };
+enum { S_R2, S_DY, S_D0, S_NUM };
+
+struct InstInfo {
+    int mE, nfin, hasY0, setupFail, haveSolution, isSetup, pad0, pad1;
+    double scale, sigma, spv, rhoAdmm, phiConst;
+    double hist[8];
+};
+
+struct DevBatch {
+    int B, n, np, nC, nComp, mA, boxcap, mEcap, capS, nblk, nd;   // nd = n + mA (dual vector, reference layout)
+    int hasLbL, hasLbR;
+    lcqp_options_t opt;
+    double *Q, *C, *E, *Et, *F1, *FK, *S, *D1, *dscr;   // per-instance matrix blocks
+    double *nv, *mv, *sv;                                // vector pools
+    int *mi, *idx, *boxidx;
+    double *lbL, *lbR;                                   // [B][nComp]
+    double *yk, *y0;                                     // [B][nd]
+    double *xout, *yout;                                 // [B][n], [B][nd]
+    lcqp_stats_t* stats;
+    InstInfo* info;
+};
+
+template <int NCH>
+struct Ctx {
+    static constexpr int np = 128 * NCH;
+    const DevBatch* db;
+    int b, n, nC, nComp, mA, mE, capS, nblk;
+    double *Q, *C, *E, *Et, *F1, *FK, *S, *D1, *dscr;
+    double *nv, *mv, *sv;
+    int *mi, *idx, *boxidx;
+    InstInfo* info;
+    Lds lds;
+    // work counters (uniform)
+    int cAdmm, cTrials, cFact, cCorr;
+
+    __device__ __forceinline__ double* V(int k) const { return nv + (size_t)k * np; }
+    __device__ __forceinline__ double* M(int k) const { return mv + (size_t)k * db->mEcap; }
+    __device__ __forceinline__ int* I(int k) const { return mi + (size_t)k * db->mEcap; }
+    __device__ __forceinline__ double* Sv(int k) const { return sv + (size_t)k * db->capS; }
+};
+
+template <int NCH>
+__device__ __forceinline__ Ctx<NCH> make_ctx(const DevBatch& db, int b, Lds lds)
+{
+    Ctx<NCH> c;
+    constexpr int np = 128 * NCH;
+    c.db = &db; c.b = b; c.n = db.n; c.nC = db.nC; c.nComp = db.nComp; c.mA = db.mA; c.capS = db.capS; c.nblk = db.nblk;
+    c.Q = db.Q + (size_t)b * np * np; c.C = db.C + (size_t)b * np * np;
+    c.E = db.E + (size_t)b * db.mEcap * np; c.Et = db.Et + (size_t)b * db.mEcap * np;
+    c.F1 = db.F1 + (size_t)b * np * np; c.FK = db.FK + (size_t)b * np * np;
+    c.S = db.S + (size_t)b * db.capS * db.capS;
+    c.D1 = db.D1 + (size_t)b * db.nblk * 4096; c.dscr = db.dscr + (size_t)b * 4096;
+    c.nv = db.nv + (size_t)b * V_NUM * np; c.mv = db.mv + (size_t)b * M_NUM * db.mEcap;
+    c.sv = db.sv + (size_t)b * S_NUM * db.capS;
+    c.mi = db.mi + (size_t)b * I_NUM * db.mEcap; c.idx = db.idx + (size_t)b * db.capS;
+    c.boxidx = db.boxidx + (size_t)b * np;
+    c.info = db.info + b;
+    c.mE = c.info->mE;
+    c.lds = lds;
+    c.cAdmm = c.cTrials = c.cFact = c.cCorr = 0;
+    return c;
+}
+
+__device__ __forceinline__ double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---------------------------------------------------------------------------------------------
+// ADMM iterations with the constant factor FK (oracle: qp_admm).  State: V_XA, M_YA, M_ZA.
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+__device__ __forceinline__ void qp_admm(Ctx<NCH>& c, const double* g, int n_it)
+{
+    constexpr int np = 128 * NCH;
+    const lcqp_options_t& o = c.db->opt;
+    const int t = threadIdx.x, mE = c.mE;
+    const double alpha = o.admmAlpha, sigma = c.info->sigma;
+    double *xa = c.V(V_XA), *rhs = c.V(V_RHS), *w = c.V(V_W);
+    double *ya = c.M(M_YA), *za = c.M(M_ZA), *rhov = c.M(M_RHOV), *coef = c.M(M_COEF), *ex = c.M(M_EX);
+    const double *l = c.M(M_L), *u = c.M(M_U);
+    for (int it = 0; it < n_it; it++) {
+        for (int r = t; r < mE; r += WG) coef[r] = rhov[r] * za[r] - ya[r];
+        __syncthreads();
+        // rhs = sigma*xa - g + E'(rho.z - y)
+        wg_rows<NCH>(c.E, nullptr, mE, nullptr, nullptr, coef, c.lds,
+                     [&](int i, double s) { rhs[i] = sigma * xa[i] - g[i] + s; });
+        wg_trsv(c.FK, np, c.nblk, rhs, true, c.lds);
+        wg_trsv(c.FK, np, c.nblk, rhs, false, c.lds);       // rhs = xt
+        wg_rows<NCH>(c.E, nullptr, mE, rhs, ex, nullptr, c.lds, [](int, double) {});   // ex = E xt
+        for (int r = t; r < mE; r += WG) {
+            const double zr = alpha * ex[r] + (1.0 - alpha) * za[r];
+            const double rv = rhov[r];
+            if (rv > 0.0) {
+                const double zn = clipd(zr + ya[r] / rv, l[r], u[r]);
+                ya[r] += rv * (zr - zn);
+                za[r] = zn;
+            } else {
+                za[r] = zr;
+                ya[r] = 0.0;
+            }
+        }
+        for (int i = t; i < np; i += WG) xa[i] = alpha * rhs[i] + (1.0 - alpha) * xa[i];
+        __syncthreads();
+        c.cAdmm++;
+    }
+    (void)w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Primal-dual active-set polish in correction form (oracle: qp_polish).
+// In/out: x = V_XT, multipliers M_YT (OSQP sign, zero on inactive rows), active set I_STT.
+// Returns 1 (uniform) on a verified KKT point.
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+__device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g)
+{
+    constexpr int np = 128 * NCH;
+    const lcqp_options_t& o = c.db->opt;
+    const int t = threadIdx.x, mE = c.mE, capS = c.capS;
+    double *x = c.V(V_XT), *r1 = c.V(V_R1), *cv = c.V(V_C), *du = c.V(V_DU), *qx = c.V(V_TMP);
+    double *yt = c.M(M_YT), *ex = c.M(M_EX), *coef = c.M(M_COEF);
+    const double *l = c.M(M_L), *u = c.M(M_U);
+    int* st = c.I(I_STT);
+    double *r2 = c.Sv(S_R2), *dy = c.Sv(S_DY), *d0 = c.Sv(S_D0);
+    int* idx = c.idx;
+    const double gs = 1.0 + wg_maxabs(g, c.n, c.lds);
+    const double ytol = o.feasTol * gs;
+    int na = 0, nblkS = 0, fact_valid = 0;
+    const int capNa = min(min(2 * c.n, mE), capS);
+
+    for (int trial = 0; trial < o.maxTrials; trial++) {
+        c.cTrials++;
+        int chg = 0;
+        // leaving rows (wrong-signed multipliers) drop out before the residual is formed
+        for (int r = t; r < mE; r += WG) {
+            double yv = yt[r];
+            if (trial > 0) {
+                const int s = st[r];
+                if ((s == ST_LOWER && yv > ytol) || (s == ST_UPPER && yv < -ytol)) { st[r] = ST_INACT; yv = 0.0; yt[r] = 0.0; chg = 1; }
+            }
+            coef[r] = yv;
+        }
+        __syncthreads();
+        // residual evaluation: one sweep over Q, one over E
+        wg_symv<NCH>(c.Q, nullptr, c.n, x, nullptr, qx, nullptr, nullptr, nullptr, c.lds);
+        wg_rows<NCH>(c.E, nullptr, mE, x, ex, coef, c.lds, [&](int i, double s) { r1[i] = -g[i] - qx[i] - s; });
+        const double res_stat = wg_maxabs(r1, np, c.lds);
+        double res_eq = 0.0, bmax = 0.0;
+        for (int r = t; r < mE; r += WG) {
+            const int s = st[r];
+            const double e = ex[r];
+            if (s == ST_INACT) {
+                if (trial > 0) {
+                    const double ftol = o.feasTol * (1.0 + fabs(e));
+                    if (e < l[r] - ftol) { st[r] = ST_LOWER; chg = 1; }
+                    else if (e > u[r] + ftol) { st[r] = ST_UPPER; chg = 1; }
+                }
+            } else {
+                const double bb = (s == ST_UPPER) ? u[r] : l[r];
+                res_eq = fmax(res_eq, fabs(bb - e));
+                bmax = fmax(bmax, fabs(bb));
+            }
+        }
+        const int changed = block_or(chg, c.lds);
+        res_eq = block_max(res_eq, c.lds);
+        bmax = block_max(bmax, c.lds);
+        if (trial > 0 && !changed && res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) return 1;
+        if (changed) fact_valid = 0;
+        if (!fact_valid) {
+            // ordered list of active rows (ascending row index, as the oracle builds it)
+            const int per = (mE + WG - 1) / WG;
+            const int r0 = t * per, r1e = min(mE, r0 + per);
+            int cnt = 0;
+            for (int r = r0; r < r1e; r++) cnt += (st[r] != ST_INACT);
+            // exclusive scan over 256 threads
+            int incl = cnt;
+#pragma unroll
+            for (int ofs = 1; ofs < 64; ofs <<= 1) { int v = __shfl_up(incl, ofs, 64); if (lane_id() >= ofs) incl += v; }
+            if (lane_id() == 63) c.lds.ired[8 + wave_id()] = incl;
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < wave_id(); w++) base += c.lds.ired[8 + w];
+            na = c.lds.ired[8] + c.lds.ired[9] + c.lds.ired[10] + c.lds.ired[11];
+            __syncthreads();
+            if (na > capNa) return 0;
+            int pos = base + incl - cnt;
+            for (int r = r0; r < r1e; r++) if (st[r] != ST_INACT) idx[pos++] = r;
+            nblkS = (na + 63) >> 6;
+            for (int a = na + t; a < 64 * nblkS; a += WG) idx[a] = -1;
+            __syncthreads();
+            // S = T T' (lower tiles), T = rows idx[] of Et; padded rows get a unit diagonal
+            const int ty = t >> 4, tx = t & 15;
+            for (int Ib = 0; Ib < nblkS; Ib++)
+                for (int Jb = 0; Jb <= Ib; Jb++) {
+                    double acc[4][4];
+                    const int* ia = idx + 64 * Ib;
+                    const int* ib = idx + 64 * Jb;
+                    wg_tile_nt(acc, c.Et, np, [=](int r) { return (long)ia[r]; }, c.Et, np, [=](int r) { return (long)ib[r]; }, np, c.lds);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int gi = 64 * Ib + 4 * ty + i, gj = 64 * Jb + 4 * tx + j;
+                            double v = acc[i][j];
+                            if (gi == gj && gi >= na) v = 1.0;
+                            c.S[(size_t)gi * capS + gj] = v;
+                        }
+                    __syncthreads();
+                }
+            if (nblkS > 0) wg_chol(c.S, capS, nblkS, na, o.depTau, c.dscr, d0, nullptr, c.lds, 0);
+            c.cFact++;
+            fact_valid = 1;
+        }
+        // correction:  c = L1^-1 r1 ;  S dy = T c - r2 ;  dx = L1^-T (c - T' dy)
+        for (int a = t; a < 64 * nblkS; a += WG) {
+            double v = 0.0;
+            if (a < na) { const int r = idx[a]; const double bb = (st[r] == ST_UPPER) ? u[r] : l[r]; v = bb - ex[r]; }
+            r2[a] = v;
+        }
+        wg_copy(cv, r1, np);
+        wg_trsv(c.F1, np, c.nblk, cv, true, c.lds);
+        if (na > 0) {
+            wg_rows<NCH>(c.Et, idx, na, cv, dy, nullptr, c.lds, [](int, double) {});
+            for (int a = t; a < 64 * nblkS; a += WG) dy[a] = (a < na) ? dy[a] - r2[a] : 0.0;
+            __syncthreads();
+            wg_trsv(c.S, capS, nblkS, dy, true, c.lds);
+            wg_trsv(c.S, capS, nblkS, dy, false, c.lds);
+            wg_rows<NCH>(c.Et, idx, na, nullptr, nullptr, dy, c.lds, [&](int i, double s) { du[i] = cv[i] - s; });
+        } else {
+            wg_copy(du, cv, np);
+        }
+        wg_trsv(c.F1, np, c.nblk, du, false, c.lds);
+        for (int i = t; i < np; i += WG) x[i] += du[i];
+        for (int a = t; a < na; a += WG) yt[idx[a]] += dy[a];
+        __syncthreads();
+        c.cCorr++;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SubsolverBase::solve on the device (oracle: orc_qp_solve).  Bounds, E, factors are already set up
+// (kernels k_prepare / k_factor).  initial: start from V_X0 / y0 (reference layout) like qp.init
+// (src/SubsolverQPOASES.cpp:152); else continue from the stored solution and working set like
+// qp.hotstart (:158).  On success the solution is left in V_XQ / M_YQ / I_ST.
+// Returns 0, or the exit flag (1 max rounds, 2 infeasible bounds, 3 setup failure).
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+__device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* g, const double* y0ref, int* iterations)
+{
+    constexpr int np = 128 * NCH;
+    const lcqp_options_t& o = c.db->opt;
+    const int t = threadIdx.x, mE = c.mE, n = c.n, nC = c.mA;
+    const int trials0 = c.cTrials, admm0 = c.cAdmm;
+    *iterations = 0;
+    if (c.info->setupFail) return 3;
+    double *xq = c.V(V_XQ), *xa = c.V(V_XA), *xt = c.V(V_XT);
+    double *yq = c.M(M_YQ), *ya = c.M(M_YA), *za = c.M(M_ZA), *yt = c.M(M_YT), *ex = c.M(M_EX);
+    const double *l = c.M(M_L), *u = c.M(M_U), *rhov = c.M(M_RHOV);
+    int *st = c.I(I_ST), *stt = c.I(I_STT);
+    int bad = 0;
+    for (int r = t; r < mE; r += WG) bad |= (l[r] > u[r]);
+    if (block_or(bad, c.lds)) return 2;
+    if (initial) {
+        const double* x0 = c.V(V_X0);
+        for (int i = t; i < np; i += WG) xq[i] = x0[i];
+        for (int r = t; r < mE; r += WG) {
+            double yr = 0.0;
+            if (y0ref) yr = (r < nC) ? -y0ref[n + r] : -y0ref[c.boxidx[r - nC]];
+            yq[r] = yr;
+        }
+        __syncthreads();
+    }
+    wg_copy(xa, xq, np);
+    wg_rows<NCH>(c.E, nullptr, mE, xa, ex, nullptr, c.lds, [](int, double) {});
+    for (int r = t; r < mE; r += WG) {
+        za[r] = clipd(ex[r], l[r], u[r]);
+        ya[r] = (rhov[r] == 0.0) ? 0.0 : yq[r];
+    }
+    __syncthreads();
+    int n_admm = initial ? o.admmFirst : o.admmHot;
+    const int use_stored = (!initial && c.info->haveSolution && n_admm == 0);
+    int solved = 0;
+    for (int round = 0; round < o.maxRounds && !solved; round++) {
+        if (n_admm > 0) qp_admm<NCH>(c, g, n_admm);
+        for (int r = t; r < mE; r += WG) {
+            int s;
+            if (round == 0 && use_stored) {
+                s = st[r];
+                if (l[r] == u[r]) s = ST_EQ;
+            } else {
+                const double lo = l[r], hi = u[r], z = za[r], y = ya[r];
+                s = ST_INACT;
+                if (isfinite(lo) && (z - lo < -y)) s = ST_LOWER;
+                if (isfinite(hi) && (hi - z < y)) s = ST_UPPER;
+                if (lo == hi) s = ST_EQ;
+            }
+            stt[r] = s;
+            yt[r] = (s != ST_INACT) ? ya[r] : 0.0;
+        }
+        for (int i = t; i < np; i += WG) xt[i] = xa[i];
+        __syncthreads();
+        if (qp_polish<NCH>(c, g)) { solved = 1; break; }
+        n_admm = 2 * n_admm;
+        if (n_admm < 10) n_admm = 10;
+        if (n_admm > 400) n_admm = 400;
+    }
+    *iterations = (c.cTrials - trials0) + (c.cAdmm - admm0);
+    if (!solved) return 1;
+    for (int i = t; i < np; i += WG) xq[i] = xt[i];
+    for (int r = t; r < mE; r += WG) { yq[r] = yt[r]; st[r] = stt[r]; }
+    if (t == 0) c.info->haveSolution = 1;
+    __syncthreads();
+    return 0;
+}
+
+// write the solution in the qpOASES layout/sign: y[0:n] box duals, y[n:] row duals
+template <int NCH>
+__device__ __forceinline__ void qp_export(Ctx<NCH>& c, double* xdst /*np or n*/, int xlen, double* yref /*n + mA*/)
+{
+    const int t = threadIdx.x, n = c.n, nC = c.mA;
+    const double *xq = c.V(V_XQ), *yq = c.M(M_YQ);
+    for (int i = t; i < xlen; i += WG) xdst[i] = xq[i];
+    for (int i = t; i < n + nC; i += WG) yref[i] = (i < n) ? 0.0 : -yq[i - n];
+    __syncthreads();
+    for (int k = t; k < c.info->nfin; k += WG) yref[c.boxidx[k]] = -yq[nC + k];
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// LCQProblem::runSolver for one instance (oracle: orc_lcqp_solve).  src/LCQProblem.cpp:444-560.
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+__device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
+{
+    constexpr int np = 128 * NCH;
+    const DevBatch& db = *c.db;
+    const lcqp_options_t& o = db.opt;
+    const int t = threadIdx.x, n = c.n, nC = c.nC, nComp = c.nComp, mA = c.mA;
+    double *g = c.V(V_G), *gphi = c.V(V_GPHI), *gtil = c.V(V_GTIL), *xk = c.V(V_XK), *pk = c.V(V_PK), *xnew = c.V(V_XNEW);
+    double *gk = c.V(V_GK), *Qx = c.V(V_QX), *Cx = c.V(V_CX), *Qp = c.V(V_QP), *Cp = c.V(V_CP), *statk = c.V(V_STATK);
+    double* yk = db.yk + (size_t)c.b * db.nd;
+    double* coef = c.M(M_COEF);
+    const bool hasPhi = db.hasLbL || db.hasLbR;
+    lcqp_stats_t st;
+    st.iterTotal = st.iterOuter = st.subproblemIter = st.status = st.qpSolverExitFlag = st.returnValue = 0;
+    st.rhoOpt = 0.0;
+    st.admmIter = st.trials = st.factorizations = st.corrections = st.qpSolves = st.reserved = 0;
+    int rc = 0, qpIter = 0, histLen = 0, algoStat = 0, totalIter = 0;
+    double alphak = 1.0, rho = o.initialPenaltyParameter;                     // :999-1000
+    const double phiConst = c.info->phiConst;
+    uint64_t perturbCounter = 0;
+    double* hist = c.info->hist;
+
+    // xk = x0, g_tilde = g   (setInitialGuess .ipp:133-158, :966-967)
+    for (int i = t; i < np; i += WG) { xk[i] = c.V(V_X0)[i]; gtil[i] = g[i]; }
+    __syncthreads();
+
+    auto getPhi = [&]() -> double {   // :1172-1185 with Cx = C*xk current
+        double s = 0.0;
+        for (int i = t; i < n; i += WG) s += (hasPhi ? gphi[i] * xk[i] : 0.0) + 0.5 * xk[i] * Cx[i];
+        return phiConst + block_sum(s, c.lds);
+    };
+    auto updatePenalty = [&]() {      // :1199-1214 (Qk = Q + rho C is never materialised: Qk v = Qv + rho Cv)
+        if (o.nDynamicPenalty > 0) histLen = 0;
+        rho *= o.penaltyUpdateFactor;
+        st.rhoOpt = rho;
+        if (hasPhi) { for (int i = t; i < np; i += WG) gtil[i] = g[i] + rho * gphi[i]; __syncthreads(); }
+    };
+    auto solveQP = [&](int initial) -> int {   // :1115-1148
+        const double* y0 = (initial && c.info->hasY0) ? db.y0 + (size_t)c.b * db.nd : nullptr;
+        const int ef = qp_solve<NCH>(c, initial, gk, y0, &qpIter);
+        st.subproblemIter += qpIter;
+        st.qpSolverExitFlag = ef;
+        st.qpSolves++;
+        if (ef != 0) return LCQP_SUBPROBLEM_SOLVER_ERROR;
+        qp_export<NCH>(c, xnew, np, yk);
+        for (int i = t; i < np; i += WG) pk[i] = xnew[i] - xk[i];
+        __syncthreads();
+        return 0;
+    };
+
+    // first QP (:452-467)
+    if (o.solveZeroPenaltyFirst) {
+        wg_copy(gk, g, np);
+    } else {
+        wg_symv<NCH>(c.C, nullptr, n, xk, nullptr, Cx, nullptr, nullptr, nullptr, c.lds);
+        for (int i = t; i < np; i += WG) gk[i] = rho * Cx[i] + gtil[i];
+        __syncthreads();
+    }
+    rc = solveQP(1);
+    if (rc == 0) {
+        st.rhoOpt = rho;   // :473
+        for (;;) {
+            // updateStep :1240-1243
+            for (int i = t; i < np; i += WG) xk[i] = xk[i] + alphak * pk[i];
+            __syncthreads();
+            // updateStationarity :1246-1272: statk = Qk xk + g_tilde - A' yk_A - yk_box
+            wg_symv<NCH>(c.Q, c.C, n, xk, nullptr, Qx, Cx, nullptr, nullptr, c.lds);
+            for (int r = t; r < mA; r += WG) coef[r] = yk[n + r];
+            __syncthreads();
+            wg_rows<NCH>(c.E, nullptr, mA, nullptr, nullptr, coef, c.lds, [&](int i, double s) {
+                statk[i] = (i < n) ? (Qx[i] + rho * Cx[i]) + gtil[i] - s - yk[i] : 0.0;
+            });
+            const double statInf = wg_maxabs(statk, n, c.lds);
+            totalIter++; st.iterTotal++;
+            // leyfferCheckPositive :1275-1313
+            bool leyffer = false;
+            {
+                const int nd = o.nDynamicPenalty;
+                if (nd > 0) {
+                    const double cur = getPhi();
+                    if (histLen < nd) { if (t == 0) hist[histLen] = cur; histLen++; __syncthreads(); }
+                    else if (cur < o.complementarityTolerance) {
+                        __syncthreads();
+                        if (t == 0) { for (int i = 0; i + 1 < nd; i++) hist[i] = hist[i + 1]; hist[nd - 1] = cur; }
+                        __syncthreads();
+                    } else {
+                        leyffer = true;
+                        for (int i = 0; i < nd; i++) if (cur < o.etaDynamicPenalty * hist[i]) { leyffer = false; break; }
+                        __syncthreads();
+                        if (t == 0) { for (int i = 0; i + 1 < nd; i++) hist[i] = hist[i + 1]; hist[nd - 1] = cur; }
+                        __syncthreads();
+                    }
+                }
+            }
+            if (leyffer) { updatePenalty(); st.iterOuter++; }
+            // stationarity / complementarity checks :511-534
+            if (statInf < o.stationarityTolerance) {
+                if (getPhi() < o.complementarityTolerance) {
+                    // transformDuals :1381-1409 (rows of L, R are rows nC.., nC+nComp.. of E)
+                    double* lx = c.M(M_EX);
+                    wg_rows<NCH>(c.E, nullptr, mA, xk, lx, nullptr, c.lds, [](int, double) {});
+                    // determineStationarityType :1412-1453 on the untransformed duals, weak set :1456-1482
+                    int sflag = 1, mflag = 1, wflag = 0;
+                    const double ctol = o.complementarityTolerance;
+                    for (int i = 0; i < nComp; i++) {   // uniform scalar loop, order matters for the W exit
+                        const double Lx = lx[nC + i], Rx = lx[nC + nComp + i];
+                        if (!(Lx <= ctol && Rx <= ctol)) continue;
+                        const double a = yk[n + nC + i], bq = yk[n + nC + nComp + i];
+                        const double dualProd = a * bq, dualMin = fmin(a, bq);
+                        if (dualMin < 0) sflag = 0;
+                        if (fabs(dualProd) >= ctol && dualMin <= 0) {
+                            if (dualProd <= ctol) { wflag = 1; break; }
+                            mflag = 0;
+                        }
+                    }
+                    algoStat = wflag ? 1 : (sflag ? 4 : (mflag ? 3 : 2));
+                    __syncthreads();
+                    for (int i = t; i < nComp; i += WG) {
+                        const double Lx = lx[nC + i], Rx = lx[nC + nComp + i];
+                        yk[n + nC + i] -= rho * Rx;
+                        yk[n + nC + nComp + i] -= rho * Lx;
+                    }
+                    __syncthreads();
+                    rc = 0;
+                    break;
+                } else {
+                    updatePenalty(); st.iterOuter++;
+                }
+            }
+            if (totalIter > o.maxIterations) { rc = LCQP_MAX_ITERATIONS_REACHED; break; }
+            if (rho > o.maxPenaltyParameter) { rc = LCQP_MAX_PENALTY_REACHED; break; }
+            // updateLinearization :1105-1112: gk = rho C xk + g_tilde
+            for (int i = t; i < np; i += WG) gk[i] = rho * Cx[i] + gtil[i];
+            __syncthreads();
+            rc = solveQP(0);
+            if (rc != 0) break;
+            // perturbStep :1353-1362 (seeded SplitMix64 instead of time-seeded rand())
+            if (o.perturbStep) {
+                for (int i = t; i < n; i += WG) {
+                    uint64_t z = o.perturbSeed + (perturbCounter + (uint64_t)i + 1ULL) * 0x9E3779B97F4A7C15ULL;
+                    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+                    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+                    z = z ^ (z >> 31);
+                    xk[i] += ((int)(z % 3ULL) - 1) * 2.221e-16;
+                }
+                perturbCounter += (uint64_t)n;
+                __syncthreads();
+            }
+            // getOptimalStepLength :1217-1237: qk = pk'Qk pk, lk = pk'(Qk xk + g_tilde)
+            wg_symv<NCH>(c.Q, c.C, n, pk, xk, Qp, Cp, Qx, Cx, c.lds);
+            double sq = 0.0, sl = 0.0;
+            for (int i = t; i < n; i += WG) {
+                sq += pk[i] * (Qp[i] + rho * Cp[i]);
+                sl += pk[i] * ((Qx[i] + rho * Cx[i]) + gtil[i]);
+            }
+            const double qk = block_sum(sq, c.lds), lk = block_sum(sl, c.lds);
+            alphak = 1.0;
+            if (qk > 0 && lk < 0) alphak = fmin(-lk / qk, 1.0);
+        }
+    }
+    st.status = algoStat;
+    st.returnValue = rc;
+    st.admmIter = c.cAdmm; st.trials = c.cTrials; st.factorizations = c.cFact; st.corrections = c.cCorr;
+    for (int i = t; i < n; i += WG) db.xout[(size_t)c.b * n + i] = xk[i];
+    for (int i = t; i < db.nd; i += WG) db.yout[(size_t)c.b * db.nd + i] = yk[i];
+    if (t == 0) db.stats[c.b] = st;
+    __syncthreads();
+}
+
+}  // namespace lcqp

@@ -1,0 +1,1120 @@
+// lcqp_hip.hip -- kernels and C-ABI of liblcqpow_hip.so (gfx950 only; see include/lcqp_hip.h).
+#include "lcqp_dev.hpp"
+#include "../../include/lcqp_synth.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace lcqp;
+
+// =================================================================================================
+// device kernels
+// =================================================================================================
+#define LCQP_LDS                                    \
+    __shared__ double sh_arena[ARENA];              \
+    __shared__ double sh_red[16];                   \
+    __shared__ int sh_ired[16];                     \
+    Lds lds{sh_arena, sh_red, sh_ired};
+
+// 64x64 tile product, TN form:  acc[i][j] = sum_{r<nrows} wgt(r) * A[r][ca+i] * B[r][cb+j]
+template <class Wgt>
+__device__ __forceinline__ void wg_tile_tn(double (&acc)[4][4], const double* __restrict__ A, int lda, int ca,
+                                           const double* __restrict__ Bm, int ldb, int cb, int nrows, Wgt wgt, Lds lds)
+{
+    constexpr int PL = 68;
+    double* As = lds.arena;
+    double* Bs = lds.arena + 16 * PL;
+    const int t = threadIdx.x;
+    const int kk = t >> 4, c4 = (t & 15) * 4;
+    const int ty = t >> 4, tx = t & 15;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+    for (int k0 = 0; k0 < nrows; k0 += 16) {
+        const int r = k0 + kk;
+        double2 a0 = {0.0, 0.0}, a1 = {0.0, 0.0}, b0 = {0.0, 0.0}, b1 = {0.0, 0.0};
+        if (r < nrows) {
+            const double wv = wgt(r);
+            const double* ap = A + (size_t)r * lda + ca + c4;
+            const double* bp = Bm + (size_t)r * ldb + cb + c4;
+            a0 = *reinterpret_cast<const double2*>(ap); a1 = *reinterpret_cast<const double2*>(ap + 2);
+            b0 = *reinterpret_cast<const double2*>(bp); b1 = *reinterpret_cast<const double2*>(bp + 2);
+            a0.x *= wv; a0.y *= wv; a1.x *= wv; a1.y *= wv;
+        }
+        __syncthreads();
+        *reinterpret_cast<double2*>(As + kk * PL + c4) = a0; *reinterpret_cast<double2*>(As + kk * PL + c4 + 2) = a1;
+        *reinterpret_cast<double2*>(Bs + kk * PL + c4) = b0; *reinterpret_cast<double2*>(Bs + kk * PL + c4 + 2) = b1;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const double2 av0 = *reinterpret_cast<const double2*>(As + q * PL + 4 * ty);
+            const double2 av1 = *reinterpret_cast<const double2*>(As + q * PL + 4 * ty + 2);
+            const double2 bv0 = *reinterpret_cast<const double2*>(Bs + q * PL + 4 * tx);
+            const double2 bv1 = *reinterpret_cast<const double2*>(Bs + q * PL + 4 * tx + 2);
+            const double a[4] = {av0.x, av0.y, av1.x, av1.y};
+            const double b[4] = {bv0.x, bv0.y, bv1.x, bv1.y};
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] += a[i] * b[j];
+        }
+    }
+    __syncthreads();
+}
+
+// lower-triangular tile index -> (I, J), I >= J
+__device__ __forceinline__ void tri_tile(int tIdx, int& I, int& J)
+{
+    I = 0;
+    while ((I + 1) * (I + 2) / 2 <= tIdx) I++;
+    J = tIdx - I * (I + 1) / 2;
+}
+
+// ---- k_prepare: scales, padding, box rows, ADMM rho vector, phi expressions ----------------------
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_prepare(DevBatch db)
+{
+    LCQP_LDS
+    constexpr int np = 128 * NCH;
+    const int b = blockIdx.x, t = threadIdx.x;
+    Ctx<NCH> c = make_ctx<NCH>(db, b, lds);
+    const int n = db.n, mA = db.mA, nC = db.nC, nComp = db.nComp;
+    double dmax = 0.0;
+    for (int i = t; i < n; i += WG) dmax = fmax(dmax, fabs(c.Q[(size_t)i * np + i]));
+    double scale = block_max(dmax, lds);
+    if (!(scale > 1e-300)) scale = 1.0;
+    for (int i = n + t; i < np; i += WG) c.Q[(size_t)i * np + i] = 1.0;
+    const int nfin = c.info->nfin;
+    const int mE = mA + nfin;
+    double *l = c.M(M_L), *u = c.M(M_U), *rhov = c.M(M_RHOV);
+    for (int k = 0; k < nfin; k++) {
+        double* row = c.E + (size_t)(mA + k) * np;
+        const int bi = c.boxidx[k];
+        for (int i = t; i < np; i += WG) row[i] = (i == bi) ? 1.0 : 0.0;
+        if (t == 0) { l[mA + k] = c.V(V_LB)[bi]; u[mA + k] = c.V(V_UB)[bi]; }
+    }
+    __syncthreads();
+    const double rho = db.opt.admmRho * scale;
+    for (int r = t; r < mE; r += WG) {
+        const double lo = l[r], hi = u[r];
+        double rv = rho;
+        if (isinf(lo) && isinf(hi)) rv = 0.0;
+        else if (lo == hi) rv = rho * db.opt.rhoEqMult;
+        rhov[r] = rv;
+    }
+    // phi expressions, src/LCQProblem.cpp:969-996
+    double phiConst = 0.0;
+    double* gphi = c.V(V_GPHI);
+    if (db.hasLbL || db.hasLbR) {
+        const double* lbL = db.lbL + (size_t)b * nComp;
+        const double* lbR = db.lbR + (size_t)b * nComp;
+        double s = 0.0;
+        for (int i = t; i < nComp; i += WG) s += lbL[i] * lbR[i];
+        phiConst = block_sum(s, lds);
+        double* coef = c.M(M_COEF);
+        for (int r = t; r < mA; r += WG) {
+            double v = 0.0;
+            if (r >= nC && r < nC + nComp) v = lbR[r - nC];          // L' * lbR
+            else if (r >= nC + nComp) v = lbL[r - nC - nComp];       // R' * lbL
+            coef[r] = v;
+        }
+        __syncthreads();
+        wg_rows<NCH>(c.E, nullptr, mA, nullptr, nullptr, coef, lds, [&](int i, double sum) { gphi[i] = -sum; });
+    } else {
+        wg_fill(gphi, 0.0, np);
+    }
+    if (t == 0) {
+        c.info->mE = mE;
+        c.info->scale = scale;
+        c.info->sigma = db.opt.admmSigma * scale;
+        c.info->rhoAdmm = rho;
+        c.info->phiConst = phiConst;
+        c.info->haveSolution = 0;
+        c.info->setupFail = 0;
+        c.info->isSetup = 1;
+    }
+}
+
+// ---- k_build_C: C = L'R + R'L (Utilities::MatrixSymmetrizationProduct, src/Utilities.cpp:104-116) ----
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_build_C(DevBatch db)
+{
+    LCQP_LDS
+    constexpr int np = 128 * NCH;
+    const int ntile = db.nblk * (db.nblk + 1) / 2;
+    const int b = blockIdx.x / ntile, tIdx = blockIdx.x % ntile;
+    int I, J;
+    tri_tile(tIdx, I, J);
+    const double* Lm = db.E + (size_t)b * db.mEcap * np + (size_t)db.nC * np;
+    const double* Rm = Lm + (size_t)db.nComp * np;
+    double* C = db.C + (size_t)b * np * np;
+    double a1[4][4], a2[4][4];
+    auto one = [](int) { return 1.0; };
+    wg_tile_tn(a1, Lm, np, 64 * I, Rm, np, 64 * J, db.nComp, one, lds);
+    wg_tile_tn(a2, Rm, np, 64 * I, Lm, np, 64 * J, db.nComp, one, lds);
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int gi = 64 * I + 4 * ty + i, gj = 64 * J + 4 * tx + j;
+            const double v = a1[i][j] + a2[i][j];
+            C[(size_t)gi * np + gj] = v;
+            C[(size_t)gj * np + gi] = v;
+        }
+}
+
+// ---- k_build_K: FK = Q + sigma I + E' diag(rho) E  (lower tiles, mirrored) -------------------------
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_build_K(DevBatch db)
+{
+    LCQP_LDS
+    constexpr int np = 128 * NCH;
+    const int ntile = db.nblk * (db.nblk + 1) / 2;
+    const int b = blockIdx.x / ntile, tIdx = blockIdx.x % ntile;
+    int I, J;
+    tri_tile(tIdx, I, J);
+    const double* E = db.E + (size_t)b * db.mEcap * np;
+    const double* Q = db.Q + (size_t)b * np * np;
+    double* FK = db.FK + (size_t)b * np * np;
+    const double* rhov = db.mv + (size_t)b * M_NUM * db.mEcap + (size_t)M_RHOV * db.mEcap;
+    const InstInfo* info = db.info + b;
+    double acc[4][4];
+    wg_tile_tn(acc, E, np, 64 * I, E, np, 64 * J, info->mE, [=](int r) { return rhov[r]; }, lds);
+    const double sigma = info->sigma;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int gi = 64 * I + 4 * ty + i, gj = 64 * J + 4 * tx + j;
+            const double v = acc[i][j] + Q[(size_t)gi * np + gj] + (gi == gj ? sigma : 0.0);
+            FK[(size_t)gi * np + gj] = v;
+            FK[(size_t)gj * np + gi] = v;
+        }
+}
+
+// ---- k_factor: the two constant factorisations (L1 of Q + sp I, LK of K) ---------------------------
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_factor(DevBatch db)
+{
+    LCQP_LDS
+    constexpr int np = 128 * NCH;
+    const int b = blockIdx.x, t = threadIdx.x;
+    Ctx<NCH> c = make_ctx<NCH>(db, b, lds);
+    const double scale = c.info->scale;
+    __shared__ int sfail;
+    int failed = 0;
+    double spv = 0.0;
+    for (int pass = 0; pass < 2; pass++) {
+        spv = (pass == 0 ? db.opt.proxSmall : db.opt.proxBig) * scale;
+        for (int e = t; e < np * np; e += WG) {
+            const int i = e / np, j = e - i * np;
+            c.F1[e] = c.Q[e] + (i == j ? spv : 0.0);
+        }
+        if (t == 0) sfail = 0;
+        __syncthreads();
+        // D1 keeps every inverted diagonal block (dense lower) for the TRSM that forms Et
+        double minpiv = INFINITY;
+        {
+            // factor block column by block column so each D block lands in its own slot of D1
+            minpiv = wg_chol(c.F1, np, c.nblk, c.n, 0.0, c.D1, nullptr, &sfail, lds, 4096);
+        }
+        __syncthreads();
+        failed = sfail;
+        if (!failed && (pass == 1 || minpiv >= db.opt.pivotThreshold * scale)) break;
+        if (pass == 1) break;
+    }
+    if (t == 0) sfail = 0;
+    __syncthreads();
+    wg_chol(c.FK, np, c.nblk, c.n, 0.0, c.dscr, nullptr, &sfail, lds, 0);
+    __syncthreads();
+    if (t == 0) {
+        c.info->spv = spv;
+        if (failed || sfail) c.info->setupFail = 3;
+    }
+}
+
+// ---- k_trsm: Et = E L1^-T, 64 rows of E per workgroup ----------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
+{
+    LCQP_LDS
+    constexpr int np = 128 * NCH;
+    const int nrb = (db.mEcap + 63) / 64;
+    const int b = blockIdx.x / nrb, rb = blockIdx.x % nrb;
+    const InstInfo* info = db.info + b;
+    if (64 * rb >= info->mE) return;
+    const double* E = db.E + (size_t)b * db.mEcap * np + (size_t)(64 * rb) * np;
+    double* Et = db.Et + (size_t)b * db.mEcap * np + (size_t)(64 * rb) * np;
+    const double* F1 = db.F1 + (size_t)b * np * np;
+    const double* D1 = db.D1 + (size_t)b * db.nblk * 4096;
+    const int rows = min(64, db.mEcap - 64 * rb);
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    auto rowok = [=](int r) { return (long)(r < rows ? r : -1); };
+    auto ident = [](int r) { return (long)r; };
+    for (int J = 0; J < db.nblk; J++) {
+        double acc[4][4];
+        if (J > 0) wg_tile_nt(acc, Et, np, rowok, F1 + (size_t)(64 * J) * np, np, ident, 64 * J, lds);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int li = 4 * ty + i, gj = 64 * J + 4 * tx + j;
+                if (li < rows) Et[(size_t)li * np + gj] = E[(size_t)li * np + gj] - acc[i][j];
+            }
+        __syncthreads();
+        double acc2[4][4];
+        wg_tile_nt(acc2, Et + 64 * J, np, rowok, D1 + (size_t)J * 4096, 64, ident, 64, lds);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int li = 4 * ty + i, gj = 64 * J + 4 * tx + j;
+                if (li < rows) Et[(size_t)li * np + gj] = acc2[i][j];
+            }
+        __syncthreads();
+    }
+}
+
+// ---- the homotopy megakernel: one persistent workgroup per LCQP -----------------------------------
+template <int NCH>
+__global__ __launch_bounds__(WG, 4) void k_lcqp_run(DevBatch db)
+{
+    LCQP_LDS
+    Ctx<NCH> c = make_ctx<NCH>(db, blockIdx.x, lds);
+    lcqp_run<NCH>(c);
+}
+
+// ---- one QP per workgroup with the SubsolverBase semantics ----------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(WG, 4) void k_qp_solve(DevBatch db, int initial)
+{
+    LCQP_LDS
+    Ctx<NCH> c = make_ctx<NCH>(db, blockIdx.x, lds);
+    const double* y0 = (initial && c.info->hasY0) ? db.y0 + (size_t)c.b * db.nd : nullptr;
+    int iters = 0;
+    const int ef = qp_solve<NCH>(c, initial, c.V(V_GK), y0, &iters);
+    if (ef == 0) qp_export<NCH>(c, db.xout + (size_t)c.b * db.n, db.n, db.yout + (size_t)c.b * db.nd);
+    if (threadIdx.x == 0) {
+        lcqp_stats_t s;
+        memset(&s, 0, sizeof(s));
+        s.subproblemIter = iters;
+        s.qpSolverExitFlag = ef;
+        s.returnValue = ef ? LCQP_SUBPROBLEM_SOLVER_ERROR : 0;
+        s.admmIter = c.cAdmm; s.trials = c.cTrials; s.factorizations = c.cFact; s.corrections = c.cCorr; s.qpSolves = 1;
+        db.stats[c.b] = s;
+    }
+}
+
+// ---- synthetic instances directly in HBM (include/lcqp_synth.h) ---------------------
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_synth_fill(DevBatch db, uint64_t seed0, uint64_t first)
+{
+    LCQP_LDS
+    constexpr int np = 128 * NCH;
+    const int b = blockIdx.x, t = threadIdx.x;
+    Ctx<NCH> c = make_ctx<NCH>(db, b, lds);
+    const int n = db.n, nC = db.nC, nComp = db.nComp, mA = db.mA;
+    const uint64_t st = lcqp_synth_state(seed0, first + (uint64_t)b);
+    double* Mm = c.F1;   // scratch: M, consumed by k_synth_Q
+    for (int e = t; e < np * np; e += WG) {
+        const int i = e / np, j = e - i * np;
+        Mm[e] = (i < n && j < n) ? lcqp_synth_M(st, n, i, j) : 0.0;
+    }
+    double* xs = c.V(V_TMP);
+    for (int i = t; i < np; i += WG) {
+        c.V(V_G)[i] = (i < n) ? lcqp_synth_g(st, n, nC, nComp, i) : 0.0;
+        xs[i] = (i < n) ? lcqp_synth_xstar(st, n, nC, nComp, i) : 0.0;
+        c.V(V_X0)[i] = 0.0;
+        c.V(V_LB)[i] = -INFINITY;
+        c.V(V_UB)[i] = INFINITY;
+    }
+    const double sn = sqrt((double)n);
+    for (int r = 0; r < mA; r++) {
+        double* row = c.E + (size_t)r * np;
+        for (int j = t; j < np; j += WG) {
+            double v = 0.0;
+            if (j < n) {
+                if (r < nC) v = lcqp_synth_Araw(st, n, nC, nComp, r, j) / sn;
+                else if (r < nC + nComp) v = (j == r - nC) ? 1.0 : 0.0;
+                else v = (j == nComp + (r - nC - nComp)) ? 1.0 : 0.0;
+            }
+            row[j] = v;
+        }
+    }
+    __syncthreads();
+    double *l = c.M(M_L), *u = c.M(M_U);
+    wg_rows<NCH>(c.E, nullptr, nC, xs, c.M(M_EX), nullptr, lds, [](int, double) {});
+    for (int r = t; r < mA; r += WG) {
+        if (r < nC) {
+            const double ax = c.M(M_EX)[r];
+            l[r] = ax - lcqp_synth_slo(st, n, nC, nComp, r);
+            u[r] = ax + lcqp_synth_shi(st, n, nC, nComp, r);
+        } else { l[r] = 0.0; u[r] = INFINITY; }
+    }
+    if (t == 0) { c.info->nfin = 0; c.info->hasY0 = 0; c.info->isSetup = 0; }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_synth_Q(DevBatch db)
+{
+    LCQP_LDS
+    constexpr int np = 128 * NCH;
+    const int ntile = db.nblk * (db.nblk + 1) / 2;
+    const int b = blockIdx.x / ntile, tIdx = blockIdx.x % ntile;
+    int I, J;
+    tri_tile(tIdx, I, J);
+    const double* Mm = db.F1 + (size_t)b * np * np;
+    double* Q = db.Q + (size_t)b * np * np;
+    double acc[4][4];
+    wg_tile_tn(acc, Mm, np, 64 * I, Mm, np, 64 * J, db.n, [](int) { return 1.0; }, lds);
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int gi = 64 * I + 4 * ty + i, gj = 64 * J + 4 * tx + j;
+            double v = 0.0;
+            if (gi < db.n && gj < db.n) v = acc[i][j] / (double)db.n + (gi == gj ? 1.0 : 0.0);
+            Q[(size_t)gi * np + gj] = v;
+            Q[(size_t)gj * np + gi] = v;
+        }
+}
+
+// ---- building-block kernels for tests / micro-benchmarks ------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_util_symv(int n, double alpha, const double* A, const double* bv, const double* cv, double* d)
+{
+    LCQP_LDS
+    constexpr int np = 128 * NCH;
+    const int b = blockIdx.x;
+    double* out = d + (size_t)b * np;
+    wg_symv<NCH>(A + (size_t)b * np * np, nullptr, n, bv + (size_t)b * np, nullptr, out, nullptr, nullptr, nullptr, lds);
+    for (int i = threadIdx.x; i < np; i += WG) out[i] = alpha * out[i] + cv[(size_t)b * np + i];
+}
+
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_util_rows(int m, const double* A, const double* x, double* dots, const double* coef, double* outT)
+{
+    LCQP_LDS
+    constexpr int np = 128 * NCH;
+    const int b = blockIdx.x;
+    double* o = outT ? outT + (size_t)b * np : nullptr;
+    wg_rows<NCH>(A + (size_t)b * m * np, nullptr, m, x ? x + (size_t)b * np : nullptr, dots ? dots + (size_t)b * m : nullptr,
+                 coef ? coef + (size_t)b * m : nullptr, lds, [&](int i, double s) { if (o) o[i] = s; });
+}
+
+__global__ __launch_bounds__(WG) void k_chol(int np, int nblk, int n, double* F, double* dscr, int* fail)
+{
+    LCQP_LDS
+    const int b = blockIdx.x;
+    wg_chol(F + (size_t)b * np * np, np, nblk, n, 0.0, dscr + (size_t)b * 4096, nullptr, fail + b, lds, 0);
+}
+
+__global__ __launch_bounds__(WG, 4) void k_backsolve(int np, int nblk, const double* F, const double* rhs, double* x)
+{
+    LCQP_LDS
+    const int b = blockIdx.x;
+    double* xv = x + (size_t)b * np;
+    for (int i = threadIdx.x; i < np; i += WG) xv[i] = rhs[(size_t)b * np + i];
+    __syncthreads();
+    wg_trsv(F + (size_t)b * np * np, np, nblk, xv, true, lds);
+    wg_trsv(F + (size_t)b * np * np, np, nblk, xv, false, lds);
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+static thread_local std::string g_err;
+static int set_err(const char* what, hipError_t e)
+{
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return LCQP_HIP_ERROR;
+}
+#define HIPCHK(call)                                               \
+    do {                                                           \
+        hipError_t e_ = (call);                                    \
+        if (e_ != hipSuccess) return set_err(#call, e_);           \
+    } while (0)
+#define HIPCHKN(call)                                              \
+    do {                                                           \
+        hipError_t e_ = (call);                                    \
+        if (e_ != hipSuccess) { set_err(#call, e_); return nullptr; } \
+    } while (0)
+
+extern "C" const char* lcqp_hip_last_error(void) { return g_err.c_str(); }
+extern "C" int lcqp_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" void lcqp_hip_options_default(lcqp_options_t* o)
+{   // src/Options.cpp:296-333
+    memset(o, 0, sizeof(*o));
+    const double EPS = 2.221e-16;   // include/Utilities.hpp:350
+    o->complementarityTolerance = 1.0e3 * EPS;
+    o->stationarityTolerance = 1.0e6 * EPS;
+    o->initialPenaltyParameter = 0.01;
+    o->penaltyUpdateFactor = 2.0;
+    o->maxPenaltyParameter = 1e8;
+    o->etaDynamicPenalty = 0.9;
+    o->solveZeroPenaltyFirst = 1;
+    o->perturbStep = 1;
+    o->maxIterations = 1000;
+    o->nDynamicPenalty = 3;
+    o->printLevel = 2;
+    o->storeSteps = 0;
+    o->perturbSeed = 0x5EEDULL;
+    o->admmRho = 0.1; o->admmSigma = 1e-6; o->admmAlpha = 1.6; o->rhoEqMult = 1e3;
+    o->proxSmall = 1e-12; o->proxBig = 1e-8; o->pivotThreshold = 1e-7; o->depTau = 1e-12;
+    o->feasTol = 1e-9; o->resTol = 1e-12;
+    o->admmFirst = 10; o->admmHot = 0; o->maxTrials = 12; o->maxRounds = 40;
+}
+
+struct lcqp_hip_batch {
+    DevBatch db;
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1, ev2;
+    std::vector<void*> allocs;
+    bool setupDone, ran;
+    int nch;
+    size_t bytesTotal;
+};
+
+template <class T>
+static int dev_alloc(lcqp_hip_batch* h, T** p, size_t count, bool zero)
+{
+    void* q = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    HIPCHK(hipMalloc(&q, bytes));
+    h->allocs.push_back(q);
+    h->bytesTotal += bytes;
+    if (zero) HIPCHK(hipMemsetAsync(q, 0, bytes, h->stream));
+    *p = (T*)q;
+    return 0;
+}
+
+extern "C" lcqp_hip_batch_t* lcqp_hip_batch_create(int batch, int nV, int nC, int nComp, int withBox, int device)
+{
+    if (batch <= 0 || nV <= 0 || nC < 0 || nComp < 0) { g_err = "invalid dimensions"; return nullptr; }
+    if (nV > 512) { g_err = "nV > 512 is not supported by this build"; return nullptr; }
+    HIPCHKN(hipSetDevice(device));
+    lcqp_hip_batch* h = new lcqp_hip_batch();
+    h->device = device; h->setupDone = false; h->ran = false; h->bytesTotal = 0;
+    HIPCHKN(hipStreamCreate(&h->stream));
+    HIPCHKN(hipEventCreate(&h->ev0)); HIPCHKN(hipEventCreate(&h->ev1)); HIPCHKN(hipEventCreate(&h->ev2));
+    DevBatch& d = h->db;
+    memset(&d, 0, sizeof(d));
+    d.B = batch; d.n = nV; d.nC = nC; d.nComp = nComp; d.mA = nC + 2 * nComp;
+    h->nch = (nV + 127) / 128;
+    d.np = 128 * h->nch;
+    d.nblk = d.np / 64;
+    d.boxcap = withBox ? nV : 0;
+    d.mEcap = d.mA + d.boxcap;
+    if (d.mEcap < 1) d.mEcap = 1;
+    int capNa = 2 * nV < d.mEcap ? 2 * nV : d.mEcap;
+    d.capS = ((capNa + 63) / 64) * 64;
+    if (d.capS < 64) d.capS = 64;
+    d.nd = nV + d.mA;
+    lcqp_hip_options_default(&d.opt);
+    const size_t B = batch, np = d.np, mE = d.mEcap;
+    int rc = 0;
+    rc |= dev_alloc(h, &d.Q, B * np * np, true);
+    rc |= dev_alloc(h, &d.C, B * np * np, true);
+    rc |= dev_alloc(h, &d.E, B * mE * np, true);
+    rc |= dev_alloc(h, &d.Et, B * mE * np, true);
+    rc |= dev_alloc(h, &d.F1, B * np * np, true);
+    rc |= dev_alloc(h, &d.FK, B * np * np, true);
+    rc |= dev_alloc(h, &d.S, B * (size_t)d.capS * d.capS, true);
+    rc |= dev_alloc(h, &d.D1, B * (size_t)d.nblk * 4096, true);
+    rc |= dev_alloc(h, &d.dscr, B * 4096, true);
+    rc |= dev_alloc(h, &d.nv, B * V_NUM * np, true);
+    rc |= dev_alloc(h, &d.mv, B * M_NUM * mE, true);
+    rc |= dev_alloc(h, &d.sv, B * S_NUM * (size_t)d.capS, true);
+    rc |= dev_alloc(h, &d.mi, B * I_NUM * mE, true);
+    rc |= dev_alloc(h, &d.idx, B * (size_t)d.capS, true);
+    rc |= dev_alloc(h, &d.boxidx, B * np, true);
+    rc |= dev_alloc(h, &d.lbL, B * (size_t)(nComp ? nComp : 1), true);
+    rc |= dev_alloc(h, &d.lbR, B * (size_t)(nComp ? nComp : 1), true);
+    rc |= dev_alloc(h, &d.yk, B * (size_t)d.nd, true);
+    rc |= dev_alloc(h, &d.y0, B * (size_t)d.nd, true);
+    rc |= dev_alloc(h, &d.xout, B * (size_t)nV, true);
+    rc |= dev_alloc(h, &d.yout, B * (size_t)d.nd, true);
+    rc |= dev_alloc(h, &d.stats, B, true);
+    rc |= dev_alloc(h, &d.info, B, true);
+    if (rc != 0 || hipStreamSynchronize(h->stream) != hipSuccess) { lcqp_hip_batch_destroy(h); return nullptr; }
+    return h;
+}
+
+extern "C" void lcqp_hip_batch_destroy(lcqp_hip_batch_t* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (void* p : h->allocs) (void)hipFree(p);
+    (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); (void)hipEventDestroy(h->ev2);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int lcqp_hip_batch_set_options(lcqp_hip_batch_t* h, const lcqp_options_t* opt)
+{
+    if (!h || !opt) return LCQP_INVALID_ARGUMENT;
+    if (opt->nDynamicPenalty > 8) { g_err = "nDynamicPenalty > 8 unsupported"; return LCQP_HIP_UNSUPPORTED; }
+    h->db.opt = *opt;
+    h->setupDone = false;   // rho / sigma / prox weights enter the factorisations
+    return 0;
+}
+
+extern "C" void* lcqp_hip_batch_stream(lcqp_hip_batch_t* h) { return h ? (void*)h->stream : nullptr; }
+
+static inline double bnd(const double* p, size_t i, double dflt) { return p ? p[i] : dflt; }
+
+extern "C" int lcqp_hip_batch_load(lcqp_hip_batch_t* h, int first, int count,
+                                   const double* Q, const double* g, const double* L, const double* R,
+                                   const double* lbL, const double* ubL, const double* lbR, const double* ubR,
+                                   const double* A, const double* lbA, const double* ubA,
+                                   const double* lb, const double* ub, const double* x0, const double* y0)
+{
+    if (!h) return LCQP_LCQPOBJECT_NOT_SETUP;
+    DevBatch& d = h->db;
+    const int n = d.n, nC = d.nC, nComp = d.nComp, mA = d.mA, np = d.np, mE = d.mEcap;
+    if (first < 0 || count <= 0 || first + count > d.B) return LCQP_INVALID_ARGUMENT;
+    if (!Q) return LCQP_INVALID_ARGUMENT;
+    if (!g) return LCQP_INVALID_OBJECTIVE_LINEAR_TERM;               // include/LCQProblem.ipp:44-45
+    if (!A && nC > 0) return LCQP_INVALID_CONSTRAINT_MATRIX;         // src/LCQProblem.cpp:569-570
+    if (!L || !R) return LCQP_INVALID_COMPLEMENTARITY_MATRIX;        // :611-612
+    if ((lb || ub) && d.boxcap == 0) { g_err = "batch was created without box-bound capacity"; return LCQP_INVALID_ARGUMENT; }
+    HIPCHK(hipSetDevice(h->device));
+    // a batch mixes instances: keep one setting of "lbL/lbR given" per batch (phi expressions :969-996)
+    const int hasL = lbL ? 1 : 0, hasR = lbR ? 1 : 0;
+    if (first == 0) { d.hasLbL = hasL; d.hasLbR = hasR; }
+    else if (d.hasLbL != hasL || d.hasLbR != hasR) { g_err = "lbL/lbR must be given for all instances of a batch or for none"; return LCQP_INVALID_ARGUMENT; }
+    std::vector<double> Qp((size_t)np * np), Ep((size_t)mE * np), nvb((size_t)V_NUM * np), mvb((size_t)M_NUM * mE), ybuf(d.nd), lbuf(nComp ? nComp : 1), rbuf(nComp ? nComp : 1);
+    std::vector<int> bidx(np);
+    for (int k = 0; k < count; k++) {
+        const size_t b = (size_t)first + k;
+        std::fill(Qp.begin(), Qp.end(), 0.0); std::fill(Ep.begin(), Ep.end(), 0.0);
+        std::fill(nvb.begin(), nvb.end(), 0.0); std::fill(mvb.begin(), mvb.end(), 0.0);
+        for (int i = 0; i < n; i++) memcpy(&Qp[(size_t)i * np], Q + ((size_t)k * n + i) * n, sizeof(double) * n);       // setQ .ipp:27-36
+        // setConstraints :563-626: stack [A; L; R]
+        for (int r = 0; r < nC; r++) memcpy(&Ep[(size_t)r * np], A + ((size_t)k * nC + r) * n, sizeof(double) * n);
+        for (int r = 0; r < nComp; r++) {
+            memcpy(&Ep[(size_t)(nC + r) * np], L + ((size_t)k * nComp + r) * n, sizeof(double) * n);
+            memcpy(&Ep[(size_t)(nC + nComp + r) * np], R + ((size_t)k * nComp + r) * n, sizeof(double) * n);
+        }
+        double* lE = &mvb[(size_t)M_L * mE];
+        double* uE = &mvb[(size_t)M_U * mE];
+        for (int r = 0; r < nC; r++) { lE[r] = bnd(lbA, (size_t)k * nC + r, -INFINITY); uE[r] = bnd(ubA, (size_t)k * nC + r, INFINITY); }
+        // setComplementarityBounds :726-785
+        for (int i = 0; i < nComp; i++) {
+            if (lbL && lbL[(size_t)k * nComp + i] <= -INFINITY) return LCQP_INVALID_LOWER_COMPLEMENTARITY_BOUND;
+            if (lbR && lbR[(size_t)k * nComp + i] <= -INFINITY) return LCQP_INVALID_LOWER_COMPLEMENTARITY_BOUND;
+            lE[nC + i] = bnd(lbL, (size_t)k * nComp + i, 0.0);
+            uE[nC + i] = bnd(ubL, (size_t)k * nComp + i, INFINITY);
+            lE[nC + nComp + i] = bnd(lbR, (size_t)k * nComp + i, 0.0);
+            uE[nC + nComp + i] = bnd(ubR, (size_t)k * nComp + i, INFINITY);
+            lbuf[i] = bnd(lbL, (size_t)k * nComp + i, 0.0);
+            rbuf[i] = bnd(lbR, (size_t)k * nComp + i, 0.0);
+        }
+        double* vg = &nvb[(size_t)V_G * np];
+        double* vlb = &nvb[(size_t)V_LB * np];
+        double* vub = &nvb[(size_t)V_UB * np];
+        double* vx0 = &nvb[(size_t)V_X0 * np];
+        int nfin = 0;
+        for (int i = 0; i < np; i++) { vlb[i] = -INFINITY; vub[i] = INFINITY; }
+        for (int i = 0; i < n; i++) {
+            vg[i] = g[(size_t)k * n + i];
+            vlb[i] = bnd(lb, (size_t)k * n + i, -INFINITY);     // setLB/setUB .ipp:54-112
+            vub[i] = bnd(ub, (size_t)k * n + i, INFINITY);
+            vx0[i] = x0 ? x0[(size_t)k * n + i] : 0.0;          // setInitialGuess .ipp:133-158
+            if (std::isfinite(vlb[i]) || std::isfinite(vub[i])) bidx[nfin++] = i;
+        }
+        InstInfo info;
+        memset(&info, 0, sizeof(info));
+        info.nfin = nfin; info.mE = mA + nfin; info.hasY0 = y0 ? 1 : 0;
+        HIPCHK(hipMemcpyAsync(d.Q + b * np * np, Qp.data(), sizeof(double) * np * np, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d.E + b * mE * np, Ep.data(), sizeof(double) * mE * np, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d.nv + b * V_NUM * np, nvb.data(), sizeof(double) * V_NUM * np, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d.mv + b * M_NUM * mE, mvb.data(), sizeof(double) * M_NUM * mE, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d.boxidx + b * np, bidx.data(), sizeof(int) * np, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d.info + b, &info, sizeof(info), hipMemcpyHostToDevice, h->stream));
+        if (nComp) {
+            HIPCHK(hipMemcpyAsync(d.lbL + b * nComp, lbuf.data(), sizeof(double) * nComp, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(d.lbR + b * nComp, rbuf.data(), sizeof(double) * nComp, hipMemcpyHostToDevice, h->stream));
+        }
+        if (y0) {
+            memcpy(ybuf.data(), y0 + (size_t)k * d.nd, sizeof(double) * d.nd);
+            HIPCHK(hipMemcpyAsync(d.y0 + b * d.nd, ybuf.data(), sizeof(double) * d.nd, hipMemcpyHostToDevice, h->stream));
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));   // staging buffers are reused
+    }
+    h->setupDone = false;
+    return 0;
+}
+
+#define DISPATCH_NCH(h, KERNEL, grid, ...)                                                              \
+    do {                                                                                               \
+        switch ((h)->nch) {                                                                            \
+            case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(grid), dim3(WG), 0, (h)->stream, __VA_ARGS__); break; \
+            case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(grid), dim3(WG), 0, (h)->stream, __VA_ARGS__); break; \
+            case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(grid), dim3(WG), 0, (h)->stream, __VA_ARGS__); break; \
+            default: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(WG), 0, (h)->stream, __VA_ARGS__); break; \
+        }                                                                                              \
+    } while (0)
+
+extern "C" int lcqp_hip_batch_generate_synthetic(lcqp_hip_batch_t* h, uint64_t seed0, uint64_t firstInstance)
+{
+    if (!h) return LCQP_LCQPOBJECT_NOT_SETUP;
+    HIPCHK(hipSetDevice(h->device));
+    DevBatch& d = h->db;
+    if (d.nComp * 2 > d.n) { g_err = "synthetic generator needs 2*nComp <= nV"; return LCQP_INVALID_ARGUMENT; }
+    d.hasLbL = d.hasLbR = 0;
+    DISPATCH_NCH(h, k_synth_fill, d.B, d, seed0, firstInstance);
+    DISPATCH_NCH(h, k_synth_Q, d.B * (d.nblk * (d.nblk + 1) / 2), d);
+    HIPCHK(hipGetLastError());
+    h->setupDone = false;
+    return 0;
+}
+
+extern "C" int lcqp_hip_batch_read_problem(lcqp_hip_batch_t* h, int b, double* Q, double* g, double* L, double* R,
+                                           double* A, double* lbA, double* ubA)
+{
+    if (!h || b < 0 || b >= h->db.B) return LCQP_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(h->device));
+    DevBatch& d = h->db;
+    const int n = d.n, nC = d.nC, nComp = d.nComp, np = d.np, mE = d.mEcap;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<double> Qp((size_t)np * np), Ep((size_t)mE * np), nvb((size_t)V_NUM * np), mvb((size_t)M_NUM * mE);
+    HIPCHK(hipMemcpy(Qp.data(), d.Q + (size_t)b * np * np, sizeof(double) * np * np, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(Ep.data(), d.E + (size_t)b * mE * np, sizeof(double) * mE * np, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nvb.data(), d.nv + (size_t)b * V_NUM * np, sizeof(double) * V_NUM * np, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(mvb.data(), d.mv + (size_t)b * M_NUM * mE, sizeof(double) * M_NUM * mE, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        if (Q) memcpy(Q + (size_t)i * n, &Qp[(size_t)i * np], sizeof(double) * n);
+        if (g) g[i] = nvb[(size_t)V_G * np + i];
+    }
+    for (int r = 0; r < nC; r++) {
+        if (A) memcpy(A + (size_t)r * n, &Ep[(size_t)r * np], sizeof(double) * n);
+        if (lbA) lbA[r] = mvb[(size_t)M_L * mE + r];
+        if (ubA) ubA[r] = mvb[(size_t)M_U * mE + r];
+    }
+    for (int r = 0; r < nComp; r++) {
+        if (L) memcpy(L + (size_t)r * n, &Ep[(size_t)(nC + r) * np], sizeof(double) * n);
+        if (R) memcpy(R + (size_t)r * n, &Ep[(size_t)(nC + nComp + r) * np], sizeof(double) * n);
+    }
+    return 0;
+}
+
+static int launch_setup(lcqp_hip_batch* h)
+{
+    DevBatch& d = h->db;
+    const int ntile = d.nblk * (d.nblk + 1) / 2;
+    DISPATCH_NCH(h, k_prepare, d.B, d);
+    if (d.nComp > 0) DISPATCH_NCH(h, k_build_C, d.B * ntile, d);
+    DISPATCH_NCH(h, k_build_K, d.B * ntile, d);
+    DISPATCH_NCH(h, k_factor, d.B, d);
+    DISPATCH_NCH(h, k_trsm, d.B * ((d.mEcap + 63) / 64), d);
+    HIPCHK(hipGetLastError());
+    h->setupDone = true;
+    return 0;
+}
+
+extern "C" int lcqp_hip_batch_setup(lcqp_hip_batch_t* h)
+{
+    if (!h) return LCQP_LCQPOBJECT_NOT_SETUP;
+    HIPCHK(hipSetDevice(h->device));
+    return launch_setup(h);
+}
+
+extern "C" int lcqp_hip_batch_run(lcqp_hip_batch_t* h)
+{
+    if (!h) return LCQP_LCQPOBJECT_NOT_SETUP;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    int rc = launch_setup(h);   // the factorisations are part of runSolver's cost (initializeSolver :885)
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    DISPATCH_NCH(h, k_lcqp_run, h->db.B, h->db);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev2, h->stream));
+    h->ran = true;
+    return 0;
+}
+
+extern "C" int lcqp_hip_batch_synchronize(lcqp_hip_batch_t* h)
+{
+    if (!h) return LCQP_LCQPOBJECT_NOT_SETUP;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int lcqp_hip_batch_last_timing(lcqp_hip_batch_t* h, float* setup_ms, float* solve_ms)
+{
+    if (!h || !h->ran) return LCQP_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventSynchronize(h->ev2));
+    if (setup_ms) HIPCHK(hipEventElapsedTime(setup_ms, h->ev0, h->ev1));
+    if (solve_ms) HIPCHK(hipEventElapsedTime(solve_ms, h->ev1, h->ev2));
+    return 0;
+}
+
+extern "C" int lcqp_hip_batch_get_solution(lcqp_hip_batch_t* h, double* x, double* y, lcqp_stats_t* stats)
+{
+    if (!h) return LCQP_LCQPOBJECT_NOT_SETUP;
+    HIPCHK(hipSetDevice(h->device));
+    DevBatch& d = h->db;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (x) HIPCHK(hipMemcpy(x, d.xout, sizeof(double) * (size_t)d.B * d.n, hipMemcpyDeviceToHost));
+    if (y) HIPCHK(hipMemcpy(y, d.yout, sizeof(double) * (size_t)d.B * d.nd, hipMemcpyDeviceToHost));
+    if (stats) HIPCHK(hipMemcpy(stats, d.stats, sizeof(lcqp_stats_t) * (size_t)d.B, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// Algorithmic HBM bytes of the last run, from the per-instance work counters:
+//   residual evaluation (trial): Q + E once           8*(np*n + mE*np)
+//   correction                  : L1 fwd+bwd + 2 sweeps over the active rows of Et + S fwd+bwd
+//   factorisation               : active rows of Et once + S written and read once
+//   ADMM iteration              : LK fwd+bwd + two sweeps over E
+//   LCQP iterate                : 2 sweeps over Q and C + one over the stacked constraint rows
+extern "C" double lcqp_hip_batch_algorithmic_bytes(lcqp_hip_batch_t* h)
+{
+    if (!h) return 0.0;
+    DevBatch& d = h->db;
+    std::vector<lcqp_stats_t> st(d.B);
+    if (hipSetDevice(h->device) != hipSuccess) return 0.0;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return 0.0;
+    if (hipMemcpy(st.data(), d.stats, sizeof(lcqp_stats_t) * (size_t)d.B, hipMemcpyDeviceToHost) != hipSuccess) return 0.0;
+    const double n = d.n, m = d.mA, N = d.n;
+    const double na = 0.5 * (d.n < d.mA ? d.n : d.mA);   // nominal active rows (half of min(n, m))
+    const double bs = 8.0 * N * (N + 2.0);
+    double total = 0.0;
+    for (int b = 0; b < d.B; b++) {
+        total += st[b].trials * 8.0 * (n * n + m * n);
+        total += st[b].corrections * (bs + 2.0 * 8.0 * na * n + 8.0 * na * (na + 2.0));
+        total += st[b].factorizations * (8.0 * na * n + 8.0 * na * na);
+        total += st[b].admmIter * (bs + 2.0 * 8.0 * m * n);
+        total += st[b].iterTotal * (2.0 * 2.0 * 8.0 * n * n + 8.0 * m * n);
+    }
+    return total;
+}
+
+// =================================================================================================
+// QP object (SubsolverBase semantics): a batch of one with nComp = 0 whose rows are the nC stacked rows
+// =================================================================================================
+struct lcqp_hip_qp {
+    lcqp_hip_batch* hb;
+    int nV, nC;
+    std::vector<double> Q, A;          // host copies (deep copy, src/SubsolverQPOASES.cpp:41-45)
+    std::vector<double> lbA, ubA, lb, ub;
+    bool haveBounds, withBox;
+    lcqp_options_t opt;
+    int device;
+    std::vector<double> xsol, ysol;
+    int cAdmm, cTrials, cFact, cCorr;
+};
+
+extern "C" lcqp_hip_qp_t* lcqp_hip_qp_create(int nV, int nC, const double* Q, const double* A, const lcqp_options_t* opt, int device)
+{
+    if (nV <= 0 || nC < 0 || !Q || (nC > 0 && !A)) { g_err = "invalid arguments"; return nullptr; }
+    lcqp_hip_qp* q = new lcqp_hip_qp();
+    q->hb = nullptr; q->nV = nV; q->nC = nC; q->device = device; q->haveBounds = false; q->withBox = false;
+    q->Q.assign(Q, Q + (size_t)nV * nV);
+    if (nC) q->A.assign(A, A + (size_t)nC * nV);
+    if (opt) q->opt = *opt; else lcqp_hip_options_default(&q->opt);
+    q->xsol.assign(nV, 0.0); q->ysol.assign((size_t)nV + nC, 0.0);
+    q->cAdmm = q->cTrials = q->cFact = q->cCorr = 0;
+    return q;
+}
+
+extern "C" lcqp_hip_qp_t* lcqp_hip_qp_clone(const lcqp_hip_qp_t* s)
+{
+    if (!s) return nullptr;
+    // The reference copies subsolvers only before their first use (src/Subsolver.cpp:125-136,
+    // src/LCQProblem.cpp:906-907): the clone carries the problem data and options; device state is
+    // rebuilt by its own first solve.
+    lcqp_hip_qp* q = new lcqp_hip_qp(*s);
+    q->hb = nullptr;
+    q->haveBounds = false;
+    return q;
+}
+
+extern "C" void lcqp_hip_qp_destroy(lcqp_hip_qp_t* q)
+{
+    if (!q) return;
+    if (q->hb) lcqp_hip_batch_destroy(q->hb);
+    delete q;
+}
+
+static bool same_pattern(const std::vector<double>& a0, const std::vector<double>& b0, const double* a1, const double* b1, size_t n)
+{
+    for (size_t i = 0; i < n; i++) {
+        const double lo1 = a1 ? a1[i] : -INFINITY, hi1 = b1 ? b1[i] : INFINITY;
+        const bool fin0 = std::isfinite(a0[i]) || std::isfinite(b0[i]), fin1 = std::isfinite(lo1) || std::isfinite(hi1);
+        const bool eq0 = a0[i] == b0[i], eq1 = lo1 == hi1;
+        if (fin0 != fin1 || eq0 != eq1) return false;
+    }
+    return true;
+}
+
+extern "C" int lcqp_hip_qp_solve(lcqp_hip_qp_t* q, int initialSolve, int* iterations, int* exit_flag,
+                                 const double* g, const double* lbA, const double* ubA,
+                                 const double* x0, const double* y0, const double* lb, const double* ub)
+{
+    if (!q || !g || !iterations || !exit_flag) return LCQP_INVALID_ARGUMENT;
+    const int n = q->nV, nC = q->nC;
+    *iterations = 0; *exit_flag = 0;
+    const bool needBox = (lb != nullptr) || (ub != nullptr);
+    bool fresh = initialSolve || !q->hb || !q->haveBounds;
+    if (!fresh) {
+        if (needBox && !q->withBox) fresh = true;
+        else if (!same_pattern(q->lbA, q->ubA, lbA, ubA, nC) || !same_pattern(q->lb, q->ub, lb, ub, n)) fresh = true;
+    }
+    if (q->hb && (fresh && (needBox && !q->withBox))) { lcqp_hip_batch_destroy(q->hb); q->hb = nullptr; }
+    if (!q->hb) {
+        q->hb = lcqp_hip_batch_create(1, n, nC, 0, needBox ? 1 : 0, q->device);
+        if (!q->hb) { *exit_flag = -1; return LCQP_SUBPROBLEM_SOLVER_ERROR; }
+        q->withBox = needBox;
+        fresh = true;
+    }
+    lcqp_hip_batch* h = q->hb;
+    DevBatch& d = h->db;
+    if (hipSetDevice(h->device) != hipSuccess) { *exit_flag = -1; return LCQP_SUBPROBLEM_SOLVER_ERROR; }
+    q->lbA.assign(nC, -INFINITY); q->ubA.assign(nC, INFINITY); q->lb.assign(n, -INFINITY); q->ub.assign(n, INFINITY);
+    for (int i = 0; i < nC; i++) { if (lbA) q->lbA[i] = lbA[i]; if (ubA) q->ubA[i] = ubA[i]; }
+    for (int i = 0; i < n; i++) { if (lb) q->lb[i] = lb[i]; if (ub) q->ub[i] = ub[i]; }
+    q->haveBounds = true;
+    int rc;
+    if (fresh) {
+        lcqp_hip_batch_set_options(h, &q->opt);
+        // batch of one, nComp = 0: the "A" block carries all stacked rows; L/R are empty
+        double dummy = 0.0;
+        rc = lcqp_hip_batch_load(h, 0, 1, q->Q.data(), g, &dummy, &dummy, nullptr, nullptr, nullptr, nullptr,
+                                 nC ? q->A.data() : nullptr, q->lbA.data(), q->ubA.data(),
+                                 q->withBox ? q->lb.data() : nullptr, q->withBox ? q->ub.data() : nullptr, x0, y0);
+        if (rc) { *exit_flag = -1; return LCQP_SUBPROBLEM_SOLVER_ERROR; }
+        rc = launch_setup(h);
+        if (rc) { *exit_flag = -1; return LCQP_SUBPROBLEM_SOLVER_ERROR; }
+        initialSolve = 1;
+    } else {
+        // same pattern: refresh bound values (finite/equality pattern unchanged, factorisations stay valid)
+        std::vector<double> l(d.mEcap, 0.0), u(d.mEcap, 0.0);
+        for (int r = 0; r < nC; r++) { l[r] = q->lbA[r]; u[r] = q->ubA[r]; }
+        int k = 0;
+        for (int i = 0; i < n; i++)
+            if (std::isfinite(q->lb[i]) || std::isfinite(q->ub[i])) { l[nC + k] = q->lb[i]; u[nC + k] = q->ub[i]; k++; }
+        if (hipMemcpyAsync(d.mv + (size_t)M_L * d.mEcap, l.data(), sizeof(double) * d.mEcap, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(d.mv + (size_t)M_U * d.mEcap, u.data(), sizeof(double) * d.mEcap, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { *exit_flag = -1; return LCQP_SUBPROBLEM_SOLVER_ERROR; }
+    }
+    // linear term of this call
+    std::vector<double> gp(d.np, 0.0);
+    memcpy(gp.data(), g, sizeof(double) * n);
+    if (hipMemcpyAsync(d.nv + (size_t)V_GK * d.np, gp.data(), sizeof(double) * d.np, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+        *exit_flag = -1; return LCQP_SUBPROBLEM_SOLVER_ERROR;
+    }
+    DISPATCH_NCH(h, k_qp_solve, 1, d, initialSolve ? 1 : 0);
+    lcqp_stats_t st;
+    if (hipStreamSynchronize(h->stream) != hipSuccess ||
+        hipMemcpy(&st, d.stats, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) { *exit_flag = -1; return LCQP_SUBPROBLEM_SOLVER_ERROR; }
+    *iterations = st.subproblemIter;
+    *exit_flag = st.qpSolverExitFlag;
+    q->cAdmm += st.admmIter; q->cTrials += st.trials; q->cFact += st.factorizations; q->cCorr += st.corrections;
+    if (st.qpSolverExitFlag != 0) return LCQP_SUBPROBLEM_SOLVER_ERROR;
+    if (hipMemcpy(q->xsol.data(), d.xout, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(q->ysol.data(), d.yout, sizeof(double) * ((size_t)n + nC), hipMemcpyDeviceToHost) != hipSuccess) {
+        *exit_flag = -1; return LCQP_SUBPROBLEM_SOLVER_ERROR;
+    }
+    return LCQP_SUCCESSFUL_RETURN;
+}
+
+extern "C" void lcqp_hip_qp_get_solution(lcqp_hip_qp_t* q, double* x, double* y)
+{
+    if (!q) return;
+    if (x) memcpy(x, q->xsol.data(), sizeof(double) * q->nV);
+    if (y) memcpy(y, q->ysol.data(), sizeof(double) * ((size_t)q->nV + q->nC));
+}
+
+extern "C" void lcqp_hip_qp_get_counters(lcqp_hip_qp_t* q, int* admm, int* trials, int* factorizations, int* corrections)
+{
+    if (!q) return;
+    if (admm) *admm = q->cAdmm;
+    if (trials) *trials = q->cTrials;
+    if (factorizations) *factorizations = q->cFact;
+    if (corrections) *corrections = q->cCorr;
+}
+
+// =================================================================================================
+// building blocks (tests, micro-benchmarks)
+// =================================================================================================
+struct TmpBuf {
+    std::vector<void*> p;
+    ~TmpBuf() { for (void* q : p) (void)hipFree(q); }
+    double* get(size_t count, bool zero = true)
+    {
+        void* q = nullptr;
+        if (hipMalloc(&q, (count ? count : 1) * sizeof(double)) != hipSuccess) return nullptr;
+        if (zero) (void)hipMemset(q, 0, (count ? count : 1) * sizeof(double));
+        p.push_back(q);
+        return (double*)q;
+    }
+};
+
+static int upload_padded(double* dst, const double* src, int batch, int rows, int cols, int ld, int rowsPad)
+{
+    // src: [batch][rows][cols] -> dst: [batch][rowsPad][ld]
+    std::vector<double> buf((size_t)rowsPad * ld);
+    for (int b = 0; b < batch; b++) {
+        std::fill(buf.begin(), buf.end(), 0.0);
+        for (int r = 0; r < rows; r++) memcpy(&buf[(size_t)r * ld], src + ((size_t)b * rows + r) * cols, sizeof(double) * cols);
+        HIPCHK(hipMemcpy(dst + (size_t)b * rowsPad * ld, buf.data(), sizeof(double) * rowsPad * ld, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+static int download_padded(double* dst, const double* src, int batch, int rows, int cols, int ld, int rowsPad)
+{
+    std::vector<double> buf((size_t)rowsPad * ld);
+    for (int b = 0; b < batch; b++) {
+        HIPCHK(hipMemcpy(buf.data(), src + (size_t)b * rowsPad * ld, sizeof(double) * rowsPad * ld, hipMemcpyDeviceToHost));
+        for (int r = 0; r < rows; r++) memcpy(dst + ((size_t)b * rows + r) * cols, &buf[(size_t)r * ld], sizeof(double) * cols);
+    }
+    return 0;
+}
+
+#define DISPATCH_NCH_PLAIN(nch, KERNEL, grid, ...)                                                      \
+    do {                                                                                               \
+        switch (nch) {                                                                                 \
+            case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(grid), dim3(WG), 0, 0, __VA_ARGS__); break;   \
+            case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(grid), dim3(WG), 0, 0, __VA_ARGS__); break;   \
+            case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(grid), dim3(WG), 0, 0, __VA_ARGS__); break;   \
+            default: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(WG), 0, 0, __VA_ARGS__); break;  \
+        }                                                                                              \
+    } while (0)
+
+extern "C" int lcqp_hip_util_symv(int batch, int n, double alpha, const double* A, const double* bv, const double* cv, double* dv)
+{
+    if (n <= 0 || n > 512 || batch <= 0) return LCQP_HIP_UNSUPPORTED;
+    const int nch = (n + 127) / 128, np = 128 * nch;
+    TmpBuf tb;
+    double *dA = tb.get((size_t)batch * np * np), *db_ = tb.get((size_t)batch * np), *dc = tb.get((size_t)batch * np), *dd = tb.get((size_t)batch * np);
+    if (!dA || !db_ || !dc || !dd) return set_err("hipMalloc", hipErrorOutOfMemory);
+    int rc = upload_padded(dA, A, batch, n, n, np, np); if (rc) return rc;
+    rc = upload_padded(db_, bv, batch, 1, n, np, 1); if (rc) return rc;
+    rc = upload_padded(dc, cv, batch, 1, n, np, 1); if (rc) return rc;
+    DISPATCH_NCH_PLAIN(nch, k_util_symv, batch, n, alpha, dA, db_, dc, dd);
+    HIPCHK(hipDeviceSynchronize());
+    return download_padded(dv, dd, batch, 1, n, np, 1);
+}
+
+static int util_rows(int batch, int m, int n, const double* A, const double* x, double* dots, const double* coef, double* outT)
+{
+    if (n <= 0 || n > 512 || batch <= 0 || m <= 0) return LCQP_HIP_UNSUPPORTED;
+    const int nch = (n + 127) / 128, np = 128 * nch;
+    TmpBuf tb;
+    double* dA = tb.get((size_t)batch * m * np);
+    double* dx = x ? tb.get((size_t)batch * np) : nullptr;
+    double* dd = dots ? tb.get((size_t)batch * m) : nullptr;
+    double* dcf = coef ? tb.get((size_t)batch * m) : nullptr;
+    double* dout = outT ? tb.get((size_t)batch * np) : nullptr;
+    if (!dA) return set_err("hipMalloc", hipErrorOutOfMemory);
+    int rc = upload_padded(dA, A, batch, m, n, np, m); if (rc) return rc;
+    if (x) { rc = upload_padded(dx, x, batch, 1, n, np, 1); if (rc) return rc; }
+    if (coef) HIPCHK(hipMemcpy(dcf, coef, sizeof(double) * (size_t)batch * m, hipMemcpyHostToDevice));
+    DISPATCH_NCH_PLAIN(nch, k_util_rows, batch, m, dA, dx, dd, dcf, dout);
+    HIPCHK(hipDeviceSynchronize());
+    if (dots) HIPCHK(hipMemcpy(dots, dd, sizeof(double) * (size_t)batch * m, hipMemcpyDeviceToHost));
+    if (outT) return download_padded(outT, dout, batch, 1, n, np, 1);
+    return 0;
+}
+
+extern "C" int lcqp_hip_util_gemv(int batch, int m, int n, const double* A, const double* b, double* c)
+{
+    return util_rows(batch, m, n, A, b, c, nullptr, nullptr);
+}
+extern "C" int lcqp_hip_util_gemv_t(int batch, int m, int n, const double* A, const double* b, double* c)
+{
+    return util_rows(batch, m, n, A, nullptr, nullptr, b, c);
+}
+
+extern "C" int lcqp_hip_util_symm_product(int batch, int m, int n, const double* A, const double* Bm, double* C)
+{
+    // goes through the batch object so that the production kernel k_build_C is what is tested
+    lcqp_hip_batch* h = lcqp_hip_batch_create(batch, n, 0, m, 0, 0);
+    if (!h) return LCQP_HIP_ERROR;
+    DevBatch& d = h->db;
+    int rc = upload_padded(d.E, A, batch, m, n, d.np, d.mEcap);
+    if (!rc) {
+        // second block (R) starts at row m of each instance
+        std::vector<double> buf((size_t)d.mEcap * d.np);
+        for (int b = 0; b < batch && !rc; b++) {
+            if (hipMemcpy(buf.data(), d.E + (size_t)b * d.mEcap * d.np, sizeof(double) * buf.size(), hipMemcpyDeviceToHost) != hipSuccess) { rc = LCQP_HIP_ERROR; break; }
+            for (int r = 0; r < m; r++) memcpy(&buf[(size_t)(m + r) * d.np], Bm + ((size_t)b * m + r) * n, sizeof(double) * n);
+            if (hipMemcpy(d.E + (size_t)b * d.mEcap * d.np, buf.data(), sizeof(double) * buf.size(), hipMemcpyHostToDevice) != hipSuccess) rc = LCQP_HIP_ERROR;
+        }
+    }
+    if (!rc) {
+        DISPATCH_NCH(h, k_build_C, d.B * (d.nblk * (d.nblk + 1) / 2), d);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) rc = LCQP_HIP_ERROR;
+    }
+    if (!rc) rc = download_padded(C, d.C, batch, n, n, d.np, d.np);
+    lcqp_hip_batch_destroy(h);
+    return rc;
+}
+
+extern "C" int lcqp_hip_chol_solve(int batch, int n, const double* K, const double* b, double* x, int repeat, float* ms)
+{
+    if (n <= 0 || n > 512 || batch <= 0) return LCQP_HIP_UNSUPPORTED;
+    const int np = ((n + 63) / 64) * 64, nblk = np / 64;
+    TmpBuf tb;
+    double *dF = tb.get((size_t)batch * np * np), *dscr = tb.get((size_t)batch * 4096), *drhs = tb.get((size_t)batch * np), *dx = tb.get((size_t)batch * np);
+    int* dfail = nullptr;
+    HIPCHK(hipMalloc((void**)&dfail, sizeof(int) * batch));
+    tb.p.push_back(dfail);
+    HIPCHK(hipMemset(dfail, 0, sizeof(int) * batch));
+    if (!dF || !dscr || !drhs || !dx) return set_err("hipMalloc", hipErrorOutOfMemory);
+    // pad with a unit diagonal
+    {
+        std::vector<double> buf((size_t)np * np);
+        for (int bb = 0; bb < batch; bb++) {
+            std::fill(buf.begin(), buf.end(), 0.0);
+            for (int i = 0; i < n; i++) memcpy(&buf[(size_t)i * np], K + ((size_t)bb * n + i) * n, sizeof(double) * n);
+            for (int i = n; i < np; i++) buf[(size_t)i * np + i] = 1.0;
+            HIPCHK(hipMemcpy(dF + (size_t)bb * np * np, buf.data(), sizeof(double) * np * np, hipMemcpyHostToDevice));
+        }
+    }
+    int rc = upload_padded(drhs, b, batch, 1, n, np, 1); if (rc) return rc;
+    hipLaunchKernelGGL(k_chol, dim3(batch), dim3(WG), 0, 0, np, nblk, n, dF, dscr, dfail);
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<int> fail(batch);
+    HIPCHK(hipMemcpy(fail.data(), dfail, sizeof(int) * batch, hipMemcpyDeviceToHost));
+    for (int i = 0; i < batch; i++) if (fail[i]) { g_err = "matrix not positive definite"; return LCQP_SUBPROBLEM_SOLVER_ERROR; }
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    if (repeat < 1) repeat = 1;
+    hipLaunchKernelGGL(k_backsolve, dim3(batch), dim3(WG), 0, 0, np, nblk, dF, drhs, dx);   // warm-up
+    HIPCHK(hipEventRecord(e0, 0));
+    for (int r = 0; r < repeat; r++) hipLaunchKernelGGL(k_backsolve, dim3(batch), dim3(WG), 0, 0, np, nblk, dF, drhs, dx);
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    if (ms) *ms = t / repeat;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return download_padded(x, dx, batch, 1, n, np, 1);
+}

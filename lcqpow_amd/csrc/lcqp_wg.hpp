@@ -1,0 +1,482 @@
+// lcqp_wg.hpp -- workgroup-cooperative fp64 building blocks for gfx950 (CDNA4).
+//
+// Execution model: ONE 256-thread workgroup (4 wave64) owns ONE LCQP instance for the whole solve
+// (DESIGN.md §Mapping).  Every routine here is called by all 256 threads with workgroup-uniform
+// arguments, reads its operands from global memory (HBM/L2), uses LDS only as routine-private
+// scratch, writes its results back to global memory and ends with a workgroup barrier.
+//
+// Streaming convention for the HBM-bound passes: a matrix row (np = 128*NCH doubles, row-major, as
+// the reference stores it -- src/Utilities.cpp:43) is read by one wave with 16-byte loads,
+// lane l taking columns 128k+2l, 128k+2l+1 (1 KiB per wave-instruction, fully coalesced).  Products
+// with the transposed / symmetric matrix are lane-local AXPY accumulations (no cross-lane traffic);
+// products with the matrix itself use one wavefront shuffle reduction per row.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lcqp {
+
+constexpr int WG = 256;          // threads per workgroup
+constexpr int NWAVE = 4;         // waves per workgroup
+constexpr int ARENA = 4352;      // doubles of routine-private LDS (34 KiB -> 4 workgroups per CU)
+constexpr int TILE_LD = 65;      // padded leading dimension of the 64x64 LDS tile
+
+enum { ST_INACT = 0, ST_LOWER = 1, ST_UPPER = 2, ST_EQ = 3 };
+
+struct Lds {
+    double* arena;  // ARENA doubles
+    double* red;    // 16 doubles
+    int* ired;      // 16 ints
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// broadcast lane `src` (must be wave-uniform) through the scalar unit: 2 v_readlane_b32, no LDS traffic
+__device__ __forceinline__ double wave_bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int wave_bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+
+// workgroup reductions; result is uniform across the workgroup. Ends with a barrier.
+__device__ __forceinline__ double block_sum(double v, Lds lds)
+{
+    v = wave_sum(v);
+    if (lane_id() == 0) lds.red[wave_id()] = v;
+    __syncthreads();
+    double r = lds.red[0] + lds.red[1] + lds.red[2] + lds.red[3];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double block_max(double v, Lds lds)
+{
+    v = wave_max(v);
+    if (lane_id() == 0) lds.red[wave_id()] = v;
+    __syncthreads();
+    double r = fmax(fmax(lds.red[0], lds.red[1]), fmax(lds.red[2], lds.red[3]));
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ int block_or(int v, Lds lds)
+{
+    int any = __any(v) ? 1 : 0;
+    if (lane_id() == 0) lds.ired[wave_id()] = any;
+    __syncthreads();
+    int r = lds.ired[0] | lds.ired[1] | lds.ired[2] | lds.ired[3];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ int block_sum_i(int v, Lds lds)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane_id() == 0) lds.ired[wave_id()] = v;
+    __syncthreads();
+    int r = lds.ired[0] + lds.ired[1] + lds.ired[2] + lds.ired[3];
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small vector helpers (global -> global, length a multiple of nothing in particular)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wg_copy(double* dst, const double* src, int n)
+{
+    for (int i = threadIdx.x; i < n; i += WG) dst[i] = src[i];
+    __syncthreads();
+}
+__device__ __forceinline__ void wg_fill(double* dst, double v, int n)
+{
+    for (int i = threadIdx.x; i < n; i += WG) dst[i] = v;
+    __syncthreads();
+}
+__device__ __forceinline__ double wg_dot(const double* a, const double* b, int n, Lds lds)
+{
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += WG) s += a[i] * b[i];
+    return block_sum(s, lds);
+}
+__device__ __forceinline__ double wg_maxabs(const double* a, int n, Lds lds)
+{
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += WG) s = fmax(s, fabs(a[i]));
+    return block_max(s, lds);
+}
+
+// cross-wave combine of per-lane accumulators acc[2*NCH] (lane l holds columns 128k+2l, +1):
+// out[c] = post(c, sum over waves).  Uses arena[0 .. 4*np).
+template <int NCH, class Post>
+__device__ __forceinline__ void wg_combine(const double (&acc)[2 * NCH], Lds lds, Post post)
+{
+    constexpr int np = 128 * NCH;
+    double* red = lds.arena;
+    const int l = lane_id(), w = wave_id();
+#pragma unroll
+    for (int k = 0; k < NCH; k++) {
+        red[w * np + 128 * k + 2 * l] = acc[2 * k];
+        red[w * np + 128 * k + 2 * l + 1] = acc[2 * k + 1];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < np; c += WG) post(c, red[c] + red[np + c] + red[2 * np + c] + red[3 * np + c]);
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Symmetric mat-vecs, AXPY form:  out_m_v[c] = sum_{r<n} M_m[r][c] * v[r]   (M symmetric)
+// Restates Utilities::AffineLinearTransformation / QuadraticFormProduct for the symmetric Q, C, Qk
+// (src/Utilities.cpp:176-186, 214-225) as one sweep over the rows of up to two matrices with up to
+// two vectors.  Any of M1, v1, outputs may be nullptr (workgroup-uniform).
+// LDS: arena[0..4np) combine, arena[4np..6np) the vectors.
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+__device__ __forceinline__ void wg_symv(const double* __restrict__ M0, const double* __restrict__ M1, int n,
+                        const double* __restrict__ v0, const double* __restrict__ v1,
+                        double* o00, double* o10, double* o01, double* o11, Lds lds)
+{
+    constexpr int np = 128 * NCH;
+    double* sv0 = lds.arena + 4 * np;
+    double* sv1 = lds.arena + 5 * np;
+    for (int i = threadIdx.x; i < np; i += WG) {
+        sv0[i] = v0[i];
+        sv1[i] = v1 ? v1[i] : 0.0;
+    }
+    __syncthreads();
+    const int l = lane_id(), w = wave_id();
+    double a00[2 * NCH], a10[2 * NCH], a01[2 * NCH], a11[2 * NCH];
+#pragma unroll
+    for (int k = 0; k < 2 * NCH; k++) a00[k] = a10[k] = a01[k] = a11[k] = 0.0;
+    const bool two_m = (M1 != nullptr), two_v = (v1 != nullptr);
+    for (int r = w; r < n; r += NWAVE) {
+        const double x0 = sv0[r], x1 = sv1[r];
+        const double2* row0 = reinterpret_cast<const double2*>(M0 + (size_t)r * np) + l;
+        double2 m0[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; k++) m0[k] = row0[64 * k];
+        if (two_m) {
+            const double2* row1 = reinterpret_cast<const double2*>(M1 + (size_t)r * np) + l;
+            double2 m1[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; k++) m1[k] = row1[64 * k];
+#pragma unroll
+            for (int k = 0; k < NCH; k++) {
+                a10[2 * k] += m1[k].x * x0; a10[2 * k + 1] += m1[k].y * x0;
+                if (two_v) { a11[2 * k] += m1[k].x * x1; a11[2 * k + 1] += m1[k].y * x1; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; k++) {
+            a00[2 * k] += m0[k].x * x0; a00[2 * k + 1] += m0[k].y * x0;
+            if (two_v) { a01[2 * k] += m0[k].x * x1; a01[2 * k + 1] += m0[k].y * x1; }
+        }
+    }
+    if (o00) wg_combine<NCH>(a00, lds, [&](int c, double s) { o00[c] = s; });
+    if (two_m && o10) wg_combine<NCH>(a10, lds, [&](int c, double s) { o10[c] = s; });
+    if (two_v && o01) wg_combine<NCH>(a01, lds, [&](int c, double s) { o01[c] = s; });
+    if (two_m && two_v && o11) wg_combine<NCH>(a11, lds, [&](int c, double s) { o11[c] = s; });
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row sweep over an m x np row-major matrix (optionally through a row-index list):
+//   dots[a]  = row_a . x                       (if x != nullptr)
+//   out[c]   = post(c, sum_a coef[a] * row_a[c])   (if coef != nullptr)
+// Restates Utilities::MatrixMultiplication (p=1) and TransponsedMatrixMultiplication (p=1),
+// src/Utilities.cpp:38-47, 62-72 -- the latter without the reference's column-strided walk.
+// Rows are dealt to waves in chunks of 16; lane j<16 of a wave carries the scalars of row j.
+// LDS: arena[0..4np) combine, arena[4np..5np) x.
+// ---------------------------------------------------------------------------------------------
+template <int NCH, class Post>
+__device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int* __restrict__ idx, int m,
+                        const double* __restrict__ x, double* dots,
+                        const double* __restrict__ coef, Lds lds, Post post)
+{
+    constexpr int np = 128 * NCH;
+    double* sx = lds.arena + 4 * np;
+    if (x) {
+        for (int i = threadIdx.x; i < np; i += WG) sx[i] = x[i];
+    }
+    __syncthreads();
+    const int l = lane_id(), w = wave_id();
+    double xr[2 * NCH], acc[2 * NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; k++) {
+        xr[2 * k] = x ? sx[128 * k + 2 * l] : 0.0;
+        xr[2 * k + 1] = x ? sx[128 * k + 2 * l + 1] : 0.0;
+        acc[2 * k] = acc[2 * k + 1] = 0.0;
+    }
+    const int nchunk = (m + 15) >> 4;
+    for (int ch = w; ch < nchunk; ch += NWAVE) {
+        const int a0 = ch << 4;
+        const int mya = a0 + l;
+        const bool mine = (l < 16) && (mya < m);
+        int myrow = mine ? (idx ? idx[mya] : mya) : -1;
+        double mycoef = (mine && coef) ? coef[mya] : 0.0;
+        double mydot = 0.0;
+        const int cnt = min(16, m - a0);
+        for (int j = 0; j < cnt; j++) {
+            const int row = wave_bcast_i(myrow, j);
+            const double cf = wave_bcast(mycoef, j);
+            if (row < 0) continue;  // padded list entry (uniform)
+            const double2* rp = reinterpret_cast<const double2*>(Mx + (size_t)row * np) + l;
+            double2 mm[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; k++) mm[k] = rp[64 * k];
+            if (x) {
+                double d = 0.0;
+#pragma unroll
+                for (int k = 0; k < NCH; k++) d += mm[k].x * xr[2 * k] + mm[k].y * xr[2 * k + 1];
+                d = wave_sum(d);
+                if (l == j) mydot = d;
+            }
+            if (coef && cf != 0.0) {
+#pragma unroll
+                for (int k = 0; k < NCH; k++) { acc[2 * k] += cf * mm[k].x; acc[2 * k + 1] += cf * mm[k].y; }
+            }
+        }
+        if (mine && dots) dots[mya] = mydot;
+    }
+    if (coef) wg_combine<NCH>(acc, lds, post);
+    else __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Triangular back-solve with a "symmetric-filled" Cholesky factor F (ld doubles per row,
+// dimension 64*nblk): off-diagonal 64x64 blocks hold L (below) and L' (above); the diagonal blocks
+// hold D = inv(L_II) below and D' above.  Forward (L y = b) and backward (L' x = b) both stream
+// 64-wide row segments with lane-local accumulation; no per-row reductions, no sequential 64-step
+// chains.   vec: global, in/out.   LDS: arena[0..nn) b, arena[nn..5nn) partials (nn <= 512).
+// Algorithmic HBM bytes: 8*N*(N+2) for forward+backward.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wg_trsv(const double* __restrict__ F, int ld, int nblk, double* vec, bool forward, Lds lds)
+{
+    const int nn = 64 * nblk;
+    double* b = lds.arena;
+    double* red = lds.arena + nn;
+    for (int i = threadIdx.x; i < nn; i += WG) b[i] = vec[i];
+    __syncthreads();
+    const int l = lane_id(), w = wave_id();
+    for (int s = 0; s < nblk; s++) {
+        const int I = forward ? s : nblk - 1 - s;
+        {   // diagonal block: y_I[l] = sum_c Fd[c][l] * b_I[c], c<=l (forward, D' above) / c>=l (backward, D below)
+            const double* Fd = F + (size_t)(64 * I) * ld + 64 * I;
+            double f[16];
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) f[cc] = Fd[(size_t)(16 * w + cc) * ld + l];
+            double acc = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) {
+                const int c = 16 * w + cc;
+                const bool use = forward ? (c <= l) : (c >= l);
+                acc += use ? f[cc] * b[64 * I + c] : 0.0;
+            }
+            red[w * 64 + l] = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) b[64 * I + threadIdx.x] = red[l] + red[64 + l] + red[128 + l] + red[192 + l];
+        __syncthreads();
+        const int cb0 = forward ? I + 1 : 0, cb1 = forward ? nblk : I;
+        if (cb1 > cb0) {
+            for (int cb = cb0; cb < cb1; cb++) {
+                const double* Fp = F + (size_t)(64 * I + 16 * w) * ld + 64 * cb + l;
+                double f[16];
+#pragma unroll
+                for (int cc = 0; cc < 16; cc++) f[cc] = Fp[(size_t)cc * ld];
+                double acc = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < 16; cc++) acc += f[cc] * b[64 * I + 16 * w + cc];
+                red[w * nn + 64 * cb + l] = acc;
+            }
+            __syncthreads();
+            for (int c = 64 * cb0 + threadIdx.x; c < 64 * cb1; c += WG)
+                b[c] -= red[c] + red[nn + c] + red[2 * nn + c] + red[3 * nn + c];
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < nn; i += WG) vec[i] = b[i];
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// 64x64 tile product  acc[i][j] = sum_{k<K} A(i)[k] * B(j)[k]   (NT form; K a multiple of 16).
+// Row i of the A operand is  A + rowA(i)*lda  (rowA(i) < 0 -> zero row), same for B.
+// Thread (ty = tid>>4, tx = tid&15) owns rows 4ty..4ty+3 and columns 4tx..4tx+3.
+// LDS: arena[0 .. 2*16*68).
+// ---------------------------------------------------------------------------------------------
+template <class RowA, class RowB>
+__device__ __forceinline__ void wg_tile_nt(double (&acc)[4][4], const double* __restrict__ A, int lda, RowA rowA,
+                                           const double* __restrict__ Bm, int ldb, RowB rowB, int K, Lds lds)
+{
+    constexpr int PL = 68;
+    double* As = lds.arena;
+    double* Bs = lds.arena + 16 * PL;
+    const int t = threadIdx.x;
+    const int lr = t >> 2, kq = (t & 3) * 4;   // loader: row lr, k-quad kq
+    const int ty = t >> 4, tx = t & 15;
+    const long ra = rowA(lr), rb = rowB(lr);
+    const double* ap = (ra >= 0) ? A + (size_t)ra * lda + kq : nullptr;
+    const double* bp = (rb >= 0) ? Bm + (size_t)rb * ldb + kq : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        double2 a0 = {0.0, 0.0}, a1 = {0.0, 0.0}, b0 = {0.0, 0.0}, b1 = {0.0, 0.0};
+        if (ap) { a0 = *reinterpret_cast<const double2*>(ap + k0); a1 = *reinterpret_cast<const double2*>(ap + k0 + 2); }
+        if (bp) { b0 = *reinterpret_cast<const double2*>(bp + k0); b1 = *reinterpret_cast<const double2*>(bp + k0 + 2); }
+        __syncthreads();   // previous panel fully consumed
+        As[(kq + 0) * PL + lr] = a0.x; As[(kq + 1) * PL + lr] = a0.y; As[(kq + 2) * PL + lr] = a1.x; As[(kq + 3) * PL + lr] = a1.y;
+        Bs[(kq + 0) * PL + lr] = b0.x; Bs[(kq + 1) * PL + lr] = b0.y; Bs[(kq + 2) * PL + lr] = b1.x; Bs[(kq + 3) * PL + lr] = b1.y;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            const double2 av0 = *reinterpret_cast<const double2*>(As + kk * PL + 4 * ty);
+            const double2 av1 = *reinterpret_cast<const double2*>(As + kk * PL + 4 * ty + 2);
+            const double2 bv0 = *reinterpret_cast<const double2*>(Bs + kk * PL + 4 * tx);
+            const double2 bv1 = *reinterpret_cast<const double2*>(Bs + kk * PL + 4 * tx + 2);
+            const double a[4] = {av0.x, av0.y, av1.x, av1.y};
+            const double b[4] = {bv0.x, bv0.y, bv1.x, bv1.y};
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] += a[i] * b[j];
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Blocked right-looking Cholesky of the SPD matrix held in the lower triangle of F (dimension
+// 64*nblk, ld doubles per row), producing the symmetric-filled factor wg_trsv consumes.
+//   tau > 0 : pivots <= tau * (original diagonal) mark linearly dependent rows (pivot := 1e150,
+//             column := 0) -- the safeguarded factorisation of the active-row Gram matrix.
+//   tau == 0: plain Cholesky; *info_fail is set when a pivot is not positive.
+// dscr0 + J*dscrStride: 64*64 doubles of global scratch (dense copy of the J-th inverted diagonal block).
+// d0  : nn doubles of global scratch (original diagonal), only used when tau > 0.
+// Returns the smallest pivot over rows < nreal (uniform).
+// LDS: arena[0..64*65) tile + arena[4160..4224) pivots.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal, double tau, double* dscr0, double* d0,
+                          int* info_fail, Lds lds, int dscrStride)
+{
+    const int t = threadIdx.x;
+    double* tile = lds.arena;
+    double* dl = lds.arena + 64 * TILE_LD;
+    double minpiv = INFINITY;
+    int fail = 0;
+    const int nn = 64 * nblk;
+    if (tau > 0.0) {
+        for (int i = t; i < nn; i += WG) d0[i] = F[(size_t)i * ld + i];
+        __syncthreads();
+    }
+    for (int J = 0; J < nblk; J++) {
+        const int o = 64 * J;
+        double* dscr = dscr0 + (size_t)J * dscrStride;
+        for (int e = t; e < 64 * 64; e += WG) {
+            const int i = e >> 6, j = e & 63;
+            tile[i * TILE_LD + j] = (j <= i) ? F[(size_t)(o + i) * ld + o + j] : 0.0;
+        }
+        __syncthreads();
+        // unblocked right-looking factorisation of the tile in LDS
+#pragma unroll 1
+        for (int k = 0; k < 64; k++) {
+            const double d = tile[k * TILE_LD + k];
+            bool dep;
+            if (tau > 0.0) dep = !(d > tau * d0[o + k]) || !(d > 0.0);
+            else { dep = false; if (!(d > 0.0)) { fail = 1; dep = true; } }
+            if (o + k < nreal) minpiv = fmin(minpiv, d);
+            const double ljj = dep ? 1e150 : sqrt(d);
+            if (t == 0) dl[k] = ljj;
+            if (t < 64 && t > k) tile[t * TILE_LD + k] = dep ? 0.0 : tile[t * TILE_LD + k] / ljj;
+            __syncthreads();
+            if (!dep) {
+                const int j = t & 63;
+                if (j > k) {
+                    const double ljk = tile[j * TILE_LD + k];
+#pragma unroll 1
+                    for (int i = k + 1 + (t >> 6); i < 64; i += 4)
+                        if (j <= i) tile[i * TILE_LD + j] -= tile[i * TILE_LD + k] * ljk;
+                }
+            }
+            __syncthreads();
+        }
+        if (t < 64) tile[t * TILE_LD + t] = dl[t];
+        __syncthreads();
+        // in-place inversion of the lower-triangular tile, one row at a time (wave 0; lanes = columns)
+        if (t < 64) {
+#pragma unroll 1
+            for (int i = 0; i < 64; i++) {
+                const double lrow = (t <= i) ? tile[i * TILE_LD + t] : 0.0;   // L[i][t]
+                const double lii = wave_bcast(lrow, i);
+                double s = 0.0;
+                for (int k = 0; k < i; k++) {
+                    const double lik = wave_bcast(lrow, k);
+                    const double dkc = (t <= k) ? tile[k * TILE_LD + t] : 0.0;   // D[k][t], rows k<i already inverted
+                    s += lik * dkc;
+                }
+                double v = 0.0;
+                if (t < i) v = -s / lii;
+                else if (t == i) v = 1.0 / lii;
+                if (t <= i) tile[i * TILE_LD + t] = v;
+            }
+        }
+        __syncthreads();
+        // write D: symmetric fill into F_JJ, dense lower copy into dscr
+        for (int e = t; e < 64 * 64; e += WG) {
+            const int i = e >> 6, j = e & 63;
+            const double v = (j <= i) ? tile[i * TILE_LD + j] : tile[j * TILE_LD + i];
+            F[(size_t)(o + i) * ld + o + j] = v;
+            dscr[e] = (j <= i) ? v : 0.0;
+        }
+        __syncthreads();
+        // panel:  L_IJ = A_IJ * D'   (rows of block I, k over block J)
+        const int ty = t >> 4, tx = t & 15;
+        for (int I = J + 1; I < nblk; I++) {
+            double acc[4][4];
+            wg_tile_nt(acc, F + (size_t)(64 * I) * ld + o, ld, [](int r) { return (long)r; },
+                       dscr, 64, [](int r) { return (long)r; }, 64, lds);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int gi = 64 * I + 4 * ty + i, gj = o + 4 * tx + j;
+                    F[(size_t)gi * ld + gj] = acc[i][j];
+                    F[(size_t)gj * ld + gi] = acc[i][j];
+                }
+            __syncthreads();
+        }
+        // trailing update:  A_IK -= L_IJ * L_KJ'   for I >= K > J
+        for (int I = J + 1; I < nblk; I++)
+            for (int Kb = J + 1; Kb <= I; Kb++) {
+                double acc[4][4];
+                wg_tile_nt(acc, F + (size_t)(64 * I) * ld + o, ld, [](int r) { return (long)r; },
+                           F + (size_t)(64 * Kb) * ld + o, ld, [](int r) { return (long)r; }, 64, lds);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int gi = 64 * I + 4 * ty + i, gj = 64 * Kb + 4 * tx + j;
+                        if (I != Kb || gj <= gi) F[(size_t)gi * ld + gj] -= acc[i][j];
+                    }
+                __syncthreads();
+            }
+    }
+    if (info_fail && fail) *info_fail = 1;   // benign same-value race
+    __syncthreads();
+    return minpiv;
+}
+
+}  // namespace lcqp
