@@ -152,7 +152,7 @@ def main():
         import oracle_py as O
         threads = os.cpu_count() or 1
         oopt = O.default_options(perturbStep=0, printLevel=0)
-        cnt = args.cpu_sample
+        cnt = max(args.cpu_sample, threads)      # at least one LCQP per host core
         tc = time.perf_counter()
         ok, xo, yo, so = O.synth_batch_solve(0, cnt, n, nC, nComp, opt=oopt, threads=threads)
         dtc = time.perf_counter() - tc

@@ -195,7 +195,9 @@ __global__ __launch_bounds__(WG) void k_build_K(DevBatch db)
             const int gi = 64 * I + 4 * ty + i, gj = 64 * J + 4 * tx + j;
             const double v = acc[i][j] + Q[(size_t)gi * np + gj] + (gi == gj ? sigma : 0.0);
             FK[(size_t)gi * np + gj] = v;
-            FK[(size_t)gj * np + gi] = v;
+            // mirror only off-diagonal tiles: inside a diagonal tile (i,j) and (j,i) are both computed, and
+            // (rho*e_i)*e_j != (rho*e_j)*e_i in the last bit -- mirroring there would be a write race
+            if (I != J) FK[(size_t)gj * np + gi] = v;
         }
 }
 
