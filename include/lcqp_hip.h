@@ -87,6 +87,8 @@ lcqp_hip_qp_t* lcqp_hip_qp_create(int nV, int nC, const double* Q, const double*
  * device copies of Q, A by reference count, duplicates solver state. */
 lcqp_hip_qp_t* lcqp_hip_qp_clone(const lcqp_hip_qp_t* src);
 void lcqp_hip_qp_destroy(lcqp_hip_qp_t* qp);
+/* SubsolverQPOASES::setOptions, src/SubsolverQPOASES.cpp:120-131 (takes effect at the next initial solve) */
+int  lcqp_hip_qp_set_options(lcqp_hip_qp_t* qp, const lcqp_options_t* opt);
 /* SubsolverBase::solve, include/SubsolverBase.hpp:52-56 / src/SubsolverQPOASES.cpp:134-169.
  * Returns LCQP_SUCCESSFUL_RETURN or LCQP_SUBPROBLEM_SOLVER_ERROR; *exit_flag != 0 on failure.
  * lbA/ubA/lb/ub/x0/y0 may be NULL as in the reference. */

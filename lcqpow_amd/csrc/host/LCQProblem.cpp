@@ -1,0 +1,325 @@
+#include "LCQProblem.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace LCQPow {
+
+LCQProblem::LCQProblem() : nV(0), nC(0), nComp(0), nDuals(0), boxDualOffset(0), device(0), loaded(false) {}
+
+LCQProblem::LCQProblem(int _nV, int _nC, int _nComp) : nV(0), nC(0), nComp(0), nDuals(0), boxDualOffset(0), device(0), loaded(false)
+{
+    // consistency checks of the reference constructor (src/LCQProblem.cpp:43-67)
+    if (_nV <= 0 || _nComp <= 0 || _nC < 0) return;
+    nV = _nV; nC = _nC; nComp = _nComp;
+}
+
+ReturnValue LCQProblem::loadLCQP(const double* const _Q, const double* const _g, const double* const _L, const double* const _R,
+                                 const double* const _lbL, const double* const _ubL, const double* const _lbR,
+                                 const double* const _ubR, const double* const _A, const double* const _lbA,
+                                 const double* const _ubA, const double* const _lb, const double* const _ub,
+                                 const double* const _x0, const double* const _y0)
+{
+    if (nV <= 0 || nComp <= 0) return LCQPOBJECT_NOT_SETUP;
+    if (!_Q) return INVALID_ARGUMENT;
+    if (!_g) return INVALID_OBJECTIVE_LINEAR_TERM;
+    if (!_A && nC > 0) return INVALID_CONSTRAINT_MATRIX;
+    if (!_L || !_R) return INVALID_COMPLEMENTARITY_MATRIX;
+    const int m = nC + 2 * nComp;
+    const double inf = INFINITY;
+    Q.assign(_Q, _Q + (size_t)nV * nV);
+    g.assign(_g, _g + nV);
+    L.assign(_L, _L + (size_t)nComp * nV);
+    R.assign(_R, _R + (size_t)nComp * nV);
+    // stacked constraint matrix [A; L; R] and its bounds (setConstraints / setComplementarityBounds)
+    A.assign((size_t)m * nV, 0.0);
+    if (nC > 0) std::copy(_A, _A + (size_t)nC * nV, A.begin());
+    std::copy(L.begin(), L.end(), A.begin() + (size_t)nC * nV);
+    std::copy(R.begin(), R.end(), A.begin() + (size_t)(nC + nComp) * nV);
+    lbA.assign(m, -inf); ubA.assign(m, inf);
+    for (int i = 0; i < nC; ++i) { if (_lbA) lbA[i] = _lbA[i]; if (_ubA) ubA[i] = _ubA[i]; }
+    haveLbL = (_lbL != 0); haveLbR = (_lbR != 0);
+    lbL.assign(nComp, 0.0); lbR.assign(nComp, 0.0);
+    for (int i = 0; i < nComp; ++i) {
+        if (_lbL) { if (_lbL[i] <= -inf) return INVALID_LOWER_COMPLEMENTARITY_BOUND; lbL[i] = _lbL[i]; }
+        if (_lbR) { if (_lbR[i] <= -inf) return INVALID_LOWER_COMPLEMENTARITY_BOUND; lbR[i] = _lbR[i]; }
+        lbA[nC + i] = lbL[i];
+        ubA[nC + i] = _ubL ? _ubL[i] : inf;
+        lbA[nC + nComp + i] = lbR[i];
+        ubA[nC + nComp + i] = _ubR ? _ubR[i] : inf;
+    }
+    C.assign((size_t)nV * nV, 0.0);
+    Utilities::MatrixSymmetrizationProduct(L.data(), R.data(), C.data(), nComp, nV);
+    lb.assign(nV, -inf); ub.assign(nV, inf);
+    for (int i = 0; i < nV; ++i) { if (_lb) lb[i] = _lb[i]; if (_ub) ub[i] = _ub[i]; }
+    xk.assign(nV, 0.0);
+    if (_x0) std::copy(_x0, _x0 + nV, xk.begin());
+    nDuals = nV + m; boxDualOffset = nV;
+    yk.assign(nDuals, 0.0);
+    haveYk = (_y0 != 0);
+    if (_y0) std::copy(_y0, _y0 + nDuals, yk.begin());
+    loaded = true;
+    return SUCCESSFUL_RETURN;
+}
+
+static ReturnValue readOpt(std::vector<double>& v, int n, const char* file, bool& given)
+{
+    given = (file != 0);
+    if (!given) return SUCCESSFUL_RETURN;
+    v.assign(n, 0.0);
+    return Utilities::readFromFile(v.data(), n, file);
+}
+
+ReturnValue LCQProblem::loadLCQP(const char* const Q_file, const char* const g_file, const char* const L_file,
+                                 const char* const R_file, const char* const lbL_file, const char* const ubL_file,
+                                 const char* const lbR_file, const char* const ubR_file, const char* const A_file,
+                                 const char* const lbA_file, const char* const ubA_file, const char* const lb_file,
+                                 const char* const ub_file, const char* const x0_file, const char* const y0_file)
+{
+    if (nV <= 0 || nComp <= 0) return LCQPOBJECT_NOT_SETUP;
+    std::vector<double> q, gg, l, r, a, vlbL, vubL, vlbR, vubR, vlbA, vubA, vlb, vub, vx0, vy0;
+    bool b[11];
+    bool dummy;
+    ReturnValue rc;
+    if ((rc = readOpt(q, nV * nV, Q_file, dummy)) != SUCCESSFUL_RETURN || !dummy) return UNABLE_TO_READ_FILE;
+    if ((rc = readOpt(gg, nV, g_file, dummy)) != SUCCESSFUL_RETURN || !dummy) return UNABLE_TO_READ_FILE;
+    if ((rc = readOpt(l, nComp * nV, L_file, dummy)) != SUCCESSFUL_RETURN || !dummy) return UNABLE_TO_READ_FILE;
+    if ((rc = readOpt(r, nComp * nV, R_file, dummy)) != SUCCESSFUL_RETURN || !dummy) return UNABLE_TO_READ_FILE;
+    if ((rc = readOpt(vlbL, nComp, lbL_file, b[0])) != SUCCESSFUL_RETURN) return rc;
+    if ((rc = readOpt(vubL, nComp, ubL_file, b[1])) != SUCCESSFUL_RETURN) return rc;
+    if ((rc = readOpt(vlbR, nComp, lbR_file, b[2])) != SUCCESSFUL_RETURN) return rc;
+    if ((rc = readOpt(vubR, nComp, ubR_file, b[3])) != SUCCESSFUL_RETURN) return rc;
+    if ((rc = readOpt(a, nC * nV, A_file, b[4])) != SUCCESSFUL_RETURN) return rc;
+    if ((rc = readOpt(vlbA, nC, lbA_file, b[5])) != SUCCESSFUL_RETURN) return rc;
+    if ((rc = readOpt(vubA, nC, ubA_file, b[6])) != SUCCESSFUL_RETURN) return rc;
+    if ((rc = readOpt(vlb, nV, lb_file, b[7])) != SUCCESSFUL_RETURN) return rc;
+    if ((rc = readOpt(vub, nV, ub_file, b[8])) != SUCCESSFUL_RETURN) return rc;
+    if ((rc = readOpt(vx0, nV, x0_file, b[9])) != SUCCESSFUL_RETURN) return rc;
+    if ((rc = readOpt(vy0, nV + nC + 2 * nComp, y0_file, b[10])) != SUCCESSFUL_RETURN) return rc;
+    auto p = [](std::vector<double>& v, bool given) -> const double* { return given ? v.data() : 0; };
+    return loadLCQP(q.data(), gg.data(), l.data(), r.data(), p(vlbL, b[0]), p(vubL, b[1]), p(vlbR, b[2]), p(vubR, b[3]),
+                    p(a, b[4]), p(vlbA, b[5]), p(vubA, b[6]), p(vlb, b[7]), p(vub, b[8]), p(vx0, b[9]), p(vy0, b[10]));
+}
+
+ReturnValue LCQProblem::initializeSolver()
+{
+    if (!loaded) return LCQPOBJECT_NOT_SETUP;
+    if (options.getQPSolver() != HIP_DENSE) return NOT_YET_IMPLEMENTED;   // qpOASES / OSQP arms need un-vendored code
+    const int m = nC + 2 * nComp;
+    Subsolver tmp(nV, m, Q.data(), A.data(), HIP_DENSE, device);
+    subsolver = tmp;
+    subsolver.setOptions(options.getHIPOptions());
+    gTilde = g;
+    phiConst = 0.0;
+    gPhi.clear();
+    if (haveLbL || haveLbR) {
+        phiConst = Utilities::DotProduct(lbL.data(), lbR.data(), nComp);
+        gPhi.assign(nV, 0.0);
+        if (haveLbL) Utilities::AddTransponsedMatrixMultiplication(R.data(), lbL.data(), gPhi.data(), nComp, nV, 1);
+        if (haveLbR) Utilities::AddTransponsedMatrixMultiplication(L.data(), lbR.data(), gPhi.data(), nComp, nV, 1);
+        for (int i = 0; i < nV; ++i) gPhi[i] = -gPhi[i];
+    }
+    Qk.assign((size_t)nV * nV, 0.0);
+    gk.assign(nV, 0.0); xnew.assign(nV, 0.0); pk.assign(nV, 0.0); statk.assign(nV, 0.0);
+    constrStatk.assign(nV, 0.0); lkTmp.assign(nV, 0.0); ykA.assign(m, 0.0);
+    alphak = 1.0;
+    rho = options.getInitialPenaltyParameter();
+    outerIter = innerIter = totalIter = 0;
+    qpIterk = qpSolverExitFlag = 0;
+    perturbCounter = 0;
+    algoStat = PROBLEM_NOT_SOLVED;
+    complHistory.clear();
+    stats.reset();
+    if (options.getPrintLevel() > NONE) std::printf("\n");
+    return SUCCESSFUL_RETURN;
+}
+
+ReturnValue LCQProblem::runSolver()
+{
+    ReturnValue ret = initializeSolver();
+    if (ret != SUCCESSFUL_RETURN) return ret;
+    if (options.getSolveZeroPenaltyFirst()) gk = g;
+    else updateLinearization();
+    ret = solveQPSubproblem(true);
+    if (ret != SUCCESSFUL_RETURN) return ret;
+    Utilities::WeightedMatrixAdd(1, Q.data(), rho, C.data(), Qk.data(), nV, nV);
+    stats.updateRhoOpt(rho);
+    for (;;) {
+        Utilities::WeightedVectorAdd(1, xk.data(), alphak, pk.data(), xk.data(), nV);
+        updateStationarity();
+        printIteration();
+        if (options.getStoreSteps()) storeSteps();
+        totalIter++; stats.updateIterTotal(1);
+        innerIter++;
+        if (leyfferCheckPositive()) {
+            updatePenalty();
+            outerIter++; stats.updateIterOuter(1); innerIter = 0;
+        }
+        updateLinearization();
+        if (Utilities::MaxAbs(statk.data(), nV) < options.getStationarityTolerance()) {
+            if (getPhi() < options.getComplementarityTolerance()) {
+                determineStationarityType();   // reads the untransformed duals copied into ykA
+                transformDuals();
+                stats.updateSolutionStatus(algoStat);
+                return SUCCESSFUL_RETURN;
+            }
+            updatePenalty();
+            outerIter++; stats.updateIterOuter(1); innerIter = 0;
+        }
+        if (totalIter > options.getMaxIterations()) return MAX_ITERATIONS_REACHED;
+        if (rho > options.getMaxPenaltyParameter()) return MAX_PENALTY_REACHED;
+        updateLinearization();
+        ret = solveQPSubproblem(false);
+        if (ret != SUCCESSFUL_RETURN) return ret;
+        if (options.getPerturbStep()) perturbStep();
+        getOptimalStepLength();
+    }
+}
+
+void LCQProblem::updateLinearization()
+{
+    Utilities::AffineLinearTransformation(rho, C.data(), xk.data(), gTilde.data(), gk.data(), nV, nV);
+}
+
+ReturnValue LCQProblem::solveQPSubproblem(bool initialSolve)
+{
+    ReturnValue ret = subsolver.solve(initialSolve, qpIterk, qpSolverExitFlag, gk.data(), lbA.data(), ubA.data(), xk.data(),
+                                      haveYk ? yk.data() : 0, lb.data(), ub.data());
+    stats.updateSubproblemIter(qpIterk);
+    stats.updateQPSolverExitFlag(qpSolverExitFlag);
+    haveYk = true;
+    if (ret != SUCCESSFUL_RETURN) return ret;
+    subsolver.getSolution(xnew.data(), yk.data());
+    for (int i = 0; i < nC + 2 * nComp; ++i) ykA[i] = yk[boxDualOffset + i];
+    Utilities::WeightedVectorAdd(1, xnew.data(), -1, xk.data(), pk.data(), nV);
+    return SUCCESSFUL_RETURN;
+}
+
+double LCQProblem::getPhi()
+{
+    double lin = gPhi.empty() ? 0.0 : Utilities::DotProduct(gPhi.data(), xk.data(), nV);
+    return phiConst + lin + Utilities::QuadraticFormProduct(C.data(), xk.data(), nV) / 2.0;
+}
+double LCQProblem::getObj() { return Utilities::DotProduct(g.data(), xk.data(), nV) + Utilities::QuadraticFormProduct(Q.data(), xk.data(), nV) / 2.0; }
+double LCQProblem::getMerit() { return Utilities::DotProduct(g.data(), xk.data(), nV) + Utilities::QuadraticFormProduct(Qk.data(), xk.data(), nV) / 2.0; }
+
+void LCQProblem::updatePenalty()
+{
+    if (options.getNDynamicPenalty() > 0) complHistory.clear();
+    rho *= options.getPenaltyUpdateFactor();
+    stats.updateRhoOpt(rho);
+    Utilities::WeightedMatrixAdd(1, Q.data(), rho, C.data(), Qk.data(), nV, nV);
+    if (!gPhi.empty()) Utilities::WeightedVectorAdd(1.0, g.data(), rho, gPhi.data(), gTilde.data(), nV);
+}
+
+void LCQProblem::getOptimalStepLength()
+{
+    const double qk = Utilities::QuadraticFormProduct(Qk.data(), pk.data(), nV);
+    Utilities::AffineLinearTransformation(1, Qk.data(), xk.data(), gTilde.data(), lkTmp.data(), nV, nV);
+    const double lk = Utilities::DotProduct(pk.data(), lkTmp.data(), nV);
+    alphak = 1.0;
+    if (qk > 0 && lk < 0) alphak = std::min(-lk / qk, 1.0);
+}
+
+void LCQProblem::updateStationarity()
+{
+    Utilities::AffineLinearTransformation(1, Qk.data(), xk.data(), gTilde.data(), statk.data(), nV, nV);
+    Utilities::TransponsedMatrixMultiplication(A.data(), ykA.data(), constrStatk.data(), nC + 2 * nComp, nV, 1);
+    for (int i = 0; i < nV; ++i) statk[i] = statk[i] - constrStatk[i] - yk[i];
+}
+
+bool LCQProblem::leyfferCheckPositive()
+{
+    const size_t n = (size_t)std::max(0, options.getNDynamicPenalty());
+    if (n == 0) return false;
+    const double cur = getPhi();
+    if (complHistory.size() < n) { complHistory.push_back(cur); return false; }
+    if (getPhi() < options.getComplementarityTolerance()) { complHistory.pop_front(); complHistory.push_back(cur); return false; }
+    bool flag = true;
+    for (size_t i = 0; i < n; ++i)
+        if (cur < options.getEtaDynamicPenalty() * complHistory[i]) { flag = false; break; }
+    complHistory.pop_front();
+    complHistory.push_back(cur);
+    return flag;
+}
+
+void LCQProblem::perturbStep()
+{
+    // same counter-based stream as the device path (lcqp_dev.hpp) and the oracle
+    const unsigned long long seed = options.getHIPOptions().perturbSeed;
+    for (int i = 0; i < nV; ++i) {
+        unsigned long long z = seed + (perturbCounter + (unsigned long long)i + 1ULL) * 0x9E3779B97F4A7C15ULL;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z = z ^ (z >> 31);
+        xk[i] += ((int)(z % 3ULL) - 1) * Utilities::EPS;
+    }
+    perturbCounter += (unsigned long long)nV;
+}
+
+void LCQProblem::transformDuals()
+{
+    std::vector<double> tmp(nComp);
+    Utilities::MatrixMultiplication(R.data(), xk.data(), tmp.data(), nComp, nV, 1);
+    for (int i = 0; i < nComp; ++i) yk[boxDualOffset + nC + i] -= rho * tmp[i];
+    Utilities::MatrixMultiplication(L.data(), xk.data(), tmp.data(), nComp, nV, 1);
+    for (int i = 0; i < nComp; ++i) yk[boxDualOffset + nC + nComp + i] -= rho * tmp[i];
+}
+
+void LCQProblem::determineStationarityType()
+{
+    std::vector<double> Lx(nComp), Rx(nComp);
+    Utilities::MatrixMultiplication(L.data(), xk.data(), Lx.data(), nComp, nV, 1);
+    Utilities::MatrixMultiplication(R.data(), xk.data(), Rx.data(), nComp, nV, 1);
+    const double ctol = options.getComplementarityTolerance();
+    bool s = true, m = true;
+    for (int i = 0; i < nComp; ++i) {
+        if (!(Lx[i] <= ctol && Rx[i] <= ctol)) continue;   // weak complementarity set
+        const double a = ykA[nC + i], b = ykA[nC + nComp + i];
+        const double prod = a * b, mn = std::min(a, b);
+        if (mn < 0) s = false;
+        if (std::abs(prod) >= ctol && mn <= 0) {
+            if (prod <= ctol) { algoStat = W_STATIONARY_SOLUTION; return; }
+            m = false;
+        }
+    }
+    algoStat = s ? S_STATIONARY_SOLUTION : (m ? M_STATIONARY_SOLUTION : C_STATIONARY_SOLUTION);
+}
+
+void LCQProblem::storeSteps()
+{
+    stats.updateTrackingVectors(xk.data(), innerIter, qpIterk, alphak, Utilities::MaxAbs(pk.data(), nV),
+                                Utilities::MaxAbs(statk.data(), nV), getObj(), getPhi(), getMerit(), nV);
+}
+
+void LCQProblem::printIteration()
+{
+    const PrintLevel pl = options.getPrintLevel();
+    if (pl == NONE) return;
+    if (pl == OUTER_LOOP_ITERATES && innerIter > 0) return;
+    const bool inner = pl >= INNER_LOOP_ITERATES;
+    if ((inner && innerIter % 10 == 0) || (!inner && outerIter % 10 == 0)) {
+        std::printf(inner ? " outer |  inner |   station  |   complem  |     rho    |   norm p   |    alpha   | sub it\n"
+                          : " outer |   station  |   complem  |     rho    |   norm p\n");
+    }
+    std::printf("%6d", outerIter);
+    if (inner) std::printf(" | %6d", innerIter);
+    std::printf(" | %10.3g | %10.3g | %10.3g | %10.3g", Utilities::MaxAbs(statk.data(), nV), getPhi(), rho, Utilities::MaxAbs(pk.data(), nV));
+    if (inner) std::printf(" | %10.3g | %6d", alphak, qpIterk);
+    std::printf(" \n");
+}
+
+AlgorithmStatus LCQProblem::getPrimalSolution(double* const xOpt) const
+{
+    if (xOpt && !xk.empty()) std::copy(xk.begin(), xk.end(), xOpt);
+    return algoStat;
+}
+
+AlgorithmStatus LCQProblem::getDualSolution(double* const yOpt) const
+{
+    if (yOpt && !yk.empty()) std::copy(yk.begin(), yk.end(), yOpt);
+    return algoStat;
+}
+
+}  // namespace LCQPow

@@ -1,0 +1,76 @@
+// LCQProblem: the reference's public surface (include/LCQProblem.hpp:56-242) on the HIP backend.
+//   LCQProblem(nV,nC,nComp) / loadLCQP (dense arrays or files) / runSolver / getPrimalSolution /
+//   getDualSolution / getNumberOfPrimals / getNumberOfDuals / getOutputStatistics / setOptions.
+// runSolver drives the penalty homotopy on the host exactly like the reference does and calls the
+// subsolver through the Subsolver dispatcher (one solve site, one getSolution site:
+// src/LCQProblem.cpp:1118,1138).  For throughput over many LCQPs use BatchLCQProblem, which runs the whole
+// loop on the device.
+#ifndef LCQPOW_AMD_LCQPROBLEM_HPP
+#define LCQPOW_AMD_LCQPROBLEM_HPP
+
+#include <deque>
+#include <vector>
+
+#include "Options.hpp"
+#include "OutputStatistics.hpp"
+#include "Subsolver.hpp"
+
+namespace LCQPow {
+
+class LCQProblem {
+  public:
+    LCQProblem();
+    LCQProblem(int nV, int nC, int nComp);
+
+    ReturnValue loadLCQP(const double* const Q, const double* const g, const double* const L, const double* const R,
+                         const double* const lbL = 0, const double* const ubL = 0, const double* const lbR = 0,
+                         const double* const ubR = 0, const double* const A = 0, const double* const lbA = 0,
+                         const double* const ubA = 0, const double* const lb = 0, const double* const ub = 0,
+                         const double* const x0 = 0, const double* const y0 = 0);
+    ReturnValue loadLCQP(const char* const Q_file, const char* const g_file, const char* const L_file,
+                         const char* const R_file, const char* const lbL_file = 0, const char* const ubL_file = 0,
+                         const char* const lbR_file = 0, const char* const ubR_file = 0, const char* const A_file = 0,
+                         const char* const lbA_file = 0, const char* const ubA_file = 0, const char* const lb_file = 0,
+                         const char* const ub_file = 0, const char* const x0_file = 0, const char* const y0_file = 0);
+    ReturnValue runSolver();
+    AlgorithmStatus getPrimalSolution(double* const xOpt) const;
+    AlgorithmStatus getDualSolution(double* const yOpt) const;
+    int getNumberOfPrimals() const { return nV; }
+    int getNumberOfDuals() const { return nDuals; }
+    void getOutputStatistics(OutputStatistics& stats_) const { stats_ = stats; }
+    void setOptions(const Options& options_) { options = options_; }
+    void setDevice(int device_) { device = device_; }
+
+  private:
+    ReturnValue initializeSolver();
+    ReturnValue solveQPSubproblem(bool initialSolve);
+    void updateLinearization();
+    void updateStationarity();
+    void updatePenalty();
+    void getOptimalStepLength();
+    bool leyfferCheckPositive();
+    void perturbStep();
+    void transformDuals();
+    void determineStationarityType();
+    void storeSteps();
+    void printIteration();
+    double getPhi();
+    double getObj();
+    double getMerit();
+
+    int nV, nC, nComp, nDuals, boxDualOffset, device;
+    bool loaded, haveYk, haveLbL, haveLbR;
+    std::vector<double> Q, g, L, R, A, lbA, ubA, lb, ub, lbL, lbR, C, Qk;
+    std::vector<double> gTilde, gPhi, xk, yk, ykA, gk, xnew, pk, statk, constrStatk, lkTmp;
+    double phiConst, alphak, rho;
+    int outerIter, innerIter, totalIter, qpIterk, qpSolverExitFlag;
+    unsigned long long perturbCounter;
+    AlgorithmStatus algoStat;
+    std::deque<double> complHistory;
+    Options options;
+    OutputStatistics stats;
+    Subsolver subsolver;
+};
+
+}  // namespace LCQPow
+#endif

@@ -864,6 +864,14 @@ extern "C" void lcqp_hip_qp_destroy(lcqp_hip_qp_t* q)
     delete q;
 }
 
+extern "C" int lcqp_hip_qp_set_options(lcqp_hip_qp_t* q, const lcqp_options_t* opt)
+{
+    if (!q || !opt) return LCQP_INVALID_ARGUMENT;
+    q->opt = *opt;
+    q->haveBounds = false;   // forces a fresh setup (rho / sigma / prox weights enter the factorisations)
+    return 0;
+}
+
 static bool same_pattern(const std::vector<double>& a0, const std::vector<double>& b0, const double* a1, const double* b1, size_t n)
 {
     for (size_t i = 0; i < n; i++) {

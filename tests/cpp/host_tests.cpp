@@ -1,0 +1,180 @@
+// C++ tests of the host layer, modelled on the reference's test/RunUnitTests.cpp and test/examples/*.cpp.
+//   host_tests cpu   Utilities known answers, Options validation, OutputStatistics (no GPU needed)
+//   host_tests gpu   SolverTest.RunWarmUp, CheckQPReturnFlag, example programs, OptimizeOnCircle,
+//                    BatchLCQProblem -- through LCQProblem / Subsolver / SubsolverHIP on GPU 0
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "BatchLCQProblem.hpp"
+#include "LCQProblem.hpp"
+
+using namespace LCQPow;
+
+static int failures = 0;
+#define CHECK(cond)                                                        \
+    do {                                                                   \
+        if (!(cond)) { std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); failures++; } \
+    } while (0)
+
+static void test_utilities()
+{   // test/RunUnitTests.cpp:33-246
+    { double A[6] = {1, 0, 2, 3, 1, 1}, B[12] = {2, 0, 0, 2, 1, 0, 0, 1, 0, -1, -1, 0}, C[8];
+      Utilities::MatrixMultiplication(A, B, C, 2, 3, 4);
+      double e[8] = {2, -2, -2, 2, 7, -1, -1, 7}; for (int i = 0; i < 8; i++) CHECK(C[i] == e[i]); }
+    { double A[6] = {1, 0, 2, 3, 1, 1}, B[2] = {98, -10}, C[3];
+      Utilities::TransponsedMatrixMultiplication(A, B, C, 2, 3, 1);
+      CHECK(C[0] == 68 && C[1] == -10 && C[2] == 186); }
+    { double A[6] = {1, 0, 2, 3, 1, 1}, B[6] = {2, 0, 1, 0, 0, -1}, C[9];
+      Utilities::MatrixSymmetrizationProduct(A, B, C, 2, 3);
+      double e[9] = {4, 0, 2, 0, 0, -1, 2, -1, 2}; for (int i = 0; i < 9; i++) CHECK(C[i] == e[i]); }
+    { double A[6] = {1, 0, 2, 3, 1, 1}, b[3] = {2, 0, 1}, c[2] = {-3, -3}, d[2];
+      Utilities::AffineLinearTransformation(2, A, b, c, d, 2, 3);
+      CHECK(d[0] == 5 && d[1] == 11); }
+    { double A[6] = {0, 1, 3, 1, 10, 1}, B[6] = {2, 0, 0, 4, 2, 2}, C[6];
+      Utilities::WeightedMatrixAdd(-1, A, 0.5, B, C, 3, 2);
+      double e[6] = {1, -1, -3, 1, -9, 0}; for (int i = 0; i < 6; i++) CHECK(C[i] == e[i]); }
+    { double a[4] = {0, 1, 2, 3}, b[4] = {10, 2, 0, 3}, d[4];
+      Utilities::WeightedVectorAdd(2, a, -1, b, d, 4);
+      CHECK(d[0] == -10 && d[1] == 0 && d[2] == 4 && d[3] == 3); }
+    { double p[3] = {1, 2, 3}, Q[9] = {0, 1, 0, 1, 2, 1, 0, 1, 0}; CHECK(Utilities::QuadraticFormProduct(Q, p, 3) == 24); }
+    { double a[4] = {0, 1, 2, 3}, b[4] = {10, 2, 0, 3}; CHECK(Utilities::DotProduct(a, b, 4) == 11); }
+    { double a[4] = {0, 1, 2, 3}, b[4] = {0, -1, 2, 0}, c[4] = {0, -4, 2, 0};
+      CHECK(Utilities::MaxAbs(a, 4) == 3 && Utilities::MaxAbs(b, 4) == 2 && Utilities::MaxAbs(c, 4) == 4); }
+}
+
+static void test_options()
+{   // src/Options.cpp:85-259,296-318; test/RunUnitTests.cpp:249-262
+    Options o;
+    CHECK(o.getComplementarityTolerance() == 1e3 * Utilities::EPS && o.getStationarityTolerance() == 1e6 * Utilities::EPS);
+    CHECK(o.getInitialPenaltyParameter() == 0.01 && o.getPenaltyUpdateFactor() == 2.0 && o.getMaxPenaltyParameter() == 1e8);
+    CHECK(o.getSolveZeroPenaltyFirst() && o.getPerturbStep() && o.getMaxIterations() == 1000);
+    CHECK(o.getNDynamicPenalty() == 3 && o.getEtaDynamicPenalty() == 0.9 && o.getPrintLevel() == INNER_LOOP_ITERATES && !o.getStoreSteps());
+    CHECK(o.setStationarityTolerance(0) == INVALID_STATIONARITY_TOLERANCE && o.setComplementarityTolerance(-1) == INVALID_COMPLEMENTARITY_TOLERANCE);
+    CHECK(o.setInitialPenaltyParameter(0) == INVALID_INITIAL_PENALTY_VALUE && o.setPenaltyUpdateFactor(1.0) == INVALID_PENALTY_UPDATE_VALUE);
+    CHECK(o.setMaxIterations(0) == INVALID_MAX_ITERATIONS_VALUE && o.setMaxPenaltyParameter(0) == INVALID_MAX_RHO_VALUE);
+    CHECK(o.setEtaDynamicPenalty(1.0) == INVALID_ETA_VALUE && o.setPrintLevel(3) == INVALID_PRINT_LEVEL_VALUE);
+    CHECK(o.setQPSolver(4) == INVALID_QPSOLVER && o.setQPSolver(3) == SUCCESSFUL_RETURN && o.getQPSolver() == HIP_DENSE);
+    o.setStationarityTolerance(1e-3);
+    Options c(o), d; d = o;
+    CHECK(c.getStationarityTolerance() == 1e-3 && d.getStationarityTolerance() == 1e-3);
+    OutputStatistics s;
+    CHECK(s.updateIterTotal(0) == INVALID_TOTAL_ITER_COUNT && s.updateIterTotal(2) == SUCCESSFUL_RETURN && s.getIterTotal() == 2);
+    CHECK(s.updateRhoOpt(-1) == INVALID_RHO_OPT && s.updateSubproblemIter(-1) == IVALID_SUBPROBLEM_ITER);
+}
+
+static const double Qw[4] = {2, 0, 0, 2}, gw[2] = {-2, -2}, Lw[2] = {1, 0}, Rw[2] = {0, 1};
+
+static void test_run_warm_up()
+{   // SolverTest.RunWarmUp, test/RunUnitTests.cpp:505-551 (20 repetitions, seeds instead of time(NULL))
+    LCQProblem lcqp(2, 0, 1);
+    Options options; options.setPrintLevel(NONE);
+    int found1 = 0, found2 = 0;
+    for (int i = 0; i < 20; i++) {
+        options.setPerturbSeed(1000 + i);
+        lcqp.setOptions(options);
+        CHECK(lcqp.loadLCQP(Qw, gw, Lw, Rw) == SUCCESSFUL_RETURN);
+        CHECK(lcqp.runSolver() == SUCCESSFUL_RETURN);
+        double x[2], y[4];
+        lcqp.getPrimalSolution(x); lcqp.getDualSolution(y);
+        const double tol = options.getStationarityTolerance();
+        const bool s1 = std::fabs(x[0] - 1) <= tol && std::fabs(x[1]) <= tol, s2 = std::fabs(x[1] - 1) <= tol && std::fabs(x[0]) <= tol;
+        CHECK(s1 || s2);
+        found1 += s1; found2 += s2;
+        CHECK(std::fabs(2 * x[0] - 2 - y[0] - y[2]) <= tol && std::fabs(2 * x[1] - 2 - y[1] - y[3]) <= tol);
+    }
+    CHECK(found1 > 0 && found2 > 0);
+    CHECK(lcqp.getNumberOfPrimals() == 2 && lcqp.getNumberOfDuals() == 4);
+}
+
+static void test_qp_return_flag()
+{   // OutputStatisticsTest.CheckQPReturnFlag, test/RunUnitTests.cpp:463-502
+    double A[2] = {1, 0}, lbA[1] = {0}, ubA[1] = {-1};
+    LCQProblem lcqp(2, 1, 1);
+    Options options; options.setPrintLevel(NONE); lcqp.setOptions(options);
+    CHECK(lcqp.loadLCQP(Qw, gw, Lw, Rw, 0, 0, 0, 0, A, lbA, ubA) == SUCCESSFUL_RETURN);
+    CHECK(lcqp.runSolver() == SUBPROBLEM_SOLVER_ERROR);
+    OutputStatistics stats; lcqp.getOutputStatistics(stats);
+    CHECK(stats.getQPSolverExitFlag() != 0);
+}
+
+static void test_examples()
+{   // test/examples/warm_up.cpp, warm_up_w_A.cpp, warm_up_binary.cpp, test_max_penalty.cpp, warm_up_store_steps.cpp
+    Options options; options.setPrintLevel(NONE);
+    { LCQProblem p(2, 0, 1); p.setOptions(options); double x0[2] = {1, 1}, y0[4] = {0, 0, 0, 0};
+      CHECK(p.loadLCQP(Qw, gw, Lw, Rw, 0, 0, 0, 0, 0, 0, 0, 0, 0, x0, y0) == SUCCESSFUL_RETURN); CHECK(p.runSolver() == SUCCESSFUL_RETURN); }
+    { LCQProblem p(2, 1, 1); p.setOptions(options); double A[2] = {1, -1}, lbA[1] = {-0.5}, ubA[1] = {INFINITY};
+      CHECK(p.loadLCQP(Qw, gw, Lw, Rw, 0, 0, 0, 0, A, lbA, ubA) == SUCCESSFUL_RETURN); CHECK(p.runSolver() == SUCCESSFUL_RETURN); }
+    { LCQProblem p(2, 0, 2); p.setOptions(options); double L[4] = {1, 0, 1, 0}, R[4] = {0, 1, -1, 0}, lbL[2] = {0, 0}, lbR[2] = {0, -0.5}, x0[2] = {0, 0};
+      CHECK(p.loadLCQP(Qw, gw, L, R, lbL, 0, lbR, 0, 0, 0, 0, 0, 0, x0) == SUCCESSFUL_RETURN); CHECK(p.runSolver() == SUCCESSFUL_RETURN); }
+    { Options o2 = options; o2.setMaxPenaltyParameter(1); LCQProblem p(2, 0, 1); p.setOptions(o2); double x0[2] = {1, 1}, y0[4] = {0, 0, 0, 0};
+      CHECK(p.loadLCQP(Qw, gw, Lw, Rw, 0, 0, 0, 0, 0, 0, 0, 0, 0, x0, y0) == SUCCESSFUL_RETURN); CHECK(p.runSolver() == MAX_PENALTY_REACHED); }
+    { Options o2 = options; o2.setStoreSteps(true); LCQProblem p(2, 0, 1); p.setOptions(o2);
+      CHECK(p.loadLCQP(Qw, gw, Lw, Rw) == SUCCESSFUL_RETURN); CHECK(p.runSolver() == SUCCESSFUL_RETURN);
+      OutputStatistics st; p.getOutputStatistics(st);
+      CHECK((int)st.getxStepsStdVec().size() == st.getIterTotal() && (int)st.getPhiValsStdVec().size() == st.getIterTotal()); }
+}
+
+static void test_circle(bool print)
+{   // examples/OptimizeOnCircle.cpp:32-99, dense path (BASELINE config C2)
+    const int N = 100, nV = 2 + 2 * N, nC = N + 1, nComp = N;
+    std::vector<double> Q(nV * nV, 0.0), g(nV, 0.0), L(nComp * nV, 0.0), R(nComp * nV, 0.0), A(nC * nV, 0.0), lbA(nC, 1.0), ubA(nC, 1.0), x0(nV, 0.0);
+    const double xr[2] = {0.5, -0.6};
+    x0[0] = xr[0]; x0[1] = xr[1];
+    Q[0] = 17; Q[nV + 1] = 17; Q[1] = -15; Q[nV] = -15;
+    for (int i = 2; i < nV; i++) Q[i * nV + i] = 5e-12;
+    g[0] = -(17 * xr[0] - 15 * xr[1]); g[1] = -(-15 * xr[0] + 17 * xr[1]);
+    for (int i = 0; i < N; i++) {
+        A[i * nV + 0] = std::cos((2 * M_PI * i) / N); A[i * nV + 1] = std::sin((2 * M_PI * i) / N); A[i * nV + 2 + 2 * i] = 1;
+        A[N * nV + 3 + 2 * i] = 1; L[i * nV + 2 + 2 * i] = 1; R[i * nV + 3 + 2 * i] = 1;
+        x0[2 * i + 2] = 1; x0[2 * i + 3] = 1;
+    }
+    LCQProblem lcqp(nV, nC, nComp);
+    Options options; options.setPrintLevel(print ? INNER_LOOP_ITERATES : NONE); options.setPerturbStep(false);
+    lcqp.setOptions(options);
+    CHECK(lcqp.loadLCQP(Q.data(), g.data(), L.data(), R.data(), 0, 0, 0, 0, A.data(), lbA.data(), ubA.data(), 0, 0, x0.data()) == SUCCESSFUL_RETURN);
+    CHECK(lcqp.runSolver() == SUCCESSFUL_RETURN);
+    std::vector<double> x(nV), y(nV + nC + 2 * nComp);
+    lcqp.getPrimalSolution(x.data()); lcqp.getDualSolution(y.data());
+    OutputStatistics st; lcqp.getOutputStatistics(st);
+    std::printf("circle xOpt = [ %.10g, %.10g ]; i = %d; k = %d; rho = %g; WSR = %d; status = %d\n", x[0], x[1], st.getIterTotal(), st.getIterOuter(), st.getRhoOpt(), st.getSubproblemIter(), (int)st.getSolutionStatus());
+    const bool glob = std::fabs(x[0] - 0.1811) < 1e-4 && std::fabs(x[1] + 0.9835) < 1e-4, loc = std::fabs(x[0] - 0.9764) < 1e-4 && std::fabs(x[1] + 0.2183) < 1e-4;
+    CHECK(glob || loc);   // examples/OptimizeOnCircle.cpp:144-145
+}
+
+static void test_batch()
+{
+    const int B = 8, n = 64, nC = 96, nComp = 16;
+    BatchLCQProblem bt(B, n, nC, nComp);
+    CHECK(bt.ok());
+    Options options; options.setPrintLevel(NONE); options.setPerturbStep(false);
+    CHECK(bt.setOptions(options) == SUCCESSFUL_RETURN);
+    CHECK(bt.generateSynthetic(0x4C43515000000001ULL, 0) == SUCCESSFUL_RETURN);
+    CHECK(bt.runSolver() == SUCCESSFUL_RETURN);
+    std::vector<double> x(n);
+    for (int i = 0; i < B; i++) {
+        CHECK(bt.getReturnValue(i) == SUCCESSFUL_RETURN);
+        AlgorithmStatus s = bt.getPrimalSolution(i, x.data());
+        CHECK(s >= W_STATIONARY_SOLUTION);
+        double phi = 0; for (int k = 0; k < nComp; k++) phi += x[k] * x[nComp + k];
+        CHECK(std::fabs(phi) < 1e3 * Utilities::EPS);
+    }
+}
+
+int main(int argc, char** argv)
+{
+    const bool gpu = argc > 1 && !std::strcmp(argv[1], "gpu");
+    test_utilities();
+    test_options();
+    if (gpu) {
+        if (lcqp_hip_device_count() < 1) { std::printf("FAIL no GPU visible\n"); return 2; }
+        test_run_warm_up();
+        test_qp_return_flag();
+        test_examples();
+        test_circle(argc > 2);
+        test_batch();
+    }
+    std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED%.0d\n", failures);
+    return failures ? 1 : 0;
+}
