@@ -124,7 +124,7 @@ def main():
                                f"SplitMix64 seed0=0x4C43515000000001, perturbStep=0, printLevel=NONE)",
                    "global_batch": B * world, "parallelism": f"batch-sharded x{world}, no collective",
                    "solved": n_ok_total, "mean_lcqp_iterates": mean("iterTotal"), "mean_outer": mean("iterOuter"),
-                   "mean_qp_trials": mean("trials"), "mean_factorizations": mean("factorizations"),
+                   "mean_qp_trials": mean("trials"), "mean_residual_sweeps": mean("reserved"), "mean_factorizations": mean("factorizations"),
                    "mean_backsolve_pairs": mean("corrections"), "mean_admm_iters": mean("admmIter"),
                    "setup_ms_per_step": setup_ms / args.steps, "homotopy_kernel_ms_per_step": solve_ms / args.steps},
         "roofline": {"bound": "hbm", "kernel": "k_lcqp_run", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -150,7 +150,7 @@ def main():
 
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         import oracle_py as O
-        threads = os.cpu_count() or 1
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         oopt = O.default_options(perturbStep=0, printLevel=0)
         cnt = max(args.cpu_sample, threads)      # at least one LCQP per host core
         tc = time.perf_counter()

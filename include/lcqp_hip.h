@@ -136,6 +136,9 @@ int  lcqp_hip_batch_last_timing(lcqp_hip_batch_t* b, float* setup_ms, float* sol
 /* getPrimalSolution / getDualSolution / getOutputStatistics, src/LCQProblem.cpp:1485-1504,1519:
  * x[B][nV], y[B][nV+nC+2nComp], stats[B]; returnValue of runSolver is stats[i].returnValue. */
 int  lcqp_hip_batch_get_solution(lcqp_hip_batch_t* b, double* x, double* y, lcqp_stats_t* stats);
+/* per-instance cycle counters of the homotopy kernel's phases, out[B][16]; all zero unless the library was
+ * built with -DLCQP_PROFILE (tools/gpu_phase_profile.py) */
+int  lcqp_hip_batch_read_profile(lcqp_hip_batch_t* b, unsigned long long* out);
 /* raw HIP stream (hipStream_t) the batch launches on, for event timing by the caller */
 void* lcqp_hip_batch_stream(lcqp_hip_batch_t* b);
 /* algorithmic HBM bytes of the last run, from the work counters the kernels keep */

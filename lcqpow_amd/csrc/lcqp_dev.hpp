@@ -13,14 +13,14 @@ namespace lcqp {
 
 // per-instance vectors of length np (padded nV)
 enum { V_G, V_GPHI, V_GTIL, V_XK, V_PK, V_XNEW, V_GK, V_QX, V_CX, V_QP, V_CP, V_STATK, V_TMP,
-       V_XQ, V_XA, V_XT, V_R1, V_C, V_DU, V_W, V_RHS, V_LB, V_UB, V_X0, V_NUM };
+       V_XQ, V_XA, V_XT, V_R1, V_C, V_DU, V_W, V_RHS, V_LB, V_UB, V_X0, V_R1S, V_GS, V_ATY, V_NUM };
 // per-instance vectors of length mEcap (rows of E = [A; L; R; box rows])
-enum { M_L, M_U, M_RHOV, M_YQ, M_YA, M_ZA, M_YT, M_EX, M_COEF, M_NUM };
+enum { M_L, M_U, M_RHOV, M_YQ, M_YA, M_ZA, M_YT, M_EX, M_COEF, M_EXS, M_NUM };
 enum { I_ST, I_STT, I_NUM };
 enum { S_R2, S_DY, S_D0, S_NUM };
 
 struct InstInfo {
-    int mE, nfin, hasY0, setupFail, haveSolution, isSetup, pad0, pad1;
+    int mE, nfin, hasY0, setupFail, haveSolution, isSetup, cacheNa, pad1;   // cacheNa: active rows the stored factor of S belongs to (-1: none)
     double scale, sigma, spv, rhoAdmm, phiConst;
     double hist[8];
 };
@@ -37,6 +37,7 @@ struct DevBatch {
     double *xout, *yout;                                 // [B][n], [B][nd]
     lcqp_stats_t* stats;
     InstInfo* info;
+    unsigned long long* prof;   // [B][16] per-phase cycle counters (filled only by -DLCQP_PROFILE builds)
 };
 
 template <int NCH>
@@ -50,7 +51,10 @@ struct Ctx {
     InstInfo* info;
     Lds lds;
     // work counters (uniform)
-    int cAdmm, cTrials, cFact, cCorr;
+    int cAdmm, cTrials, cFact, cCorr, cSweeps;
+#ifdef LCQP_PROFILE
+    unsigned long long prof[16], tlast;
+#endif
 
     __device__ __forceinline__ double* V(int k) const { return nv + (size_t)k * np; }
     __device__ __forceinline__ double* M(int k) const { return mv + (size_t)k * db->mEcap; }
@@ -76,9 +80,21 @@ __device__ __forceinline__ Ctx<NCH> make_ctx(const DevBatch& db, int b, Lds lds)
     c.info = db.info + b;
     c.mE = c.info->mE;
     c.lds = lds;
-    c.cAdmm = c.cTrials = c.cFact = c.cCorr = 0;
+    c.cAdmm = c.cTrials = c.cFact = c.cCorr = c.cSweeps = 0;
+#ifdef LCQP_PROFILE
+    for (int k = 0; k < 16; k++) c.prof[k] = 0;
+    c.tlast = clock64();
+#endif
     return c;
 }
+
+// phase buckets of the diagnostic build (tools/gpu_phase_profile.py)
+enum { P_LCQP = 0, P_RESID = 1, P_GRAM = 2, P_CHOL = 3, P_CORR_L1 = 4, P_CORR_ROWS = 5, P_CORR_S = 6, P_ADMM = 7, P_MISC = 8 };
+#ifdef LCQP_PROFILE
+#define PROF(c, k) do { unsigned long long t_ = clock64(); (c).prof[k] += t_ - (c).tlast; (c).tlast = t_; } while (0)
+#else
+#define PROF(c, k) do { } while (0)
+#endif
 
 __device__ __forceinline__ double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -95,6 +111,7 @@ __device__ __forceinline__ void qp_admm(Ctx<NCH>& c, const double* g, int n_it)
     double *xa = c.V(V_XA), *rhs = c.V(V_RHS), *w = c.V(V_W);
     double *ya = c.M(M_YA), *za = c.M(M_ZA), *rhov = c.M(M_RHOV), *coef = c.M(M_COEF), *ex = c.M(M_EX);
     const double *l = c.M(M_L), *u = c.M(M_U);
+    PROF(c, P_MISC);
     for (int it = 0; it < n_it; it++) {
         for (int r = t; r < mE; r += WG) coef[r] = rhov[r] * za[r] - ya[r];
         __syncthreads();
@@ -120,6 +137,7 @@ __device__ __forceinline__ void qp_admm(Ctx<NCH>& c, const double* g, int n_it)
         __syncthreads();
         c.cAdmm++;
     }
+    PROF(c, P_ADMM);
     (void)w;
 }
 
@@ -127,9 +145,11 @@ __device__ __forceinline__ void qp_admm(Ctx<NCH>& c, const double* g, int n_it)
 // Primal-dual active-set polish in correction form (oracle: qp_polish).
 // In/out: x = V_XT, multipliers M_YT (OSQP sign, zero on inactive rows), active set I_STT.
 // Returns 1 (uniform) on a verified KKT point.
+// reuse != 0 (hot start from the last verified solution): the first trial needs no sweep, because
+// r1 = r1_last + (g_last - g) and E x = ex_last hold exactly for an unchanged (x, y).
 // ---------------------------------------------------------------------------------------------
 template <int NCH>
-__device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g)
+__device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse)
 {
     constexpr int np = 128 * NCH;
     const lcqp_options_t& o = c.db->opt;
@@ -148,6 +168,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g)
     for (int trial = 0; trial < o.maxTrials; trial++) {
         c.cTrials++;
         int chg = 0;
+        PROF(c, P_MISC);
         // leaving rows (wrong-signed multipliers) drop out before the residual is formed
         for (int r = t; r < mE; r += WG) {
             double yv = yt[r];
@@ -158,9 +179,17 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g)
             coef[r] = yv;
         }
         __syncthreads();
-        // residual evaluation: one sweep over Q, one over E
-        wg_symv<NCH>(c.Q, nullptr, c.n, x, nullptr, qx, nullptr, nullptr, nullptr, c.lds);
-        wg_rows<NCH>(c.E, nullptr, mE, x, ex, coef, c.lds, [&](int i, double s) { r1[i] = -g[i] - qx[i] - s; });
+        if (trial == 0 && reuse) {
+            const double *r1s = c.V(V_R1S), *gs0 = c.V(V_GS), *exs = c.M(M_EXS);
+            for (int i = t; i < np; i += WG) r1[i] = r1s[i] + (gs0[i] - g[i]);
+            for (int r = t; r < mE; r += WG) ex[r] = exs[r];
+            __syncthreads();
+        } else {
+            // residual evaluation: one sweep over Q, one over E
+            wg_symv<NCH>(c.Q, nullptr, c.n, x, nullptr, qx, nullptr, nullptr, nullptr, c.lds);
+            wg_rows<NCH>(c.E, nullptr, mE, x, ex, coef, c.lds, [&](int i, double s) { r1[i] = -g[i] - qx[i] - s; });
+            c.cSweeps++;
+        }
         const double res_stat = wg_maxabs(r1, np, c.lds);
         double res_eq = 0.0, bmax = 0.0;
         for (int r = t; r < mE; r += WG) {
@@ -181,7 +210,15 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g)
         const int changed = block_or(chg, c.lds);
         res_eq = block_max(res_eq, c.lds);
         bmax = block_max(bmax, c.lds);
-        if (trial > 0 && !changed && res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) return 1;
+        PROF(c, P_RESID);
+        if (trial > 0 && !changed && res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) {
+            double *r1s = c.V(V_R1S), *gs0 = c.V(V_GS), *exs = c.M(M_EXS), *aty = c.V(V_ATY);
+            // A'y_A + y_box = -E'y = g + Qx + r1 at the verified point (all three are direct sums of this trial)
+            for (int i = t; i < np; i += WG) { r1s[i] = r1[i]; gs0[i] = g[i]; aty[i] = g[i] + qx[i] + r1[i]; }
+            for (int r = t; r < mE; r += WG) exs[r] = ex[r];
+            __syncthreads();
+            return 1;
+        }
         if (changed) fact_valid = 0;
         if (!fact_valid) {
             // ordered list of active rows (ascending row index, as the oracle builds it)
@@ -200,11 +237,15 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g)
             na = c.lds.ired[8] + c.lds.ired[9] + c.lds.ired[10] + c.lds.ired[11];
             __syncthreads();
             if (na > capNa) return 0;
-            int pos = base + incl - cnt;
-            for (int r = r0; r < r1e; r++) if (st[r] != ST_INACT) idx[pos++] = r;
+            // the factor of S only depends on the list: reuse it when the list is the one it was built for
+            const int cachedNa = c.info->cacheNa;
+            int pos = base + incl - cnt, differs = (cachedNa != na);
+            for (int r = r0; r < r1e; r++)
+                if (st[r] != ST_INACT) { differs |= (idx[pos] != r); idx[pos++] = r; }
             nblkS = (na + 63) >> 6;
             for (int a = na + t; a < 64 * nblkS; a += WG) idx[a] = -1;
-            __syncthreads();
+            const int rebuild = block_or(differs, c.lds);
+            if (rebuild) {
             // S = T T' (lower tiles), T = rows idx[] of Et; padded rows get a unit diagonal
             const int ty = t >> 4, tx = t & 15;
             for (int Ib = 0; Ib < nblkS; Ib++)
@@ -224,8 +265,13 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g)
                         }
                     __syncthreads();
                 }
+            PROF(c, P_GRAM);
             if (nblkS > 0) wg_chol(c.S, capS, nblkS, na, o.depTau, c.dscr, d0, nullptr, c.lds, 0);
+            PROF(c, P_CHOL);
             c.cFact++;
+            if (t == 0) c.info->cacheNa = na;
+            __syncthreads();
+            }   // rebuild
             fact_valid = 1;
         }
         // correction:  c = L1^-1 r1 ;  S dy = T c - r2 ;  dx = L1^-T (c - T' dy)
@@ -235,18 +281,24 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g)
             r2[a] = v;
         }
         wg_copy(cv, r1, np);
+        PROF(c, P_MISC);
         wg_trsv(c.F1, np, c.nblk, cv, true, c.lds);
+        PROF(c, P_CORR_L1);
         if (na > 0) {
             wg_rows<NCH>(c.Et, idx, na, cv, dy, nullptr, c.lds, [](int, double) {});
             for (int a = t; a < 64 * nblkS; a += WG) dy[a] = (a < na) ? dy[a] - r2[a] : 0.0;
             __syncthreads();
+            PROF(c, P_CORR_ROWS);
             wg_trsv(c.S, capS, nblkS, dy, true, c.lds);
             wg_trsv(c.S, capS, nblkS, dy, false, c.lds);
+            PROF(c, P_CORR_S);
             wg_rows<NCH>(c.Et, idx, na, nullptr, nullptr, dy, c.lds, [&](int i, double s) { du[i] = cv[i] - s; });
+            PROF(c, P_CORR_ROWS);
         } else {
             wg_copy(du, cv, np);
         }
         wg_trsv(c.F1, np, c.nblk, du, false, c.lds);
+        PROF(c, P_CORR_L1);
         for (int i = t; i < np; i += WG) x[i] += du[i];
         for (int a = t; a < na; a += WG) yt[idx[a]] += dy[a];
         __syncthreads();
@@ -289,16 +341,21 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         __syncthreads();
     }
     wg_copy(xa, xq, np);
-    wg_rows<NCH>(c.E, nullptr, mE, xa, ex, nullptr, c.lds, [](int, double) {});
-    for (int r = t; r < mE; r += WG) {
-        za[r] = clipd(ex[r], l[r], u[r]);
-        ya[r] = (rhov[r] == 0.0) ? 0.0 : yq[r];
-    }
+    for (int r = t; r < mE; r += WG) ya[r] = yq[r];
     __syncthreads();
     int n_admm = initial ? o.admmFirst : o.admmHot;
     const int use_stored = (!initial && c.info->haveSolution && n_admm == 0);
-    int solved = 0;
+    int solved = 0, admm_ready = 0;   // za = clip(E xa) is only needed once ADMM runs
     for (int round = 0; round < o.maxRounds && !solved; round++) {
+        if (!admm_ready && (n_admm > 0 || !(round == 0 && use_stored))) {
+            wg_rows<NCH>(c.E, nullptr, mE, xa, ex, nullptr, c.lds, [](int, double) {});
+            for (int r = t; r < mE; r += WG) {
+                za[r] = clipd(ex[r], l[r], u[r]);
+                if (rhov[r] == 0.0) ya[r] = 0.0;
+            }
+            __syncthreads();
+            admm_ready = 1;
+        }
         if (n_admm > 0) qp_admm<NCH>(c, g, n_admm);
         for (int r = t; r < mE; r += WG) {
             int s;
@@ -317,7 +374,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         }
         for (int i = t; i < np; i += WG) xt[i] = xa[i];
         __syncthreads();
-        if (qp_polish<NCH>(c, g)) { solved = 1; break; }
+        if (qp_polish<NCH>(c, g, round == 0 && use_stored)) { solved = 1; break; }
         n_admm = 2 * n_admm;
         if (n_admm < 10) n_admm = 10;
         if (n_admm > 400) n_admm = 400;
@@ -357,7 +414,6 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     double *g = c.V(V_G), *gphi = c.V(V_GPHI), *gtil = c.V(V_GTIL), *xk = c.V(V_XK), *pk = c.V(V_PK), *xnew = c.V(V_XNEW);
     double *gk = c.V(V_GK), *Qx = c.V(V_QX), *Cx = c.V(V_CX), *Qp = c.V(V_QP), *Cp = c.V(V_CP), *statk = c.V(V_STATK);
     double* yk = db.yk + (size_t)c.b * db.nd;
-    double* coef = c.M(M_COEF);
     const bool hasPhi = db.hasLbL || db.hasLbR;
     lcqp_stats_t st;
     st.iterTotal = st.iterOuter = st.subproblemIter = st.status = st.qpSolverExitFlag = st.returnValue = 0;
@@ -386,7 +442,9 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     };
     auto solveQP = [&](int initial) -> int {   // :1115-1148
         const double* y0 = (initial && c.info->hasY0) ? db.y0 + (size_t)c.b * db.nd : nullptr;
+        PROF(c, P_LCQP);
         const int ef = qp_solve<NCH>(c, initial, gk, y0, &qpIter);
+        PROF(c, P_MISC);
         st.subproblemIter += qpIter;
         st.qpSolverExitFlag = ef;
         st.qpSolves++;
@@ -408,17 +466,25 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     rc = solveQP(1);
     if (rc == 0) {
         st.rhoOpt = rho;   // :473
+        // One sweep over Q and C per iterate: Q*[pk, xk] and C*[pk, xk] (the sweep getOptimalStepLength needs,
+        // :1217-1237).  Q*(xk + alpha pk) at the top of the next pass follows by linearity from these two
+        // direct products (no recurrence over iterates), and A'yk_A + yk_box is taken from the verified KKT
+        // residual of the subproblem (V_ATY), so updateStationarity needs no sweep of its own.
+        wg_symv<NCH>(c.Q, c.C, n, pk, xk, Qp, Cp, Qx, Cx, c.lds);
         for (;;) {
             // updateStep :1240-1243
-            for (int i = t; i < np; i += WG) xk[i] = xk[i] + alphak * pk[i];
+            for (int i = t; i < np; i += WG) {
+                xk[i] = xk[i] + alphak * pk[i];
+                Qx[i] = Qx[i] + alphak * Qp[i];
+                Cx[i] = Cx[i] + alphak * Cp[i];
+            }
             __syncthreads();
             // updateStationarity :1246-1272: statk = Qk xk + g_tilde - A' yk_A - yk_box
-            wg_symv<NCH>(c.Q, c.C, n, xk, nullptr, Qx, Cx, nullptr, nullptr, c.lds);
-            for (int r = t; r < mA; r += WG) coef[r] = yk[n + r];
-            __syncthreads();
-            wg_rows<NCH>(c.E, nullptr, mA, nullptr, nullptr, coef, c.lds, [&](int i, double s) {
-                statk[i] = (i < n) ? (Qx[i] + rho * Cx[i]) + gtil[i] - s - yk[i] : 0.0;
-            });
+            {
+                const double* aty = c.V(V_ATY);
+                for (int i = t; i < np; i += WG) statk[i] = (i < n) ? (Qx[i] + rho * Cx[i]) + gtil[i] - aty[i] : 0.0;
+                __syncthreads();
+            }
             const double statInf = wg_maxabs(statk, n, c.lds);
             totalIter++; st.iterTotal++;
             // leyfferCheckPositive :1275-1313
@@ -509,10 +575,14 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     }
     st.status = algoStat;
     st.returnValue = rc;
-    st.admmIter = c.cAdmm; st.trials = c.cTrials; st.factorizations = c.cFact; st.corrections = c.cCorr;
+    st.admmIter = c.cAdmm; st.trials = c.cTrials; st.factorizations = c.cFact; st.corrections = c.cCorr; st.reserved = c.cSweeps;
     for (int i = t; i < n; i += WG) db.xout[(size_t)c.b * n + i] = xk[i];
     for (int i = t; i < db.nd; i += WG) db.yout[(size_t)c.b * db.nd + i] = yk[i];
     if (t == 0) db.stats[c.b] = st;
+    PROF(c, P_LCQP);
+#ifdef LCQP_PROFILE
+    if (t == 0) for (int k = 0; k < 16; k++) db.prof[(size_t)c.b * 16 + k] = c.prof[k];
+#endif
     __syncthreads();
 }
 

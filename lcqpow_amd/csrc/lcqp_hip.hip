@@ -135,6 +135,7 @@ __global__ __launch_bounds__(WG) void k_prepare(DevBatch db)
         c.info->rhoAdmm = rho;
         c.info->phiConst = phiConst;
         c.info->haveSolution = 0;
+        c.info->cacheNa = -1;
         c.info->setupFail = 0;
         c.info->isSetup = 1;
     }
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(WG, 4) void k_qp_solve(DevBatch db, int initial)
         s.subproblemIter = iters;
         s.qpSolverExitFlag = ef;
         s.returnValue = ef ? LCQP_SUBPROBLEM_SOLVER_ERROR : 0;
-        s.admmIter = c.cAdmm; s.trials = c.cTrials; s.factorizations = c.cFact; s.corrections = c.cCorr; s.qpSolves = 1;
+        s.admmIter = c.cAdmm; s.trials = c.cTrials; s.factorizations = c.cFact; s.corrections = c.cCorr; s.qpSolves = 1; s.reserved = c.cSweeps;
         db.stats[c.b] = s;
     }
 }
@@ -559,6 +560,7 @@ extern "C" lcqp_hip_batch_t* lcqp_hip_batch_create(int batch, int nV, int nC, in
     rc |= dev_alloc(h, &d.yout, B * (size_t)d.nd, true);
     rc |= dev_alloc(h, &d.stats, B, true);
     rc |= dev_alloc(h, &d.info, B, true);
+    rc |= dev_alloc(h, &d.prof, B * 16, true);
     if (rc != 0 || hipStreamSynchronize(h->stream) != hipSuccess) { lcqp_hip_batch_destroy(h); return nullptr; }
     return h;
 }
@@ -580,6 +582,16 @@ extern "C" int lcqp_hip_batch_set_options(lcqp_hip_batch_t* h, const lcqp_option
     if (opt->nDynamicPenalty > 8) { g_err = "nDynamicPenalty > 8 unsupported"; return LCQP_HIP_UNSUPPORTED; }
     h->db.opt = *opt;
     h->setupDone = false;   // rho / sigma / prox weights enter the factorisations
+    return 0;
+}
+
+// diagnostic builds (-DLCQP_PROFILE): per-instance cycle counters of the megakernel's phases, [B][16]
+extern "C" int lcqp_hip_batch_read_profile(lcqp_hip_batch_t* h, unsigned long long* out)
+{
+    if (!h || !out) return LCQP_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->db.prof, sizeof(unsigned long long) * (size_t)h->db.B * 16, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -790,11 +802,11 @@ extern "C" int lcqp_hip_batch_get_solution(lcqp_hip_batch_t* h, double* x, doubl
 }
 
 // Algorithmic HBM bytes of the last run, from the per-instance work counters:
-//   residual evaluation (trial): Q + E once           8*(np*n + mE*np)
+//   residual evaluation (trial with sweeps, stats.reserved): Q + E once   8*(n*n + m*n)
 //   correction                  : L1 fwd+bwd + 2 sweeps over the active rows of Et + S fwd+bwd
 //   factorisation               : active rows of Et once + S written and read once
 //   ADMM iteration              : LK fwd+bwd + two sweeps over E
-//   LCQP iterate                : 2 sweeps over Q and C + one over the stacked constraint rows
+//   LCQP iterate                : one sweep over Q and C (Q*[pk,xk], C*[pk,xk])
 extern "C" double lcqp_hip_batch_algorithmic_bytes(lcqp_hip_batch_t* h)
 {
     if (!h) return 0.0;
@@ -808,11 +820,11 @@ extern "C" double lcqp_hip_batch_algorithmic_bytes(lcqp_hip_batch_t* h)
     const double bs = 8.0 * N * (N + 2.0);
     double total = 0.0;
     for (int b = 0; b < d.B; b++) {
-        total += st[b].trials * 8.0 * (n * n + m * n);
+        total += st[b].reserved * 8.0 * (n * n + m * n);   // trials that swept Q and E (hot-start trials reuse the last residual)
         total += st[b].corrections * (bs + 2.0 * 8.0 * na * n + 8.0 * na * (na + 2.0));
         total += st[b].factorizations * (8.0 * na * n + 8.0 * na * na);
         total += st[b].admmIter * (bs + 2.0 * 8.0 * m * n);
-        total += st[b].iterTotal * (2.0 * 2.0 * 8.0 * n * n + 8.0 * m * n);
+        total += (st[b].iterTotal + 1) * (2.0 * 8.0 * n * n);   // one sweep over Q and C per LCQP iterate
     }
     return total;
 }

@@ -18,7 +18,7 @@ namespace lcqp {
 
 constexpr int WG = 256;          // threads per workgroup
 constexpr int NWAVE = 4;         // waves per workgroup
-constexpr int ARENA = 4352;      // doubles of routine-private LDS (34 KiB -> 4 workgroups per CU)
+constexpr int ARENA = 4512;      // doubles of routine-private LDS (35.25 KiB -> 4 workgroups per CU)
 constexpr int TILE_LD = 65;      // padded leading dimension of the 64x64 LDS tile
 
 enum { ST_INACT = 0, ST_LOWER = 1, ST_UPPER = 2, ST_EQ = 3 };
@@ -367,7 +367,7 @@ __device__ __forceinline__ void wg_tile_nt(double (&acc)[4][4], const double* __
 // dscr0 + J*dscrStride: 64*64 doubles of global scratch (dense copy of the J-th inverted diagonal block).
 // d0  : nn doubles of global scratch (original diagonal), only used when tau > 0.
 // Returns the smallest pivot over rows < nreal (uniform).
-// LDS: arena[0..64*65) tile + arena[4160..4224) pivots.
+// LDS: arena[0..64*65) tile + arena[4160..4224) flags + arena[4224..4496) 16x17 scratch.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal, double tau, double* dscr0, double* d0,
                           int* info_fail, Lds lds, int dscrStride)
@@ -390,50 +390,114 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
             tile[i * TILE_LD + j] = (j <= i) ? F[(size_t)(o + i) * ld + o + j] : 0.0;
         }
         __syncthreads();
-        // unblocked right-looking factorisation of the tile in LDS
-#pragma unroll 1
-        for (int k = 0; k < 64; k++) {
-            const double d = tile[k * TILE_LD + k];
-            bool dep;
-            if (tau > 0.0) dep = !(d > tau * d0[o + k]) || !(d > 0.0);
-            else { dep = false; if (!(d > 0.0)) { fail = 1; dep = true; } }
-            if (o + k < nreal) minpiv = fmin(minpiv, d);
-            const double ljj = dep ? 1e150 : sqrt(d);
-            if (t == 0) dl[k] = ljj;
-            if (t < 64 && t > k) tile[t * TILE_LD + k] = dep ? 0.0 : tile[t * TILE_LD + k] / ljj;
-            __syncthreads();
-            if (!dep) {
-                const int j = t & 63;
-                if (j > k) {
-                    const double ljk = tile[j * TILE_LD + k];
-#pragma unroll 1
-                    for (int i = k + 1 + (t >> 6); i < 64; i += 4)
-                        if (j <= i) tile[i * TILE_LD + j] -= tile[i * TILE_LD + k] * ljk;
+        // Factor and invert the 64x64 tile in LDS with 16x16 sub-blocks.  Per sub-block column jb:
+        //  (1) wave 0, lanes 0..15: row-per-lane Cholesky of the 16x16 diagonal sub-block in registers
+        //      (wave-synchronous, v_readlane broadcasts, no barriers), then its inverse, column-per-lane;
+        //  (2) all threads: panel rows below  L_rj = sum_q A_rq * Dd[j][q];
+        //  (3) all threads: rank-16 update of the remaining lower triangle of the tile.
+        // Afterwards the diagonal sub-blocks hold their inverses, the off-diagonal ones L; step (4) turns the
+        // tile into inv(L) block column by block column:  D_ij = -D_ii * sum_{k=j}^{i-1} L_ik D_kj.
+        double* tsc = dl + 64;                   // 16 x 17 scratch
+        for (int jb = 0; jb < 4; jb++) {
+            const int c0 = 16 * jb;
+            if (t < 64) {
+                const int l = t;
+                double a[16], dcol[16];
+                double d0v = (tau > 0.0 && l < 16) ? d0[o + c0 + l] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) a[j] = (l < 16 && j <= l) ? tile[(c0 + l) * TILE_LD + c0 + j] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const double dk = wave_bcast(a[k], k);
+                    bool dep;
+                    if (tau > 0.0) dep = !(dk > tau * wave_bcast(d0v, k)) || !(dk > 0.0);
+                    else { dep = false; if (!(dk > 0.0)) { fail = 1; dep = true; } }
+                    if (o + c0 + k < nreal) minpiv = fmin(minpiv, dk);
+                    const double ljj = dep ? 1e150 : sqrt(dk);
+                    if (l == k) a[k] = ljj;
+                    else if (l > k) a[k] = dep ? 0.0 : a[k] / ljj;
+#pragma unroll
+                    for (int j = k + 1; j < 16; j++) {
+                        const double ljk = wave_bcast(a[k], j);
+                        if (l >= j) a[j] -= a[k] * ljk;
+                    }
                 }
+                // inverse of the 16x16 lower-triangular block: lane c builds column c by forward substitution
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < i; k++) sacc += wave_bcast(a[k], i) * dcol[k];
+                    const double lii = wave_bcast(a[i], i);
+                    dcol[i] = (l == i) ? 1.0 / lii : ((l < i) ? -sacc / lii : 0.0);
+                }
+                if (l < 16) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        if (i >= l) tile[(c0 + i) * TILE_LD + c0 + l] = dcol[i];   // Dd[i][l]
+                }
+                if (l == 0) { dl[jb] = minpiv; dl[4 + jb] = (double)fail; }
             }
             __syncthreads();
-        }
-        if (t < 64) tile[t * TILE_LD + t] = dl[t];
-        __syncthreads();
-        // in-place inversion of the lower-triangular tile, one row at a time (wave 0; lanes = columns)
-        if (t < 64) {
-#pragma unroll 1
-            for (int i = 0; i < 64; i++) {
-                const double lrow = (t <= i) ? tile[i * TILE_LD + t] : 0.0;   // L[i][t]
-                const double lii = wave_bcast(lrow, i);
-                double s = 0.0;
-                for (int k = 0; k < i; k++) {
-                    const double lik = wave_bcast(lrow, k);
-                    const double dkc = (t <= k) ? tile[k * TILE_LD + t] : 0.0;   // D[k][t], rows k<i already inverted
-                    s += lik * dkc;
+            minpiv = fmin(minpiv, dl[jb]);
+            if (dl[4 + jb] != 0.0) fail = 1;
+            const int nrem = 64 - (c0 + 16);     // rows below the diagonal sub-block
+            if (nrem > 0) {
+                // (2) panel: outputs (r, j), r in [c0+16, 64), j in [0,16)
+                double pv[3];
+#pragma unroll
+                for (int q3 = 0; q3 < 3; q3++) {
+                    const int e = t + WG * q3;
+                    pv[q3] = 0.0;
+                    if (e < nrem * 16) {
+                        const int r = c0 + 16 + (e >> 4), j = e & 15;
+                        double sacc = 0.0;
+                        for (int q = 0; q <= j; q++) sacc += tile[r * TILE_LD + c0 + q] * tile[(c0 + j) * TILE_LD + c0 + q];
+                        pv[q3] = sacc;
+                    }
                 }
-                double v = 0.0;
-                if (t < i) v = -s / lii;
-                else if (t == i) v = 1.0 / lii;
-                if (t <= i) tile[i * TILE_LD + t] = v;
+                __syncthreads();
+#pragma unroll
+                for (int q3 = 0; q3 < 3; q3++) {
+                    const int e = t + WG * q3;
+                    if (e < nrem * 16) tile[(c0 + 16 + (e >> 4)) * TILE_LD + c0 + (e & 15)] = pv[q3];
+                }
+                __syncthreads();
+                // (3) trailing update of rows/cols >= c0+16 (lower triangle)
+                for (int e = t; e < nrem * nrem; e += WG) {
+                    const int ri = e / nrem, ci = e - ri * nrem;
+                    if (ci <= ri) {
+                        const int r = c0 + 16 + ri, cc = c0 + 16 + ci;
+                        double sacc = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 16; q++) sacc += tile[r * TILE_LD + c0 + q] * tile[cc * TILE_LD + c0 + q];
+                        tile[r * TILE_LD + cc] -= sacc;
+                    }
+                }
+                __syncthreads();
             }
         }
-        __syncthreads();
+        // (4) blocked inversion: thread (r, c) of a 16x16 block
+        {
+            const int r = t >> 4, cidx = t & 15;
+            for (int jb = 0; jb < 3; jb++)
+                for (int ib = jb + 1; ib < 4; ib++) {
+                    double tv = 0.0;
+                    for (int kb = jb; kb < ib; kb++) {
+#pragma unroll
+                        for (int q = 0; q < 16; q++)
+                            tv += tile[(16 * ib + r) * TILE_LD + 16 * kb + q] * tile[(16 * kb + q) * TILE_LD + 16 * jb + cidx];
+                    }
+                    tsc[r * 17 + cidx] = tv;
+                    __syncthreads();
+                    double dv = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 16; q++) dv -= tile[(16 * ib + r) * TILE_LD + 16 * ib + q] * tsc[q * 17 + cidx];
+                    __syncthreads();
+                    tile[(16 * ib + r) * TILE_LD + 16 * jb + cidx] = dv;
+                    __syncthreads();
+                }
+        }
         // write D: symmetric fill into F_JJ, dense lower copy into dscr
         for (int e = t; e < 64 * 64; e += WG) {
             const int i = e >> 6, j = e & 63;

@@ -240,12 +240,13 @@ struct orc_qp {
     double *xa, *ya, *za;
     /* scratch */
     double *w_n1, *w_n2, *w_n3, *w_m1, *T, *S, *w_a1, *w_a2;
-    int *idx, *newst;
-    int cap_na;
+    double *r1_last, *ex_last, *g_last; /* residual, E x and linear term of the last verified solution */
+    int *idx, *newst, *idx_new;
+    int cap_na, cache_na; /* cache_na: active rows the stored factor of S belongs to (-1: none) */
     /* outputs */
     double *xsol, *ysol;
     /* counters */
-    int c_admm, c_trials, c_fact, c_corr;
+    int c_admm, c_trials, c_fact, c_corr, c_sweeps;
 };
 
 orc_qp_t* orc_qp_create(int nV, int nC, const double* Q, const double* A, const orc_options_t* opt)
@@ -267,7 +268,8 @@ static void qp_free_setup(orc_qp_t* q)
     free(q->boxidx); free(q->E); free(q->Et); free(q->l); free(q->u); free(q->rhov);
     free(q->L1); free(q->LK); free(q->x); free(q->y); free(q->st); free(q->xa); free(q->ya); free(q->za);
     free(q->w_n1); free(q->w_n2); free(q->w_n3); free(q->w_m1); free(q->T); free(q->S); free(q->w_a1); free(q->w_a2);
-    free(q->idx); free(q->newst);
+    free(q->idx); free(q->newst); free(q->idx_new); free(q->r1_last); free(q->ex_last); free(q->g_last);
+    q->idx_new = NULL; q->r1_last = q->ex_last = q->g_last = NULL;
     q->boxidx = NULL; q->E = q->Et = q->l = q->u = q->rhov = q->L1 = q->LK = q->x = q->y = NULL;
     q->st = NULL; q->xa = q->ya = q->za = q->w_n1 = q->w_n2 = q->w_n3 = q->w_m1 = q->T = q->S = q->w_a1 = q->w_a2 = NULL;
     q->idx = q->newst = NULL;
@@ -289,6 +291,8 @@ void orc_qp_get_counters(orc_qp_t* q, int* admm, int* trials, int* facts, int* c
     if (facts) *facts = q->c_fact;
     if (corrections) *corrections = q->c_corr;
 }
+
+int orc_qp_get_sweeps(orc_qp_t* q) { return q->c_sweeps; }
 
 static double bound_or(const double* b, int i, double dflt) { return b ? b[i] : dflt; }
 
@@ -373,6 +377,9 @@ static int qp_setup(orc_qp_t* q, const double* lbA, const double* ubA, const dou
     q->w_a1 = dalloc(q->cap_na); q->w_a2 = dalloc(q->cap_na);
     q->idx = (int*)calloc(q->cap_na ? q->cap_na : 1, sizeof(int));
     q->newst = (int*)calloc(mE ? mE : 1, sizeof(int));
+    q->idx_new = (int*)calloc(q->cap_na ? q->cap_na : 1, sizeof(int));
+    q->cache_na = -1;
+    q->r1_last = dalloc(n); q->ex_last = dalloc(mE); q->g_last = dalloc(n);
     q->have_solution = 0;
     q->is_setup = 1;
     return 0;
@@ -467,7 +474,9 @@ static void qp_guess_from_admm(orc_qp_t* q, int* st)
  * residuals (one pass over Q and E), tests optimality, else updates the active set (all violated rows
  * enter, all wrong-signed multipliers leave) and solves one correction with the constant factor L1 and
  * the Cholesky factor of S = Et_act Et_act'.   Returns 1 on a verified KKT point. */
-static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int* st)
+/* reuse != 0 (hot start from the last verified solution): the first trial needs no sweep --
+ * r1 = r1_last + (g_last - g) and E x = ex_last hold exactly for an unchanged (x, y). */
+static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int* st, int reuse)
 {
     const int n = q->nV, mE = q->mE;
     const orc_options_t* o = &q->opt;
@@ -479,6 +488,11 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
 
     for (int trial = 0; trial < o->maxTrials; trial++) {
         q->c_trials++;
+        if (trial == 0 && reuse) {
+            for (int i = 0; i < n; i++) r1[i] = q->r1_last[i] + (q->g_last[i] - g[i]);
+            memcpy(Ex, q->ex_last, sizeof(double) * mE);
+        } else {
+        q->c_sweeps++;
         /* residual evaluation */
         for (int i = 0; i < n; i++) {
             const double* qr = q->Q + (size_t)i * n;
@@ -494,6 +508,7 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
             double yr = yfull[r];
             if (yr != 0.0)
                 for (int k = 0; k < n; k++) r1[k] -= e[k] * yr;
+        }
         }
         double res_stat = 0, res_eq = 0, bmax = 0;
         for (int i = 0; i < n; i++) { double a = fabs(r1[i]); if (a > res_stat) res_stat = a; }
@@ -516,8 +531,12 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
             q->newst[r] = ns;
             if (ns != s) changed = 1;
         }
-        if (trial > 0 && !changed && res_stat <= o->resTol * gs && res_eq <= o->resTol * (1.0 + bmax))
+        if (trial > 0 && !changed && res_stat <= o->resTol * gs && res_eq <= o->resTol * (1.0 + bmax)) {
+            memcpy(q->r1_last, r1, sizeof(double) * n);
+            memcpy(q->ex_last, Ex, sizeof(double) * mE);
+            memcpy(q->g_last, g, sizeof(double) * n);
             return 1;
+        }
         if (changed && trial > 0) {
             for (int r = 0; r < mE; r++) {
                 int ns = q->newst[r];
@@ -539,8 +558,16 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
             for (int r = 0; r < mE; r++)
                 if (st[r] != ST_INACT) {
                     if (na >= q->cap_na) return 0;
-                    q->idx[na++] = r;
+                    q->idx_new[na++] = r;
                 }
+            /* the factor of S depends only on the ordered list of active rows: reuse it when unchanged */
+            int differs = (q->cache_na != na);
+            for (int a = 0; a < na && !differs; a++) differs = (q->idx[a] != q->idx_new[a]);
+            if (!differs) { fact_valid = 1; }
+        }
+        if (!fact_valid) {
+            memcpy(q->idx, q->idx_new, sizeof(int) * na);
+            q->cache_na = na;
             for (int a = 0; a < na; a++) memcpy(q->T + (size_t)a * n, q->Et + (size_t)q->idx[a] * n, sizeof(double) * n);
             for (int a = 0; a < na; a++)
                 for (int b2 = 0; b2 <= a; b2++) {
@@ -617,20 +644,24 @@ int orc_qp_solve(orc_qp_t* q, int initialSolve, int* iterations, int* exit_flag,
     }
     memcpy(q->xa, q->x, sizeof(double) * n);
     memcpy(q->ya, q->y, sizeof(double) * mE);
-    for (int r = 0; r < mE; r++) {
-        const double* e = q->E + (size_t)r * n;
-        double s = 0;
-        for (int k = 0; k < n; k++) s += e[k] * q->xa[k];
-        q->za[r] = clipd(s, q->l[r], q->u[r]);
-        if (q->rhov[r] == 0.0) q->ya[r] = 0.0;
-    }
     int n_admm = initialSolve ? o->admmFirst : o->admmHot;
     int use_stored_set = (!initialSolve && q->have_solution && n_admm == 0);
+    int admm_ready = 0; /* za = clip(E xa) is only needed once ADMM runs */
     double* xt = (double*)malloc(sizeof(double) * (n ? n : 1));
     double* yt = (double*)malloc(sizeof(double) * (mE ? mE : 1));
     int* stt = (int*)malloc(sizeof(int) * (mE ? mE : 1));
     int solved = 0;
     for (int round = 0; round < o->maxRounds && !solved; round++) {
+        if (!admm_ready && (n_admm > 0 || !(round == 0 && use_stored_set))) {
+            for (int r = 0; r < mE; r++) {
+                const double* e = q->E + (size_t)r * n;
+                double s = 0;
+                for (int k = 0; k < n; k++) s += e[k] * q->xa[k];
+                q->za[r] = clipd(s, q->l[r], q->u[r]);
+                if (q->rhov[r] == 0.0) q->ya[r] = 0.0;
+            }
+            admm_ready = 1;
+        }
         if (n_admm > 0) qp_admm(q, g, n_admm);
         if (round == 0 && use_stored_set) {
             memcpy(stt, q->st, sizeof(int) * mE);
@@ -640,7 +671,7 @@ int orc_qp_solve(orc_qp_t* q, int initialSolve, int* iterations, int* exit_flag,
         }
         memcpy(xt, q->xa, sizeof(double) * n);
         for (int r = 0; r < mE; r++) yt[r] = (stt[r] != ST_INACT) ? q->ya[r] : 0.0;
-        if (qp_polish(q, g, xt, yt, stt)) { solved = 1; break; }
+        if (qp_polish(q, g, xt, yt, stt, round == 0 && use_stored_set)) { solved = 1; break; }
         n_admm = 2 * n_admm;
         if (n_admm < 10) n_admm = 10;
         if (n_admm > 400) n_admm = 400;
@@ -941,6 +972,7 @@ int orc_lcqp_solve(int nV, int nC, int nComp,
     stats->returnValue = rc;
     if (p->qp) {
         orc_qp_get_counters(p->qp, &stats->admmIter, &stats->trials, &stats->factorizations, &stats->corrections);
+        stats->reserved = orc_qp_get_sweeps(p->qp);
         orc_qp_destroy(p->qp);
     }
     free(p->Q); free(p->g); free(p->A); free(p->lbA); free(p->ubA); free(p->L); free(p->R); free(p->C);

@@ -109,6 +109,7 @@ int       orc_qp_solve(orc_qp_t* q, int initialSolve, int* iterations, int* exit
                        const double* lb, const double* ub);                                          /* :134-169 */
 void      orc_qp_get_solution(orc_qp_t* q, double* x, double* y);                                    /* :172-181 */
 void      orc_qp_get_counters(orc_qp_t* q, int* admm, int* trials, int* facts, int* corrections);
+int       orc_qp_get_sweeps(orc_qp_t* q);   /* trials that swept Q and E (stats.reserved) */
 
 /* ---- LCQP solve (LCQProblem::loadLCQP dense + runSolver) ----
  * NULL is allowed wherever the reference allows it (lbL,ubL,lbR,ubR,A (nC==0),lbA,ubA,lb,ub,x0,y0).

@@ -1,0 +1,29 @@
+"""Diagnostic: where does k_lcqp_run spend its cycles?  Builds a -DLCQP_PROFILE copy of the library
+(clock64 stamps between phases, thread 0 of every workgroup), runs the BASELINE batch once and prints the
+share of each phase.  Shares only -- the stamped build is not the measured build."""
+import ctypes as C, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+so = os.path.join(ROOT, "gpurun_out", "liblcqpow_hip_prof.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+if not os.path.exists(so) or "--rebuild" in sys.argv:
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DLCQP_PROFILE",
+                           "-Wno-pass-failed", "-o", so, os.path.join(ROOT, "lcqpow_amd", "csrc", "lcqp_hip.hip")])
+import lcqpow_amd.capi as capi
+capi._SO = so
+la = capi
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1024
+bt = la.BatchLCQP(B, 256, 512, 64, opt=la.default_options(perturbStep=0))
+bt.generate_synthetic(0)
+bt.run(); bt.run()
+x, y, st = bt.solution()
+print("timing (setup ms, solve ms):", bt.last_timing(), "solved", sum(s["returnValue"] == 0 for s in st))
+prof = np.zeros((B, 16), dtype=np.uint64)
+la.lib().lcqp_hip_batch_read_profile.argtypes = [C.c_void_p, C.c_void_p]
+la.lib().lcqp_hip_batch_read_profile(bt.h, prof.ctypes.data_as(C.c_void_p))
+names = ["lcqp-level sweeps", "trial residual (Q+E sweep)", "gram S=TT'", "chol(S)", "corr: L1 trsv", "corr: rows of Et", "corr: S trsv", "admm", "misc/logic"]
+tot = prof[:, :9].sum(axis=1).astype(float)
+print("mean cycles per instance: %.3e  (max %.3e, min %.3e)" % (tot.mean(), tot.max(), tot.min()))
+for k, nme in enumerate(names):
+    print(f"  {nme:28s} {100 * prof[:, k].astype(float).sum() / tot.sum():6.2f} %")
