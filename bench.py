@@ -59,7 +59,8 @@ def main():
     import lcqpow_amd as la
 
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
+        # launched by torch.distributed.run: one rank per GPU over RCCL (backend "nccl" is RCCL on ROCm)
         import torch.distributed as dist_
         dist = dist_
         torch.cuda.set_device(local_rank)

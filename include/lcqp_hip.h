@@ -156,6 +156,9 @@ int lcqp_hip_util_gemv_t(int batch, int m, int n, const double* A, const double*
 int lcqp_hip_util_gemv(int batch, int m, int n, const double* A, const double* b, double* c);
 /* Utilities::MatrixSymmetrizationProduct, src/Utilities.cpp:104-116: C = A'B + B'A (A, B are m x n) */
 int lcqp_hip_util_symm_product(int batch, int m, int n, const double* A, const double* B, double* C);
+/* micro-benchmark of the row sweep on device-resident random data (batch matrices of m x n):
+ * mode 1 = A x (dots), 2 = A'y (axpy), 3 = both in one sweep; *ms = time per launch */
+int lcqp_hip_bench_rows(int batch, int m, int n, int mode, int repeat, float* ms);
 /* Cholesky factorisation + nrhs back-solves of an SPD n x n matrix: x = K^-1 b (the factor-once /
  * back-solve-many kernel pair).  repeat > 1 re-runs the back-solve for timing; *ms gets the
  * per-back-solve kernel time. */

@@ -253,7 +253,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                     double acc[4][4];
                     const int* ia = idx + 64 * Ib;
                     const int* ib = idx + 64 * Jb;
-                    wg_tile_nt(acc, c.Et, np, [=](int r) { return (long)ia[r]; }, c.Et, np, [=](int r) { return (long)ib[r]; }, np, c.lds);
+                    wg_tile_nt(acc, c.Et, np, [=](int r) { return (long)ia[r]; }, c.Et, np, [=](int r) { return (long)ib[r]; }, np, c.lds, na - 64 * Ib);
 #pragma unroll
                     for (int i = 0; i < 4; i++)
 #pragma unroll

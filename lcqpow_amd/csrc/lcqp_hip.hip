@@ -292,8 +292,11 @@ __global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
 }
 
 // ---- the homotopy megakernel: one persistent workgroup per LCQP -----------------------------------
+#ifndef LCQP_MINWAVES
+#define LCQP_MINWAVES 4      // waves per SIMD the register allocation is held to (4 workgroups per CU)
+#endif
 template <int NCH>
-__global__ __launch_bounds__(WG, 4) void k_lcqp_run(DevBatch db)
+__global__ __launch_bounds__(WG, LCQP_MINWAVES) void k_lcqp_run(DevBatch db)
 {
     LCQP_LDS
     Ctx<NCH> c = make_ctx<NCH>(db, blockIdx.x, lds);
@@ -485,7 +488,7 @@ extern "C" void lcqp_hip_options_default(lcqp_options_t* o)
     o->admmRho = 0.1; o->admmSigma = 1e-6; o->admmAlpha = 1.6; o->rhoEqMult = 1e3;
     o->proxSmall = 1e-12; o->proxBig = 1e-8; o->pivotThreshold = 1e-7; o->depTau = 1e-12;
     o->feasTol = 1e-9; o->resTol = 1e-12;
-    o->admmFirst = 10; o->admmHot = 0; o->maxTrials = 12; o->maxRounds = 40;
+    o->admmFirst = 0; o->admmHot = 0; o->maxTrials = 12; o->maxRounds = 40;
 }
 
 struct lcqp_hip_batch {
@@ -1097,6 +1100,44 @@ extern "C" int lcqp_hip_util_symm_product(int batch, int m, int n, const double*
     if (!rc) rc = download_padded(C, d.C, batch, n, n, d.np, d.np);
     lcqp_hip_batch_destroy(h);
     return rc;
+}
+
+// micro-benchmark of the row sweep (wg_rows) on device-resident random data: mode 1 = dots only (A x),
+// 2 = axpy only (A'y), 3 = both in one sweep; *ms = time per launch
+__global__ void k_fill_random(double* p, size_t n, uint64_t seed)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = 2.0 * lcqp_u01(seed, i) - 1.0;
+}
+
+extern "C" int lcqp_hip_bench_rows(int batch, int m, int n, int mode, int repeat, float* ms)
+{
+    if (n <= 0 || n > 512 || batch <= 0 || m <= 0) return LCQP_HIP_UNSUPPORTED;
+    const int nch = (n + 127) / 128, np = 128 * nch;
+    TmpBuf tb;
+    double *dA = tb.get((size_t)batch * m * np, false), *dx = tb.get((size_t)batch * np, false), *dd = tb.get((size_t)batch * m, false);
+    double *dcf = tb.get((size_t)batch * m, false), *dout = tb.get((size_t)batch * np, false);
+    if (!dA || !dx || !dd || !dcf || !dout) return set_err("hipMalloc", hipErrorOutOfMemory);
+    hipLaunchKernelGGL(k_fill_random, dim3(2048), dim3(256), 0, 0, dA, (size_t)batch * m * np, 1ULL);
+    hipLaunchKernelGGL(k_fill_random, dim3(256), dim3(256), 0, 0, dx, (size_t)batch * np, 2ULL);
+    hipLaunchKernelGGL(k_fill_random, dim3(256), dim3(256), 0, 0, dcf, (size_t)batch * m, 3ULL);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    const double* px = (mode & 1) ? dx : nullptr;
+    double* pd = (mode & 1) ? dd : nullptr;
+    const double* pc = (mode & 2) ? dcf : nullptr;
+    double* po = (mode & 2) ? dout : nullptr;
+    for (int r = 0; r <= repeat; r++) {
+        if (r == 1) HIPCHK(hipEventRecord(e0, 0));
+        DISPATCH_NCH_PLAIN(nch, k_util_rows, batch, m, dA, px, pd, pc, po);
+    }
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    if (ms) *ms = t / (repeat > 0 ? repeat : 1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return 0;
 }
 
 extern "C" int lcqp_hip_chol_solve(int batch, int n, const double* K, const double* b, double* x, int repeat, float* ms)

@@ -318,8 +318,11 @@ __device__ __forceinline__ void wg_trsv(const double* __restrict__ F, int ld, in
 // ---------------------------------------------------------------------------------------------
 template <class RowA, class RowB>
 __device__ __forceinline__ void wg_tile_nt(double (&acc)[4][4], const double* __restrict__ A, int lda, RowA rowA,
-                                           const double* __restrict__ Bm, int ldb, RowB rowB, int K, Lds lds)
+                                           const double* __restrict__ Bm, int ldb, RowB rowB, int K, Lds lds,
+                                           int rowsValid = 64)
 {
+    // waves whose 16 output rows are all padding (>= rowsValid) skip the FMAs (their A rows are zero)
+    const bool active = 16 * wave_id() < rowsValid;
     constexpr int PL = 68;
     double* As = lds.arena;
     double* Bs = lds.arena + 16 * PL;
@@ -341,6 +344,7 @@ __device__ __forceinline__ void wg_tile_nt(double (&acc)[4][4], const double* __
         As[(kq + 0) * PL + lr] = a0.x; As[(kq + 1) * PL + lr] = a0.y; As[(kq + 2) * PL + lr] = a1.x; As[(kq + 3) * PL + lr] = a1.y;
         Bs[(kq + 0) * PL + lr] = b0.x; Bs[(kq + 1) * PL + lr] = b0.y; Bs[(kq + 2) * PL + lr] = b1.x; Bs[(kq + 3) * PL + lr] = b1.y;
         __syncthreads();
+        if (active) {
 #pragma unroll
         for (int kk = 0; kk < 16; kk++) {
             const double2 av0 = *reinterpret_cast<const double2*>(As + kk * PL + 4 * ty);
@@ -353,6 +357,7 @@ __device__ __forceinline__ void wg_tile_nt(double (&acc)[4][4], const double* __
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) acc[i][j] += a[i] * b[j];
+        }
         }
     }
     __syncthreads();
@@ -511,7 +516,7 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
         for (int I = J + 1; I < nblk; I++) {
             double acc[4][4];
             wg_tile_nt(acc, F + (size_t)(64 * I) * ld + o, ld, [](int r) { return (long)r; },
-                       dscr, 64, [](int r) { return (long)r; }, 64, lds);
+                       dscr, 64, [](int r) { return (long)r; }, 64, lds, tau > 0.0 ? nreal - 64 * I : 64);
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -527,7 +532,8 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
             for (int Kb = J + 1; Kb <= I; Kb++) {
                 double acc[4][4];
                 wg_tile_nt(acc, F + (size_t)(64 * I) * ld + o, ld, [](int r) { return (long)r; },
-                           F + (size_t)(64 * Kb) * ld + o, ld, [](int r) { return (long)r; }, 64, lds);
+                           F + (size_t)(64 * Kb) * ld + o, ld, [](int r) { return (long)r; }, 64, lds,
+                           tau > 0.0 ? nreal - 64 * I : 64);
 #pragma unroll
                 for (int i = 0; i < 4; i++)
 #pragma unroll

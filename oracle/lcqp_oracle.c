@@ -41,7 +41,7 @@ void orc_options_default(orc_options_t* o)
     o->depTau = 1e-12;
     o->feasTol = 1e-9;
     o->resTol = 1e-12;
-    o->admmFirst = 10;
+    o->admmFirst = 0;
     o->admmHot = 0;
     o->maxTrials = 12;
     o->maxRounds = 40;

@@ -72,7 +72,7 @@ typedef struct {
     double depTau;                   /* 1e-12: relative pivot below which an active row is dependent */
     double feasTol;                  /* 1e-9 */
     double resTol;                   /* 1e-12 */
-    int    admmFirst;                /* 10: ADMM iterations before the first polish of an initial solve */
+    int    admmFirst;                /* 0: ADMM iterations before the first polish of an initial solve (ADMM is the fallback) */
     int    admmHot;                  /* 0: ADMM iterations before the first polish of a hot-started solve */
     int    maxTrials;                /* 12: active-set trials per polish */
     int    maxRounds;                /* 40: ADMM/polish rounds per QP */
