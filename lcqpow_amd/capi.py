@@ -80,6 +80,7 @@ def lib():
         L.lcqp_hip_batch_synchronize.argtypes = [C.c_void_p]
         L.lcqp_hip_batch_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.lcqp_hip_batch_get_solution.argtypes = [C.c_void_p, c_double_p, c_double_p, C.POINTER(Stats)]
+        L.lcqp_hip_batch_get_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, C.POINTER(C.c_int)]
         L.lcqp_hip_batch_stream.restype = C.c_void_p
         L.lcqp_hip_batch_stream.argtypes = [C.c_void_p]
         L.lcqp_hip_batch_algorithmic_bytes.restype = C.c_double
@@ -212,6 +213,12 @@ class BatchLCQP:
         st = (Stats * self.B)()
         _check(lib().lcqp_hip_batch_get_solution(self.h, _p(x), _p(y), st), "get_solution")
         return x, y, [s.asdict() for s in st]
+
+    def trace(self, instance, cap=1024):
+        """per-iterate (|statk|inf, phi, rho, alphak) and xk of one instance (needs options.storeSteps)"""
+        sc = np.zeros((cap, 4)); xs = np.zeros((cap, self.nV)); n = C.c_int(0)
+        _check(lib().lcqp_hip_batch_get_trace(self.h, instance, cap, _p(sc), _p(xs), C.byref(n)), "get_trace")
+        return sc[:n.value].copy(), xs[:n.value].copy()
 
     def algorithmic_bytes(self):
         return lib().lcqp_hip_batch_algorithmic_bytes(self.h)

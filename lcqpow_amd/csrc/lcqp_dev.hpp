@@ -38,6 +38,11 @@ struct DevBatch {
     lcqp_stats_t* stats;
     InstInfo* info;
     unsigned long long* prof;   // [B][16] per-phase cycle counters (filled only by -DLCQP_PROFILE builds)
+    // per-iterate tracking (options.storeSteps, src/LCQProblem.cpp:1365-1378): [B][traceCap][4] = (|statk|inf, phi, rho, alphak)
+    // and [B][traceCap][n] = xk; traceLen[B].  traceCap == 0: not allocated.
+    double *traceS, *traceX;
+    int* traceLen;
+    int traceCap;
 };
 
 template <int NCH>
@@ -486,6 +491,13 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
                 __syncthreads();
             }
             const double statInf = wg_maxabs(statk, n, c.lds);
+            if (db.traceCap > 0 && totalIter < db.traceCap) {   // storeSteps :488-490
+                const double phiNow = getPhi();
+                double* ts = db.traceS + ((size_t)c.b * db.traceCap + totalIter) * 4;
+                double* tx = db.traceX + ((size_t)c.b * db.traceCap + totalIter) * n;
+                if (t == 0) { ts[0] = statInf; ts[1] = phiNow; ts[2] = rho; ts[3] = alphak; db.traceLen[c.b] = totalIter + 1; }
+                for (int i = t; i < n; i += WG) tx[i] = xk[i];
+            }
             totalIter++; st.iterTotal++;
             // leyfferCheckPositive :1275-1313
             bool leyffer = false;

@@ -583,8 +583,36 @@ extern "C" int lcqp_hip_batch_set_options(lcqp_hip_batch_t* h, const lcqp_option
 {
     if (!h || !opt) return LCQP_INVALID_ARGUMENT;
     if (opt->nDynamicPenalty > 8) { g_err = "nDynamicPenalty > 8 unsupported"; return LCQP_HIP_UNSUPPORTED; }
+    if (opt->storeSteps && h->db.traceCap == 0) {
+        // tracking vectors of OutputStatistics (src/OutputStatistics.cpp:131-164), first 1024 iterates
+        HIPCHK(hipSetDevice(h->device));
+        DevBatch& d = h->db;
+        const int cap = opt->maxIterations + 1 < 1024 ? opt->maxIterations + 1 : 1024;
+        if (dev_alloc(h, &d.traceS, (size_t)d.B * cap * 4, true) || dev_alloc(h, &d.traceX, (size_t)d.B * cap * d.n, true) ||
+            dev_alloc(h, &d.traceLen, (size_t)d.B, true)) return LCQP_HIP_ERROR;
+        d.traceCap = cap;
+    }
+    if (!opt->storeSteps && h->db.traceCap > 0) h->db.traceCap = -h->db.traceCap;        // keep the buffers, stop recording
+    else if (opt->storeSteps && h->db.traceCap < 0) h->db.traceCap = -h->db.traceCap;
     h->db.opt = *opt;
     h->setupDone = false;   // rho / sigma / prox weights enter the factorisations
+    return 0;
+}
+
+extern "C" int lcqp_hip_batch_get_trace(lcqp_hip_batch_t* h, int instance, int cap, double* scalars, double* x, int* len)
+{
+    if (!h || instance < 0 || instance >= h->db.B || !len) return LCQP_INVALID_ARGUMENT;
+    DevBatch& d = h->db;
+    *len = 0;
+    if (d.traceCap <= 0) return 0;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int n = 0;
+    HIPCHK(hipMemcpy(&n, d.traceLen + instance, sizeof(int), hipMemcpyDeviceToHost));
+    if (n > cap) n = cap;
+    if (scalars && n) HIPCHK(hipMemcpy(scalars, d.traceS + (size_t)instance * d.traceCap * 4, sizeof(double) * 4 * n, hipMemcpyDeviceToHost));
+    if (x && n) HIPCHK(hipMemcpy(x, d.traceX + (size_t)instance * d.traceCap * d.n, sizeof(double) * (size_t)d.n * n, hipMemcpyDeviceToHost));
+    *len = n;
     return 0;
 }
 

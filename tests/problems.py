@@ -76,7 +76,7 @@ def oracle_solve(O, d, opt, trace=0):
     return O.lcqp_solve(d["Q"], d["g"], d["L"], d["R"], opt=opt, trace=trace, nV=d["nV"], nC=d["nC"], nComp=d["nComp"], **kw)
 
 
-def hip_solve(la, d, opt, device=0):
+def hip_solve(la, d, opt, device=0, trace=False):
     """one-instance batch through the C ABI"""
     with_box = d.get("lb") is not None or d.get("ub") is not None
     bt = la.BatchLCQP(1, d["nV"], d["nC"], d["nComp"], with_box=with_box, device=device, opt=opt)
@@ -87,8 +87,11 @@ def hip_solve(la, d, opt, device=0):
         return dict(ret=rc, x=None, y=None, stats=None)
     bt.run()
     x, y, st = bt.solution()
+    out = dict(ret=st[0]["returnValue"], x=x[0], y=y[0], stats=st[0])
+    if trace:
+        out["trace_scalars"], out["trace_x"] = bt.trace(0)
     bt.close()
-    return dict(ret=st[0]["returnValue"], x=x[0], y=y[0], stats=st[0])
+    return out
 
 
 def kkt_residuals(Q, g, A, lbA, ubA, lb, ub, x, y):

@@ -163,6 +163,26 @@ def test_lcqp_reference_problems(hip, oracle, name):
         assert np.abs(rh["x"][:2] - [0.1811, -0.9835]).max() < 1e-4
 
 
+@pytest.mark.parametrize("name", ["circle", "warm_up_binary", "synthetic", "example_data"])
+def test_lcqp_iterate_level_match(hip, oracle, name):
+    """BASELINE config C2: per-iterate match against the CPU restatement (storeSteps tracking on the device):
+    same number of iterates, same rho sequence, ||xk_gpu - xk_cpu||_inf, stationarity and complementarity per
+    iterate.  (The step length alpha = -lk/qk is not compared: it is an ill-conditioned ratio once |pk| ~ 1e-8.)"""
+    if name == "synthetic":
+        d = oracle.synth_generate(1, 64, 96, 16)
+    else:
+        d = getattr(P, name)()
+    ro = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0), trace=400)
+    rh = P.hip_solve(hip, d, hip.default_options(perturbStep=0, storeSteps=1), trace=True)
+    so, sh = ro["trace_scalars"], rh["trace_scalars"]
+    assert len(so) == len(sh) == ro["stats"]["iterTotal"] == rh["stats"]["iterTotal"]
+    assert np.array_equal(so[:, 2], sh[:, 2])                                   # rho per iterate
+    tol = 1e-7 if name in ("circle", "example_data") else 1e-9                  # PSD Hessians: flat directions
+    assert np.abs(ro["trace_x"] - rh["trace_x"]).max() < tol
+    assert np.abs(so[:, 1] - sh[:, 1]).max() < 10 * tol                         # complementarity per iterate
+    assert np.abs(so[:, 0] - sh[:, 0]).max() < 10 * tol                         # stationarity per iterate
+
+
 def test_lcqp_run_warm_up(hip):
     """SolverTest.RunWarmUp (test/RunUnitTests.cpp:505-551) on the HIP path, 20 seeds"""
     d = P.warm_up()
