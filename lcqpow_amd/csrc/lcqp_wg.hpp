@@ -403,9 +403,13 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
         // Afterwards the diagonal sub-blocks hold their inverses, the off-diagonal ones L; step (4) turns the
         // tile into inv(L) block column by block column:  D_ij = -D_ii * sum_{k=j}^{i-1} L_ik D_kj.
         double* tsc = dl + 64;                   // 16 x 17 scratch
-        for (int jb = 0; jb < 4; jb++) {
+        // padded rows (>= nreal, only in the safeguarded Gram factorisation) form an identity block: its
+        // 16x16 sub-blocks are their own factors and inverses, nothing to do for them
+        const int nsub = (tau > 0.0) ? min(4, max(0, (nreal - o + 15) >> 4)) : 4;
+        for (int jb = 0; jb < nsub; jb++) {
             const int c0 = 16 * jb;
             if (t < 64) {
+                __builtin_amdgcn_s_setprio(3);   // the only sequential stretch: let it win issue slots from streaming waves
                 const int l = t;
                 double a[16], dcol[16];
                 double d0v = (tau > 0.0 && l < 16) ? d0[o + c0 + l] : 0.0;
@@ -442,11 +446,12 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
                         if (i >= l) tile[(c0 + i) * TILE_LD + c0 + l] = dcol[i];   // Dd[i][l]
                 }
                 if (l == 0) { dl[jb] = minpiv; dl[4 + jb] = (double)fail; }
+                __builtin_amdgcn_s_setprio(0);
             }
             __syncthreads();
             minpiv = fmin(minpiv, dl[jb]);
             if (dl[4 + jb] != 0.0) fail = 1;
-            const int nrem = 64 - (c0 + 16);     // rows below the diagonal sub-block
+            const int nrem = 16 * nsub - (c0 + 16);     // (non-padded) rows below the diagonal sub-block
             if (nrem > 0) {
                 // (2) panel: outputs (r, j), r in [c0+16, 64), j in [0,16)
                 double pv[3];
@@ -485,8 +490,8 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
         // (4) blocked inversion: thread (r, c) of a 16x16 block
         {
             const int r = t >> 4, cidx = t & 15;
-            for (int jb = 0; jb < 3; jb++)
-                for (int ib = jb + 1; ib < 4; ib++) {
+            for (int jb = 0; jb + 1 < nsub; jb++)
+                for (int ib = jb + 1; ib < nsub; ib++) {
                     double tv = 0.0;
                     for (int kb = jb; kb < ib; kb++) {
 #pragma unroll
