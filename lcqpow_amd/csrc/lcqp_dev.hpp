@@ -83,7 +83,7 @@ __device__ __forceinline__ Ctx<NCH> make_ctx(const DevBatch& db, int b, Lds lds)
     c.mi = db.mi + (size_t)b * I_NUM * db.mEcap; c.idx = db.idx + (size_t)b * db.capS;
     c.boxidx = db.boxidx + (size_t)b * np;
     c.info = db.info + b;
-    c.mE = c.info->mE;
+    c.mE = uniform_i(c.info->mE);
     c.lds = lds;
     c.cAdmm = c.cTrials = c.cFact = c.cCorr = c.cSweeps = 0;
 #ifdef LCQP_PROFILE
@@ -239,7 +239,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             __syncthreads();
             int base = 0;
             for (int w = 0; w < wave_id(); w++) base += c.lds.ired[8 + w];
-            na = c.lds.ired[8] + c.lds.ired[9] + c.lds.ired[10] + c.lds.ired[11];
+            na = uniform_i(c.lds.ired[8] + c.lds.ired[9] + c.lds.ired[10] + c.lds.ired[11]);
             __syncthreads();
             if (na > capNa) return 0;
             // the factor of S only depends on the list: reuse it when the list is the one it was built for
@@ -252,7 +252,6 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             const int rebuild = block_or(differs, c.lds);
             if (rebuild) {
             // S = T T' (lower tiles), T = rows idx[] of Et; padded rows get a unit diagonal
-            const int ty = t >> 4, tx = t & 15;
             for (int Ib = 0; Ib < nblkS; Ib++)
                 for (int Jb = 0; Jb <= Ib; Jb++) {
                     double acc[4][4];
@@ -263,7 +262,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                     for (int i = 0; i < 4; i++)
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
-                            const int gi = 64 * Ib + 4 * ty + i, gj = 64 * Jb + 4 * tx + j;
+                            const int gi = 64 * Ib + tile_li(i, j), gj = 64 * Jb + tile_lj(i, j);
                             double v = acc[i][j];
                             if (gi == gj && gi >= na) v = 1.0;
                             c.S[(size_t)gi * capS + gj] = v;

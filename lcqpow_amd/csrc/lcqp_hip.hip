@@ -25,12 +25,11 @@ template <class Wgt>
 __device__ __forceinline__ void wg_tile_tn(double (&acc)[4][4], const double* __restrict__ A, int lda, int ca,
                                            const double* __restrict__ Bm, int ldb, int cb, int nrows, Wgt wgt, Lds lds)
 {
-    constexpr int PL = 68;
+    constexpr int PL = TILE_PL;
     double* As = lds.arena;
     double* Bs = lds.arena + 16 * PL;
     const int t = threadIdx.x;
     const int kk = t >> 4, c4 = (t & 15) * 4;
-    const int ty = t >> 4, tx = t & 15;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -50,19 +49,7 @@ __device__ __forceinline__ void wg_tile_tn(double (&acc)[4][4], const double* __
         *reinterpret_cast<double2*>(As + kk * PL + c4) = a0; *reinterpret_cast<double2*>(As + kk * PL + c4 + 2) = a1;
         *reinterpret_cast<double2*>(Bs + kk * PL + c4) = b0; *reinterpret_cast<double2*>(Bs + kk * PL + c4 + 2) = b1;
         __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const double2 av0 = *reinterpret_cast<const double2*>(As + q * PL + 4 * ty);
-            const double2 av1 = *reinterpret_cast<const double2*>(As + q * PL + 4 * ty + 2);
-            const double2 bv0 = *reinterpret_cast<const double2*>(Bs + q * PL + 4 * tx);
-            const double2 bv1 = *reinterpret_cast<const double2*>(Bs + q * PL + 4 * tx + 2);
-            const double a[4] = {av0.x, av0.y, av1.x, av1.y};
-            const double b[4] = {bv0.x, bv0.y, bv1.x, bv1.y};
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] += a[i] * b[j];
-        }
+        tile_panel(acc, As, Bs);
     }
     __syncthreads();
 }
@@ -158,12 +145,11 @@ __global__ __launch_bounds__(WG) void k_build_C(DevBatch db)
     auto one = [](int) { return 1.0; };
     wg_tile_tn(a1, Lm, np, 64 * I, Rm, np, 64 * J, db.nComp, one, lds);
     wg_tile_tn(a2, Rm, np, 64 * I, Lm, np, 64 * J, db.nComp, one, lds);
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int gi = 64 * I + 4 * ty + i, gj = 64 * J + 4 * tx + j;
+            const int gi = 64 * I + tile_li(i, j), gj = 64 * J + tile_lj(i, j);
             const double v = a1[i][j] + a2[i][j];
             C[(size_t)gi * np + gj] = v;
             C[(size_t)gj * np + gi] = v;
@@ -188,12 +174,11 @@ __global__ __launch_bounds__(WG) void k_build_K(DevBatch db)
     double acc[4][4];
     wg_tile_tn(acc, E, np, 64 * I, E, np, 64 * J, info->mE, [=](int r) { return rhov[r]; }, lds);
     const double sigma = info->sigma;
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int gi = 64 * I + 4 * ty + i, gj = 64 * J + 4 * tx + j;
+            const int gi = 64 * I + tile_li(i, j), gj = 64 * J + tile_lj(i, j);
             const double v = acc[i][j] + Q[(size_t)gi * np + gj] + (gi == gj ? sigma : 0.0);
             FK[(size_t)gi * np + gj] = v;
             // mirror only off-diagonal tiles: inside a diagonal tile (i,j) and (j,i) are both computed, and
@@ -258,7 +243,6 @@ __global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
     const double* F1 = db.F1 + (size_t)b * np * np;
     const double* D1 = db.D1 + (size_t)b * db.nblk * 4096;
     const int rows = min(64, db.mEcap - 64 * rb);
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
     auto rowok = [=](int r) { return (long)(r < rows ? r : -1); };
     auto ident = [](int r) { return (long)r; };
     for (int J = 0; J < db.nblk; J++) {
@@ -274,7 +258,7 @@ __global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int li = 4 * ty + i, gj = 64 * J + 4 * tx + j;
+                const int li = tile_li(i, j), gj = 64 * J + tile_lj(i, j);
                 if (li < rows) Et[(size_t)li * np + gj] = E[(size_t)li * np + gj] - acc[i][j];
             }
         __syncthreads();
@@ -284,7 +268,7 @@ __global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int li = 4 * ty + i, gj = 64 * J + 4 * tx + j;
+                const int li = tile_li(i, j), gj = 64 * J + tile_lj(i, j);
                 if (li < rows) Et[(size_t)li * np + gj] = acc2[i][j];
             }
         __syncthreads();
@@ -386,12 +370,11 @@ __global__ __launch_bounds__(WG) void k_synth_Q(DevBatch db)
     double* Q = db.Q + (size_t)b * np * np;
     double acc[4][4];
     wg_tile_tn(acc, Mm, np, 64 * I, Mm, np, 64 * J, db.n, [](int) { return 1.0; }, lds);
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int gi = 64 * I + 4 * ty + i, gj = 64 * J + 4 * tx + j;
+            const int gi = 64 * I + tile_li(i, j), gj = 64 * J + tile_lj(i, j);
             double v = 0.0;
             if (gi < db.n && gj < db.n) v = acc[i][j] / (double)db.n + (gi == gj ? 1.0 : 0.0);
             Q[(size_t)gi * np + gj] = v;

@@ -53,7 +53,16 @@ __device__ __forceinline__ double wave_bcast(double v, int src)
 }
 __device__ __forceinline__ int wave_bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
-// workgroup reductions; result is uniform across the workgroup. Ends with a barrier.
+// make a value the compiler cannot prove wave-uniform live in scalar registers
+__device__ __forceinline__ double uniform_d(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// workgroup reductions; result is uniform across the workgroup (and held in SGPRs). Ends with a barrier.
 __device__ __forceinline__ double block_sum(double v, Lds lds)
 {
     v = wave_sum(v);
@@ -61,7 +70,7 @@ __device__ __forceinline__ double block_sum(double v, Lds lds)
     __syncthreads();
     double r = lds.red[0] + lds.red[1] + lds.red[2] + lds.red[3];
     __syncthreads();
-    return r;
+    return uniform_d(r);
 }
 __device__ __forceinline__ double block_max(double v, Lds lds)
 {
@@ -70,7 +79,7 @@ __device__ __forceinline__ double block_max(double v, Lds lds)
     __syncthreads();
     double r = fmax(fmax(lds.red[0], lds.red[1]), fmax(lds.red[2], lds.red[3]));
     __syncthreads();
-    return r;
+    return uniform_d(r);
 }
 __device__ __forceinline__ int block_or(int v, Lds lds)
 {
@@ -79,7 +88,7 @@ __device__ __forceinline__ int block_or(int v, Lds lds)
     __syncthreads();
     int r = lds.ired[0] | lds.ired[1] | lds.ired[2] | lds.ired[3];
     __syncthreads();
-    return r;
+    return uniform_i(r);
 }
 __device__ __forceinline__ int block_sum_i(int v, Lds lds)
 {
@@ -89,7 +98,7 @@ __device__ __forceinline__ int block_sum_i(int v, Lds lds)
     __syncthreads();
     int r = lds.ired[0] + lds.ired[1] + lds.ired[2] + lds.ired[3];
     __syncthreads();
-    return r;
+    return uniform_i(r);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -311,24 +320,89 @@ __device__ __forceinline__ void wg_trsv(const double* __restrict__ F, int ld, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// 64x64 output tiles are accumulated from k-major LDS panels As[16][TILE_PL], Bs[16][TILE_PL]
+// (As[k][i] = A operand of output row i, Bs[k][j] = B operand of output column j).
+// Default: fp64 matrix cores, v_mfma_f64_16x16x4_f64 -- wave w owns output rows 16w..16w+15 as four 16x16
+// blocks; acc[a][b] is block a (columns 16a..16a+15), accumulator register b:
+//     row = 16w + (lane>>4) + 4b,   col = 16a + (lane&15)            (C/D layout of the f64 MFMA)
+// A operand: one f64 per lane, A[i = lane&15][k = lane>>4]; B operand: B[k = lane>>4][j = lane&15].
+// -DLCQP_TILE_VALU selects the 4x4-per-thread v_fma_f64 micro-kernel instead (same peak rate on gfx950;
+// kept as the cross-check of the MFMA lane maps): row = 4*(tid>>4) + a, col = 4*(tid&15) + b.
+// ---------------------------------------------------------------------------------------------
+constexpr int TILE_PL = 80;   // panel pitch in doubles: 160 dwords = 32 mod 64 banks -> conflict-free MFMA operand reads
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int tile_li(int a, int b)
+{
+#ifdef LCQP_TILE_VALU
+    (void)b; return 4 * (threadIdx.x >> 4) + a;
+#else
+    (void)a; return 16 * wave_id() + (lane_id() >> 4) + 4 * b;
+#endif
+}
+__device__ __forceinline__ int tile_lj(int a, int b)
+{
+#ifdef LCQP_TILE_VALU
+    (void)a; return 4 * (threadIdx.x & 15) + b;
+#else
+    (void)b; return 16 * a + (lane_id() & 15);
+#endif
+}
+
+// acc += As' * Bs over the 16 staged k values
+__device__ __forceinline__ void tile_panel(double (&acc)[4][4], const double* As, const double* Bs)
+{
+#ifdef LCQP_TILE_VALU
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+        const double2 av0 = *reinterpret_cast<const double2*>(As + kk * TILE_PL + 4 * ty);
+        const double2 av1 = *reinterpret_cast<const double2*>(As + kk * TILE_PL + 4 * ty + 2);
+        const double2 bv0 = *reinterpret_cast<const double2*>(Bs + kk * TILE_PL + 4 * tx);
+        const double2 bv1 = *reinterpret_cast<const double2*>(Bs + kk * TILE_PL + 4 * tx + 2);
+        const double a[4] = {av0.x, av0.y, av1.x, av1.y};
+        const double b[4] = {bv0.x, bv0.y, bv1.x, bv1.y};
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] += a[i] * b[j];
+    }
+#else
+    const int il = lane_id() & 15, kl = lane_id() >> 4, w = wave_id();
+    d4_t c[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) c[a] = d4_t{acc[a][0], acc[a][1], acc[a][2], acc[a][3]};
+#pragma unroll
+    for (int k4 = 0; k4 < 4; k4++) {
+        const double av = As[(4 * k4 + kl) * TILE_PL + 16 * w + il];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const double bv = Bs[(4 * k4 + kl) * TILE_PL + 16 * a + il];
+            c[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c[a], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++) { acc[a][0] = c[a][0]; acc[a][1] = c[a][1]; acc[a][2] = c[a][2]; acc[a][3] = c[a][3]; }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // 64x64 tile product  acc[i][j] = sum_{k<K} A(i)[k] * B(j)[k]   (NT form; K a multiple of 16).
 // Row i of the A operand is  A + rowA(i)*lda  (rowA(i) < 0 -> zero row), same for B.
-// Thread (ty = tid>>4, tx = tid&15) owns rows 4ty..4ty+3 and columns 4tx..4tx+3.
-// LDS: arena[0 .. 2*16*68).
+// acc[a][b] holds output (tile_li(a,b), tile_lj(a,b)).   LDS: arena[0 .. 2*16*TILE_PL).
 // ---------------------------------------------------------------------------------------------
 template <class RowA, class RowB>
 __device__ __forceinline__ void wg_tile_nt(double (&acc)[4][4], const double* __restrict__ A, int lda, RowA rowA,
                                            const double* __restrict__ Bm, int ldb, RowB rowB, int K, Lds lds,
                                            int rowsValid = 64)
 {
-    // waves whose 16 output rows are all padding (>= rowsValid) skip the FMAs (their A rows are zero)
+    // waves whose 16 output rows are all padding (>= rowsValid) skip the products (their A rows are zero)
     const bool active = 16 * wave_id() < rowsValid;
-    constexpr int PL = 68;
+    constexpr int PL = TILE_PL;
     double* As = lds.arena;
     double* Bs = lds.arena + 16 * PL;
     const int t = threadIdx.x;
     const int lr = t >> 2, kq = (t & 3) * 4;   // loader: row lr, k-quad kq
-    const int ty = t >> 4, tx = t & 15;
     const long ra = rowA(lr), rb = rowB(lr);
     const double* ap = (ra >= 0) ? A + (size_t)ra * lda + kq : nullptr;
     const double* bp = (rb >= 0) ? Bm + (size_t)rb * ldb + kq : nullptr;
@@ -344,21 +418,7 @@ __device__ __forceinline__ void wg_tile_nt(double (&acc)[4][4], const double* __
         As[(kq + 0) * PL + lr] = a0.x; As[(kq + 1) * PL + lr] = a0.y; As[(kq + 2) * PL + lr] = a1.x; As[(kq + 3) * PL + lr] = a1.y;
         Bs[(kq + 0) * PL + lr] = b0.x; Bs[(kq + 1) * PL + lr] = b0.y; Bs[(kq + 2) * PL + lr] = b1.x; Bs[(kq + 3) * PL + lr] = b1.y;
         __syncthreads();
-        if (active) {
-#pragma unroll
-        for (int kk = 0; kk < 16; kk++) {
-            const double2 av0 = *reinterpret_cast<const double2*>(As + kk * PL + 4 * ty);
-            const double2 av1 = *reinterpret_cast<const double2*>(As + kk * PL + 4 * ty + 2);
-            const double2 bv0 = *reinterpret_cast<const double2*>(Bs + kk * PL + 4 * tx);
-            const double2 bv1 = *reinterpret_cast<const double2*>(Bs + kk * PL + 4 * tx + 2);
-            const double a[4] = {av0.x, av0.y, av1.x, av1.y};
-            const double b[4] = {bv0.x, bv0.y, bv1.x, bv1.y};
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] += a[i] * b[j];
-        }
-        }
+        if (active) tile_panel(acc, As, Bs);
     }
     __syncthreads();
 }
@@ -517,7 +577,6 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
         }
         __syncthreads();
         // panel:  L_IJ = A_IJ * D'   (rows of block I, k over block J)
-        const int ty = t >> 4, tx = t & 15;
         for (int I = J + 1; I < nblk; I++) {
             double acc[4][4];
             wg_tile_nt(acc, F + (size_t)(64 * I) * ld + o, ld, [](int r) { return (long)r; },
@@ -526,7 +585,7 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const int gi = 64 * I + 4 * ty + i, gj = o + 4 * tx + j;
+                    const int gi = 64 * I + tile_li(i, j), gj = o + tile_lj(i, j);
                     F[(size_t)gi * ld + gj] = acc[i][j];
                     F[(size_t)gj * ld + gi] = acc[i][j];
                 }
@@ -543,7 +602,7 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
                 for (int i = 0; i < 4; i++)
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const int gi = 64 * I + 4 * ty + i, gj = 64 * Kb + 4 * tx + j;
+                        const int gi = 64 * I + tile_li(i, j), gj = 64 * Kb + tile_lj(i, j);
                         if (I != Kb || gj <= gi) F[(size_t)gi * ld + gj] -= acc[i][j];
                     }
                 __syncthreads();
