@@ -4,7 +4,9 @@
 //                    BatchLCQProblem -- through LCQProblem / Subsolver / SubsolverHIP on GPU 0
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "BatchLCQProblem.hpp"
@@ -162,8 +164,27 @@ static void test_batch()
     }
 }
 
+static int run_from_files(const char* dir, int nV, int nC, int nComp)
+{   // examples/solve_lcqp_from_file.cpp: loadLCQP(file names) + runSolver, then print the solution
+    auto f = [&](const char* name) { static std::vector<std::string> keep; keep.push_back(std::string(dir) + "/" + name + ".txt"); return keep.back().c_str(); };
+    LCQProblem lcqp(nV, nC, nComp);
+    Options options; options.setPrintLevel(NONE); options.setPerturbStep(false);
+    lcqp.setOptions(options);
+    ReturnValue rc = lcqp.loadLCQP(f("Q"), f("g"), f("L"), f("R"), f("lbL"), f("ubL"), f("lbR"), f("ubR"), f("A"), f("lbA"), f("ubA"), f("lb"), f("ub"), f("x0"));
+    if (rc != SUCCESSFUL_RETURN) { std::printf("load failed %d\n", (int)rc); return 1; }
+    rc = lcqp.runSolver();
+    std::vector<double> x(nV);
+    lcqp.getPrimalSolution(x.data());
+    OutputStatistics st; lcqp.getOutputStatistics(st);
+    std::printf("files ret = %d; i = %d; k = %d; rho = %g; status = %d\nx =", (int)rc, st.getIterTotal(), st.getIterOuter(), st.getRhoOpt(), (int)st.getSolutionStatus());
+    for (int i = 0; i < nV; i++) std::printf(" %.17g", x[i]);
+    std::printf("\n");
+    return rc == SUCCESSFUL_RETURN ? 0 : 1;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc > 5 && !std::strcmp(argv[1], "files")) return run_from_files(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]));
     const bool gpu = argc > 1 && !std::strcmp(argv[1], "gpu");
     test_utilities();
     test_options();

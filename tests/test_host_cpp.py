@@ -29,3 +29,25 @@ def test_host_layer_gpu():
     assert r.returncode == 0 and "ALL PASSED" in r.stdout, r.stdout + r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith("circle xOpt")][0]
     assert "i = 26; k = 8; rho = 2.56" in line, line     # same iterate counts as the oracle / device loop
+
+
+@pytest.mark.gpu
+def test_host_file_loader_example_data(tmp_path, oracle):
+    """LCQProblem::loadLCQP(file names) (src/LCQProblem.cpp:147-387, Utilities::readFromFile :341-366) on the
+    reference's example_data fixture (one value per line, inf accepted), solved through SubsolverHIP and
+    compared with the oracle."""
+    import numpy as np
+    import problems as P
+    z = np.load(os.path.join(P.GOLDEN, "example_data.npz"))
+    for k in z.files:
+        with open(tmp_path / (k + ".txt"), "w") as f:
+            for v in np.ravel(z[k]):
+                f.write("Inf\n" if v == np.inf else "-Inf\n" if v == -np.inf else repr(float(v)) + "\n")
+    d = P.example_data()
+    r = subprocess.run([_exe(), "files", str(tmp_path), str(d["nV"]), str(d["nC"]), str(d["nComp"])], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.splitlines()
+    assert "ret = 0; i = 34; k = 8; rho = 2.56" in lines[0], lines[0]
+    x = np.array([float(t) for t in lines[1].split()[2:]])
+    ro = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0))
+    assert np.abs(x - ro["x"]).max() < 1e-7
