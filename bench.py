@@ -35,6 +35,19 @@ def shard_range(rank, world, per_rank):
     return first, first + per_rank
 
 
+def pmc_traffic(B, n, nC, nComp):
+    """HBM bytes per k_lcqp_run launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/round1/README.md: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes); counters cannot be
+    read from inside an un-profiled run, so the value is null for any other workload or when the file is absent."""
+    if (B, n, nC, nComp) != (1024, 256, 512, 64):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
+            return float(json.load(f)["traffic_bytes_guide_recipe"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +142,7 @@ def main():
                    "mean_backsolve_pairs": mean("corrections"), "mean_admm_iters": mean("admmIter"),
                    "setup_ms_per_step": setup_ms / args.steps, "homotopy_kernel_ms_per_step": solve_ms / args.steps},
         "roofline": {"bound": "hbm", "kernel": "k_lcqp_run", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(B, n, nC, nComp),
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
 

@@ -284,3 +284,39 @@ def test_lcqp_full_batch_properties(hip):
     x2, y2, st2 = bt.solution()
     assert np.array_equal(x, x2) and np.array_equal(y, y2)
     bt.close()
+
+
+def test_lcqp_default_options_with_perturbation(hip, oracle):
+    """reference defaults (perturbStep = true, src/Options.cpp:303) on the synthetic workload: the seeded
+    perturbation stream is identical on both sides, so iterates still match the oracle"""
+    B, n, nC, nComp = 16, 256, 512, 64
+    bt = hip.BatchLCQP(B, n, nC, nComp, opt=hip.default_options())
+    bt.generate_synthetic(0)
+    bt.run()
+    x, y, st = bt.solution()
+    assert all(s["returnValue"] == 0 for s in st)
+    oopt = oracle.default_options()
+    for b in (0, 7, 15):
+        d = bt.read_problem(b)
+        ro = oracle.lcqp_solve(d["Q"], d["g"], d["L"], d["R"], A=d["A"], lbA=d["lbA"], ubA=d["ubA"], opt=oopt)
+        assert ro["ret"] == 0 and np.abs(ro["x"] - x[b]).max() < X_TOL
+    bt.close()
+
+
+def test_lcqp_node_sized_batch_on_one_gpu(hip):
+    """BASELINE config C4's 8192 instances (8 x 1024) resident on ONE GPU (51 GB of the 288 GB): every
+    instance solves; the shard [1024, 2048) equals what rank 1 of the sharded run computes."""
+    n, nC, nComp = 256, 512, 64
+    bt = hip.BatchLCQP(8192, n, nC, nComp, opt=hip.default_options(perturbStep=0))
+    bt.generate_synthetic(0)
+    bt.run()
+    x, y, st = bt.solution()
+    assert all(s["returnValue"] == 0 for s in st)
+    assert np.abs((x[:, :nComp] * x[:, nComp:2 * nComp]).sum(axis=1)).max() < 1e3 * 2.221e-16
+    bt.close()
+    b1 = hip.BatchLCQP(1024, n, nC, nComp, opt=hip.default_options(perturbStep=0))
+    b1.generate_synthetic(1024)          # rank 1's slice of instance ids
+    b1.run()
+    x1, _, _ = b1.solution()
+    b1.close()
+    assert np.array_equal(x1, x[1024:2048])
