@@ -170,13 +170,16 @@ def main():
         tc = time.perf_counter()
         ok, xo, yo, so = O.synth_batch_solve(0, cnt, n, nC, nComp, opt=oopt, threads=threads)
         dtc = time.perf_counter() - tc
+        t1 = time.perf_counter()
+        O.synth_batch_solve(0, 4, n, nC, nComp, opt=oopt, threads=1, want_xy=False)     # one core, no contention
+        single = 4 / (time.perf_counter() - t1)
         dx = float(np.abs(xo[: min(cnt, B)] - x[: min(cnt, B)]).max())
         out["cpu_baseline"] = {"value": cnt / dtc, "unit": "LCQPs/s", "cores": threads, "kind": "port",
                                "sample": f"instances 0..{cnt - 1} of the same synthetic workload, CPU oracle "
                                          f"(oracle/lcqp_oracle.c, same algorithm in scalar C; the reference's qpOASES "
                                          f"path cannot be built: external/qpOASES is empty), one LCQP per thread, "
                                          f"{ok}/{cnt} solved in {dtc:.2f} s",
-                               "max_abs_dx_vs_gpu": dx}
+                               "single_core_value": single, "max_abs_dx_vs_gpu": dx}
     bt.close()
     if dist is not None:
         dist.barrier()
