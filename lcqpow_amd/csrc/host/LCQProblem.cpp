@@ -6,9 +6,13 @@
 
 namespace LCQPow {
 
-LCQProblem::LCQProblem() : nV(0), nC(0), nComp(0), nDuals(0), boxDualOffset(0), device(0), loaded(false) {}
+LCQProblem::LCQProblem()
+    : nV(0), nC(0), nComp(0), nDuals(0), boxDualOffset(0), device(0), loaded(false), sparseSolver(false),
+      Q_sparse(0), A_sparse(0), L_sparse(0), R_sparse(0), C_sparse(0) {}
 
-LCQProblem::LCQProblem(int _nV, int _nC, int _nComp) : nV(0), nC(0), nComp(0), nDuals(0), boxDualOffset(0), device(0), loaded(false)
+LCQProblem::LCQProblem(int _nV, int _nC, int _nComp)
+    : nV(0), nC(0), nComp(0), nDuals(0), boxDualOffset(0), device(0), loaded(false), sparseSolver(false),
+      Q_sparse(0), A_sparse(0), L_sparse(0), R_sparse(0), C_sparse(0)
 {
     // consistency checks of the reference constructor (src/LCQProblem.cpp:43-67)
     if (_nV <= 0 || _nComp <= 0 || _nC < 0) return;
@@ -28,6 +32,8 @@ ReturnValue LCQProblem::loadLCQP(const double* const _Q, const double* const _g,
     if (!_L || !_R) return INVALID_COMPLEMENTARITY_MATRIX;
     const int m = nC + 2 * nComp;
     const double inf = INFINITY;
+    clearSparse();
+    sparseSolver = false;
     Q.assign(_Q, _Q + (size_t)nV * nV);
     g.assign(_g, _g + nV);
     L.assign(_L, _L + (size_t)nComp * nV);
@@ -102,13 +108,124 @@ ReturnValue LCQProblem::loadLCQP(const char* const Q_file, const char* const g_f
                     p(a, b[4]), p(vlbA, b[5]), p(vubA, b[6]), p(vlb, b[7]), p(vub, b[8]), p(vx0, b[9]), p(vy0, b[10]));
 }
 
+LCQProblem::~LCQProblem() { clearSparse(); }
+
+void LCQProblem::clearSparse()
+{
+    Utilities::ClearSparseMat(&Q_sparse); Utilities::ClearSparseMat(&A_sparse); Utilities::ClearSparseMat(&L_sparse);
+    Utilities::ClearSparseMat(&R_sparse); Utilities::ClearSparseMat(&C_sparse);
+}
+
+ReturnValue LCQProblem::loadLCQP(const csc* const _Q, const double* const _g, const csc* const _L, const csc* const _R,
+                                 const double* const _lbL, const double* const _ubL, const double* const _lbR,
+                                 const double* const _ubR, const csc* const _A, const double* const _lbA,
+                                 const double* const _ubA, const double* const _lb, const double* const _ub,
+                                 const double* const _x0, const double* const _y0)
+{
+    // going through the dense loader keeps one implementation of the bound handling (setConstraints /
+    // setComplementarityBounds / setInitialGuess); the data are then held in CSC form as the reference does
+    if (nV <= 0 || nComp <= 0) return LCQPOBJECT_NOT_SETUP;
+    if (!_Q) return INVALID_ARGUMENT;
+    if (!_L || !_R) return INVALID_COMPLEMENTARITY_MATRIX;
+    if (!_A && nC > 0) return INVALID_CONSTRAINT_MATRIX;
+    double *dQ = Utilities::csc_to_dns(_Q), *dL = Utilities::csc_to_dns(_L), *dR = Utilities::csc_to_dns(_R);
+    double* dA = (_A && nC > 0) ? Utilities::csc_to_dns(_A) : 0;
+    ReturnValue rc = (dQ && dL && dR && (dA || nC == 0)) ? loadLCQP(dQ, _g, dL, dR, _lbL, _ubL, _lbR, _ubR, dA, _lbA, _ubA, _lb, _ub, _x0, _y0)
+                                                         : INDEX_OUT_OF_BOUNDS;
+    delete[] dQ; delete[] dL; delete[] dR; delete[] dA;
+    if (rc != SUCCESSFUL_RETURN) return rc;
+    return switchToSparseMode();
+}
+
+ReturnValue LCQProblem::switchToSparseMode()
+{
+    if (!loaded) return LCQPOBJECT_NOT_SETUP;
+    if (sparseSolver) return SUCCESSFUL_RETURN;
+    const int m = nC + 2 * nComp;
+    Q_sparse = Utilities::dns_to_csc(Q.data(), nV, nV);
+    A_sparse = Utilities::dns_to_csc(A.data(), m, nV);
+    L_sparse = Utilities::dns_to_csc(L.data(), nComp, nV);
+    R_sparse = Utilities::dns_to_csc(R.data(), nComp, nV);
+    C_sparse = Utilities::dns_to_csc(C.data(), nV, nV);
+    if (!Q_sparse || !A_sparse || !L_sparse || !R_sparse || !C_sparse) { clearSparse(); return FAILED_SWITCH_TO_SPARSE; }
+    std::vector<double>().swap(Q); std::vector<double>().swap(A); std::vector<double>().swap(L);
+    std::vector<double>().swap(R); std::vector<double>().swap(C);
+    sparseSolver = true;
+    return SUCCESSFUL_RETURN;
+}
+
+ReturnValue LCQProblem::switchToDenseMode()
+{
+    if (!loaded) return LCQPOBJECT_NOT_SETUP;
+    if (!sparseSolver) return SUCCESSFUL_RETURN;
+    double *q = Utilities::csc_to_dns(Q_sparse), *a = Utilities::csc_to_dns(A_sparse), *l = Utilities::csc_to_dns(L_sparse);
+    double *r = Utilities::csc_to_dns(R_sparse), *c = Utilities::csc_to_dns(C_sparse);
+    const bool ok = q && a && l && r && c;
+    if (ok) {
+        const int m = nC + 2 * nComp;
+        Q.assign(q, q + (size_t)nV * nV); A.assign(a, a + (size_t)m * nV); L.assign(l, l + (size_t)nComp * nV);
+        R.assign(r, r + (size_t)nComp * nV); C.assign(c, c + (size_t)nV * nV);
+        clearSparse();
+        sparseSolver = false;
+    }
+    delete[] q; delete[] a; delete[] l; delete[] r; delete[] c;
+    return ok ? SUCCESSFUL_RETURN : FAILED_SWITCH_TO_DENSE;
+}
+
+void LCQProblem::mulQ(const double* v, double* out) const
+{
+    if (sparseSolver) { std::vector<double> z(nV, 0.0); Utilities::AffineLinearTransformation(1.0, Q_sparse, v, z.data(), out, nV); }
+    else Utilities::MatrixMultiplication(Q.data(), v, out, nV, nV, 1);
+}
+void LCQProblem::mulC(const double* v, double* out) const
+{
+    if (sparseSolver) { std::vector<double> z(nV, 0.0); Utilities::AffineLinearTransformation(1.0, C_sparse, v, z.data(), out, nV); }
+    else Utilities::MatrixMultiplication(C.data(), v, out, nV, nV, 1);
+}
+void LCQProblem::mulAT(const double* y, double* out) const
+{
+    if (sparseSolver) Utilities::TransponsedMatrixMultiplication(A_sparse, y, out);
+    else Utilities::TransponsedMatrixMultiplication(A.data(), y, out, nC + 2 * nComp, nV, 1);
+}
+void LCQProblem::mulL(const double* v, double* out) const
+{
+    if (sparseSolver) Utilities::MatrixMultiplication(L_sparse, v, out);
+    else Utilities::MatrixMultiplication(L.data(), v, out, nComp, nV, 1);
+}
+void LCQProblem::mulR(const double* v, double* out) const
+{
+    if (sparseSolver) Utilities::MatrixMultiplication(R_sparse, v, out);
+    else Utilities::MatrixMultiplication(R.data(), v, out, nComp, nV, 1);
+}
+void LCQProblem::addLT(const double* y, double* out) const
+{
+    if (sparseSolver) Utilities::AddTransponsedMatrixMultiplication(L_sparse, y, out);
+    else Utilities::AddTransponsedMatrixMultiplication(L.data(), y, out, nComp, nV, 1);
+}
+void LCQProblem::addRT(const double* y, double* out) const
+{
+    if (sparseSolver) Utilities::AddTransponsedMatrixMultiplication(R_sparse, y, out);
+    else Utilities::AddTransponsedMatrixMultiplication(R.data(), y, out, nComp, nV, 1);
+}
+
 ReturnValue LCQProblem::initializeSolver()
 {
     if (!loaded) return LCQPOBJECT_NOT_SETUP;
     if (options.getQPSolver() != HIP_DENSE) return NOT_YET_IMPLEMENTED;   // qpOASES / OSQP arms need un-vendored code
     const int m = nC + 2 * nComp;
-    Subsolver tmp(nV, m, Q.data(), A.data(), HIP_DENSE, device);
-    subsolver = tmp;
+    if (sparseSolver) {
+        // CSC problem data: the loop below runs on the CSC Utilities; the device subsolver of this round is dense,
+        // so it receives dense copies of Q and [A;L;R] (the reference's QPOASES_SPARSE arm hands the CSC arrays to
+        // qpOASES instead, src/LCQProblem.cpp:908-927; its dual layout -- box duals first -- is the one used here)
+        double *q = Utilities::csc_to_dns(Q_sparse), *a = Utilities::csc_to_dns(A_sparse);
+        if (!q || !a) { delete[] q; delete[] a; return FAILED_SWITCH_TO_DENSE; }
+        Subsolver tmp(nV, m, q, a, HIP_DENSE, device);
+        subsolver = tmp;
+        delete[] q; delete[] a;
+    } else {
+        Subsolver tmp(nV, m, Q.data(), A.data(), HIP_DENSE, device);
+        subsolver = tmp;
+    }
     subsolver.setOptions(options.getHIPOptions());
     gTilde = g;
     phiConst = 0.0;
@@ -116,11 +233,11 @@ ReturnValue LCQProblem::initializeSolver()
     if (haveLbL || haveLbR) {
         phiConst = Utilities::DotProduct(lbL.data(), lbR.data(), nComp);
         gPhi.assign(nV, 0.0);
-        if (haveLbL) Utilities::AddTransponsedMatrixMultiplication(R.data(), lbL.data(), gPhi.data(), nComp, nV, 1);
-        if (haveLbR) Utilities::AddTransponsedMatrixMultiplication(L.data(), lbR.data(), gPhi.data(), nComp, nV, 1);
+        if (haveLbL) addRT(lbL.data(), gPhi.data());
+        if (haveLbR) addLT(lbR.data(), gPhi.data());
         for (int i = 0; i < nV; ++i) gPhi[i] = -gPhi[i];
     }
-    Qk.assign((size_t)nV * nV, 0.0);
+    Qx.assign(nV, 0.0); Cx.assign(nV, 0.0); Qp.assign(nV, 0.0); Cp.assign(nV, 0.0);
     gk.assign(nV, 0.0); xnew.assign(nV, 0.0); pk.assign(nV, 0.0); statk.assign(nV, 0.0);
     constrStatk.assign(nV, 0.0); lkTmp.assign(nV, 0.0); ykA.assign(m, 0.0);
     alphak = 1.0;
@@ -143,8 +260,7 @@ ReturnValue LCQProblem::runSolver()
     else updateLinearization();
     ret = solveQPSubproblem(true);
     if (ret != SUCCESSFUL_RETURN) return ret;
-    Utilities::WeightedMatrixAdd(1, Q.data(), rho, C.data(), Qk.data(), nV, nV);
-    stats.updateRhoOpt(rho);
+    stats.updateRhoOpt(rho);   // Qk = Q + rho C is applied as Q v + rho C v (dense and CSC mode alike)
     for (;;) {
         Utilities::WeightedVectorAdd(1, xk.data(), alphak, pk.data(), xk.data(), nV);
         updateStationarity();
@@ -179,7 +295,8 @@ ReturnValue LCQProblem::runSolver()
 
 void LCQProblem::updateLinearization()
 {
-    Utilities::AffineLinearTransformation(rho, C.data(), xk.data(), gTilde.data(), gk.data(), nV, nV);
+    mulC(xk.data(), Cx.data());
+    for (int i = 0; i < nV; ++i) gk[i] = rho * Cx[i] + gTilde[i];
 }
 
 ReturnValue LCQProblem::solveQPSubproblem(bool initialSolve)
@@ -199,24 +316,36 @@ ReturnValue LCQProblem::solveQPSubproblem(bool initialSolve)
 double LCQProblem::getPhi()
 {
     double lin = gPhi.empty() ? 0.0 : Utilities::DotProduct(gPhi.data(), xk.data(), nV);
-    return phiConst + lin + Utilities::QuadraticFormProduct(C.data(), xk.data(), nV) / 2.0;
+    mulC(xk.data(), Cx.data());
+    return phiConst + lin + Utilities::DotProduct(xk.data(), Cx.data(), nV) / 2.0;
 }
-double LCQProblem::getObj() { return Utilities::DotProduct(g.data(), xk.data(), nV) + Utilities::QuadraticFormProduct(Q.data(), xk.data(), nV) / 2.0; }
-double LCQProblem::getMerit() { return Utilities::DotProduct(g.data(), xk.data(), nV) + Utilities::QuadraticFormProduct(Qk.data(), xk.data(), nV) / 2.0; }
+double LCQProblem::getObj()
+{
+    mulQ(xk.data(), Qx.data());
+    return Utilities::DotProduct(g.data(), xk.data(), nV) + Utilities::DotProduct(xk.data(), Qx.data(), nV) / 2.0;
+}
+double LCQProblem::getMerit()
+{
+    mulQ(xk.data(), Qx.data()); mulC(xk.data(), Cx.data());
+    double s = 0.0;
+    for (int i = 0; i < nV; ++i) s += xk[i] * (Qx[i] + rho * Cx[i]);
+    return Utilities::DotProduct(g.data(), xk.data(), nV) + s / 2.0;
+}
 
 void LCQProblem::updatePenalty()
 {
     if (options.getNDynamicPenalty() > 0) complHistory.clear();
     rho *= options.getPenaltyUpdateFactor();
     stats.updateRhoOpt(rho);
-    Utilities::WeightedMatrixAdd(1, Q.data(), rho, C.data(), Qk.data(), nV, nV);
     if (!gPhi.empty()) Utilities::WeightedVectorAdd(1.0, g.data(), rho, gPhi.data(), gTilde.data(), nV);
 }
 
 void LCQProblem::getOptimalStepLength()
 {
-    const double qk = Utilities::QuadraticFormProduct(Qk.data(), pk.data(), nV);
-    Utilities::AffineLinearTransformation(1, Qk.data(), xk.data(), gTilde.data(), lkTmp.data(), nV, nV);
+    mulQ(pk.data(), Qp.data()); mulC(pk.data(), Cp.data());
+    mulQ(xk.data(), Qx.data()); mulC(xk.data(), Cx.data());
+    double qk = 0.0;
+    for (int i = 0; i < nV; ++i) { qk += pk[i] * (Qp[i] + rho * Cp[i]); lkTmp[i] = (Qx[i] + rho * Cx[i]) + gTilde[i]; }
     const double lk = Utilities::DotProduct(pk.data(), lkTmp.data(), nV);
     alphak = 1.0;
     if (qk > 0 && lk < 0) alphak = std::min(-lk / qk, 1.0);
@@ -224,9 +353,9 @@ void LCQProblem::getOptimalStepLength()
 
 void LCQProblem::updateStationarity()
 {
-    Utilities::AffineLinearTransformation(1, Qk.data(), xk.data(), gTilde.data(), statk.data(), nV, nV);
-    Utilities::TransponsedMatrixMultiplication(A.data(), ykA.data(), constrStatk.data(), nC + 2 * nComp, nV, 1);
-    for (int i = 0; i < nV; ++i) statk[i] = statk[i] - constrStatk[i] - yk[i];
+    mulQ(xk.data(), Qx.data()); mulC(xk.data(), Cx.data());
+    mulAT(ykA.data(), constrStatk.data());
+    for (int i = 0; i < nV; ++i) statk[i] = ((Qx[i] + rho * Cx[i]) + gTilde[i]) - constrStatk[i] - yk[i];
 }
 
 bool LCQProblem::leyfferCheckPositive()
@@ -261,17 +390,17 @@ void LCQProblem::perturbStep()
 void LCQProblem::transformDuals()
 {
     std::vector<double> tmp(nComp);
-    Utilities::MatrixMultiplication(R.data(), xk.data(), tmp.data(), nComp, nV, 1);
+    mulR(xk.data(), tmp.data());
     for (int i = 0; i < nComp; ++i) yk[boxDualOffset + nC + i] -= rho * tmp[i];
-    Utilities::MatrixMultiplication(L.data(), xk.data(), tmp.data(), nComp, nV, 1);
+    mulL(xk.data(), tmp.data());
     for (int i = 0; i < nComp; ++i) yk[boxDualOffset + nC + nComp + i] -= rho * tmp[i];
 }
 
 void LCQProblem::determineStationarityType()
 {
     std::vector<double> Lx(nComp), Rx(nComp);
-    Utilities::MatrixMultiplication(L.data(), xk.data(), Lx.data(), nComp, nV, 1);
-    Utilities::MatrixMultiplication(R.data(), xk.data(), Rx.data(), nComp, nV, 1);
+    mulL(xk.data(), Lx.data());
+    mulR(xk.data(), Rx.data());
     const double ctol = options.getComplementarityTolerance();
     bool s = true, m = true;
     for (int i = 0; i < nComp; ++i) {

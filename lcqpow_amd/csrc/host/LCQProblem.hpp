@@ -32,6 +32,18 @@ class LCQProblem {
                          const char* const lbR_file = 0, const char* const ubR_file = 0, const char* const A_file = 0,
                          const char* const lbA_file = 0, const char* const ubA_file = 0, const char* const lb_file = 0,
                          const char* const ub_file = 0, const char* const x0_file = 0, const char* const y0_file = 0);
+    // sparse overload of loadLCQP (src/LCQProblem.cpp:390-441): CSC matrices, copied
+    ReturnValue loadLCQP(const csc* const Q, const double* const g, const csc* const L, const csc* const R,
+                         const double* const lbL = 0, const double* const ubL = 0, const double* const lbR = 0,
+                         const double* const ubR = 0, const csc* const A = 0, const double* const lbA = 0,
+                         const double* const ubA = 0, const double* const lb = 0, const double* const ub = 0,
+                         const double* const x0 = 0, const double* const y0 = 0);
+    // src/LCQProblem.cpp:1037-1102: convert the stored problem between dense arrays and CSC
+    ReturnValue switchToSparseMode();
+    ReturnValue switchToDenseMode();
+    ~LCQProblem();
+    LCQProblem(const LCQProblem&) = delete;
+    LCQProblem& operator=(const LCQProblem&) = delete;
     ReturnValue runSolver();
     AlgorithmStatus getPrimalSolution(double* const xOpt) const;
     AlgorithmStatus getDualSolution(double* const yOpt) const;
@@ -58,10 +70,21 @@ class LCQProblem {
     double getObj();
     double getMerit();
 
+    // products with the stored matrices in whichever mode the problem is held (dense arrays or CSC)
+    void mulQ(const double* v, double* out) const;      // out = Q v
+    void mulC(const double* v, double* out) const;      // out = C v
+    void mulAT(const double* y, double* out) const;     // out = [A;L;R]' y
+    void mulL(const double* v, double* out) const;      // out = L v
+    void mulR(const double* v, double* out) const;      // out = R v
+    void addLT(const double* y, double* out) const;     // out += L' y
+    void addRT(const double* y, double* out) const;     // out += R' y
+    void clearSparse();
+
     int nV, nC, nComp, nDuals, boxDualOffset, device;
-    bool loaded, haveYk, haveLbL, haveLbR;
+    bool loaded, haveYk, haveLbL, haveLbR, sparseSolver;
+    csc *Q_sparse, *A_sparse, *L_sparse, *R_sparse, *C_sparse;
     std::vector<double> Q, g, L, R, A, lbA, ubA, lb, ub, lbL, lbR, C, Qk;
-    std::vector<double> gTilde, gPhi, xk, yk, ykA, gk, xnew, pk, statk, constrStatk, lkTmp;
+    std::vector<double> gTilde, gPhi, xk, yk, ykA, gk, xnew, pk, statk, constrStatk, lkTmp, Qx, Cx, Qp, Cp;
     double phiConst, alphak, rho;
     int outerIter, innerIter, totalIter, qpIterk, qpSolverExitFlag;
     unsigned long long perturbCounter;

@@ -102,3 +102,155 @@ ReturnValue Utilities::readFromFile(double* data, int n, const char* datafilenam
 }
 
 }  // namespace LCQPow
+
+// -------------------------------------------------------------------------------------------------
+// CSC half.  Storage is malloc'ed like in the reference so that ClearSparseMat can free what createCSC
+// was handed (src/Utilities.cpp:268-309,469-484).
+// -------------------------------------------------------------------------------------------------
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace LCQPow {
+
+csc* Utilities::createCSC(int m, int n, int nnx, double* x, int* i, int* p)
+{
+    csc* M = (csc*)std::malloc(sizeof(csc));
+    if (!M) return 0;
+    M->m = m; M->n = n; M->p = p; M->i = i; M->x = x; M->nz = -1; M->nzmax = nnx;
+    return M;
+}
+
+csc* Utilities::copyCSC(int m, int n, int nnx, const double* x, const int* i, const int* p)
+{
+    int* rows = (int*)std::malloc(sizeof(int) * (size_t)(nnx > 0 ? nnx : 1));
+    double* data = (double*)std::malloc(sizeof(double) * (size_t)(nnx > 0 ? nnx : 1));
+    int* cols = (int*)std::malloc(sizeof(int) * (size_t)(n + 1));
+    if (nnx > 0) { std::memcpy(rows, i, sizeof(int) * (size_t)nnx); std::memcpy(data, x, sizeof(double) * (size_t)nnx); }
+    std::memcpy(cols, p, sizeof(int) * (size_t)(n + 1));
+    return createCSC(m, n, nnx, data, rows, cols);
+}
+
+csc* Utilities::copyCSC(const csc* src, bool toUpperTriangular)
+{
+    if (!src) return 0;
+    if (!toUpperTriangular) return copyCSC(src->m, src->n, src->p[src->n], src->x, src->i, src->p);
+    std::vector<int> rows;
+    std::vector<double> data;
+    int* cols = (int*)std::malloc(sizeof(int) * (size_t)(src->n + 1));
+    cols[0] = 0;
+    for (int c = 0; c < src->n; ++c) {
+        for (int k = src->p[c]; k < src->p[c + 1]; ++k)
+            if (src->i[k] <= c) { rows.push_back(src->i[k]); data.push_back(src->x[k]); }   // on or above the diagonal
+        cols[c + 1] = (int)rows.size();
+    }
+    csc* M = copyCSC(src->m, src->n, (int)rows.size(), data.data(), rows.data(), cols);
+    std::free(cols);
+    return M;
+}
+
+void Utilities::ClearSparseMat(csc** M)
+{
+    if (!M || !*M) return;
+    std::free((*M)->p); std::free((*M)->i); std::free((*M)->x);
+    std::free(*M);
+    *M = 0;
+}
+
+double* Utilities::csc_to_dns(const csc* S)
+{
+    const int m = S->m, n = S->n;
+    double* full = new double[(size_t)m * n]();
+    for (int c = 0; c < n; ++c)
+        for (int k = S->p[c]; k < S->p[c + 1]; ++k) {
+            if (k == S->nzmax) return full;
+            if (S->i[k] < 0 || S->i[k] >= m) { delete[] full; return 0; }   // INDEX_OUT_OF_BOUNDS
+            full[(size_t)S->i[k] * n + c] = S->x[k];
+        }
+    return full;
+}
+
+csc* Utilities::dns_to_csc(const double* full, int m, int n)
+{
+    std::vector<int> rows;
+    std::vector<double> data;
+    std::vector<int> cols(n + 1, 0);
+    for (int c = 0; c < n; ++c) {
+        for (int r = 0; r < m; ++r) {
+            const double v = full[(size_t)r * n + c];
+            if (v > 0 || v < 0) { rows.push_back(r); data.push_back(v); }
+        }
+        cols[c + 1] = (int)rows.size();
+    }
+    return copyCSC(m, n, (int)rows.size(), data.data(), rows.data(), cols.data());
+}
+
+void Utilities::MatrixMultiplication(const csc* A, const double* b, double* c)
+{
+    for (int r = 0; r < A->m; ++r) c[r] = 0.0;
+    for (int col = 0; col < A->n; ++col)
+        for (int k = A->p[col]; k < A->p[col + 1]; ++k) c[A->i[k]] += A->x[k] * b[col];
+}
+
+void Utilities::TransponsedMatrixMultiplication(const csc* A, const double* b, double* c)
+{
+    for (int col = 0; col < A->n; ++col) c[col] = 0.0;
+    AddTransponsedMatrixMultiplication(A, b, c);
+}
+
+void Utilities::AddTransponsedMatrixMultiplication(const csc* A, const double* b, double* c)
+{
+    for (int col = 0; col < A->n; ++col) {
+        double s = 0.0;
+        for (int k = A->p[col]; k < A->p[col + 1]; ++k) s += b[A->i[k]] * A->x[k];
+        c[col] += s;
+    }
+}
+
+csc* Utilities::MatrixSymmetrizationProduct(const csc* L, const csc* R)
+{
+    // C = L'R + R'L column by column: column j of L'R is L' * (column j of R); a dense accumulator per column
+    const int n = L->n;
+    std::vector<int> rows, cols(n + 1, 0);
+    std::vector<double> data, acc(n, 0.0), colL(L->m, 0.0), colR(R->m, 0.0);
+    for (int j = 0; j < n; ++j) {
+        for (int k = R->p[j]; k < R->p[j + 1]; ++k) colR[R->i[k]] = R->x[k];
+        for (int k = L->p[j]; k < L->p[j + 1]; ++k) colL[L->i[k]] = L->x[k];
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0;
+            for (int k = L->p[i]; k < L->p[i + 1]; ++k) s += L->x[k] * colR[L->i[k]];
+            for (int k = R->p[i]; k < R->p[i + 1]; ++k) s += R->x[k] * colL[R->i[k]];
+            acc[i] = s;
+        }
+        for (int i = 0; i < n; ++i)
+            if (std::fabs(acc[i]) > ZERO) { rows.push_back(i); data.push_back(acc[i]); }
+        cols[j + 1] = (int)rows.size();
+        for (int k = R->p[j]; k < R->p[j + 1]; ++k) colR[R->i[k]] = 0.0;
+        for (int k = L->p[j]; k < L->p[j + 1]; ++k) colL[L->i[k]] = 0.0;
+    }
+    if (rows.empty()) return 0;
+    return copyCSC(n, n, (int)rows.size(), data.data(), rows.data(), cols.data());
+}
+
+void Utilities::AffineLinearTransformation(double alpha, const csc* S, const double* b, const double* c, double* d, int m)
+{
+    // column sums, i.e. S'b: equal to S b for the symmetric matrices it is used with (as in the reference)
+    for (int col = 0; col < m; ++col) {
+        double s = 0.0;
+        for (int k = S->p[col]; k < S->p[col + 1]; ++k) s += S->x[k] * b[S->i[k]];
+        d[col] = alpha * s + c[col];
+    }
+}
+
+double Utilities::QuadraticFormProduct(const csc* S, const double* p, int m)
+{
+    double total = 0.0;
+    for (int col = 0; col < m; ++col) {
+        double s = 0.0;
+        for (int k = S->p[col]; k < S->p[col + 1]; ++k) s += S->x[k] * p[S->i[k]];
+        total += p[col] * s;
+    }
+    return total;
+}
+
+}  // namespace LCQPow

@@ -61,6 +61,16 @@ enum PrintLevel { NONE = 0, OUTER_LOOP_ITERATES = 1, INNER_LOOP_ITERATES = 2 };
 // include/Utilities.hpp:125-129 plus the new backend (SURVEY.md §8b touch-point 1)
 enum QPSolver { QPOASES_DENSE = 0, QPOASES_SPARSE = 1, OSQP_SPARSE = 2, HIP_DENSE = 3 };
 
+// Compressed sparse column matrix with the fields of the `csc` struct the reference takes from <osqp.h>
+// (used at src/Utilities.cpp:469-484): column pointers p[n+1], row indices i[nzmax], values x[nzmax].
+struct csc {
+    int nzmax, m, n;
+    int* p;
+    int* i;
+    double* x;
+    int nz;   // -1: compressed-column form
+};
+
 class Utilities {
   public:
     static constexpr double EPS = 2.221e-16;
@@ -86,6 +96,20 @@ class Utilities {
     static double DotProduct(const double* a, const double* b, int m);
     static double MaxAbs(const double* a, int m);
     static ReturnValue readFromFile(double* data, int n, const char* datafilename);   // src/Utilities.cpp:341-366
+
+    // ---- CSC half (src/Utilities.cpp:49-59,75-82,96-102,118-173,189-199,228-241,268-309,469-650) ----
+    static csc* createCSC(int m, int n, int nnx, double* x, int* i, int* p);          // takes ownership of x, i, p
+    static csc* copyCSC(int m, int n, int nnx, const double* x, const int* i, const int* p);
+    static csc* copyCSC(const csc* M, bool toUpperTriangular = false);
+    static void ClearSparseMat(csc** M);
+    static double* csc_to_dns(const csc* sparse);                                      // new[]; caller delete[]s
+    static csc* dns_to_csc(const double* full, int m, int n);
+    static void MatrixMultiplication(const csc* A, const double* b, double* c);       // c = A b
+    static void TransponsedMatrixMultiplication(const csc* A, const double* b, double* c);      // c = A' b
+    static void AddTransponsedMatrixMultiplication(const csc* A, const double* b, double* c);   // c += A' b
+    static csc* MatrixSymmetrizationProduct(const csc* L, const csc* R);               // L'R + R'L, 0 when empty
+    static void AffineLinearTransformation(double alpha, const csc* S, const double* b, const double* c, double* d, int m);
+    static double QuadraticFormProduct(const csc* S, const double* p, int m);
 };
 
 }  // namespace LCQPow

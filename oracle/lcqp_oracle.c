@@ -1069,3 +1069,163 @@ int orc_synth_batch_solve(uint64_t seed0, int first, int count, int n, int nC, i
     pthread_mutex_destroy(&c.mu);
     return c.ok;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * CSC utilities restated (src/Utilities.cpp:49-59,75-82,96-102,118-173,189-199,228-241,469-650)
+ * ---------------------------------------------------------------------------------------------- */
+orc_csc_t* orc_csc_create(int m, int n, int nnz, const double* x, const int* i, const int* p)
+{ /* copyCSC(int,int,int,...) :487-513 */
+    orc_csc_t* M = (orc_csc_t*)malloc(sizeof(orc_csc_t));
+    M->m = m; M->n = n; M->nzmax = nnz; M->nz = -1;
+    M->p = (int*)malloc(sizeof(int) * (n + 1));
+    M->i = (int*)malloc(sizeof(int) * (nnz ? nnz : 1));
+    M->x = (double*)malloc(sizeof(double) * (nnz ? nnz : 1));
+    memcpy(M->p, p, sizeof(int) * (n + 1));
+    if (nnz) { memcpy(M->i, i, sizeof(int) * nnz); memcpy(M->x, x, sizeof(double) * nnz); }
+    return M;
+}
+
+void orc_csc_free(orc_csc_t* M)
+{
+    if (!M) return;
+    free(M->p); free(M->i); free(M->x); free(M);
+}
+
+orc_csc_t* orc_csc_upper(const orc_csc_t* A)
+{ /* copyCSC(M, toUpperTriangular = true) :516-560: keep entries on or above the diagonal */
+    int cnt = 0;
+    for (int j = 0; j < A->n; j++)
+        for (int k = A->p[j]; k < A->p[j + 1]; k++) cnt += (A->i[k] <= j);
+    orc_csc_t* M = (orc_csc_t*)malloc(sizeof(orc_csc_t));
+    M->m = A->m; M->n = A->n; M->nzmax = cnt; M->nz = -1;
+    M->p = (int*)malloc(sizeof(int) * (A->n + 1));
+    M->i = (int*)malloc(sizeof(int) * (cnt ? cnt : 1));
+    M->x = (double*)malloc(sizeof(double) * (cnt ? cnt : 1));
+    M->p[0] = 0;
+    int w = 0;
+    for (int j = 0; j < A->n; j++) {
+        for (int k = A->p[j]; k < A->p[j + 1]; k++) {
+            if (A->i[k] > j) continue;
+            M->i[w] = A->i[k]; M->x[w] = A->x[k]; w++;
+        }
+        M->p[j + 1] = w;
+    }
+    return M;
+}
+
+double* orc_csc_to_dns(const orc_csc_t* S)
+{ /* :593-617 */
+    const int m = S->m, n = S->n;
+    const size_t mn = (size_t)m * (size_t)n;
+    double* full = (double*)calloc(mn > 0 ? mn : 1, sizeof(double));
+    for (int j = 0; j < n; j++)
+        for (int k = S->p[j]; k < S->p[j + 1]; k++) {
+            if (k == S->nzmax) return full;
+            if ((long)S->i[k] * n + j >= (long)m * n || S->i[k] < 0) { free(full); return NULL; }
+            full[(size_t)S->i[k] * n + j] = S->x[k];
+        }
+    return full;
+}
+
+orc_csc_t* orc_dns_to_csc(const double* full, int m, int n)
+{ /* :620-650: column by column, every entry that is > 0 or < 0 */
+    int nnz = 0;
+    for (size_t e = 0; e < (size_t)m * n; e++) nnz += (full[e] > 0 || full[e] < 0);
+    orc_csc_t* M = (orc_csc_t*)malloc(sizeof(orc_csc_t));
+    M->m = m; M->n = n; M->nzmax = nnz; M->nz = -1;
+    M->p = (int*)malloc(sizeof(int) * (n + 1));
+    M->i = (int*)malloc(sizeof(int) * (nnz ? nnz : 1));
+    M->x = (double*)malloc(sizeof(double) * (nnz ? nnz : 1));
+    M->p[0] = 0;
+    int w = 0;
+    for (int c = 0; c < n; c++) {
+        for (int r = 0; r < m; r++) {
+            const double v = full[(size_t)r * n + c];
+            if (v > 0 || v < 0) { M->i[w] = r; M->x[w] = v; w++; }
+        }
+        M->p[c + 1] = w;
+    }
+    return M;
+}
+
+void orc_csc_matmul(const orc_csc_t* A, const double* b, double* c)
+{ /* :49-59  c = A b */
+    for (int i = 0; i < A->m; i++) c[i] = 0;
+    for (int j = 0; j < A->n; j++)
+        for (int k = A->p[j]; k < A->p[j + 1]; k++) c[A->i[k]] += A->x[k] * b[j];
+}
+
+void orc_csc_matmul_t(const orc_csc_t* A, const double* b, double* c)
+{ /* :75-82  c = A' b */
+    for (int j = 0; j < A->n; j++) {
+        c[j] = 0;
+        for (int k = A->p[j]; k < A->p[j + 1]; k++) c[j] += b[A->i[k]] * A->x[k];
+    }
+}
+
+void orc_csc_add_matmul_t(const orc_csc_t* A, const double* b, double* c)
+{ /* :96-102  c += A' b */
+    for (int j = 0; j < A->n; j++)
+        for (int k = A->p[j]; k < A->p[j + 1]; k++) c[j] += b[A->i[k]] * A->x[k];
+}
+
+static int csc_index_of(int val, const int* sorted, int beg, int end)
+{ /* getIndexOfIn :727-737 */
+    for (int k = beg; k < end; k++) {
+        if (sorted[k] == val) return k;
+        if (sorted[k] > val) break;
+    }
+    return -1;
+}
+
+orc_csc_t* orc_csc_symm_product(const orc_csc_t* L, const orc_csc_t* R)
+{ /* :118-173  C = L'R + R'L, entries with |value| <= ZERO (1e-25) dropped, NULL when empty */
+    const int n = L->n;
+    int cap = 16, w = 0;
+    int* ci = (int*)malloc(sizeof(int) * cap);
+    double* cx = (double*)malloc(sizeof(double) * cap);
+    int* cp = (int*)malloc(sizeof(int) * (n + 1));
+    cp[0] = 0;
+    for (int j = 0; j < n; j++) {
+        for (int i = 0; i < n; i++) {
+            double tmp = 0;
+            for (int k = L->p[i]; k < L->p[i + 1]; k++) {
+                int s2 = csc_index_of(L->i[k], R->i, R->p[j], R->p[j + 1]);
+                if (s2 != -1) tmp += L->x[k] * R->x[s2];
+            }
+            for (int k = R->p[i]; k < R->p[i + 1]; k++) {
+                int s1 = csc_index_of(R->i[k], L->i, L->p[j], L->p[j + 1]);
+                if (s1 != -1) tmp += R->x[k] * L->x[s1];
+            }
+            if (!(fabs(tmp) <= 1.0e-25)) {
+                if (w == cap) { cap *= 2; ci = (int*)realloc(ci, sizeof(int) * cap); cx = (double*)realloc(cx, sizeof(double) * cap); }
+                ci[w] = i; cx[w] = tmp; w++;
+            }
+        }
+        cp[j + 1] = w;
+    }
+    if (w == 0) { free(ci); free(cx); free(cp); return NULL; }
+    orc_csc_t* M = (orc_csc_t*)malloc(sizeof(orc_csc_t));
+    M->m = n; M->n = n; M->nzmax = w; M->nz = -1; M->p = cp; M->i = ci; M->x = cx;
+    return M;
+}
+
+void orc_csc_affine(double alpha, const orc_csc_t* S, const double* b, const double* c, double* d, int m)
+{ /* :189-199  d = alpha * S' b + c  (the reference relies on S being symmetric) */
+    for (int j = 0; j < m; j++) {
+        double tmp = 0;
+        for (int k = S->p[j]; k < S->p[j + 1]; k++) tmp += S->x[k] * b[S->i[k]];
+        d[j] = alpha * tmp + c[j];
+    }
+}
+
+double orc_csc_quadform(const orc_csc_t* S, const double* p, int m)
+{ /* :228-241 */
+    double ret = 0;
+    for (int j = 0; j < m; j++) {
+        double tmp = 0;
+        for (int k = S->p[j]; k < S->p[j + 1]; k++) tmp += S->x[k] * p[S->i[k]];
+        ret += p[j] * tmp;
+    }
+    return ret;
+}

@@ -134,3 +134,29 @@ int orc_synth_batch_solve(uint64_t seed0, int first, int count, int n, int nC, i
 }
 #endif
 #endif
+
+/* ------------------------------------------------------------------------------------------------
+ * CSC (compressed sparse column) half of Utilities, SURVEY.md §8(f-1).  orc_csc_t has the fields of the
+ * OSQP `csc` struct the reference uses (src/Utilities.cpp:469-484): nzmax, m, n, p[n+1], i[nzmax], x[nzmax].
+ * ---------------------------------------------------------------------------------------------- */
+#ifndef ORC_CSC_DEFINED
+#define ORC_CSC_DEFINED
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct { int nzmax, m, n; int* p; int* i; double* x; int nz; } orc_csc_t;
+orc_csc_t* orc_csc_create(int m, int n, int nnz, const double* x, const int* i, const int* p);   /* copyCSC :487-513 (deep copy) */
+void       orc_csc_free(orc_csc_t* M);                                                           /* ClearSparseMat :268-287 */
+orc_csc_t* orc_csc_upper(const orc_csc_t* M);                                                    /* copyCSC(M, true) :516-560 */
+double*    orc_csc_to_dns(const orc_csc_t* M);                                                   /* :593-617, caller frees */
+orc_csc_t* orc_dns_to_csc(const double* full, int m, int n);                                     /* :620-650 */
+void       orc_csc_matmul(const orc_csc_t* A, const double* b, double* c);                       /* MatrixMultiplication :49-59 */
+void       orc_csc_matmul_t(const orc_csc_t* A, const double* b, double* c);                     /* TransponsedMatrixMultiplication :75-82 */
+void       orc_csc_add_matmul_t(const orc_csc_t* A, const double* b, double* c);                 /* :96-102 */
+orc_csc_t* orc_csc_symm_product(const orc_csc_t* L, const orc_csc_t* R);                         /* MatrixSymmetrizationProduct :118-173 */
+void       orc_csc_affine(double alpha, const orc_csc_t* S, const double* b, const double* c, double* d, int m);  /* :189-199 (S'b) */
+double     orc_csc_quadform(const orc_csc_t* S, const double* p, int m);                         /* :228-241 */
+#ifdef __cplusplus
+}
+#endif
+#endif

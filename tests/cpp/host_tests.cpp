@@ -66,7 +66,83 @@ static void test_options()
     CHECK(s.updateRhoOpt(-1) == INVALID_RHO_OPT && s.updateSubproblemIter(-1) == IVALID_SUBPROBLEM_ITER);
 }
 
+static void test_csc_utilities()
+{   // test/RunUnitTests.cpp:265-410
+    { double x[3] = {2.0, 1.0, 2.0}; int i[3] = {0, 0, 1}, p[4] = {0, 1, 3, 4};
+      csc* Q = Utilities::copyCSC(2, 3, 3, x, i, p);
+      double* F = Utilities::csc_to_dns(Q);
+      double e[6] = {2, 1, 0, 0, 2, 0}; for (int k = 0; k < 6; k++) CHECK(F[k] == e[k]);
+      delete[] F; Utilities::ClearSparseMat(&Q); CHECK(Q == 0); }
+    { double x[3] = {2.0, 1.0, 10.0}; int i[3] = {0, 1, 1}, p[4] = {0, 2, 2, 4};
+      csc* Q = Utilities::copyCSC(2, 3, 3, x, i, p);
+      double* F = Utilities::csc_to_dns(Q);
+      double e[6] = {2, 0, 0, 1, 0, 10}; for (int k = 0; k < 6; k++) CHECK(F[k] == e[k]);
+      delete[] F; Utilities::ClearSparseMat(&Q); }
+    { double x[3] = {2.0, 10.0, 1.0}; int i[3] = {0, 2, 0}, p[3] = {0, 2, 3};
+      csc* T = Utilities::copyCSC(3, 2, 3, x, i, p);
+      double* F = Utilities::csc_to_dns(T);
+      double e[6] = {2, 1, 0, 0, 10, 0}; for (int k = 0; k < 6; k++) CHECK(F[k] == e[k]);
+      delete[] F; Utilities::ClearSparseMat(&T); }
+    {   // SparseDenseBackAndForth :335-375 (fixed seed)
+        unsigned s = 12345u;
+        for (int rep = 0; rep < 100; rep++) {
+            double Q[10];
+            for (int j = 0; j < 10; j++) { s = s * 1664525u + 1013904223u; unsigned rd = s >> 8; Q[j] = (rd % 4 == 0) ? (double)(rd % 9) : 0.0; }
+            csc* S = Utilities::dns_to_csc(Q, 2, 5);
+            double* F = Utilities::csc_to_dns(S);
+            for (int j = 0; j < 10; j++) CHECK(F[j] == Q[j]);
+            delete[] F; Utilities::ClearSparseMat(&S);
+        }
+    }
+    { double x[4] = {2.0, 3.0, 3.0, 2.0}; int i[4] = {0, 1, 0, 1}, p[3] = {0, 2, 4};   // CSCtoTriangular :378-410
+      csc* M = Utilities::copyCSC(2, 2, 4, x, i, p);
+      csc* U = Utilities::copyCSC(M, true);
+      CHECK(U && U->p[0] == 0 && U->p[1] == 1 && U->p[2] == 3 && U->i[0] == 0 && U->i[1] == 0 && U->i[2] == 1);
+      CHECK(U->x[0] == 2 && U->x[1] == 3 && U->x[2] == 2 && U->m == 2 && U->n == 2 && U->nz == -1 && U->nzmax == 3);
+      Utilities::ClearSparseMat(&M); Utilities::ClearSparseMat(&U); }
+    {   // sparse products against the dense known answers (:33-104, :107-129, :190-204)
+        double A[6] = {1, 0, 2, 3, 1, 1}, B[6] = {2, 0, 1, 0, 0, -1};
+        csc *As = Utilities::dns_to_csc(A, 2, 3), *Bs = Utilities::dns_to_csc(B, 2, 3);
+        double b[3] = {2, 0, 1}, c[2], bt[2] = {98, -10}, ct[3];
+        Utilities::MatrixMultiplication(As, b, c); CHECK(c[0] == 4 && c[1] == 7);
+        Utilities::TransponsedMatrixMultiplication(As, bt, ct); CHECK(ct[0] == 68 && ct[1] == -10 && ct[2] == 186);
+        csc* Cs = Utilities::MatrixSymmetrizationProduct(As, Bs);
+        double* Cd = Utilities::csc_to_dns(Cs);
+        double e[9] = {4, 0, 2, 0, 0, -1, 2, -1, 2}; for (int k = 0; k < 9; k++) CHECK(Cd[k] == e[k]);
+        double Qd[9] = {0, 1, 0, 1, 2, 1, 0, 1, 0}, p3[3] = {1, 2, 3}, z[3] = {-3, -3, -3}, d[3];
+        csc* Qs = Utilities::dns_to_csc(Qd, 3, 3);
+        CHECK(Utilities::QuadraticFormProduct(Qs, p3, 3) == 24);
+        Utilities::AffineLinearTransformation(2, Qs, p3, z, d, 3); CHECK(d[0] == 1 && d[1] == 13 && d[2] == 1);
+        delete[] Cd;
+        Utilities::ClearSparseMat(&As); Utilities::ClearSparseMat(&Bs); Utilities::ClearSparseMat(&Cs); Utilities::ClearSparseMat(&Qs);
+    }
+}
+
 static const double Qw[4] = {2, 0, 0, 2}, gw[2] = {-2, -2}, Lw[2] = {1, 0}, Rw[2] = {0, 1};
+
+static void test_dense_to_sparse()
+{   // LoadDataTest.DenseToSparse, test/RunUnitTests.cpp:413-460: dense -> sparse -> solve -> dense -> solve
+    LCQProblem lcqp(2, 0, 1);
+    Options options; options.setPrintLevel(NONE); lcqp.setOptions(options);
+    CHECK(lcqp.loadLCQP(Qw, gw, Lw, Rw) == SUCCESSFUL_RETURN);
+    CHECK(lcqp.switchToDenseMode() == SUCCESSFUL_RETURN);
+    CHECK(lcqp.switchToSparseMode() == SUCCESSFUL_RETURN);
+    CHECK(lcqp.switchToSparseMode() == SUCCESSFUL_RETURN);
+    CHECK(lcqp.runSolver() == SUCCESSFUL_RETURN);
+    double xs[2]; lcqp.getPrimalSolution(xs);
+    CHECK(lcqp.switchToDenseMode() == SUCCESSFUL_RETURN);
+    CHECK(lcqp.runSolver() == SUCCESSFUL_RETURN);
+    // sparse overload of loadLCQP (src/LCQProblem.cpp:390-441) on the w_A example
+    double A[2] = {1, -1}, lbA[1] = {-0.5}, ubA[1] = {INFINITY};
+    csc *Qs = Utilities::dns_to_csc(Qw, 2, 2), *Ls = Utilities::dns_to_csc(Lw, 1, 2), *Rs = Utilities::dns_to_csc(Rw, 1, 2), *As = Utilities::dns_to_csc(A, 1, 2);
+    LCQProblem p2(2, 1, 1); p2.setOptions(options);
+    CHECK(p2.loadLCQP(Qs, gw, Ls, Rs, 0, 0, 0, 0, As, lbA, ubA) == SUCCESSFUL_RETURN);
+    CHECK(p2.runSolver() == SUCCESSFUL_RETURN);
+    double x2[2]; p2.getPrimalSolution(x2);
+    const double tol = options.getStationarityTolerance();
+    CHECK((std::fabs(x2[0] - 1) <= tol && std::fabs(x2[1]) <= tol) || (std::fabs(x2[1] - 1) <= tol && std::fabs(x2[0]) <= tol));
+    Utilities::ClearSparseMat(&Qs); Utilities::ClearSparseMat(&Ls); Utilities::ClearSparseMat(&Rs); Utilities::ClearSparseMat(&As);
+}
 
 static void test_run_warm_up()
 {   // SolverTest.RunWarmUp, test/RunUnitTests.cpp:505-551 (20 repetitions, seeds instead of time(NULL))
@@ -187,12 +263,14 @@ int main(int argc, char** argv)
     if (argc > 5 && !std::strcmp(argv[1], "files")) return run_from_files(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]));
     const bool gpu = argc > 1 && !std::strcmp(argv[1], "gpu");
     test_utilities();
+    test_csc_utilities();
     test_options();
     if (gpu) {
         if (lcqp_hip_device_count() < 1) { std::printf("FAIL no GPU visible\n"); return 2; }
         test_run_warm_up();
         test_qp_return_flag();
         test_examples();
+        test_dense_to_sparse();
         test_circle(argc > 2);
         test_batch();
     }

@@ -246,3 +246,57 @@ def util_dot(a, b, m):
 def util_maxabs(a, m):
     a = _arr(a)
     return lib().orc_util_maxabs(_p(a), m)
+
+
+# ---- CSC utilities (orc_csc_*) -------------------------------------------------------------------
+class CSC(C.Structure):
+    _fields_ = [("nzmax", C.c_int), ("m", C.c_int), ("n", C.c_int), ("p", C.POINTER(C.c_int)), ("i", C.POINTER(C.c_int)),
+                ("x", c_double_p), ("nz", C.c_int)]
+
+
+def _csc_setup():
+    L = lib()
+    if getattr(L, "_csc_ready", False):
+        return L
+    P = C.POINTER(CSC)
+    L.orc_csc_create.restype = P
+    L.orc_csc_create.argtypes = [C.c_int, C.c_int, C.c_int, c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_csc_free.argtypes = [P]
+    L.orc_csc_upper.restype = P; L.orc_csc_upper.argtypes = [P]
+    L.orc_csc_to_dns.restype = c_double_p; L.orc_csc_to_dns.argtypes = [P]
+    L.orc_dns_to_csc.restype = P; L.orc_dns_to_csc.argtypes = [c_double_p, C.c_int, C.c_int]
+    for f in ("orc_csc_matmul", "orc_csc_matmul_t", "orc_csc_add_matmul_t"):
+        getattr(L, f).argtypes = [P, c_double_p, c_double_p]
+    L.orc_csc_symm_product.restype = P; L.orc_csc_symm_product.argtypes = [P, P]
+    L.orc_csc_affine.argtypes = [C.c_double, P, c_double_p, c_double_p, c_double_p, C.c_int]
+    L.orc_csc_quadform.restype = C.c_double; L.orc_csc_quadform.argtypes = [P, c_double_p, C.c_int]
+    L._csc_ready = True
+    return L
+
+
+def csc_create(m, n, x, i, p):
+    L = _csc_setup()
+    x = _arr(x); i = np.ascontiguousarray(i, dtype=np.int32); p = np.ascontiguousarray(p, dtype=np.int32)
+    return L.orc_csc_create(m, n, len(x), _p(x), i.ctypes.data_as(C.POINTER(C.c_int)), p.ctypes.data_as(C.POINTER(C.c_int)))
+
+
+def csc_arrays(M):
+    """(m, n, p, i, x) of a CSC* as numpy copies"""
+    c = M.contents
+    p = np.array([c.p[k] for k in range(c.n + 1)], dtype=np.int32)
+    nnz = int(p[-1])
+    return c.m, c.n, p, np.array([c.i[k] for k in range(nnz)], dtype=np.int32), np.array([c.x[k] for k in range(nnz)])
+
+
+def csc_to_dns(M):
+    L = _csc_setup()
+    c = M.contents
+    ptr = L.orc_csc_to_dns(M)
+    out = np.array([ptr[k] for k in range(c.m * c.n)]).reshape(c.m, c.n)
+    return out
+
+
+def dns_to_csc(full):
+    L = _csc_setup()
+    full = _arr(full)
+    return L.orc_dns_to_csc(_p(full), full.shape[0], full.shape[1])
