@@ -160,6 +160,16 @@ int lcqp_hip_util_gemv_t(int batch, int m, int n, const double* A, const double*
 int lcqp_hip_util_gemv(int batch, int m, int n, const double* A, const double* b, double* c);
 /* Utilities::MatrixSymmetrizationProduct, src/Utilities.cpp:104-116: C = A'B + B'A (A, B are m x n) */
 int lcqp_hip_util_symm_product(int batch, int m, int n, const double* A, const double* B, double* C);
+/* ---- CSC utilities on the device (host pointers, synchronous) ----
+ * Handle on one CSC matrix (fields of the reference's `csc`, src/Utilities.cpp:469-484) and its transpose. */
+typedef struct lcqp_hip_csc lcqp_hip_csc_t;
+lcqp_hip_csc_t* lcqp_hip_csc_create(int m, int n, int nnz, const int* p, const int* i, const double* x, int device);
+void lcqp_hip_csc_destroy(lcqp_hip_csc_t* M);
+/* d = alpha * op(A) b + c (c may be NULL).  transposed == 0: Utilities::MatrixMultiplication(csc) src/Utilities.cpp:49-59;
+ * transposed != 0: TransponsedMatrixMultiplication(csc) :75-82 and, for symmetric S, AffineLinearTransformation(csc)
+ * :189-199 (QuadraticFormProduct :228-241 is b'd).  repeat > 1 re-launches for timing, *ms = time per launch. */
+int lcqp_hip_csc_apply(lcqp_hip_csc_t* M, int transposed, double alpha, const double* b, const double* c, double* d,
+                       int repeat, float* ms);
 /* micro-benchmark of the row sweep on device-resident random data (batch matrices of m x n):
  * mode 1 = A x (dots), 2 = A'y (axpy), 3 = both in one sweep; *ms = time per launch */
 int lcqp_hip_bench_rows(int batch, int m, int n, int mode, int repeat, float* ms);

@@ -7,4 +7,4 @@ package is only the ctypes plumbing used by tests and ``bench.py``; it never fal
 path: importing :mod:`lcqpow_amd.capi` without the built library raises.
 """
 from .capi import (Options, Stats, BatchLCQP, SubsolverHIP, default_options, lib, library_path,  # noqa: F401
-                   util_symv, util_gemv, util_gemv_t, util_symm_product, chol_solve, device_count)
+                   util_symv, util_gemv, util_gemv_t, util_symm_product, chol_solve, device_count, CSCMatrix)

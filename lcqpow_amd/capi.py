@@ -89,6 +89,10 @@ def lib():
         L.lcqp_hip_util_gemv.argtypes = [C.c_int, C.c_int, C.c_int] + [c_double_p] * 3
         L.lcqp_hip_util_gemv_t.argtypes = [C.c_int, C.c_int, C.c_int] + [c_double_p] * 3
         L.lcqp_hip_util_symm_product.argtypes = [C.c_int, C.c_int, C.c_int] + [c_double_p] * 3
+        L.lcqp_hip_csc_create.restype = C.c_void_p
+        L.lcqp_hip_csc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), c_double_p, C.c_int]
+        L.lcqp_hip_csc_destroy.argtypes = [C.c_void_p]
+        L.lcqp_hip_csc_apply.argtypes = [C.c_void_p, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, C.c_int, C.POINTER(C.c_float)]
         L.lcqp_hip_chol_solve.argtypes = [C.c_int, C.c_int] + [c_double_p] * 3 + [C.c_int, C.POINTER(C.c_float)]
         _lib = L
     return _lib
@@ -276,3 +280,33 @@ def chol_solve(K, b, repeat=1):
     x = np.zeros((batch, n)); ms = C.c_float(0)
     _check(lib().lcqp_hip_chol_solve(batch, n, _p(K), _p(b), _p(x), repeat, C.byref(ms)), "chol_solve")
     return x, ms.value
+
+
+class CSCMatrix:
+    """Device copy of a CSC matrix (and its transpose) for the sparse Utilities products."""
+
+    def __init__(self, m, n, p, i, x, device=0):
+        self.m, self.n = m, n
+        p = np.ascontiguousarray(p, dtype=np.int32); i = np.ascontiguousarray(i, dtype=np.int32); x = _arr(x)
+        ip = C.POINTER(C.c_int)
+        self.h = lib().lcqp_hip_csc_create(m, n, len(x), p.ctypes.data_as(ip), i.ctypes.data_as(ip), _p(x), device)
+        if not self.h:
+            raise RuntimeError("lcqp_hip_csc_create failed: " + last_error())
+
+    def apply(self, b, transposed=False, alpha=1.0, c=None, repeat=1):
+        b = _arr(b); c = _arr(c)
+        d = np.zeros(self.n if transposed else self.m); ms = C.c_float(0)
+        _check(lib().lcqp_hip_csc_apply(self.h, int(transposed), alpha, _p(b), _p(c), _p(d), repeat, C.byref(ms)), "csc_apply")
+        self.last_ms = ms.value
+        return d
+
+    def close(self):
+        if self.h:
+            lib().lcqp_hip_csc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

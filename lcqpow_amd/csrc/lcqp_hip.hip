@@ -1113,6 +1113,108 @@ extern "C" int lcqp_hip_util_symm_product(int batch, int m, int n, const double*
     return rc;
 }
 
+// =================================================================================================
+// CSC utilities on the device: compressed-segment gather products.
+// A CSC matrix is uploaded together with its transpose (the CSC of A' is the CSR of A), so both
+// MatrixMultiplication (A b) and TransponsedMatrixMultiplication (A'b) are gathers over compressed segments --
+// no atomics, deterministic, the same summation order as the reference's inner loops
+// (src/Utilities.cpp:49-59,75-82,189-199,228-241).
+// =================================================================================================
+// out[s] = alpha * sum_{k in [ptr[s], ptr[s+1])} val[k] * v[idx[k]] + (add ? add[s] : 0); 16 lanes per segment
+__global__ __launch_bounds__(256) void k_seg_gather(int nseg, const int* __restrict__ ptr, const int* __restrict__ idx,
+                                                    const double* __restrict__ val, const double* __restrict__ v, double alpha,
+                                                    const double* __restrict__ add, double* __restrict__ out)
+{
+    const int sub = threadIdx.x & 15;
+    const int seg = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    double s = 0.0;
+    if (seg < nseg) {
+        const int k0 = ptr[seg], k1 = ptr[seg + 1];
+        for (int k = k0 + sub; k < k1; k += 16) s += val[k] * v[idx[k]];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+    if (seg < nseg && sub == 0) out[seg] = alpha * s + (add ? add[seg] : 0.0);
+}
+
+struct lcqp_hip_csc {
+    int m, n, nnz, device;
+    int *p, *i, *tp, *ti;        // CSC of A and CSC of A' (device)
+    double *x, *tx;
+    double *vin, *vout, *vadd;   // staging vectors of length max(m, n)
+};
+
+extern "C" lcqp_hip_csc_t* lcqp_hip_csc_create(int m, int n, int nnz, const int* p, const int* i, const double* x, int device)
+{
+    if (m <= 0 || n <= 0 || nnz < 0 || !p || (nnz && (!i || !x))) { g_err = "invalid CSC arguments"; return nullptr; }
+    HIPCHKN(hipSetDevice(device));
+    // transpose on the host: counting sort by row index (stable, so columns stay ascending inside a row)
+    std::vector<int> tp(m + 1, 0), ti(nnz ? nnz : 1);
+    std::vector<double> tx(nnz ? nnz : 1);
+    for (int k = 0; k < nnz; k++) { if (i[k] < 0 || i[k] >= m) { g_err = "CSC row index out of bounds"; return nullptr; } tp[i[k] + 1]++; }
+    for (int r = 0; r < m; r++) tp[r + 1] += tp[r];
+    std::vector<int> cur(tp.begin(), tp.end() - 1);
+    for (int c = 0; c < n; c++)
+        for (int k = p[c]; k < p[c + 1]; k++) { const int d = cur[i[k]]++; ti[d] = c; tx[d] = x[k]; }
+    lcqp_hip_csc* h = new lcqp_hip_csc();
+    h->m = m; h->n = n; h->nnz = nnz; h->device = device;
+    const size_t nz = nnz ? nnz : 1, mx = (size_t)(m > n ? m : n);
+    if (hipMalloc((void**)&h->p, sizeof(int) * (n + 1)) != hipSuccess || hipMalloc((void**)&h->i, sizeof(int) * nz) != hipSuccess ||
+        hipMalloc((void**)&h->x, sizeof(double) * nz) != hipSuccess || hipMalloc((void**)&h->tp, sizeof(int) * (m + 1)) != hipSuccess ||
+        hipMalloc((void**)&h->ti, sizeof(int) * nz) != hipSuccess || hipMalloc((void**)&h->tx, sizeof(double) * nz) != hipSuccess ||
+        hipMalloc((void**)&h->vin, sizeof(double) * mx) != hipSuccess || hipMalloc((void**)&h->vout, sizeof(double) * mx) != hipSuccess ||
+        hipMalloc((void**)&h->vadd, sizeof(double) * mx) != hipSuccess) { g_err = "hipMalloc failed"; delete h; return nullptr; }
+    HIPCHKN(hipMemcpy(h->p, p, sizeof(int) * (n + 1), hipMemcpyHostToDevice));
+    HIPCHKN(hipMemcpy(h->tp, tp.data(), sizeof(int) * (m + 1), hipMemcpyHostToDevice));
+    if (nnz) {
+        HIPCHKN(hipMemcpy(h->i, i, sizeof(int) * nnz, hipMemcpyHostToDevice));
+        HIPCHKN(hipMemcpy(h->x, x, sizeof(double) * nnz, hipMemcpyHostToDevice));
+        HIPCHKN(hipMemcpy(h->ti, ti.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
+        HIPCHKN(hipMemcpy(h->tx, tx.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
+    }
+    return h;
+}
+
+extern "C" void lcqp_hip_csc_destroy(lcqp_hip_csc_t* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->p); (void)hipFree(h->i); (void)hipFree(h->x); (void)hipFree(h->tp); (void)hipFree(h->ti); (void)hipFree(h->tx);
+    (void)hipFree(h->vin); (void)hipFree(h->vout); (void)hipFree(h->vadd);
+    delete h;
+}
+
+// d = alpha * op(A) * b + (c ? c : 0);  transposed != 0: op(A) = A' (b has m entries, d has n), else op(A) = A.
+// repeat > 1 re-launches the product for timing; *ms = time per launch.
+extern "C" int lcqp_hip_csc_apply(lcqp_hip_csc_t* h, int transposed, double alpha, const double* b, const double* c, double* d,
+                                  int repeat, float* ms)
+{
+    if (!h || !b || !d) return LCQP_INVALID_ARGUMENT;
+    HIPCHK(hipSetDevice(h->device));
+    const int nin = transposed ? h->m : h->n, nout = transposed ? h->n : h->m;
+    HIPCHK(hipMemcpy(h->vin, b, sizeof(double) * nin, hipMemcpyHostToDevice));
+    if (c) HIPCHK(hipMemcpy(h->vadd, c, sizeof(double) * nout, hipMemcpyHostToDevice));
+    const int* ptr = transposed ? h->p : h->tp;     // A'b gathers over the columns of A, A b over the columns of A'
+    const int* idx = transposed ? h->i : h->ti;
+    const double* val = transposed ? h->x : h->tx;
+    const int grid = (nout * 16 + 255) / 256;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    if (repeat < 1) repeat = 1;
+    hipLaunchKernelGGL(k_seg_gather, dim3(grid), dim3(256), 0, 0, nout, ptr, idx, val, h->vin, alpha, c ? h->vadd : nullptr, h->vout);
+    HIPCHK(hipEventRecord(e0, 0));
+    for (int r = 0; r < repeat; r++)
+        hipLaunchKernelGGL(k_seg_gather, dim3(grid), dim3(256), 0, 0, nout, ptr, idx, val, h->vin, alpha, c ? h->vadd : nullptr, h->vout);
+    HIPCHK(hipEventRecord(e1, 0));
+    HIPCHK(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    if (ms) *ms = t / repeat;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HIPCHK(hipMemcpy(d, h->vout, sizeof(double) * nout, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // micro-benchmark of the row sweep (wg_rows) on device-resident random data: mode 1 = dots only (A x),
 // 2 = axpy only (A'y), 3 = both in one sweep; *ms = time per launch
 __global__ void k_fill_random(double* p, size_t n, uint64_t seed)

@@ -320,3 +320,43 @@ def test_lcqp_node_sized_batch_on_one_gpu(hip):
     x1, _, _ = b1.solution()
     b1.close()
     assert np.array_equal(x1, x[1024:2048])
+
+
+def test_csc_products_on_device(hip, oracle):
+    """CSC Utilities on the device vs the oracle restatement: the reference's dense known
+    answers through CSC, and random sparse matrices up to the BASELINE config-5 size n = 4096."""
+    L = oracle._csc_setup()
+    # known answers of test/RunUnitTests.cpp:33-78 through CSC
+    A = np.array([[1., 0, 2], [3, 1, 1]])
+    S = oracle.dns_to_csc(A); m, n, p, i, x = oracle.csc_arrays(S)
+    M = hip.CSCMatrix(m, n, p, i, x)
+    assert list(M.apply([98., -10], transposed=True)) == [68, -10, 186]
+    assert list(M.apply([2., 0, 1])) == [4, 7]
+    M.close()
+    rng = np.random.default_rng(4)
+    for (m, n, dens) in ((7, 5, 0.4), (640, 256, 0.05), (4096, 4096, 0.003)):
+        A = np.where(rng.random((m, n)) < dens, rng.standard_normal((m, n)), 0.0)
+        if m == n:
+            A = A + A.T
+        S = oracle.dns_to_csc(A); _, _, p, i, x = oracle.csc_arrays(S) if m < 1000 else (None, None, *_csc_np(A))
+        M = hip.CSCMatrix(m, n, p, i, x)
+        b = rng.standard_normal(n); bt = rng.standard_normal(m); c = rng.standard_normal(n)
+        ref = np.zeros(m); L.orc_csc_matmul(S, oracle._p(b), oracle._p(ref))
+        assert np.abs(M.apply(b) - ref).max() < 1e-12 * max(1, np.abs(ref).max())
+        reft = np.zeros(n); L.orc_csc_matmul_t(S, oracle._p(bt), oracle._p(reft))
+        assert np.abs(M.apply(bt, transposed=True) - reft).max() < 1e-12 * max(1, np.abs(reft).max())
+        if m == n:      # AffineLinearTransformation / QuadraticFormProduct for symmetric S
+            d = np.zeros(n); L.orc_csc_affine(2.0, S, oracle._p(b), oracle._p(c), oracle._p(d), n)
+            dh = M.apply(b, transposed=True, alpha=2.0, c=c)
+            assert np.abs(dh - d).max() < 1e-12 * max(1, np.abs(d).max())
+            qf = L.orc_csc_quadform(S, oracle._p(b), n)
+            assert abs(b @ M.apply(b, transposed=True) - qf) < 1e-10 * max(1, abs(qf))
+        M.close()
+
+
+def _csc_np(A):
+    """CSC arrays of a dense matrix with numpy (column-major scan, as dns_to_csc does)"""
+    cols, rows = np.nonzero(A.T)
+    p = np.zeros(A.shape[1] + 1, dtype=np.int32)
+    np.add.at(p, cols + 1, 1)
+    return np.cumsum(p).astype(np.int32), rows.astype(np.int32), A.T[cols, rows]
