@@ -360,3 +360,21 @@ def _csc_np(A):
     p = np.zeros(A.shape[1] + 1, dtype=np.int32)
     np.add.at(p, cols + 1, 1)
     return np.cumsum(p).astype(np.int32), rows.astype(np.int32), A.T[cols, rows]
+
+
+@pytest.mark.parametrize("n,nC,nComp", [(512, 256, 128), (384, 700, 100), (100, 0, 50), (33, 17, 16), (256, 1500, 64),
+                                        (2, 0, 1), (129, 64, 1), (64, 640, 8)])
+def test_lcqp_shape_sweep(hip, oracle, n, nC, nComp):
+    """every padded-size variant of the kernels (np = 128, 256, 384, 512), nC = 0, more rows than the BASELINE shape"""
+    B = 3
+    bt = hip.BatchLCQP(B, n, nC, nComp, opt=hip.default_options(perturbStep=0))
+    bt.generate_synthetic(0)
+    bt.run()
+    x, y, st = bt.solution()
+    for b in range(B):
+        d = bt.read_problem(b)
+        ro = oracle.lcqp_solve(d["Q"], d["g"], d["L"], d["R"], A=d["A"] if nC else None, lbA=d["lbA"] if nC else None,
+                               ubA=d["ubA"] if nC else None, opt=oracle.default_options(perturbStep=0), nV=n, nC=nC, nComp=nComp)
+        assert st[b]["returnValue"] == ro["ret"] == 0
+        assert np.abs(ro["x"] - x[b]).max() < X_TOL and np.abs(ro["y"] - y[b]).max() < Y_TOL
+    bt.close()
