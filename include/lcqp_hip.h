@@ -83,8 +83,9 @@ typedef struct lcqp_hip_qp lcqp_hip_qp_t;
  * nC is the number of stacked rows (nC + 2*nComp).  Host pointers.  Returns NULL on failure. */
 lcqp_hip_qp_t* lcqp_hip_qp_create(int nV, int nC, const double* Q, const double* A,
                                   const lcqp_options_t* opt, int device);
-/* copy-ctor / operator= of the reference (src/SubsolverQPOASES.cpp:184-230): shares the immutable
- * device copies of Q, A by reference count, duplicates solver state. */
+/* copy-ctor / operator= of the reference (src/SubsolverQPOASES.cpp:184-230): the clone carries the host copies
+ * of Q, A and the options; its device state is built by its own first (initial) solve -- the reference only
+ * copies subsolvers before their first use (src/Subsolver.cpp:125-136, src/LCQProblem.cpp:906-907). */
 lcqp_hip_qp_t* lcqp_hip_qp_clone(const lcqp_hip_qp_t* src);
 void lcqp_hip_qp_destroy(lcqp_hip_qp_t* qp);
 /* SubsolverQPOASES::setOptions, src/SubsolverQPOASES.cpp:120-131 (takes effect at the next initial solve) */

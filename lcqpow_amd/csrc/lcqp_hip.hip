@@ -479,6 +479,10 @@ struct lcqp_hip_batch {
     int device;
     hipStream_t stream;
     hipEvent_t ev0, ev1, ev2;
+    // two pinned staging slots for loadLCQP: instance k is packed into slot k&1 while slot (k-1)&1 is in flight
+    void* stage[2];
+    hipEvent_t stageDone[2];
+    size_t stageBytes;
     std::vector<void*> allocs;
     bool setupDone, ran;
     int nch;
@@ -505,6 +509,7 @@ extern "C" lcqp_hip_batch_t* lcqp_hip_batch_create(int batch, int nV, int nC, in
     HIPCHKN(hipSetDevice(device));
     lcqp_hip_batch* h = new lcqp_hip_batch();
     h->device = device; h->setupDone = false; h->ran = false; h->bytesTotal = 0;
+    h->stage[0] = h->stage[1] = nullptr; h->stageBytes = 0;
     HIPCHKN(hipStreamCreate(&h->stream));
     HIPCHKN(hipEventCreate(&h->ev0)); HIPCHKN(hipEventCreate(&h->ev1)); HIPCHKN(hipEventCreate(&h->ev2));
     DevBatch& d = h->db;
@@ -557,6 +562,7 @@ extern "C" void lcqp_hip_batch_destroy(lcqp_hip_batch_t* h)
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) (void)hipFree(p);
+    for (int k = 0; k < 2; k++) if (h->stage[k]) { (void)hipHostFree(h->stage[k]); (void)hipEventDestroy(h->stageDone[k]); }
     (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); (void)hipEventDestroy(h->ev2);
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -633,12 +639,30 @@ extern "C" int lcqp_hip_batch_load(lcqp_hip_batch_t* h, int first, int count,
     const int hasL = lbL ? 1 : 0, hasR = lbR ? 1 : 0;
     if (first == 0) { d.hasLbL = hasL; d.hasLbR = hasR; }
     else if (d.hasLbL != hasL || d.hasLbR != hasR) { g_err = "lbL/lbR must be given for all instances of a batch or for none"; return LCQP_INVALID_ARGUMENT; }
-    std::vector<double> Qp((size_t)np * np), Ep((size_t)mE * np), nvb((size_t)V_NUM * np), mvb((size_t)M_NUM * mE), ybuf(d.nd), lbuf(nComp ? nComp : 1), rbuf(nComp ? nComp : 1);
-    std::vector<int> bidx(np);
+    // pinned staging: [Qp | Ep | nvb | mvb | ybuf | lbuf | rbuf | info | bidx]
+    const size_t nQ = (size_t)np * np, nE = (size_t)mE * np, nNV = (size_t)V_NUM * np, nMV = (size_t)M_NUM * mE;
+    const size_t nY = (size_t)d.nd, nLR = (size_t)(nComp ? nComp : 1);
+    const size_t infoDbl = (sizeof(InstInfo) + 7) / 8, bidxDbl = ((size_t)np * sizeof(int) + 7) / 8;
+    const size_t slotBytes = sizeof(double) * (nQ + nE + nNV + nMV + nY + 2 * nLR + infoDbl + bidxDbl);
+    if (h->stageBytes < slotBytes) {
+        for (int k = 0; k < 2; k++) {
+            if (h->stage[k]) { (void)hipHostFree(h->stage[k]); (void)hipEventDestroy(h->stageDone[k]); h->stage[k] = nullptr; }
+            HIPCHK(hipHostMalloc(&h->stage[k], slotBytes, hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&h->stageDone[k], hipEventDisableTiming));
+            HIPCHK(hipEventRecord(h->stageDone[k], h->stream));
+        }
+        h->stageBytes = slotBytes;
+    }
     for (int k = 0; k < count; k++) {
         const size_t b = (size_t)first + k;
-        std::fill(Qp.begin(), Qp.end(), 0.0); std::fill(Ep.begin(), Ep.end(), 0.0);
-        std::fill(nvb.begin(), nvb.end(), 0.0); std::fill(mvb.begin(), mvb.end(), 0.0);
+        const int slot = k & 1;
+        HIPCHK(hipEventSynchronize(h->stageDone[slot]));            // the copies that last used this slot are done
+        double* Qp = (double*)h->stage[slot];
+        double* Ep = Qp + nQ; double* nvb = Ep + nE; double* mvb = nvb + nNV; double* ybuf = mvb + nMV;
+        double* lbuf = ybuf + nY; double* rbuf = lbuf + nLR;
+        InstInfo* info = (InstInfo*)(rbuf + nLR);
+        int* bidx = (int*)((double*)info + infoDbl);
+        memset(Qp, 0, slotBytes);
         for (int i = 0; i < n; i++) memcpy(&Qp[(size_t)i * np], Q + ((size_t)k * n + i) * n, sizeof(double) * n);       // setQ .ipp:27-36
         // setConstraints :563-626: stack [A; L; R]
         for (int r = 0; r < nC; r++) memcpy(&Ep[(size_t)r * np], A + ((size_t)k * nC + r) * n, sizeof(double) * n);
@@ -673,25 +697,24 @@ extern "C" int lcqp_hip_batch_load(lcqp_hip_batch_t* h, int first, int count,
             vx0[i] = x0 ? x0[(size_t)k * n + i] : 0.0;          // setInitialGuess .ipp:133-158
             if (std::isfinite(vlb[i]) || std::isfinite(vub[i])) bidx[nfin++] = i;
         }
-        InstInfo info;
-        memset(&info, 0, sizeof(info));
-        info.nfin = nfin; info.mE = mA + nfin; info.hasY0 = y0 ? 1 : 0;
-        HIPCHK(hipMemcpyAsync(d.Q + b * np * np, Qp.data(), sizeof(double) * np * np, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(d.E + b * mE * np, Ep.data(), sizeof(double) * mE * np, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(d.nv + b * V_NUM * np, nvb.data(), sizeof(double) * V_NUM * np, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(d.mv + b * M_NUM * mE, mvb.data(), sizeof(double) * M_NUM * mE, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(d.boxidx + b * np, bidx.data(), sizeof(int) * np, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(d.info + b, &info, sizeof(info), hipMemcpyHostToDevice, h->stream));
+        info->nfin = nfin; info->mE = mA + nfin; info->hasY0 = y0 ? 1 : 0;
+        HIPCHK(hipMemcpyAsync(d.Q + b * nQ, Qp, sizeof(double) * nQ, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d.E + b * nE, Ep, sizeof(double) * nE, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d.nv + b * nNV, nvb, sizeof(double) * nNV, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d.mv + b * nMV, mvb, sizeof(double) * nMV, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d.boxidx + b * np, bidx, sizeof(int) * np, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d.info + b, info, sizeof(InstInfo), hipMemcpyHostToDevice, h->stream));
         if (nComp) {
-            HIPCHK(hipMemcpyAsync(d.lbL + b * nComp, lbuf.data(), sizeof(double) * nComp, hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipMemcpyAsync(d.lbR + b * nComp, rbuf.data(), sizeof(double) * nComp, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(d.lbL + b * nComp, lbuf, sizeof(double) * nComp, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(d.lbR + b * nComp, rbuf, sizeof(double) * nComp, hipMemcpyHostToDevice, h->stream));
         }
         if (y0) {
-            memcpy(ybuf.data(), y0 + (size_t)k * d.nd, sizeof(double) * d.nd);
-            HIPCHK(hipMemcpyAsync(d.y0 + b * d.nd, ybuf.data(), sizeof(double) * d.nd, hipMemcpyHostToDevice, h->stream));
+            memcpy(ybuf, y0 + (size_t)k * d.nd, sizeof(double) * d.nd);
+            HIPCHK(hipMemcpyAsync(d.y0 + b * nY, ybuf, sizeof(double) * nY, hipMemcpyHostToDevice, h->stream));
         }
-        HIPCHK(hipStreamSynchronize(h->stream));   // staging buffers are reused
+        HIPCHK(hipEventRecord(h->stageDone[slot], h->stream));
     }
+    HIPCHK(hipStreamSynchronize(h->stream));
     h->setupDone = false;
     return 0;
 }
@@ -1157,13 +1180,14 @@ extern "C" lcqp_hip_csc_t* lcqp_hip_csc_create(int m, int n, int nnz, const int*
     for (int c = 0; c < n; c++)
         for (int k = p[c]; k < p[c + 1]; k++) { const int d = cur[i[k]]++; ti[d] = c; tx[d] = x[k]; }
     lcqp_hip_csc* h = new lcqp_hip_csc();
+    memset(h, 0, sizeof(*h));
     h->m = m; h->n = n; h->nnz = nnz; h->device = device;
     const size_t nz = nnz ? nnz : 1, mx = (size_t)(m > n ? m : n);
     if (hipMalloc((void**)&h->p, sizeof(int) * (n + 1)) != hipSuccess || hipMalloc((void**)&h->i, sizeof(int) * nz) != hipSuccess ||
         hipMalloc((void**)&h->x, sizeof(double) * nz) != hipSuccess || hipMalloc((void**)&h->tp, sizeof(int) * (m + 1)) != hipSuccess ||
         hipMalloc((void**)&h->ti, sizeof(int) * nz) != hipSuccess || hipMalloc((void**)&h->tx, sizeof(double) * nz) != hipSuccess ||
         hipMalloc((void**)&h->vin, sizeof(double) * mx) != hipSuccess || hipMalloc((void**)&h->vout, sizeof(double) * mx) != hipSuccess ||
-        hipMalloc((void**)&h->vadd, sizeof(double) * mx) != hipSuccess) { g_err = "hipMalloc failed"; delete h; return nullptr; }
+        hipMalloc((void**)&h->vadd, sizeof(double) * mx) != hipSuccess) { g_err = "hipMalloc failed"; lcqp_hip_csc_destroy(h); return nullptr; }
     HIPCHKN(hipMemcpy(h->p, p, sizeof(int) * (n + 1), hipMemcpyHostToDevice));
     HIPCHKN(hipMemcpy(h->tp, tp.data(), sizeof(int) * (m + 1), hipMemcpyHostToDevice));
     if (nnz) {
