@@ -51,3 +51,15 @@ def test_host_file_loader_example_data(tmp_path, oracle):
     x = np.array([float(t) for t in lines[1].split()[2:]])
     ro = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0))
     assert np.abs(x - ro["x"]).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_example_programs():
+    """examples/warm_up.cpp and examples/batch_synthetic.cpp run to completion on the GPU"""
+    import __graft_entry__ as g
+    g.build_examples()
+    bindir = os.path.join(ROOT, "examples", "bin")
+    r = subprocess.run([os.path.join(bindir, "warm_up")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "xOpt = [" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([os.path.join(bindir, "batch_synthetic"), "64", "64", "96", "16"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "64/64 LCQPs solved" in r.stdout, r.stdout + r.stderr
