@@ -1,0 +1,235 @@
+"""lcqpow_amd.lcqpow: the reference's Python surface (interfaces/python/lcqpow/*.cpp) over include/lcqp_host.h.
+
+CPU part: the host C ABI exports what the header declares; Options and load-time argument checks behave like the
+reference (test/RunUnitTests.cpp:249-262; src/Options.cpp:80-259; src/LCQProblem.cpp:87-144).
+GPU part: the reference's Python example scripts (interfaces/python/examples/*.py), re-stated against this module with
+the same calls and argument conventions, checked against the oracle.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import problems as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lcqpow():
+    import lcqpow_amd.lcqpow as lcqpow
+    return lcqpow
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+
+def test_host_library_exports_declared_symbols():
+    src = open(os.path.join(ROOT, "include", "lcqp_host.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(lcqp_host_[a-z_0-9]+)\s*\(", src)))
+    assert len(names) == 24, names
+    L = ctypes.CDLL(os.path.join(ROOT, "lcqpow_amd", "liblcqpow_host.so"))
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_options_kat_and_validation():
+    lcqpow = _lcqpow()
+    opts = lcqpow.Options()
+    # defaults: src/Options.cpp:296-333
+    assert opts.getComplementarityTolerance() == 1e3 * 2.221e-16 and opts.getStationarityTolerance() == 1e6 * 2.221e-16
+    assert (opts.getInitialPenaltyParameter(), opts.getPenaltyUpdateFactor(), opts.getMaxPenaltyParameter()) == (0.01, 2.0, 1e8)
+    assert (opts.getSolveZeroPenaltyFirst(), opts.getPerturbStep(), opts.getMaxIterations()) == (True, True, 1000)
+    assert (opts.getNDynamicPenalty(), opts.getEtaDynamicPenalty(), opts.getStoreSteps()) == (3, 0.9, False)
+    assert opts.getPrintLevel() == lcqpow.PrintLevel.INNER_LOOP_ITERATES
+    # test/RunUnitTests.cpp:249-262
+    opts.setInitialPenaltyParameter(100)
+    opts.setPenaltyUpdateFactor(100)
+    assert opts.getInitialPenaltyParameter() == 100 and opts.getPenaltyUpdateFactor() == 100
+    opts2 = lcqpow.Options(opts)
+    assert opts2.getInitialPenaltyParameter() == 100 and opts2.getPenaltyUpdateFactor() == 100
+    opts.setToDefault()
+    assert opts.getInitialPenaltyParameter() == 0.01 and opts2.getInitialPenaltyParameter() == 100
+    # setter validation, src/Options.cpp:85-259
+    RV = lcqpow.ReturnValue
+    assert opts.setStationarityTolerance(0.0) == RV.INVALID_STATIONARITY_TOLERANCE
+    assert opts.setComplementarityTolerance(1e-17) == RV.INVALID_COMPLEMENTARITY_TOLERANCE
+    assert opts.setInitialPenaltyParameter(0.0) == RV.INVALID_INITIAL_PENALTY_VALUE
+    assert opts.setPenaltyUpdateFactor(1.0) == RV.INVALID_PENALTY_UPDATE_VALUE
+    assert opts.setMaxIterations(0) == RV.INVALID_MAX_ITERATIONS_VALUE
+    assert opts.setMaxPenaltyParameter(0.0) == RV.INVALID_MAX_RHO_VALUE
+    assert opts.setEtaDynamicPenalty(1.0) == RV.INVALID_ETA_VALUE
+    assert opts.setPrintLevel(3) == RV.INVALID_PRINT_LEVEL_VALUE
+    assert opts.setQPSolver(4) == RV.INVALID_QPSOLVER and opts.setQPSolver(-1) == RV.INVALID_QPSOLVER
+    assert opts.getStationarityTolerance() == 1e6 * 2.221e-16          # rejected values leave the option unchanged
+    assert opts.setStationarityTolerance(10e-3) == RV.SUCCESSFUL_RETURN and opts.getStationarityTolerance() == 10e-3
+    assert opts.setQPSolver(lcqpow.QPSolver.HIP_DENSE) == RV.SUCCESSFUL_RETURN
+    assert opts.setPrintLevel(lcqpow.PrintLevel.NONE) == RV.SUCCESSFUL_RETURN and opts.getPrintLevel() == 0
+    # module-level enum values like pybind11's export_values()
+    assert lcqpow.SUCCESSFUL_RETURN == 0 and lcqpow.MAX_PENALTY_REACHED == 201 and lcqpow.S_STATIONARY_SOLUTION == 4
+    h = opts.getHIPOptions()
+    h.maxTrials = 20
+    opts.setHIPOptions(h)
+    assert opts.getHIPOptions().maxTrials == 20
+
+
+def test_load_argument_checks_and_layout():
+    lcqpow = _lcqpow()
+    RV = lcqpow.ReturnValue
+    d = P.warm_up_w_A()
+    lc = lcqpow.LCQProblem(nV=2, nC=1, nComp=1)
+    assert lc.loadLCQP(Q=d["Q"], g=d["g"], L=d["L"], R=d["R"], A=d["A"], lbA=d["lbA"], ubA=d["ubA"]) == RV.SUCCESSFUL_RETURN
+    assert lc.getNumberOfPrimals() == 2 and lc.getNumberOfDuals() == 2 + 1 + 2
+    # src/LCQProblem.cpp:101-107 / :563-571 / :726-733
+    assert lc.loadLCQP(Q=d["Q"], g=None, L=d["L"], R=d["R"], A=d["A"]) == RV.INVALID_OBJECTIVE_LINEAR_TERM
+    assert lc.loadLCQP(Q=d["Q"], g=d["g"], L=d["L"], R=d["R"]) == RV.INVALID_CONSTRAINT_MATRIX            # nC = 1 but no A
+    assert lc.loadLCQP(Q=d["Q"], g=d["g"], L=None, R=d["R"], A=d["A"]) == RV.INVALID_COMPLEMENTARITY_MATRIX
+    assert lc.loadLCQP(Q=d["Q"], g=d["g"], L=d["L"], R=d["R"], A=d["A"], lbL=np.array([-np.inf])) == RV.INVALID_LOWER_COMPLEMENTARITY_BOUND
+    assert lc.loadLCQP("/nonexistent/Q.txt", "/nonexistent/g.txt", "/nonexistent/L.txt", "/nonexistent/R.txt") == RV.UNABLE_TO_READ_FILE
+    with pytest.raises(TypeError):
+        lcqpow.LCQProblem()
+    # the Eigen element order of the reference's binding: a (nV x nC) array A.T is read as row-major (nC x nV)
+    A = np.arange(6.0).reshape(2, 3)
+    assert list(lcqpow._mat(A.T, "F")) == list(A.ravel()) and list(lcqpow._mat(A, "C")) == list(A.ravel())
+    assert lcqpow._mat(np.zeros((0, 0)), "F") is None and lcqpow._vec(np.zeros(0)) is None
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+
+def _solve(lcqpow, d, order="F", tweak=None, files=None):
+    """the call sequence of interfaces/python/examples/warm_up.py:20-47"""
+    lcqp = lcqpow.LCQProblem(nV=d["nV"], nC=d["nC"], nComp=d["nComp"])
+    options = lcqpow.Options()
+    options.setPrintLevel(lcqpow.PrintLevel.NONE)
+    options.setQPSolver(lcqpow.QPSolver.HIP_DENSE)
+    options.setPerturbStep(False)
+    if tweak:
+        tweak(options)
+    lcqp.setOptions(options)
+    if files is not None:
+        ret = lcqp.loadLCQP(**files)
+    else:
+        T = (lambda M: None if M is None else M.T) if order == "F" else (lambda M: M)
+        ret = lcqp.loadLCQP(Q=d["Q"], g=d["g"], L=T(d["L"]), R=T(d["R"]), A=T(d.get("A")), order=order,
+                            **{k: d[k] for k in ("lbL", "ubL", "lbR", "ubR", "lbA", "ubA", "lb", "ub", "x0", "y0") if k in d})
+    assert ret == lcqpow.ReturnValue.SUCCESSFUL_RETURN
+    ret = lcqp.runSolver()
+    stats = lcqpow.OutputStatistics()
+    lcqp.getOutputStatistics(stats)
+    return ret, lcqp.getPrimalSolution(), lcqp.getDualSolution(), stats
+
+
+@pytest.mark.gpu
+def test_python_warm_up(hip):
+    """interfaces/python/examples/warm_up.py; expectations of test/RunUnitTests.cpp:505-551"""
+    lcqpow = _lcqpow()
+    ret, x, y, stats = _solve(lcqpow, P.warm_up_x0())
+    assert ret == lcqpow.ReturnValue.SUCCESSFUL_RETURN
+    assert min(np.abs(x - [1, 0]).max(), np.abs(x - [0, 1]).max()) < 2.2e-10
+    d = P.warm_up()
+    stat = d["Q"] @ x + d["g"] - y[:2] - d["L"].T @ y[2:3] - d["R"].T @ y[3:4]
+    assert np.abs(stat).max() < 1e-9
+    assert stats.getSolutionStatus() == lcqpow.AlgorithmStatus.S_STATIONARY_SOLUTION
+    assert stats.getIterTotal() >= stats.getIterOuter() >= 1 and stats.getRhoOpt() > 0 and stats.getQPSolverExitFlag() == 0
+    assert stats.getInnerIters() == [] and stats.getPhiVals() == []          # storeSteps is off
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,order", [("warm_up_w_A", "F"), ("warm_up_binary", "F"), ("circle", "F"), ("circle", "C")])
+def test_python_examples_match_oracle(hip, oracle, name, order):
+    """warm_up_w_A.py, warm_up_binary.py, OptimizeOnCircle.py (L.T, R.T, A.T as at :76) vs the oracle"""
+    lcqpow = _lcqpow()
+    d = getattr(P, name)()
+    ret, x, y, stats = _solve(lcqpow, d, order=order)
+    ro = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0))
+    assert int(ret) == ro["ret"] == 0
+    assert np.abs(x - ro["x"]).max() < 1e-7
+    assert np.abs(y - ro["y"]).max() < 1e-5
+    so = ro["stats"]
+    assert (stats.getIterTotal(), stats.getIterOuter(), stats.getRhoOpt(), int(stats.getSolutionStatus())) == \
+        (so["iterTotal"], so["iterOuter"], so["rhoOpt"], so["status"])
+    if name == "circle":          # examples/OptimizeOnCircle.cpp:144
+        assert np.abs(x[:2] - [0.1811, -0.9835]).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_python_store_steps(hip, oracle):
+    """OptimizeOnCircleStoreSteps.py: tracking vectors of OutputStatistics (src/OutputStatistics.cpp:131-164)"""
+    lcqpow = _lcqpow()
+    d = P.circle(20)
+    ret, x, y, stats = _solve(lcqpow, d, tweak=lambda o: o.setStoreSteps(True))
+    assert ret == 0
+    n = len(stats.getInnerIters())
+    assert n == stats.getIterTotal() + 1 or n == stats.getIterTotal()
+    for v in (stats.getSubproblemIters(), stats.getAccuSubproblemIters(), stats.getStepLength(), stats.getStepSize(),
+              stats.getStatVals(), stats.getObjVals(), stats.getPhiVals(), stats.getMeritVals()):
+        assert len(v) == n
+    assert stats.getAccuSubproblemIters()[-1] == stats.getSubproblemIter()
+    assert stats.getxSteps().shape == (n, d["nV"]) and np.abs(stats.getxSteps()[-1] - x).max() < 1e-12
+    assert stats.getPhiVals()[-1] < 1e3 * 2.221e-16
+    # per-iterate values against the oracle's trace of the same run
+    ro = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0), trace=256)
+    assert abs(stats.getPhiVals()[-1] - ro["trace"][-1, 1]) < 1e-12 and np.abs(ro["x"] - x).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_python_sparse_and_mode_switch(hip, oracle):
+    """warm_up_sparse.py restated with explicit cscWrapper inputs (LCQProblem.cpp:118-148) + switchToDenseMode"""
+    lcqpow = _lcqpow()
+
+    def csc(M):
+        m, n = M.shape
+        p, i, x = [0], [], []
+        for c in range(n):
+            for r in range(m):
+                if M[r, c] != 0:
+                    i.append(r); x.append(M[r, c])
+            p.append(len(i))
+        return lcqpow.cscWrapper(m, n, len(x), np.array(x, dtype=float), i, p)
+
+    d = P.circle(10)
+    ro = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0))
+    for switch in (False, True):
+        lcqp = lcqpow.LCQProblem(nV=d["nV"], nC=d["nC"], nComp=d["nComp"])
+        options = lcqpow.Options()
+        options.setPrintLevel(0)
+        options.setPerturbStep(False)
+        lcqp.setOptions(options)
+        assert lcqp.loadLCQP(Q=csc(d["Q"]), g=d["g"], L=csc(d["L"]), R=csc(d["R"]), A=csc(d["A"]), lbA=d["lbA"], ubA=d["ubA"],
+                             x0=d["x0"]) == 0
+        if switch:
+            assert lcqp.switchToDenseMode() == 0
+        assert lcqp.runSolver() == 0
+        assert np.abs(lcqp.getPrimalSolution() - ro["x"]).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_python_from_files(hip, oracle, tmp_path):
+    """solve_lcqp_from_file.py: the file overload with the reference's keyword names (LCQProblem.cpp:149-163)"""
+    lcqpow = _lcqpow()
+    z = np.load(os.path.join(P.GOLDEN, "example_data.npz"))
+    for k in z.files:
+        with open(tmp_path / (k + ".txt"), "w") as f:
+            for v in np.ravel(z[k]):
+                f.write("Inf\n" if v == np.inf else "-Inf\n" if v == -np.inf else repr(float(v)) + "\n")
+    d = P.example_data()
+    files = {k + "_file": str(tmp_path / (k + ".txt")) for k in ("Q", "g", "L", "R", "lbL", "ubL", "lbR", "ubR", "A", "lbA", "ubA", "lb", "ub", "x0")}
+    ret, x, y, stats = _solve(lcqpow, d, files=files)
+    ro = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0))
+    assert ret == 0 and np.abs(x - ro["x"]).max() < 1e-7
+    assert (stats.getIterTotal(), stats.getIterOuter()) == (ro["stats"]["iterTotal"], ro["stats"]["iterOuter"])
+
+
+@pytest.mark.gpu
+def test_python_max_penalty_and_infeasible(hip):
+    """test_max_penalty.py (maxPenaltyParameter = 1 -> MAX_PENALTY_REACHED, test/examples/test_max_penalty.cpp:49,75-79) and
+    the infeasible QP of test/RunUnitTests.cpp:463-502 (SUBPROBLEM_SOLVER_ERROR, non-zero exit flag)"""
+    lcqpow = _lcqpow()
+    ret, x, y, stats = _solve(lcqpow, P.warm_up_x0(), tweak=lambda o: o.setMaxPenaltyParameter(1.0))
+    assert ret == lcqpow.ReturnValue.MAX_PENALTY_REACHED
+    ret, x, y, stats = _solve(lcqpow, P.infeasible())
+    assert ret == lcqpow.ReturnValue.SUBPROBLEM_SOLVER_ERROR and stats.getQPSolverExitFlag() != 0
+    # a reference solver arm that needs un-vendored code is refused, not silently replaced
+    ret, x, y, stats = _solve(lcqpow, P.warm_up(), tweak=lambda o: o.setQPSolver(lcqpow.QPSolver.QPOASES_DENSE))
+    assert ret == lcqpow.ReturnValue.NOT_YET_IMPLEMENTED
