@@ -124,7 +124,8 @@ def _solve(lcqpow, d, order="F", tweak=None, files=None):
 def test_python_warm_up(hip):
     """interfaces/python/examples/warm_up.py; expectations of test/RunUnitTests.cpp:505-551"""
     lcqpow = _lcqpow()
-    ret, x, y, stats = _solve(lcqpow, P.warm_up_x0())
+    # perturbStep stays on (the default): from x0 = (1, 1) the unperturbed iterates keep x1 = x2 and end at the origin
+    ret, x, y, stats = _solve(lcqpow, P.warm_up_x0(), tweak=lambda o: o.setPerturbStep(True))
     assert ret == lcqpow.ReturnValue.SUCCESSFUL_RETURN
     assert min(np.abs(x - [1, 0]).max(), np.abs(x - [0, 1]).max()) < 2.2e-10
     d = P.warm_up()
@@ -170,7 +171,11 @@ def test_python_store_steps(hip, oracle):
     assert stats.getPhiVals()[-1] < 1e3 * 2.221e-16
     # per-iterate values against the oracle's trace of the same run
     ro = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0), trace=256)
-    assert abs(stats.getPhiVals()[-1] - ro["trace"][-1, 1]) < 1e-12 and np.abs(ro["x"] - x).max() < 1e-7
+    ts = ro["trace_scalars"]                      # rows of [statk_inf, phi, rho, alphak], one per stored iterate
+    assert len(ts) == n and np.abs(ro["x"] - x).max() < 1e-7
+    assert np.abs(np.array(stats.getPhiVals()) - ts[:, 1]).max() < 1e-9
+    assert np.abs(np.array(stats.getStatVals()) - ts[:, 0]).max() < 1e-9
+    assert np.abs(stats.getxSteps() - ro["trace_x"]).max() < 1e-7
 
 
 @pytest.mark.gpu
