@@ -117,6 +117,8 @@ def main():
     kernel_s = (solve_ms / args.steps) * 1e-3
     achieved = alg_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
     mean = lambda k: float(np.mean([s[k] for s in st]))
+    ws = bt.work_sums()
+    n_corr = max(1, sum(s["corrections"] for s in st)); n_fact = max(1, sum(s["factorizations"] for s in st))
 
     if dist is not None:
         ok_t = torch.tensor([n_ok], dtype=torch.int64, device="cuda")
@@ -140,6 +142,7 @@ def main():
                    "solved": n_ok_total, "mean_lcqp_iterates": mean("iterTotal"), "mean_outer": mean("iterOuter"),
                    "mean_qp_trials": mean("trials"), "mean_residual_sweeps": mean("reserved"), "mean_factorizations": mean("factorizations"),
                    "mean_backsolve_pairs": mean("corrections"), "mean_admm_iters": mean("admmIter"),
+                   "mean_active_rows_per_backsolve": float(ws[0] / n_corr), "mean_active_rows_per_factorization": float(ws[2] / n_fact),
                    "setup_ms_per_step": setup_ms / args.steps, "homotopy_kernel_ms_per_step": solve_ms / args.steps},
         "roofline": {"bound": "hbm", "kernel": "k_lcqp_run", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(B, n, nC, nComp),

@@ -148,6 +148,9 @@ int  lcqp_hip_batch_read_profile(lcqp_hip_batch_t* b, unsigned long long* out);
 void* lcqp_hip_batch_stream(lcqp_hip_batch_t* b);
 /* algorithmic HBM bytes of the last run, from the work counters the kernels keep */
 double lcqp_hip_batch_algorithmic_bytes(lcqp_hip_batch_t* b);
+/* the work sums that enter it, summed over the batch: out[0] = sum of active rows na over all corrections,
+ * out[1] = sum of na^2 over corrections, out[2], out[3] = the same over factorisations (counted by the kernel) */
+int    lcqp_hip_batch_work_sums(lcqp_hip_batch_t* b, double out[4]);
 
 /* ------------------------------------------------------------------------------------------------
  * Building blocks exposed for parity tests and micro-benchmarks (each is one kernel launch over a

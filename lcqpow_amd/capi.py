@@ -85,6 +85,7 @@ def lib():
         L.lcqp_hip_batch_stream.argtypes = [C.c_void_p]
         L.lcqp_hip_batch_algorithmic_bytes.restype = C.c_double
         L.lcqp_hip_batch_algorithmic_bytes.argtypes = [C.c_void_p]
+        L.lcqp_hip_batch_work_sums.argtypes = [C.c_void_p, c_double_p]
         L.lcqp_hip_util_symv.argtypes = [C.c_int, C.c_int, C.c_double] + [c_double_p] * 4
         L.lcqp_hip_util_gemv.argtypes = [C.c_int, C.c_int, C.c_int] + [c_double_p] * 3
         L.lcqp_hip_util_gemv_t.argtypes = [C.c_int, C.c_int, C.c_int] + [c_double_p] * 3
@@ -226,6 +227,12 @@ class BatchLCQP:
 
     def algorithmic_bytes(self):
         return lib().lcqp_hip_batch_algorithmic_bytes(self.h)
+
+    def work_sums(self):
+        """batch totals of (sum na, sum na^2) over corrections and over factorisations, counted by the kernel"""
+        out = np.zeros(4)
+        _check(lib().lcqp_hip_batch_work_sums(self.h, _p(out)), "work_sums")
+        return out
 
     def stream(self):
         return lib().lcqp_hip_batch_stream(self.h)

@@ -23,6 +23,7 @@ struct InstInfo {
     int mE, nfin, hasY0, setupFail, haveSolution, isSetup, cacheNa, pad1;   // cacheNa: active rows the stored factor of S belongs to (-1: none)
     double scale, sigma, spv, rhoAdmm, phiConst;
     double hist[8];
+    double work[4];   // exact work sums for the byte accounting: sum(na), sum(na^2) over corrections; the same over factorisations
 };
 
 struct DevBatch {
@@ -273,7 +274,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             if (nblkS > 0) wg_chol(c.S, capS, nblkS, na, o.depTau, c.dscr, d0, nullptr, c.lds, 0);
             PROF(c, P_CHOL);
             c.cFact++;
-            if (t == 0) c.info->cacheNa = na;
+            if (t == 0) { c.info->cacheNa = na; c.info->work[2] += (double)na; c.info->work[3] += (double)na * na; }
             __syncthreads();
             }   // rebuild
             fact_valid = 1;
@@ -305,6 +306,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
         PROF(c, P_CORR_L1);
         for (int i = t; i < np; i += WG) x[i] += du[i];
         for (int a = t; a < na; a += WG) yt[idx[a]] += dy[a];
+        if (t == 0) { c.info->work[0] += (double)na; c.info->work[1] += (double)na * na; }
         __syncthreads();
         c.cCorr++;
     }
@@ -428,6 +430,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     const double phiConst = c.info->phiConst;
     uint64_t perturbCounter = 0;
     double* hist = c.info->hist;
+    if (t == 0) c.info->work[0] = c.info->work[1] = c.info->work[2] = c.info->work[3] = 0.0;
 
     // xk = x0, g_tilde = g   (setInitialGuess .ipp:133-158, :966-967)
     for (int i = t; i < np; i += WG) { xk[i] = c.V(V_X0)[i]; gtil[i] = g[i]; }

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -507,13 +508,18 @@ extern "C" lcqp_hip_batch_t* lcqp_hip_batch_create(int batch, int nV, int nC, in
     if (batch <= 0 || nV <= 0 || nC < 0 || nComp < 0) { g_err = "invalid dimensions"; return nullptr; }
     if (nV > 512) { g_err = "nV > 512 is not supported by this build"; return nullptr; }
     HIPCHKN(hipSetDevice(device));
-    lcqp_hip_batch* h = new lcqp_hip_batch();
+    lcqp_hip_batch* h = new (std::nothrow) lcqp_hip_batch();
+    if (!h) { g_err = "out of host memory"; return nullptr; }
     h->device = device; h->setupDone = false; h->ran = false; h->bytesTotal = 0;
     h->stage[0] = h->stage[1] = nullptr; h->stageBytes = 0;
-    HIPCHKN(hipStreamCreate(&h->stream));
-    HIPCHKN(hipEventCreate(&h->ev0)); HIPCHKN(hipEventCreate(&h->ev1)); HIPCHKN(hipEventCreate(&h->ev2));
+    h->stream = nullptr; h->ev0 = h->ev1 = h->ev2 = nullptr;
     DevBatch& d = h->db;
     memset(&d, 0, sizeof(d));
+    hipError_t e0 = hipStreamCreate(&h->stream);
+    if (e0 == hipSuccess) e0 = hipEventCreate(&h->ev0);
+    if (e0 == hipSuccess) e0 = hipEventCreate(&h->ev1);
+    if (e0 == hipSuccess) e0 = hipEventCreate(&h->ev2);
+    if (e0 != hipSuccess) { set_err("stream/event creation", e0); lcqp_hip_batch_destroy(h); return nullptr; }
     d.B = batch; d.n = nV; d.nC = nC; d.nComp = nComp; d.mA = nC + 2 * nComp;
     h->nch = (nV + 127) / 128;
     d.np = 128 * h->nch;
@@ -560,11 +566,13 @@ extern "C" void lcqp_hip_batch_destroy(lcqp_hip_batch_t* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) (void)hipFree(p);
     for (int k = 0; k < 2; k++) if (h->stage[k]) { (void)hipHostFree(h->stage[k]); (void)hipEventDestroy(h->stageDone[k]); }
-    (void)hipEventDestroy(h->ev0); (void)hipEventDestroy(h->ev1); (void)hipEventDestroy(h->ev2);
-    (void)hipStreamDestroy(h->stream);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev2) (void)hipEventDestroy(h->ev2);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -852,18 +860,34 @@ extern "C" double lcqp_hip_batch_algorithmic_bytes(lcqp_hip_batch_t* h)
     if (hipSetDevice(h->device) != hipSuccess) return 0.0;
     if (hipStreamSynchronize(h->stream) != hipSuccess) return 0.0;
     if (hipMemcpy(st.data(), d.stats, sizeof(lcqp_stats_t) * (size_t)d.B, hipMemcpyDeviceToHost) != hipSuccess) return 0.0;
+    std::vector<InstInfo> info(d.B);
+    if (hipMemcpy(info.data(), d.info, sizeof(InstInfo) * (size_t)d.B, hipMemcpyDeviceToHost) != hipSuccess) return 0.0;
     const double n = d.n, m = d.mA, N = d.n;
-    const double na = 0.5 * (d.n < d.mA ? d.n : d.mA);   // nominal active rows (half of min(n, m))
     const double bs = 8.0 * N * (N + 2.0);
     double total = 0.0;
     for (int b = 0; b < d.B; b++) {
+        // active rows na of each correction / factorisation are summed by the kernel (InstInfo::work), not estimated
+        const double naC = info[b].work[0], na2C = info[b].work[1], naF = info[b].work[2], na2F = info[b].work[3];
         total += st[b].reserved * 8.0 * (n * n + m * n);   // trials that swept Q and E (hot-start trials reuse the last residual)
-        total += st[b].corrections * (bs + 2.0 * 8.0 * na * n + 8.0 * na * (na + 2.0));
-        total += st[b].factorizations * (8.0 * na * n + 8.0 * na * na);
+        total += st[b].corrections * bs + 2.0 * 8.0 * naC * n + 8.0 * (na2C + 2.0 * naC);
+        total += 8.0 * naF * n + 8.0 * na2F;
         total += st[b].admmIter * (bs + 2.0 * 8.0 * m * n);
         total += (st[b].iterTotal + 1) * (2.0 * 8.0 * n * n);   // one sweep over Q and C per LCQP iterate
     }
     return total;
+}
+
+extern "C" int lcqp_hip_batch_work_sums(lcqp_hip_batch_t* h, double out[4])
+{
+    if (!h || !out) return LCQP_INVALID_ARGUMENT;
+    DevBatch& d = h->db;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<InstInfo> info(d.B);
+    HIPCHK(hipMemcpy(info.data(), d.info, sizeof(InstInfo) * (size_t)d.B, hipMemcpyDeviceToHost));
+    out[0] = out[1] = out[2] = out[3] = 0.0;
+    for (int b = 0; b < d.B; b++) for (int k = 0; k < 4; k++) out[k] += info[b].work[k];
+    return 0;
 }
 
 // =================================================================================================
