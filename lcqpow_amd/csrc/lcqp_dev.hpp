@@ -169,7 +169,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
     const double gs = 1.0 + wg_maxabs(g, c.n, c.lds);
     const double ytol = o.feasTol * gs;
     int na = 0, nblkS = 0, fact_valid = 0;
-    const int capNa = min(min(2 * c.n, mE), capS);
+    const int capNa = min(min(max(2 * c.n, 64), mE), capS);   // room for the degenerate vertices of small problems
 
     for (int trial = 0; trial < o.maxTrials; trial++) {
         c.cTrials++;

@@ -527,7 +527,8 @@ extern "C" lcqp_hip_batch_t* lcqp_hip_batch_create(int batch, int nV, int nC, in
     d.boxcap = withBox ? nV : 0;
     d.mEcap = d.mA + d.boxcap;
     if (d.mEcap < 1) d.mEcap = 1;
-    int capNa = 2 * nV < d.mEcap ? 2 * nV : d.mEcap;
+    int capNa = 2 * nV > 64 ? 2 * nV : 64;      // active rows the Gram factor has room for (qp_polish)
+    if (capNa > d.mEcap) capNa = d.mEcap;
     d.capS = ((capNa + 63) / 64) * 64;
     if (d.capS < 64) d.capS = 64;
     d.nd = nV + d.mA;

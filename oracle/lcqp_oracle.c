@@ -371,7 +371,8 @@ static int qp_setup(orc_qp_t* q, const double* lbA, const double* ubA, const dou
     q->x = dalloc(n); q->y = dalloc(mE); q->st = (int*)calloc(mE ? mE : 1, sizeof(int));
     q->xa = dalloc(n); q->ya = dalloc(mE); q->za = dalloc(mE);
     q->w_n1 = dalloc(n); q->w_n2 = dalloc(n); q->w_n3 = dalloc(n); q->w_m1 = dalloc(mE);
-    q->cap_na = (2 * n < mE) ? 2 * n : mE;
+    q->cap_na = (2 * n > 64) ? 2 * n : 64;   /* room for the degenerate vertices of small problems (many rows, few variables) */
+    if (q->cap_na > mE) q->cap_na = mE;
     q->T = dalloc((size_t)q->cap_na * n);
     q->S = dalloc((size_t)q->cap_na * q->cap_na);
     q->w_a1 = dalloc(q->cap_na); q->w_a2 = dalloc(q->cap_na);

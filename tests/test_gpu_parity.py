@@ -89,7 +89,7 @@ def test_subsolver_matches_oracle_and_kkt(hip, oracle, n, m, seed):
         g = g + 0.2 * r2.standard_normal(n)
         ro = qo.solve(False, g, lbA, ubA, None, None, lb, ub)
         rh = qh.solve(False, g, lbA, ubA, None, None, lb, ub)
-        assert (ro[0], ro[2]) == (rh[0], rh[2]) == (0, 0) and abs(ro[1] - rh[1]) <= 8
+        assert (ro[0], ro[2]) == (rh[0], rh[2]) == (0, 0) and abs(ro[1] - rh[1]) <= max(8, 0.03 * ro[1])
         (xo, yo), (xh, yh) = qo.solution(), qh.getSolution()
         assert np.abs(xo - xh).max() < X_TOL and np.abs(yo - yh).max() < Y_TOL
         stat, pf, cs = P.kkt_residuals(Q, g, A, lbA, ubA, lb, ub, xh, yh)
@@ -378,3 +378,20 @@ def test_lcqp_shape_sweep(hip, oracle, n, nC, nComp):
         assert st[b]["returnValue"] == ro["ret"] == 0
         assert np.abs(ro["x"] - x[b]).max() < X_TOL and np.abs(ro["y"] - y[b]).max() < Y_TOL
     bt.close()
+
+
+def test_lcqp_structure_fuzz(hip, oracle):
+    """tools/gpu_fuzz.py: random small LCQPs with the irregular structure the synthetic generator never produces (singular
+    Hessians, dense / overlapping complementarity rows, equalities, duplicate and empty rows, finite upper complementarity
+    bounds, box bounds, warm-start duals; about a quarter are infeasible or unbounded by construction).  HIP and oracle must
+    end the same way: same return code and, on success, the same solution.  A few per cent may legitimately differ -- a
+    trial accepted on one side and rejected on the other at the residual tolerance sends a degenerate or nonconvex problem
+    down another path -- so the bound is 5 %."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    count = 150
+    cats, rets = fz.run(count, seed=5, verbose=False)
+    assert cats["same"] + cats["same solution, other iterate count"] >= count - count // 20, (cats, rets)
+    assert rets.get((0, 0), 0) >= count // 2, rets          # the generator is not mostly producing failures

@@ -1,0 +1,132 @@
+"""Structure fuzzer: random small LCQPs with the irregular features the synthetic generator never produces
+(rank-deficient Q, dense / overlapping complementarity rows, equalities, duplicate rows, finite upper complementarity
+bounds, shifted lower bounds, box bounds, warm-start duals), HIP single-instance batch vs the CPU oracle.
+
+usage: python tools/gpu_fuzz.py [count] [seed]   (prints one line per divergence and a summary; exit code 1 when more
+than 5 % of the problems end differently)
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import lcqpow_amd as la  # noqa: E402
+import oracle_py as O  # noqa: E402
+import problems as P  # noqa: E402
+
+INF = np.inf
+
+
+def make(rng):
+    n = int(rng.integers(2, 41))
+    nComp = int(rng.integers(1, n // 2 + 1))
+    nC = int(rng.integers(0, 31))
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        M = rng.uniform(-1, 1, (n, n)); Q = M.T @ M / n + np.eye(n)
+    elif kind == 1:                                   # rank-deficient PSD
+        k = max(1, n // 2); M = rng.uniform(-1, 1, (k, n)); Q = M.T @ M / k
+    elif kind == 2:                                   # diagonal with tiny entries (the circle example's regularisation)
+        Q = np.diag(np.where(rng.random(n) < 0.5, 5e-12, rng.uniform(0.5, 20, n)))
+    else:
+        Q = 2.0 * np.eye(n)
+    g = rng.uniform(-2, 2, n)
+    perm = rng.permutation(n)
+    L = np.zeros((nComp, n)); R = np.zeros((nComp, n))
+    style = rng.integers(0, 3)
+    for i in range(nComp):
+        L[i, perm[2 * i]] = 1.0
+        R[i, perm[2 * i + 1]] = 1.0
+        if style == 1 and rng.random() < 0.5:         # R selects -x + const like warm_up_binary (x (1 - x) = 0)
+            R[i, :] = 0; R[i, perm[2 * i]] = -1.0
+        if style == 2:                                # dense rows
+            L[i] += rng.uniform(-0.2, 0.2, n) * (rng.random(n) < 0.2)
+            R[i] += rng.uniform(-0.2, 0.2, n) * (rng.random(n) < 0.2)
+    xs = rng.uniform(-1, 1, n)                        # a point that is made feasible
+    Lx, Rx = L @ xs, R @ xs
+    d = dict(Q=Q, g=g, L=L, R=R, nV=n, nC=nC, nComp=nComp)
+    lbL = np.zeros(nComp); lbR = np.zeros(nComp)
+    for i in range(nComp):                            # shift bounds so that xs satisfies the complementarity exactly
+        if rng.random() < 0.5:
+            lbL[i] = Lx[i]; lbR[i] = Rx[i] - rng.uniform(0, 1)
+        else:
+            lbR[i] = Rx[i]; lbL[i] = Lx[i] - rng.uniform(0, 1)
+    if rng.random() < 0.6:
+        d["lbL"], d["lbR"] = lbL, lbR
+    else:                                             # default bounds 0: move xs instead is not possible in general; keep 0 bounds
+        pass
+    if rng.random() < 0.3 and "lbL" in d:
+        d["ubL"] = np.where(rng.random(nComp) < 0.5, np.maximum(Lx, lbL) + rng.uniform(0.5, 2, nComp), INF)
+        d["ubR"] = np.where(rng.random(nComp) < 0.5, np.maximum(Rx, lbR) + rng.uniform(0.5, 2, nComp), INF)
+    if nC:
+        A = rng.uniform(-1, 1, (nC, n)) * (rng.random((nC, n)) < rng.uniform(0.1, 1.0))
+        if nC > 2 and rng.random() < 0.3:
+            A[1] = A[0]                               # duplicate row
+        if nC > 3 and rng.random() < 0.2:
+            A[2] = 0.0                                # empty row
+        Ax = A @ xs
+        lo = Ax - rng.uniform(0, 1, nC); hi = Ax + rng.uniform(0, 1, nC)
+        eq = rng.random(nC) < 0.2
+        lo[eq] = Ax[eq]; hi[eq] = Ax[eq]
+        lo[rng.random(nC) < 0.2] = -INF
+        hi[rng.random(nC) < 0.2] = INF
+        d.update(A=A, lbA=lo, ubA=hi)
+    if kind in (1, 2) and rng.random() < 0.7:         # singular Hessian: bound the feasible set so that every QP has a solution
+        d["lb"] = xs - rng.uniform(0.5, 2, n)
+        d["ub"] = xs + rng.uniform(0.5, 2, n)
+    elif rng.random() < 0.4:
+        lb = np.where(rng.random(n) < 0.5, xs - rng.uniform(0, 2, n), -INF)
+        ub = np.where(rng.random(n) < 0.5, xs + rng.uniform(0, 2, n), INF)
+        if rng.random() < 0.5:
+            d["lb"] = lb
+        if rng.random() < 0.5 or "lb" not in d:
+            d["ub"] = ub
+    if rng.random() < 0.5:
+        d["x0"] = rng.uniform(-1, 1, n)
+    if rng.random() < 0.2:
+        d["y0"] = rng.uniform(-0.1, 0.1, n + nC + 2 * nComp)
+    return d
+
+
+def run(count, seed, verbose=True):
+    O.build(); O.lib()
+    rng = np.random.default_rng(seed)
+    rets = {}
+    cats = {"same": 0, "same solution, other iterate count": 0, "other stationary point": 0, "return codes differ": 0}
+    for k in range(count):
+        d = make(rng)
+        ro = P.oracle_solve(O, d, O.default_options(perturbStep=0))
+        rh = P.hip_solve(la, d, la.default_options(perturbStep=0))
+        rets[(ro["ret"], rh["ret"])] = rets.get((ro["ret"], rh["ret"]), 0) + 1
+        msg, cat = None, "same"
+        if ro["ret"] != rh["ret"]:
+            cat, msg = "return codes differ", f"oracle {ro['ret']} hip {rh['ret']}"
+        elif ro["ret"] == 0:
+            dx = float(np.abs(ro["x"] - rh["x"]).max())
+            so, sh = ro["stats"], rh["stats"]
+            if dx > 1e-6 * (1 + float(np.abs(ro["x"]).max())):
+                # the LCQP is nonconvex: a trial accepted on one side and not on the other (residual at the tolerance)
+                # can send the two homotopies to different stationary points; both returned SUCCESSFUL_RETURN
+                cat, msg = "other stationary point", f"x differs by {dx:.2e} (iter {so['iterTotal']}/{sh['iterTotal']}, outer {so['iterOuter']}/{sh['iterOuter']})"
+            elif (so["iterTotal"], so["iterOuter"], so["status"]) != (sh["iterTotal"], sh["iterOuter"], sh["status"]):
+                cat = "same solution, other iterate count"
+        cats[cat] += 1
+        if msg and verbose:
+            print(f"[{k}] n={d['nV']} nC={d['nC']} nComp={d['nComp']} keys={sorted(set(d) - {'Q', 'g', 'L', 'R', 'nV', 'nC', 'nComp'})}: {cat}: {msg}", flush=True)
+    if verbose:
+        print(f"fuzz: {count} problems (seed {seed}): {cats}; (oracle ret, hip ret) histogram: {dict(sorted(rets.items()))}")
+    return cats, rets
+
+
+def main():
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    cats, _ = run(count, seed)
+    return 1 if cats["return codes differ"] + cats["other stationary point"] > count // 20 else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
