@@ -16,11 +16,12 @@ enum { V_G, V_GPHI, V_GTIL, V_XK, V_PK, V_XNEW, V_GK, V_QX, V_CX, V_QP, V_CP, V_
        V_XQ, V_XA, V_XT, V_R1, V_C, V_DU, V_W, V_RHS, V_LB, V_UB, V_X0, V_R1S, V_GS, V_ATY, V_NUM };
 // per-instance vectors of length mEcap (rows of E = [A; L; R; box rows])
 enum { M_L, M_U, M_RHOV, M_YQ, M_YA, M_ZA, M_YT, M_EX, M_COEF, M_EXS, M_NUM };
-enum { I_ST, I_STT, I_NUM };
+enum { I_ST, I_STT, I_DEP, I_PRIO, I_NUM };   // I_DEP: row flagged dependent by the last factorisation of S; I_PRIO: promotion stamp (0: none)
 enum { S_R2, S_DY, S_D0, S_NUM };
 
 struct InstInfo {
-    int mE, nfin, hasY0, setupFail, haveSolution, isSetup, cacheNa, pad1;   // cacheNa: active rows the stored factor of S belongs to (-1: none)
+    int mE, nfin, hasY0, setupFail, haveSolution, isSetup, cacheNa, prioCtr;   // cacheNa: active rows the stored factor of S belongs to (-1: none); prioCtr: promotion stamps in use (I_PRIO)
+    int ndep, pad2;                                                            // ndep: rows the stored factor of S flagged as dependent (I_DEP)
     double scale, sigma, spv, rhoAdmm, phiConst;
     double hist[8];
     double work[4];   // exact work sums for the byte accounting: sum(na), sum(na^2) over corrections; the same over factorisations
@@ -148,13 +149,63 @@ __device__ __forceinline__ void qp_admm(Ctx<NCH>& c, const double* g, int n_it)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Dependent-row rules of the single-QP kernel (k_qp_solve, ROBUST = true; oracle: q->robust).  k_lcqp_run runs without
+// them: inside the persistent kernel they cost 6 % through register allocation.
+// (1) Rows the last factorisation of S flagged as linearly dependent on the rows before them: the correction neither
+//     moved their multipliers nor enforced their equations.  Strictly inside its bound: the row is not active.
+//     Violated: it must be active, so it is promoted to the front of the list and another row becomes the dependent
+//     one.  Returns bit 0 (a row left) | bit 1 (a row was promoted), per thread.
+// (2) The promoted part of the ordered active list: latest promotion first, ascending row index within one promotion.
+//     Every promoted active row counts the rows that precede it.  Returns (number of promoted active rows) << 1 |
+//     (the list differs from the stored one), uniform.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int polish_dependent_rows(int* st, const int* dep, int* prio, const double* ex, const double* l,
+                                                     const double* u, int mE, double feasTol, int stamp)
+{
+    int chg = 0;
+    for (int r = threadIdx.x; r < mE; r += WG) {
+        const int s = st[r];
+        if (s == ST_INACT || !dep[r]) continue;
+        const double e = ex[r], ftol = feasTol * (1.0 + fabs(e));
+        bool viol, inside = false;
+        if (s == ST_LOWER) { viol = e < l[r] - ftol; inside = e > l[r] + ftol; }
+        else if (s == ST_UPPER) { viol = e > u[r] + ftol; inside = e < u[r] - ftol; }
+        else viol = fabs(e - l[r]) > ftol;
+        if (inside) { st[r] = ST_INACT; chg |= 1; }
+        else if (viol) { prio[r] = stamp; chg |= 2; }
+    }
+    return chg;
+}
+
+__device__ __forceinline__ int polish_promoted_list(const int* st, const int* prio, int* idx, int mE, int r0, int r1e, int cap, Lds lds)
+{
+    int mine = 0, differs = 0;
+    for (int r = r0; r < r1e; r++) mine += (st[r] != ST_INACT && prio[r] > 0);
+    const int nprom = block_sum_i(mine, lds);
+    if (nprom <= cap)
+        for (int r = r0; r < r1e; r++) {
+            const int pr = prio[r];
+            if (st[r] == ST_INACT || pr == 0) continue;
+            int rank = 0;
+            for (int q = 0; q < mE; q++) {
+                const int pq = prio[q];
+                rank += (pq > 0 && st[q] != ST_INACT && (pq > pr || (pq == pr && q < r)));
+            }
+            differs |= (idx[rank] != r);
+            idx[rank] = r;
+        }
+    differs = block_or(differs, lds);
+    return (nprom << 1) | differs;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Primal-dual active-set polish in correction form (oracle: qp_polish).
 // In/out: x = V_XT, multipliers M_YT (OSQP sign, zero on inactive rows), active set I_STT.
 // Returns 1 (uniform) on a verified KKT point.
 // reuse != 0 (hot start from the last verified solution): the first trial needs no sweep, because
 // r1 = r1_last + (g_last - g) and E x = ex_last hold exactly for an unchanged (x, y).
 // ---------------------------------------------------------------------------------------------
-template <int NCH>
+template <int NCH, bool ROBUST>
 __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse)
 {
     constexpr int np = 128 * NCH;
@@ -164,11 +215,13 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
     double *yt = c.M(M_YT), *ex = c.M(M_EX), *coef = c.M(M_COEF);
     const double *l = c.M(M_L), *u = c.M(M_U);
     int* st = c.I(I_STT);
+    int *dep = c.I(I_DEP), *prio = c.I(I_PRIO);
     double *r2 = c.Sv(S_R2), *dy = c.Sv(S_DY), *d0 = c.Sv(S_D0);
     int* idx = c.idx;
     const double gs = 1.0 + wg_maxabs(g, c.n, c.lds);
     const double ytol = o.feasTol * gs;
     int na = 0, nblkS = 0, fact_valid = 0;
+    int prioCtr = ROBUST ? uniform_i(c.info->prioCtr) : 0;
     const int capNa = min(min(max(2 * c.n, 64), mE), capS);   // room for the degenerate vertices of small problems
 
     for (int trial = 0; trial < o.maxTrials; trial++) {
@@ -181,6 +234,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             if (trial > 0) {
                 const int s = st[r];
                 if ((s == ST_LOWER && yv > ytol) || (s == ST_UPPER && yv < -ytol)) { st[r] = ST_INACT; yv = 0.0; yt[r] = 0.0; chg = 1; }
+                else if (ROBUST && s == ST_INACT && yv != 0.0) { yv = 0.0; yt[r] = 0.0; }   // left as "dependent, inside" in the last trial
             }
             coef[r] = yv;
         }
@@ -213,7 +267,15 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                 bmax = fmax(bmax, fabs(bb));
             }
         }
-        const int changed = block_or(chg, c.lds);
+        int changed;
+        if (ROBUST) {
+            if (trial > 0 && uniform_i(c.info->ndep) > 0) chg |= polish_dependent_rows(st, dep, prio, ex, l, u, mE, o.feasTol, prioCtr + 1);
+            const int chgBits = block_or_bits(chg, c.lds);
+            if (chgBits & 2) { prioCtr++; if (t == 0) c.info->prioCtr = prioCtr; }
+            changed = chgBits != 0;
+        } else {
+            changed = block_or(chg, c.lds);
+        }
         res_eq = block_max(res_eq, c.lds);
         bmax = block_max(bmax, c.lds);
         PROF(c, P_RESID);
@@ -230,8 +292,16 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             // ordered list of active rows (ascending row index, as the oracle builds it)
             const int per = (mE + WG - 1) / WG;
             const int r0 = t * per, r1e = min(mE, r0 + per);
+            int differs = 0, nprom = 0;
+            if (ROBUST && prioCtr > 0) {
+                // promoted rows come first in the list
+                __syncthreads();
+                const int packed = polish_promoted_list(st, prio, idx, mE, r0, r1e, capNa, c.lds);
+                nprom = packed >> 1; differs = packed & 1;
+                if (nprom > capNa) return 0;
+            }
             int cnt = 0;
-            for (int r = r0; r < r1e; r++) cnt += (st[r] != ST_INACT);
+            for (int r = r0; r < r1e; r++) cnt += (st[r] != ST_INACT && (!ROBUST || prioCtr == 0 || prio[r] == 0));
             // exclusive scan over 256 threads
             int incl = cnt;
 #pragma unroll
@@ -240,14 +310,15 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             __syncthreads();
             int base = 0;
             for (int w = 0; w < wave_id(); w++) base += c.lds.ired[8 + w];
-            na = uniform_i(c.lds.ired[8] + c.lds.ired[9] + c.lds.ired[10] + c.lds.ired[11]);
+            na = uniform_i(c.lds.ired[8] + c.lds.ired[9] + c.lds.ired[10] + c.lds.ired[11]) + nprom;
             __syncthreads();
             if (na > capNa) return 0;
             // the factor of S only depends on the list: reuse it when the list is the one it was built for
             const int cachedNa = c.info->cacheNa;
-            int pos = base + incl - cnt, differs = (cachedNa != na);
+            int pos = nprom + base + incl - cnt;
+            differs |= (cachedNa != na);
             for (int r = r0; r < r1e; r++)
-                if (st[r] != ST_INACT) { differs |= (idx[pos] != r); idx[pos++] = r; }
+                if (st[r] != ST_INACT && (!ROBUST || prioCtr == 0 || prio[r] == 0)) { differs |= (idx[pos] != r); idx[pos++] = r; }
             nblkS = (na + 63) >> 6;
             for (int a = na + t; a < 64 * nblkS; a += WG) idx[a] = -1;
             const int rebuild = block_or(differs, c.lds);
@@ -274,6 +345,18 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             if (nblkS > 0) wg_chol(c.S, capS, nblkS, na, o.depTau, c.dscr, d0, nullptr, c.lds, 0);
             PROF(c, P_CHOL);
             c.cFact++;
+            if (ROBUST) {
+                // rows the safeguarded factorisation flagged as dependent: the diagonal of the stored inverse blocks is 1/l_aa = 1e-150
+                int nflag = 0;
+                for (int a = t; a < na; a += WG) nflag += (c.S[(size_t)a * capS + a] < 1e-100);
+                nflag = block_sum_i(nflag, c.lds);
+                if (nflag > 0 || uniform_i(c.info->ndep) > 0) {
+                    for (int r = t; r < mE; r += WG) dep[r] = 0;
+                    __syncthreads();
+                    for (int a = t; a < na; a += WG) if (c.S[(size_t)a * capS + a] < 1e-100) dep[idx[a]] = 1;
+                }
+                if (t == 0) c.info->ndep = nflag;
+            }
             if (t == 0) { c.info->cacheNa = na; c.info->work[2] += (double)na; c.info->work[3] += (double)na * na; }
             __syncthreads();
             }   // rebuild
@@ -320,7 +403,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
 // qp.hotstart (:158).  On success the solution is left in V_XQ / M_YQ / I_ST.
 // Returns 0, or the exit flag (1 max rounds, 2 infeasible bounds, 3 setup failure).
 // ---------------------------------------------------------------------------------------------
-template <int NCH>
+template <int NCH, bool ROBUST>
 __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* g, const double* y0ref, int* iterations)
 {
     constexpr int np = 128 * NCH;
@@ -336,6 +419,13 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
     int bad = 0;
     for (int r = t; r < mE; r += WG) bad |= (l[r] > u[r]);
     if (block_or(bad, c.lds)) return 2;
+    if (ROBUST && uniform_i(c.info->prioCtr) != 0) {     // promotions of dependent rows last for one solve
+        int* prio = c.I(I_PRIO);
+        for (int r = t; r < mE; r += WG) prio[r] = 0;
+        __syncthreads();
+        if (t == 0) c.info->prioCtr = 0;
+        __syncthreads();
+    }
     if (initial) {
         const double* x0 = c.V(V_X0);
         for (int i = t; i < np; i += WG) xq[i] = x0[i];
@@ -380,7 +470,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         }
         for (int i = t; i < np; i += WG) xt[i] = xa[i];
         __syncthreads();
-        if (qp_polish<NCH>(c, g, round == 0 && use_stored)) { solved = 1; break; }
+        if (qp_polish<NCH, ROBUST>(c, g, round == 0 && use_stored)) { solved = 1; break; }
         n_admm = 2 * n_admm;
         if (n_admm < 10) n_admm = 10;
         if (n_admm > 400) n_admm = 400;
@@ -450,7 +540,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     auto solveQP = [&](int initial) -> int {   // :1115-1148
         const double* y0 = (initial && c.info->hasY0) ? db.y0 + (size_t)c.b * db.nd : nullptr;
         PROF(c, P_LCQP);
-        const int ef = qp_solve<NCH>(c, initial, gk, y0, &qpIter);
+        const int ef = qp_solve<NCH, false>(c, initial, gk, y0, &qpIter);
         PROF(c, P_MISC);
         st.subproblemIter += qpIter;
         st.qpSolverExitFlag = ef;

@@ -116,7 +116,13 @@ __global__ __launch_bounds__(WG) void k_prepare(DevBatch db)
     } else {
         wg_fill(gphi, 0.0, np);
     }
+    {   // no dependent-row flags or promotions survive a new setup (qp_polish<ROBUST>)
+        int *dep = c.I(I_DEP), *prio = c.I(I_PRIO);
+        for (int r = t; r < db.mEcap; r += WG) { dep[r] = 0; prio[r] = 0; }
+    }
     if (t == 0) {
+        c.info->prioCtr = 0;
+        c.info->ndep = 0;
         c.info->mE = mE;
         c.info->scale = scale;
         c.info->sigma = db.opt.admmSigma * scale;
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(WG, 4) void k_qp_solve(DevBatch db, int initial)
     Ctx<NCH> c = make_ctx<NCH>(db, blockIdx.x, lds);
     const double* y0 = (initial && c.info->hasY0) ? db.y0 + (size_t)c.b * db.nd : nullptr;
     int iters = 0;
-    const int ef = qp_solve<NCH>(c, initial, c.V(V_GK), y0, &iters);
+    const int ef = qp_solve<NCH, true>(c, initial, c.V(V_GK), y0, &iters);   // single-QP path: with the dependent-row rules
     if (ef == 0) qp_export<NCH>(c, db.xout + (size_t)c.b * db.n, db.n, db.yout + (size_t)c.b * db.nd);
     if (threadIdx.x == 0) {
         lcqp_stats_t s;

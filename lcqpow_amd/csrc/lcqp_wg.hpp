@@ -90,6 +90,16 @@ __device__ __forceinline__ int block_or(int v, Lds lds)
     __syncthreads();
     return uniform_i(r);
 }
+// bitwise OR over the block of a value in {0,1,2,3} (uniform result)
+__device__ __forceinline__ int block_or_bits(int v, Lds lds)
+{
+    const int any = (__any(v & 1) ? 1 : 0) | (__any(v & 2) ? 2 : 0);
+    if (lane_id() == 0) lds.ired[wave_id()] = any;
+    __syncthreads();
+    int r = lds.ired[0] | lds.ired[1] | lds.ired[2] | lds.ired[3];
+    __syncthreads();
+    return uniform_i(r);
+}
 __device__ __forceinline__ int block_sum_i(int v, Lds lds)
 {
 #pragma unroll

@@ -242,6 +242,11 @@ struct orc_qp {
     double *w_n1, *w_n2, *w_n3, *w_m1, *T, *S, *w_a1, *w_a2;
     double *r1_last, *ex_last, *g_last; /* residual, E x and linear term of the last verified solution */
     int *idx, *newst, *idx_new;
+    /* dependent-row rules of the single-QP path (SubsolverHIP / k_qp_solve); the batched homotopy kernel runs without them */
+    int robust;
+    int *dep;      /* per row: 1 = flagged linearly dependent by the last factorisation of S, 2 = left because of it */
+    int *prio;     /* per row: 0, or the stamp of the trial that promoted the row to the front of the active list */
+    int prio_ctr;
     int cap_na, cache_na; /* cache_na: active rows the stored factor of S belongs to (-1: none) */
     /* outputs */
     double *xsol, *ysol;
@@ -258,6 +263,7 @@ orc_qp_t* orc_qp_create(int nV, int nC, const double* Q, const double* A, const 
     memcpy(q->Q, Q, sizeof(double) * nV * nV);           /* deep copy: SubsolverQPOASES.cpp:41-45 */
     if (nC > 0) memcpy(q->A, A, sizeof(double) * nC * nV);
     if (opt) q->opt = *opt; else orc_options_default(&q->opt);
+    q->robust = 1;
     q->xsol = dalloc(nV);
     q->ysol = dalloc((size_t)nV + nC);
     return q;
@@ -268,7 +274,7 @@ static void qp_free_setup(orc_qp_t* q)
     free(q->boxidx); free(q->E); free(q->Et); free(q->l); free(q->u); free(q->rhov);
     free(q->L1); free(q->LK); free(q->x); free(q->y); free(q->st); free(q->xa); free(q->ya); free(q->za);
     free(q->w_n1); free(q->w_n2); free(q->w_n3); free(q->w_m1); free(q->T); free(q->S); free(q->w_a1); free(q->w_a2);
-    free(q->idx); free(q->newst); free(q->idx_new); free(q->r1_last); free(q->ex_last); free(q->g_last);
+    free(q->idx); free(q->newst); free(q->idx_new); free(q->dep); free(q->prio); q->dep = q->prio = NULL; free(q->r1_last); free(q->ex_last); free(q->g_last);
     q->idx_new = NULL; q->r1_last = q->ex_last = q->g_last = NULL;
     q->boxidx = NULL; q->E = q->Et = q->l = q->u = q->rhov = q->L1 = q->LK = q->x = q->y = NULL;
     q->st = NULL; q->xa = q->ya = q->za = q->w_n1 = q->w_n2 = q->w_n3 = q->w_m1 = q->T = q->S = q->w_a1 = q->w_a2 = NULL;
@@ -378,6 +384,9 @@ static int qp_setup(orc_qp_t* q, const double* lbA, const double* ubA, const dou
     q->w_a1 = dalloc(q->cap_na); q->w_a2 = dalloc(q->cap_na);
     q->idx = (int*)calloc(q->cap_na ? q->cap_na : 1, sizeof(int));
     q->newst = (int*)calloc(mE ? mE : 1, sizeof(int));
+    q->dep = (int*)calloc(mE ? mE : 1, sizeof(int));
+    q->prio = (int*)calloc(mE ? mE : 1, sizeof(int));
+    q->prio_ctr = 0;
     q->idx_new = (int*)calloc(q->cap_na ? q->cap_na : 1, sizeof(int));
     q->cache_na = -1;
     q->r1_last = dalloc(n); q->ex_last = dalloc(mE); q->g_last = dalloc(n);
@@ -475,11 +484,14 @@ static void qp_guess_from_admm(orc_qp_t* q, int* st)
  * residuals (one pass over Q and E), tests optimality, else updates the active set (all violated rows
  * enter, all wrong-signed multipliers leave) and solves one correction with the constant factor L1 and
  * the Cholesky factor of S = Et_act Et_act'.   Returns 1 on a verified KKT point. */
+/* q->robust (the single-QP path; the batched device loop runs without it): rows the safeguarded factorisation flags as
+ * linearly dependent get two extra rules -- strictly inside the bound: the row leaves; violated: the row is promoted to
+ * the front of the ordered active list, so that another row becomes the dependent one. */
 /* reuse != 0 (hot start from the last verified solution): the first trial needs no sweep --
  * r1 = r1_last + (g_last - g) and E x = ex_last hold exactly for an unchanged (x, y). */
 static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int* st, int reuse)
 {
-    const int n = q->nV, mE = q->mE;
+    const int n = q->nV, mE = q->mE, robust = q->robust;
     const orc_options_t* o = &q->opt;
     double gmax = 0;
     for (int i = 0; i < n; i++) { double a = fabs(g[i]); if (a > gmax) gmax = a; }
@@ -494,6 +506,7 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
             memcpy(Ex, q->ex_last, sizeof(double) * mE);
         } else {
         q->c_sweeps++;
+        if (robust) for (int r = 0; r < mE; r++) if (st[r] == ST_INACT) yfull[r] = 0.0;   /* rows that left as "dependent, inside" */
         /* residual evaluation */
         for (int i = 0; i < n; i++) {
             const double* qr = q->Q + (size_t)i * n;
@@ -513,7 +526,7 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
         }
         double res_stat = 0, res_eq = 0, bmax = 0;
         for (int i = 0; i < n; i++) { double a = fabs(r1[i]); if (a > res_stat) res_stat = a; }
-        int changed = 0;
+        int changed = 0, promoted = 0;
         for (int r = 0; r < mE; r++) {
             int s = st[r], ns = s;
             if (s == ST_INACT) {
@@ -528,10 +541,24 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
                 double ytol = o->feasTol * gs;
                 if (s == ST_LOWER && yfull[r] > ytol) ns = ST_INACT;
                 if (s == ST_UPPER && yfull[r] < -ytol) ns = ST_INACT;
+                if (robust && ns == s && trial > 0 && q->dep[r]) {
+                    /* the last factorisation flagged this row as dependent on the rows before it, so the correction
+                     * left its multiplier alone and did not enforce its equation.  Strictly inside its bound: the row
+                     * is not active.  Violated: it must be active, so it moves to the front of the list and a
+                     * different row becomes the dependent one. */
+                    const double ftol = o->feasTol * (1.0 + fabs(Ex[r]));
+                    int viol, inside = 0;
+                    if (s == ST_LOWER) { viol = Ex[r] < q->l[r] - ftol; inside = Ex[r] > q->l[r] + ftol; }
+                    else if (s == ST_UPPER) { viol = Ex[r] > q->u[r] + ftol; inside = Ex[r] < q->u[r] - ftol; }
+                    else viol = fabs(Ex[r] - q->l[r]) > ftol;
+                    if (inside) { ns = ST_INACT; q->dep[r] = 2; }
+                    else if (viol) { q->prio[r] = q->prio_ctr + 1; promoted = 1; }
+                }
             }
             q->newst[r] = ns;
             if (ns != s) changed = 1;
         }
+        if (promoted) { q->prio_ctr++; changed = 1; }
         if (trial > 0 && !changed && res_stat <= o->resTol * gs && res_eq <= o->resTol * (1.0 + bmax)) {
             memcpy(q->r1_last, r1, sizeof(double) * n);
             memcpy(q->ex_last, Ex, sizeof(double) * mE);
@@ -541,8 +568,9 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
         if (changed && trial > 0) {
             for (int r = 0; r < mE; r++) {
                 int ns = q->newst[r];
-                if (ns == ST_INACT && st[r] != ST_INACT) {
-                    /* leaving row: remove its multiplier from the stationarity residual */
+                if (ns == ST_INACT && st[r] != ST_INACT && !(robust && q->dep[r] == 2)) {
+                    /* leaving row: remove its multiplier from the stationarity residual (a row that leaves as
+                     * "dependent, inside" keeps it until the next sweep, as the device code does) */
                     double yr = yfull[r];
                     if (yr != 0.0) {
                         const double* e = q->E + (size_t)r * n;
@@ -556,8 +584,15 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
         }
         if (!fact_valid) {
             na = 0;
+            /* promoted rows first (latest promotion first, ascending row index within one promotion), then the rest */
+            for (int stamp = robust ? q->prio_ctr : 0; stamp >= 1; stamp--)
+                for (int r = 0; r < mE; r++)
+                    if (st[r] != ST_INACT && q->prio[r] == stamp) {
+                        if (na >= q->cap_na) return 0;
+                        q->idx_new[na++] = r;
+                    }
             for (int r = 0; r < mE; r++)
-                if (st[r] != ST_INACT) {
+                if (st[r] != ST_INACT && (!robust || q->prio[r] == 0)) {
                     if (na >= q->cap_na) return 0;
                     q->idx_new[na++] = r;
                 }
@@ -578,6 +613,10 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
                     q->S[(size_t)a * na + b2] = s;
                 }
             safe_chol(q->S, na, o->depTau);
+            if (robust) {
+                memset(q->dep, 0, sizeof(int) * mE);
+                for (int a = 0; a < na; a++) if (q->S[(size_t)a * na + a] > 1e100) q->dep[q->idx[a]] = 1;
+            }
             q->c_fact++;
             fact_valid = 1;
         }
@@ -632,6 +671,7 @@ int orc_qp_solve(orc_qp_t* q, int initialSolve, int* iterations, int* exit_flag,
     const int mE = q->mE;
     for (int r = 0; r < mE; r++)
         if (q->l[r] > q->u[r]) { *exit_flag = 2; return ORC_SUBPROBLEM_SOLVER_ERROR; } /* infeasible bounds */
+    if (q->prio_ctr) { memset(q->prio, 0, sizeof(int) * mE); q->prio_ctr = 0; }   /* promotions last for one solve */
 
     /* starting point: initial solve uses (x0, y0) like qp.init (SubsolverQPOASES.cpp:152); a hot start
      * continues from the previous solution and working set like qp.hotstart (:158) */
@@ -837,6 +877,9 @@ static void lcqp_determineStationarityType(lcqp_t* p)
     p->algoStat = ORC_C_STATIONARY;
 }
 
+static int g_lcqp_robust = 0;
+void orc_lcqp_set_robust(int on) { g_lcqp_robust = on; }
+
 int orc_lcqp_solve(int nV, int nC, int nComp,
                    const double* Q, const double* g, const double* L, const double* R,
                    const double* lbL, const double* ubL, const double* lbR, const double* ubR,
@@ -916,6 +959,7 @@ int orc_lcqp_solve(int nV, int nC, int nComp,
         p->alphak = 1; p->rho = opt->initialPenaltyParameter;                  /* :999-1004 */
         p->algoStat = ORC_PROBLEM_NOT_SOLVED;
         p->qp = orc_qp_create(nV, m, p->Q, p->A, opt);                          /* :906-907 */
+        p->qp->robust = g_lcqp_robust;   /* 0 mirrors k_lcqp_run; 1 mirrors the host loop over SubsolverHIP (k_qp_solve) */
 
         /* runSolver :444-560 */
         if (opt->solveZeroPenaltyFirst) memcpy(p->gk, p->g, sizeof(double) * nV);

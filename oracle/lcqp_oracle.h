@@ -122,6 +122,10 @@ int orc_lcqp_solve(int nV, int nC, int nComp,
                    const orc_options_t* opt, double* xOpt, double* yOpt, orc_stats_t* stats,
                    int traceCap, double* traceScalars /* traceCap x 4 */, double* traceX /* traceCap x nV */, int* traceLen);
 
+/* which QP path orc_lcqp_solve mirrors: 0 (default) the batched homotopy kernel k_lcqp_run, 1 the reference's host loop
+ * over SubsolverHIP, whose single-QP kernel also applies the dependent-row rules of orc_qp_*  */
+void orc_lcqp_set_robust(int on);
+
 /* ---- synthetic instances (include/lcqp_synth.h) and a threaded batch driver for the CPU baseline ---- */
 void orc_synth_generate(uint64_t seed0, uint64_t instance, int n, int nC, int nComp,
                         double* Q, double* g, double* L, double* R, double* A, double* lbA, double* ubA);

@@ -123,6 +123,11 @@ def _arr(a):
 SEED0 = 0x4C43515000000001
 
 
+def lcqp_set_robust(on):
+    """orc_lcqp_solve mirrors k_lcqp_run (False, default) or the host loop over SubsolverHIP (True)"""
+    lib().orc_lcqp_set_robust(int(bool(on)))
+
+
 def synth_generate(instance, n=256, nC=512, nComp=64, seed0=SEED0):
     Q = np.empty((n, n)); g = np.empty(n); L = np.empty((nComp, n)); R = np.empty((nComp, n))
     A = np.empty((nC, n)); lbA = np.empty(nC); ubA = np.empty(nC)

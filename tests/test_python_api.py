@@ -238,3 +238,19 @@ def test_python_max_penalty_and_infeasible(hip):
     # a reference solver arm that needs un-vendored code is refused, not silently replaced
     ret, x, y, stats = _solve(lcqpow, P.warm_up(), tweak=lambda o: o.setQPSolver(lcqpow.QPSolver.QPOASES_DENSE))
     assert ret == lcqpow.ReturnValue.NOT_YET_IMPLEMENTED
+
+
+@pytest.mark.gpu
+def test_python_structure_fuzz_host_loop(hip, oracle):
+    """tools/gpu_fuzz.py in host mode: the reference's call sequence (host homotopy loop, every QP through SubsolverHIP /
+    k_qp_solve, which applies the dependent-row rules) against the oracle running the same rules, on random small LCQPs with
+    degenerate structure.  Same bound as the batched variant of this test (tests/test_gpu_parity.py): 5 % may end
+    differently."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_fuzz", os.path.join(ROOT, "tools", "gpu_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    count = 100
+    cats, rets = fz.run(count, seed=7, verbose=False, host=True)
+    assert cats["same"] + cats["same solution, other iterate count"] >= count - count // 20, (cats, rets)
+    assert rets.get((0, 0), 0) >= count // 2, rets

@@ -2,7 +2,7 @@
 (rank-deficient Q, dense / overlapping complementarity rows, equalities, duplicate rows, finite upper complementarity
 bounds, shifted lower bounds, box bounds, warm-start duals), HIP single-instance batch vs the CPU oracle.
 
-usage: python tools/gpu_fuzz.py [count] [seed]   (prints one line per divergence and a summary; exit code 1 when more
+usage: python tools/gpu_fuzz.py [count] [seed] [host]   (prints one line per divergence and a summary; exit code 1 when more
 than 5 % of the problems end differently)
 """
 import os
@@ -91,15 +91,37 @@ def make(rng):
     return d
 
 
-def run(count, seed, verbose=True):
+def host_solve(d):
+    """the reference's Python call sequence (lcqpow_amd.lcqpow): host homotopy loop, every QP through SubsolverHIP"""
+    import lcqpow_amd.lcqpow as lcqpow
+    lcqp = lcqpow.LCQProblem(nV=d["nV"], nC=d["nC"], nComp=d["nComp"])
+    options = lcqpow.Options()
+    options.setPrintLevel(lcqpow.PrintLevel.NONE)
+    options.setPerturbStep(False)
+    lcqp.setOptions(options)
+    ret = lcqp.loadLCQP(Q=d["Q"], g=d["g"], L=d["L"], R=d["R"], A=d.get("A"), order="C",
+                        **{k: d[k] for k in ("lbL", "ubL", "lbR", "ubR", "lbA", "ubA", "lb", "ub", "x0", "y0") if k in d})
+    if ret != 0:
+        return dict(ret=int(ret), x=None, y=None, stats=None)
+    ret = lcqp.runSolver()
+    st = lcqpow.OutputStatistics()
+    lcqp.getOutputStatistics(st)
+    return dict(ret=int(ret), x=lcqp.getPrimalSolution(), y=lcqp.getDualSolution(),
+                stats=dict(iterTotal=st.getIterTotal(), iterOuter=st.getIterOuter(), status=int(st.getSolutionStatus())))
+
+
+def run(count, seed, verbose=True, host=False):
+    """host=False: batched device loop (k_lcqp_run) vs the oracle; host=True: host loop over SubsolverHIP (k_qp_solve, with the
+    dependent-row rules) vs the oracle with the same rules"""
     O.build(); O.lib()
+    O.lcqp_set_robust(host)
     rng = np.random.default_rng(seed)
     rets = {}
     cats = {"same": 0, "same solution, other iterate count": 0, "other stationary point": 0, "return codes differ": 0}
     for k in range(count):
         d = make(rng)
         ro = P.oracle_solve(O, d, O.default_options(perturbStep=0))
-        rh = P.hip_solve(la, d, la.default_options(perturbStep=0))
+        rh = host_solve(d) if host else P.hip_solve(la, d, la.default_options(perturbStep=0))
         rets[(ro["ret"], rh["ret"])] = rets.get((ro["ret"], rh["ret"]), 0) + 1
         msg, cat = None, "same"
         if ro["ret"] != rh["ret"]:
@@ -116,15 +138,16 @@ def run(count, seed, verbose=True):
         cats[cat] += 1
         if msg and verbose:
             print(f"[{k}] n={d['nV']} nC={d['nC']} nComp={d['nComp']} keys={sorted(set(d) - {'Q', 'g', 'L', 'R', 'nV', 'nC', 'nComp'})}: {cat}: {msg}", flush=True)
+    O.lcqp_set_robust(False)
     if verbose:
-        print(f"fuzz: {count} problems (seed {seed}): {cats}; (oracle ret, hip ret) histogram: {dict(sorted(rets.items()))}")
+        print(f"fuzz[{'host loop + SubsolverHIP' if host else 'batched device loop'}]: {count} problems (seed {seed}): {cats}; (oracle ret, hip ret) histogram: {dict(sorted(rets.items()))}")
     return cats, rets
 
 
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    cats, _ = run(count, seed)
+    cats, _ = run(count, seed, host=len(sys.argv) > 3 and sys.argv[3] == "host")
     return 1 if cats["return codes differ"] + cats["other stationary point"] > count // 20 else 0
 
 
