@@ -2,9 +2,9 @@
  * lcqp_synth.h -- counter-based synthetic dense LCQP instance generator.
  *
  * Shared by the HIP product (device-side generation, lcqpow_amd/csrc) and by the CPU oracle
- * (oracle/), so both sides see bit-identical inputs for every element that does not involve a
- * floating-point reduction (M, g, A, x*, slacks).  Q = M'M/n + I involves a reduction; parity
- * tests therefore read Q back from whichever side generated it.
+ * (oracle/), so both sides see bit-identical inputs: M, g, A, x*, slacks are single expressions, and the two
+ * reductions (Q = M'M/n + I, A x* for the bounds) are summed in the same order with separately rounded
+ * products on both sides (k_synth_Q / k_synth_fill, orc_synth_generate; tests compare them bit for bit).
  *
  * Structure follows the reference's own examples: one-hot complementarity selectors on disjoint
  * variables (examples/warm_up.cpp:34-35, examples/OptimizeOnCircle.cpp:86-87), zero lower
@@ -83,13 +83,22 @@ LCQP_SYNTH_FN double lcqp_synth_Araw(uint64_t st, int n, int nC, int nComp, int 
 {
     return 2.0 * lcqp_u01(st, lcqp_synth_off_A(n, nC, nComp) + (uint64_t)r * n + c) - 1.0;
 }
+/* 0.1 + 0.9 u: product and sum rounded separately on both sides (hipcc would otherwise fuse them on the device) */
+LCQP_SYNTH_FN double lcqp_synth_slack(double u)
+{
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const double p = 0.9 * u;
+    return 0.1 + p;
+}
 LCQP_SYNTH_FN double lcqp_synth_slo(uint64_t st, int n, int nC, int nComp, int r)
 {
-    return 0.1 + 0.9 * lcqp_u01(st, lcqp_synth_off_slo(n, nC, nComp) + r);
+    return lcqp_synth_slack(lcqp_u01(st, lcqp_synth_off_slo(n, nC, nComp) + r));
 }
 LCQP_SYNTH_FN double lcqp_synth_shi(uint64_t st, int n, int nC, int nComp, int r)
 {
-    return 0.1 + 0.9 * lcqp_u01(st, lcqp_synth_off_shi(n, nC, nComp) + r);
+    return lcqp_synth_slack(lcqp_u01(st, lcqp_synth_off_shi(n, nC, nComp) + r));
 }
 
 #endif /* LCQP_SYNTH_H */

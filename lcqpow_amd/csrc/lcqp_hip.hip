@@ -353,10 +353,16 @@ __global__ __launch_bounds__(WG) void k_synth_fill(DevBatch db, uint64_t seed0, 
     }
     __syncthreads();
     double *l = c.M(M_L), *u = c.M(M_U);
-    wg_rows<NCH>(c.E, nullptr, nC, xs, c.M(M_EX), nullptr, lds, [](int, double) {});
     for (int r = t; r < mA; r += WG) {
         if (r < nC) {
-            const double ax = c.M(M_EX)[r];
+            // A x* summed left to right with separately rounded products, as the host generator does
+            const double* row = c.E + (size_t)r * np;
+            double ax = 0.0;
+            for (int j = 0; j < n; j++) {
+#pragma clang fp contract(off)
+                const double pr = row[j] * xs[j];
+                ax = ax + pr;
+            }
             l[r] = ax - lcqp_synth_slo(st, n, nC, nComp, r);
             u[r] = ax + lcqp_synth_shi(st, n, nC, nComp, r);
         } else { l[r] = 0.0; u[r] = INFINITY; }
@@ -364,26 +370,44 @@ __global__ __launch_bounds__(WG) void k_synth_fill(DevBatch db, uint64_t seed0, 
     if (t == 0) { c.info->nfin = 0; c.info->hasY0 = 0; c.info->isSetup = 0; }
 }
 
+// Q = M'M/n + I in exactly the arithmetic of the host generator (oracle: orc_synth_generate): every element is the sum over
+// k ascending of separately rounded products (no FMA contraction), then one division and one addition -- so the instances
+// generated in HBM are bit-identical to the ones the CPU oracle generates.  One 64x64 tile of the lower triangle per
+// workgroup, a 4x4 block per thread; the generator runs before the timed region of bench.py.
 template <int NCH>
 __global__ __launch_bounds__(WG) void k_synth_Q(DevBatch db)
 {
-    LCQP_LDS
     constexpr int np = 128 * NCH;
     const int ntile = db.nblk * (db.nblk + 1) / 2;
-    const int b = blockIdx.x / ntile, tIdx = blockIdx.x % ntile;
+    const int b = blockIdx.x / ntile, tIdx = blockIdx.x % ntile, t = threadIdx.x;
     int I, J;
     tri_tile(tIdx, I, J);
     const double* Mm = db.F1 + (size_t)b * np * np;
     double* Q = db.Q + (size_t)b * np * np;
+    const int gi0 = 64 * I + 4 * (t >> 4), gj0 = 64 * J + 4 * (t & 15);
     double acc[4][4];
-    wg_tile_tn(acc, Mm, np, 64 * I, Mm, np, 64 * J, db.n, [](int) { return 1.0; }, lds);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+    for (int k = 0; k < db.n; k++) {
+#pragma clang fp contract(off)      // separately rounded product and sum (plain operators: the pragma does not reach into __dmul_rn)
+        const double* mk = Mm + (size_t)k * np;
+        double mi[4], mj[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { mi[i] = mk[gi0 + i]; mj[i] = mk[gj0 + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const double pr = mi[i] * mj[j]; acc[i][j] = acc[i][j] + pr; }
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int gi = 64 * I + tile_li(i, j), gj = 64 * J + tile_lj(i, j);
+            const int gi = gi0 + i, gj = gj0 + j;
             double v = 0.0;
-            if (gi < db.n && gj < db.n) v = acc[i][j] / (double)db.n + (gi == gj ? 1.0 : 0.0);
+            if (gi < db.n && gj < db.n) v = acc[i][j] / (double)db.n + (gi == gj ? 1.0 : 0.0);   // a quotient plus 0 or 1: nothing to fuse
             Q[(size_t)gi * np + gj] = v;
             Q[(size_t)gj * np + gi] = v;
         }
