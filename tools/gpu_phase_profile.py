@@ -28,5 +28,9 @@ la.lib().lcqp_hip_batch_read_profile(bt.h, prof.ctypes.data_as(C.c_void_p))
 names = ["lcqp-level sweeps", "trial residual (Q+E sweep)", "gram S=TT'", "chol(S)", "corr: L1 trsv", "corr: rows of Et", "corr: S trsv", "admm", "misc/logic"]
 tot = prof[:, :9].sum(axis=1).astype(float)
 print("mean cycles per instance: %.3e  (max %.3e, min %.3e)" % (tot.mean(), tot.max(), tot.min()))
+qs = np.percentile(tot, [10, 50, 90, 99])
+print("percentiles 10/50/90/99: %.3e %.3e %.3e %.3e;  mean/max = %.3f (share of the launch an average workgroup slot is busy)" % (*qs, tot.mean() / tot.max()))
+it = np.array([s["iterTotal"] for s in st], dtype=float)
+print("correlation of cycles with LCQP iterates: %.3f; iterates min/mean/max %d/%.1f/%d" % (np.corrcoef(tot, it)[0, 1], it.min(), it.mean(), it.max()))
 for k, nme in enumerate(names):
     print(f"  {nme:28s} {100 * prof[:, k].astype(float).sum() / tot.sum():6.2f} %")
