@@ -286,6 +286,16 @@ def test_lcqp_full_batch_properties(hip):
     bt.run()
     x2, y2, st2 = bt.solution()
     assert np.array_equal(x, x2) and np.array_equal(y, y2)
+    # byte accounting of bench.py's roofline: the C ABI's total is the documented formula applied to the work
+    # counters and active-row sums the kernel keeps
+    ws = bt.work_sums()
+    m = nC + 2 * nComp
+    bs = 8.0 * n * (n + 2)
+    tot = lambda k: float(sum(s[k] for s in st2))
+    expect = (tot("reserved") * 8.0 * (n * n + m * n) + tot("corrections") * bs + 16.0 * ws[0] * n + 8.0 * (ws[1] + 2.0 * ws[0])
+              + 8.0 * ws[2] * n + 8.0 * ws[3] + tot("admmIter") * (bs + 16.0 * m * n) + (tot("iterTotal") + B) * 16.0 * n * n)
+    assert abs(bt.algorithmic_bytes() - expect) <= 1e-9 * expect
+    assert 64 < ws[0] / tot("corrections") < n and ws[1] >= ws[0] ** 2 / tot("corrections")      # mean active rows, Cauchy-Schwarz
     bt.close()
 
 
