@@ -29,12 +29,13 @@ extern "C" {
 lcqp_host_options_t* lcqp_host_options_create(void) { return new (std::nothrow) lcqp_host_options(); }
 
 lcqp_host_options_t* lcqp_host_options_copy(const lcqp_host_options_t* rhs)
-{
+try {
     if (!rhs) return nullptr;
     lcqp_host_options_t* o = new (std::nothrow) lcqp_host_options();
     if (o) o->opt = rhs->opt;
     return o;
 }
+catch (...) { return nullptr; }
 
 void lcqp_host_options_destroy(lcqp_host_options_t* o) { delete o; }
 
@@ -97,9 +98,10 @@ void lcqp_host_options_set_hip(lcqp_host_options_t* o, const lcqp_options_t* in)
 }
 
 lcqp_host_problem_t* lcqp_host_problem_create(int nV, int nC, int nComp)
-{
+try {
     return new (std::nothrow) lcqp_host_problem(nV, nC, nComp);
 }
+catch (...) { return nullptr; }   // nothing throws across the C boundary
 
 void lcqp_host_problem_destroy(lcqp_host_problem_t* p) { delete p; }
 
@@ -114,10 +116,11 @@ int lcqp_host_problem_load_dense(lcqp_host_problem_t* p, const double* Q, const 
                                  const double* lbL, const double* ubL, const double* lbR, const double* ubR,
                                  const double* A, const double* lbA, const double* ubA,
                                  const double* lb, const double* ub, const double* x0, const double* y0)
-{
+try {
     if (!p) return INVALID_ARGUMENT;
     return p->lcqp.loadLCQP(Q, g, L, R, lbL, ubL, lbR, ubR, A, lbA, ubA, lb, ub, x0, y0);
 }
+catch (...) { return INVALID_ARGUMENT; }
 
 // borrowed view of a caller's CSC triple; loadLCQP(csc) deep-copies (src/LCQProblem.cpp:409-414)
 static const csc* view(const lcqp_csc_arg_t* a, csc& store)
@@ -136,29 +139,37 @@ int lcqp_host_problem_load_csc(lcqp_host_problem_t* p, const lcqp_csc_arg_t* Q, 
                                const double* lbL, const double* ubL, const double* lbR, const double* ubR,
                                const lcqp_csc_arg_t* A, const double* lbA, const double* ubA,
                                const double* lb, const double* ub, const double* x0, const double* y0)
-{
+try {
     if (!p) return INVALID_ARGUMENT;
     csc sQ, sL, sR, sA;
     return p->lcqp.loadLCQP(view(Q, sQ), g, view(L, sL), view(R, sR), lbL, ubL, lbR, ubR, view(A, sA), lbA, ubA, lb, ub, x0, y0);
 }
+catch (...) { return INVALID_ARGUMENT; }
 
 int lcqp_host_problem_load_files(lcqp_host_problem_t* p, const char* const f[15])
-{
+try {
     if (!p || !f) return INVALID_ARGUMENT;
     return p->lcqp.loadLCQP(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], f[8], f[9], f[10], f[11], f[12], f[13], f[14]);
 }
+catch (...) { return UNABLE_TO_READ_FILE; }
 
-int lcqp_host_problem_switch_to_sparse(lcqp_host_problem_t* p) { return p ? p->lcqp.switchToSparseMode() : INVALID_ARGUMENT; }
-int lcqp_host_problem_switch_to_dense(lcqp_host_problem_t* p) { return p ? p->lcqp.switchToDenseMode() : INVALID_ARGUMENT; }
+int lcqp_host_problem_switch_to_sparse(lcqp_host_problem_t* p)
+try { return p ? p->lcqp.switchToSparseMode() : INVALID_ARGUMENT; }
+catch (...) { return FAILED_SWITCH_TO_SPARSE; }
+int lcqp_host_problem_switch_to_dense(lcqp_host_problem_t* p)
+try { return p ? p->lcqp.switchToDenseMode() : INVALID_ARGUMENT; }
+catch (...) { return FAILED_SWITCH_TO_DENSE; }
 
-int lcqp_host_problem_run(lcqp_host_problem_t* p) { return p ? p->lcqp.runSolver() : INVALID_ARGUMENT; }
+int lcqp_host_problem_run(lcqp_host_problem_t* p)
+try { return p ? p->lcqp.runSolver() : INVALID_ARGUMENT; }
+catch (...) { return SUBPROBLEM_SOLVER_ERROR; }   // host memory exhausted inside the solver
 int lcqp_host_problem_number_of_primals(const lcqp_host_problem_t* p) { return p ? p->lcqp.getNumberOfPrimals() : 0; }
 int lcqp_host_problem_number_of_duals(const lcqp_host_problem_t* p) { return p ? p->lcqp.getNumberOfDuals() : 0; }
 int lcqp_host_problem_get_primal(const lcqp_host_problem_t* p, double* xOpt) { return p ? p->lcqp.getPrimalSolution(xOpt) : PROBLEM_NOT_SOLVED; }
 int lcqp_host_problem_get_dual(const lcqp_host_problem_t* p, double* yOpt) { return p ? p->lcqp.getDualSolution(yOpt) : PROBLEM_NOT_SOLVED; }
 
 void lcqp_host_problem_get_stats(const lcqp_host_problem_t* p, lcqp_host_stats_t* out)
-{
+try {
     if (!p || !out) return;
     OutputStatistics s;
     p->lcqp.getOutputStatistics(s);
@@ -170,9 +181,10 @@ void lcqp_host_problem_get_stats(const lcqp_host_problem_t* p, lcqp_host_stats_t
     out->nSteps = (int)s.getInnerItersStdVec().size();
     out->rhoOpt = s.getRhoOpt();
 }
+catch (...) { }
 
 int lcqp_host_problem_get_track(const lcqp_host_problem_t* p, int which, double* out, int cap)
-{
+try {
     if (!p) return 0;
     OutputStatistics s;
     p->lcqp.getOutputStatistics(s);
@@ -196,5 +208,6 @@ int lcqp_host_problem_get_track(const lcqp_host_problem_t* p, int which, double*
     }
     return 0;
 }
+catch (...) { return 0; }
 
 }  // extern "C"

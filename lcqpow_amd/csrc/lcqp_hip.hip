@@ -476,11 +476,12 @@ static int set_err(const char* what, hipError_t e)
 
 extern "C" const char* lcqp_hip_last_error(void) { return g_err.c_str(); }
 extern "C" int lcqp_hip_device_count(void)
-{
+try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 extern "C" void lcqp_hip_options_default(lcqp_options_t* o)
 {   // src/Options.cpp:296-333
@@ -534,7 +535,7 @@ static int dev_alloc(lcqp_hip_batch* h, T** p, size_t count, bool zero)
 }
 
 extern "C" lcqp_hip_batch_t* lcqp_hip_batch_create(int batch, int nV, int nC, int nComp, int withBox, int device)
-{
+try {
     if (batch <= 0 || nV <= 0 || nC < 0 || nComp < 0) { g_err = "invalid dimensions"; return nullptr; }
     if (nV > 512) { g_err = "nV > 512 is not supported by this build"; return nullptr; }
     HIPCHKN(hipSetDevice(device));
@@ -592,9 +593,10 @@ extern "C" lcqp_hip_batch_t* lcqp_hip_batch_create(int batch, int nV, int nC, in
     if (rc != 0 || hipStreamSynchronize(h->stream) != hipSuccess) { lcqp_hip_batch_destroy(h); return nullptr; }
     return h;
 }
+catch (...) { g_err = "out of host memory"; return nullptr; }   // nothing throws across the C boundary
 
 extern "C" void lcqp_hip_batch_destroy(lcqp_hip_batch_t* h)
-{
+try {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -606,9 +608,10 @@ extern "C" void lcqp_hip_batch_destroy(lcqp_hip_batch_t* h)
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
+catch (...) { }   // nothing throws across the C boundary
 
 extern "C" int lcqp_hip_batch_set_options(lcqp_hip_batch_t* h, const lcqp_options_t* opt)
-{
+try {
     if (!h || !opt) return LCQP_INVALID_ARGUMENT;
     if (opt->nDynamicPenalty > 8) { g_err = "nDynamicPenalty > 8 unsupported"; return LCQP_HIP_UNSUPPORTED; }
     if (opt->storeSteps && h->db.traceCap == 0) {
@@ -626,9 +629,10 @@ extern "C" int lcqp_hip_batch_set_options(lcqp_hip_batch_t* h, const lcqp_option
     h->setupDone = false;   // rho / sigma / prox weights enter the factorisations
     return 0;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 extern "C" int lcqp_hip_batch_get_trace(lcqp_hip_batch_t* h, int instance, int cap, double* scalars, double* x, int* len)
-{
+try {
     if (!h || instance < 0 || instance >= h->db.B || !len) return LCQP_INVALID_ARGUMENT;
     DevBatch& d = h->db;
     *len = 0;
@@ -643,16 +647,18 @@ extern "C" int lcqp_hip_batch_get_trace(lcqp_hip_batch_t* h, int instance, int c
     *len = n;
     return 0;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 // diagnostic builds (-DLCQP_PROFILE): per-instance cycle counters of the megakernel's phases, [B][16]
 extern "C" int lcqp_hip_batch_read_profile(lcqp_hip_batch_t* h, unsigned long long* out)
-{
+try {
     if (!h || !out) return LCQP_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, h->db.prof, sizeof(unsigned long long) * (size_t)h->db.B * 16, hipMemcpyDeviceToHost));
     return 0;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 extern "C" void* lcqp_hip_batch_stream(lcqp_hip_batch_t* h) { return h ? (void*)h->stream : nullptr; }
 
@@ -663,7 +669,7 @@ extern "C" int lcqp_hip_batch_load(lcqp_hip_batch_t* h, int first, int count,
                                    const double* lbL, const double* ubL, const double* lbR, const double* ubR,
                                    const double* A, const double* lbA, const double* ubA,
                                    const double* lb, const double* ub, const double* x0, const double* y0)
-{
+try {
     if (!h) return LCQP_LCQPOBJECT_NOT_SETUP;
     DevBatch& d = h->db;
     const int n = d.n, nC = d.nC, nComp = d.nComp, mA = d.mA, np = d.np, mE = d.mEcap;
@@ -757,6 +763,7 @@ extern "C" int lcqp_hip_batch_load(lcqp_hip_batch_t* h, int first, int count,
     h->setupDone = false;
     return 0;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 #define DISPATCH_NCH(h, KERNEL, grid, ...)                                                              \
     do {                                                                                               \
@@ -769,7 +776,7 @@ extern "C" int lcqp_hip_batch_load(lcqp_hip_batch_t* h, int first, int count,
     } while (0)
 
 extern "C" int lcqp_hip_batch_generate_synthetic(lcqp_hip_batch_t* h, uint64_t seed0, uint64_t firstInstance)
-{
+try {
     if (!h) return LCQP_LCQPOBJECT_NOT_SETUP;
     HIPCHK(hipSetDevice(h->device));
     DevBatch& d = h->db;
@@ -781,10 +788,11 @@ extern "C" int lcqp_hip_batch_generate_synthetic(lcqp_hip_batch_t* h, uint64_t s
     h->setupDone = false;
     return 0;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 extern "C" int lcqp_hip_batch_read_problem(lcqp_hip_batch_t* h, int b, double* Q, double* g, double* L, double* R,
                                            double* A, double* lbA, double* ubA)
-{
+try {
     if (!h || b < 0 || b >= h->db.B) return LCQP_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(h->device));
     DevBatch& d = h->db;
@@ -810,6 +818,7 @@ extern "C" int lcqp_hip_batch_read_problem(lcqp_hip_batch_t* h, int b, double* Q
     }
     return 0;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 static int launch_setup(lcqp_hip_batch* h)
 {
@@ -826,14 +835,15 @@ static int launch_setup(lcqp_hip_batch* h)
 }
 
 extern "C" int lcqp_hip_batch_setup(lcqp_hip_batch_t* h)
-{
+try {
     if (!h) return LCQP_LCQPOBJECT_NOT_SETUP;
     HIPCHK(hipSetDevice(h->device));
     return launch_setup(h);
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 extern "C" int lcqp_hip_batch_run(lcqp_hip_batch_t* h)
-{
+try {
     if (!h) return LCQP_LCQPOBJECT_NOT_SETUP;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -846,17 +856,19 @@ extern "C" int lcqp_hip_batch_run(lcqp_hip_batch_t* h)
     h->ran = true;
     return 0;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 extern "C" int lcqp_hip_batch_synchronize(lcqp_hip_batch_t* h)
-{
+try {
     if (!h) return LCQP_LCQPOBJECT_NOT_SETUP;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 extern "C" int lcqp_hip_batch_last_timing(lcqp_hip_batch_t* h, float* setup_ms, float* solve_ms)
-{
+try {
     if (!h || !h->ran) return LCQP_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipEventSynchronize(h->ev2));
@@ -864,9 +876,10 @@ extern "C" int lcqp_hip_batch_last_timing(lcqp_hip_batch_t* h, float* setup_ms, 
     if (solve_ms) HIPCHK(hipEventElapsedTime(solve_ms, h->ev1, h->ev2));
     return 0;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 extern "C" int lcqp_hip_batch_get_solution(lcqp_hip_batch_t* h, double* x, double* y, lcqp_stats_t* stats)
-{
+try {
     if (!h) return LCQP_LCQPOBJECT_NOT_SETUP;
     HIPCHK(hipSetDevice(h->device));
     DevBatch& d = h->db;
@@ -876,6 +889,7 @@ extern "C" int lcqp_hip_batch_get_solution(lcqp_hip_batch_t* h, double* x, doubl
     if (stats) HIPCHK(hipMemcpy(stats, d.stats, sizeof(lcqp_stats_t) * (size_t)d.B, hipMemcpyDeviceToHost));
     return 0;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 // Algorithmic HBM bytes of the last run, from the per-instance work counters:
 //   residual evaluation (trial with sweeps, stats.reserved): Q + E once   8*(n*n + m*n)
@@ -884,7 +898,7 @@ extern "C" int lcqp_hip_batch_get_solution(lcqp_hip_batch_t* h, double* x, doubl
 //   ADMM iteration              : LK fwd+bwd + two sweeps over E
 //   LCQP iterate                : one sweep over Q and C (Q*[pk,xk], C*[pk,xk])
 extern "C" double lcqp_hip_batch_algorithmic_bytes(lcqp_hip_batch_t* h)
-{
+try {
     if (!h) return 0.0;
     DevBatch& d = h->db;
     std::vector<lcqp_stats_t> st(d.B);
@@ -907,9 +921,10 @@ extern "C" double lcqp_hip_batch_algorithmic_bytes(lcqp_hip_batch_t* h)
     }
     return total;
 }
+catch (...) { return 0.0; }   // nothing throws across the C boundary
 
 extern "C" int lcqp_hip_batch_work_sums(lcqp_hip_batch_t* h, double out[4])
-{
+try {
     if (!h || !out) return LCQP_INVALID_ARGUMENT;
     DevBatch& d = h->db;
     HIPCHK(hipSetDevice(h->device));
@@ -920,6 +935,7 @@ extern "C" int lcqp_hip_batch_work_sums(lcqp_hip_batch_t* h, double out[4])
     for (int b = 0; b < d.B; b++) for (int k = 0; k < 4; k++) out[k] += info[b].work[k];
     return 0;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 // =================================================================================================
 // QP object (SubsolverBase semantics): a batch of one with nComp = 0 whose rows are the nC stacked rows
@@ -937,7 +953,7 @@ struct lcqp_hip_qp {
 };
 
 extern "C" lcqp_hip_qp_t* lcqp_hip_qp_create(int nV, int nC, const double* Q, const double* A, const lcqp_options_t* opt, int device)
-{
+try {
     if (nV <= 0 || nC < 0 || !Q || (nC > 0 && !A)) { g_err = "invalid arguments"; return nullptr; }
     lcqp_hip_qp* q = new lcqp_hip_qp();
     q->hb = nullptr; q->nV = nV; q->nC = nC; q->device = device; q->haveBounds = false; q->withBox = false;
@@ -948,9 +964,10 @@ extern "C" lcqp_hip_qp_t* lcqp_hip_qp_create(int nV, int nC, const double* Q, co
     q->cAdmm = q->cTrials = q->cFact = q->cCorr = 0;
     return q;
 }
+catch (...) { g_err = "out of host memory"; return nullptr; }   // nothing throws across the C boundary
 
 extern "C" lcqp_hip_qp_t* lcqp_hip_qp_clone(const lcqp_hip_qp_t* s)
-{
+try {
     if (!s) return nullptr;
     // The reference copies subsolvers only before their first use (src/Subsolver.cpp:125-136,
     // src/LCQProblem.cpp:906-907): the clone carries the problem data and options; device state is
@@ -960,21 +977,24 @@ extern "C" lcqp_hip_qp_t* lcqp_hip_qp_clone(const lcqp_hip_qp_t* s)
     q->haveBounds = false;
     return q;
 }
+catch (...) { g_err = "out of host memory"; return nullptr; }   // nothing throws across the C boundary
 
 extern "C" void lcqp_hip_qp_destroy(lcqp_hip_qp_t* q)
-{
+try {
     if (!q) return;
     if (q->hb) lcqp_hip_batch_destroy(q->hb);
     delete q;
 }
+catch (...) { }   // nothing throws across the C boundary
 
 extern "C" int lcqp_hip_qp_set_options(lcqp_hip_qp_t* q, const lcqp_options_t* opt)
-{
+try {
     if (!q || !opt) return LCQP_INVALID_ARGUMENT;
     q->opt = *opt;
     q->haveBounds = false;   // forces a fresh setup (rho / sigma / prox weights enter the factorisations)
     return 0;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 static bool same_pattern(const std::vector<double>& a0, const std::vector<double>& b0, const double* a1, const double* b1, size_t n)
 {
@@ -990,7 +1010,7 @@ static bool same_pattern(const std::vector<double>& a0, const std::vector<double
 extern "C" int lcqp_hip_qp_solve(lcqp_hip_qp_t* q, int initialSolve, int* iterations, int* exit_flag,
                                  const double* g, const double* lbA, const double* ubA,
                                  const double* x0, const double* y0, const double* lb, const double* ub)
-{
+try {
     if (!q || !g || !iterations || !exit_flag) return LCQP_INVALID_ARGUMENT;
     const int n = q->nV, nC = q->nC;
     *iterations = 0; *exit_flag = 0;
@@ -1057,22 +1077,25 @@ extern "C" int lcqp_hip_qp_solve(lcqp_hip_qp_t* q, int initialSolve, int* iterat
     }
     return LCQP_SUCCESSFUL_RETURN;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 extern "C" void lcqp_hip_qp_get_solution(lcqp_hip_qp_t* q, double* x, double* y)
-{
+try {
     if (!q) return;
     if (x) memcpy(x, q->xsol.data(), sizeof(double) * q->nV);
     if (y) memcpy(y, q->ysol.data(), sizeof(double) * ((size_t)q->nV + q->nC));
 }
+catch (...) { }   // nothing throws across the C boundary
 
 extern "C" void lcqp_hip_qp_get_counters(lcqp_hip_qp_t* q, int* admm, int* trials, int* factorizations, int* corrections)
-{
+try {
     if (!q) return;
     if (admm) *admm = q->cAdmm;
     if (trials) *trials = q->cTrials;
     if (factorizations) *factorizations = q->cFact;
     if (corrections) *corrections = q->cCorr;
 }
+catch (...) { }   // nothing throws across the C boundary
 
 // =================================================================================================
 // building blocks (tests, micro-benchmarks)
@@ -1122,7 +1145,7 @@ static int download_padded(double* dst, const double* src, int batch, int rows, 
     } while (0)
 
 extern "C" int lcqp_hip_util_symv(int batch, int n, double alpha, const double* A, const double* bv, const double* cv, double* dv)
-{
+try {
     if (n <= 0 || n > 512 || batch <= 0) return LCQP_HIP_UNSUPPORTED;
     const int nch = (n + 127) / 128, np = 128 * nch;
     TmpBuf tb;
@@ -1135,6 +1158,7 @@ extern "C" int lcqp_hip_util_symv(int batch, int n, double alpha, const double* 
     HIPCHK(hipDeviceSynchronize());
     return download_padded(dv, dd, batch, 1, n, np, 1);
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 static int util_rows(int batch, int m, int n, const double* A, const double* x, double* dots, const double* coef, double* outT)
 {
@@ -1158,16 +1182,18 @@ static int util_rows(int batch, int m, int n, const double* A, const double* x, 
 }
 
 extern "C" int lcqp_hip_util_gemv(int batch, int m, int n, const double* A, const double* b, double* c)
-{
+try {
     return util_rows(batch, m, n, A, b, c, nullptr, nullptr);
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 extern "C" int lcqp_hip_util_gemv_t(int batch, int m, int n, const double* A, const double* b, double* c)
-{
+try {
     return util_rows(batch, m, n, A, nullptr, nullptr, b, c);
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 extern "C" int lcqp_hip_util_symm_product(int batch, int m, int n, const double* A, const double* Bm, double* C)
-{
+try {
     // goes through the batch object so that the production kernel k_build_C is what is tested
     lcqp_hip_batch* h = lcqp_hip_batch_create(batch, n, 0, m, 0, 0);
     if (!h) return LCQP_HIP_ERROR;
@@ -1190,6 +1216,7 @@ extern "C" int lcqp_hip_util_symm_product(int batch, int m, int n, const double*
     lcqp_hip_batch_destroy(h);
     return rc;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 // =================================================================================================
 // CSC utilities on the device: compressed-segment gather products.
@@ -1223,7 +1250,7 @@ struct lcqp_hip_csc {
 };
 
 extern "C" lcqp_hip_csc_t* lcqp_hip_csc_create(int m, int n, int nnz, const int* p, const int* i, const double* x, int device)
-{
+try {
     if (m <= 0 || n <= 0 || nnz < 0 || !p || (nnz && (!i || !x))) { g_err = "invalid CSC arguments"; return nullptr; }
     HIPCHKN(hipSetDevice(device));
     // transpose on the host: counting sort by row index (stable, so columns stay ascending inside a row)
@@ -1253,21 +1280,23 @@ extern "C" lcqp_hip_csc_t* lcqp_hip_csc_create(int m, int n, int nnz, const int*
     }
     return h;
 }
+catch (...) { g_err = "out of host memory"; return nullptr; }   // nothing throws across the C boundary
 
 extern "C" void lcqp_hip_csc_destroy(lcqp_hip_csc_t* h)
-{
+try {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipFree(h->p); (void)hipFree(h->i); (void)hipFree(h->x); (void)hipFree(h->tp); (void)hipFree(h->ti); (void)hipFree(h->tx);
     (void)hipFree(h->vin); (void)hipFree(h->vout); (void)hipFree(h->vadd);
     delete h;
 }
+catch (...) { }   // nothing throws across the C boundary
 
 // d = alpha * op(A) * b + (c ? c : 0);  transposed != 0: op(A) = A' (b has m entries, d has n), else op(A) = A.
 // repeat > 1 re-launches the product for timing; *ms = time per launch.
 extern "C" int lcqp_hip_csc_apply(lcqp_hip_csc_t* h, int transposed, double alpha, const double* b, const double* c, double* d,
                                   int repeat, float* ms)
-{
+try {
     if (!h || !b || !d) return LCQP_INVALID_ARGUMENT;
     HIPCHK(hipSetDevice(h->device));
     const int nin = transposed ? h->m : h->n, nout = transposed ? h->n : h->m;
@@ -1293,6 +1322,7 @@ extern "C" int lcqp_hip_csc_apply(lcqp_hip_csc_t* h, int transposed, double alph
     HIPCHK(hipMemcpy(d, h->vout, sizeof(double) * nout, hipMemcpyDeviceToHost));
     return 0;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 // micro-benchmark of the row sweep (wg_rows) on device-resident random data: mode 1 = dots only (A x),
 // 2 = axpy only (A'y), 3 = both in one sweep; *ms = time per launch
@@ -1303,7 +1333,7 @@ __global__ void k_fill_random(double* p, size_t n, uint64_t seed)
 }
 
 extern "C" int lcqp_hip_bench_rows(int batch, int m, int n, int mode, int repeat, float* ms)
-{
+try {
     if (n <= 0 || n > 512 || batch <= 0 || m <= 0) return LCQP_HIP_UNSUPPORTED;
     const int nch = (n + 127) / 128, np = 128 * nch;
     TmpBuf tb;
@@ -1331,9 +1361,10 @@ extern "C" int lcqp_hip_bench_rows(int batch, int m, int n, int mode, int repeat
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return 0;
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
 extern "C" int lcqp_hip_chol_solve(int batch, int n, const double* K, const double* b, double* x, int repeat, float* ms)
-{
+try {
     if (n <= 0 || n > 512 || batch <= 0) return LCQP_HIP_UNSUPPORTED;
     const int np = ((n + 63) / 64) * 64, nblk = np / 64;
     TmpBuf tb;
@@ -1373,3 +1404,4 @@ extern "C" int lcqp_hip_chol_solve(int batch, int n, const double* K, const doub
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return download_padded(x, dx, batch, 1, n, np, 1);
 }
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
