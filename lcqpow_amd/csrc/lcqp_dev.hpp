@@ -500,7 +500,9 @@ __device__ __forceinline__ void qp_export(Ctx<NCH>& c, double* xdst /*np or n*/,
 // ---------------------------------------------------------------------------------------------
 // LCQProblem::runSolver for one instance (oracle: orc_lcqp_solve).  src/LCQProblem.cpp:444-560.
 // ---------------------------------------------------------------------------------------------
-template <int NCH>
+// ROBUST selects the QP subsolver variant (qp_solve<NCH, ROBUST>): false in k_lcqp_run, true in k_lcqp_rerun, which repeats
+// the instances that ended with SUBPROBLEM_SOLVER_ERROR.
+template <int NCH, bool ROBUST>
 __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
 {
     constexpr int np = 128 * NCH;
@@ -540,7 +542,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     auto solveQP = [&](int initial) -> int {   // :1115-1148
         const double* y0 = (initial && c.info->hasY0) ? db.y0 + (size_t)c.b * db.nd : nullptr;
         PROF(c, P_LCQP);
-        const int ef = qp_solve<NCH, false>(c, initial, gk, y0, &qpIter);
+        const int ef = qp_solve<NCH, ROBUST>(c, initial, gk, y0, &qpIter);
         PROF(c, P_MISC);
         st.subproblemIter += qpIter;
         st.qpSolverExitFlag = ef;

@@ -291,7 +291,21 @@ __global__ __launch_bounds__(WG, LCQP_MINWAVES) void k_lcqp_run(DevBatch db)
 {
     LCQP_LDS
     Ctx<NCH> c = make_ctx<NCH>(db, blockIdx.x, lds);
-    lcqp_run<NCH>(c);
+    lcqp_run<NCH, false>(c);
+}
+
+// ---- second chance for instances whose QP subsolver gave up: the same homotopy with the dependent-row rules --------
+// (a separate kernel, so that the rules cost the first pass nothing; oracle counterpart: the robust switch of its LCQP loop)
+template <int NCH>
+__global__ __launch_bounds__(WG, 4) void k_lcqp_rerun(DevBatch db, const int* list)
+{
+    LCQP_LDS
+    Ctx<NCH> c = make_ctx<NCH>(db, list[blockIdx.x], lds);
+    int *dep = c.I(I_DEP), *prio = c.I(I_PRIO);
+    for (int r = threadIdx.x; r < db.mEcap; r += WG) { dep[r] = 0; prio[r] = 0; }
+    if (threadIdx.x == 0) { c.info->haveSolution = 0; c.info->cacheNa = -1; c.info->prioCtr = 0; c.info->ndep = 0; }
+    __syncthreads();
+    lcqp_run<NCH, true>(c);
 }
 
 // ---- one QP per workgroup with the SubsolverBase semantics ----------------------------------------
@@ -517,6 +531,7 @@ struct lcqp_hip_batch {
     size_t stageBytes;
     std::vector<void*> allocs;
     bool setupDone, ran;
+    int* rerunList;     // device buffer of instance ids for k_lcqp_rerun (allocated on first use)
     int nch;
     size_t bytesTotal;
 };
@@ -543,7 +558,7 @@ try {
     if (!h) { g_err = "out of host memory"; return nullptr; }
     h->device = device; h->setupDone = false; h->ran = false; h->bytesTotal = 0;
     h->stage[0] = h->stage[1] = nullptr; h->stageBytes = 0;
-    h->stream = nullptr; h->ev0 = h->ev1 = h->ev2 = nullptr;
+    h->stream = nullptr; h->ev0 = h->ev1 = h->ev2 = nullptr; h->rerunList = nullptr;
     DevBatch& d = h->db;
     memset(&d, 0, sizeof(d));
     hipError_t e0 = hipStreamCreate(&h->stream);
@@ -854,6 +869,28 @@ try {
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev2, h->stream));
     h->ran = true;
+    return 0;
+}
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
+
+extern "C" int lcqp_hip_batch_rerun_failed(lcqp_hip_batch_t* h, int* count)
+try {
+    if (!h || !count) return LCQP_INVALID_ARGUMENT;
+    *count = 0;
+    if (!h->ran) return LCQP_LCQPOBJECT_NOT_SETUP;
+    HIPCHK(hipSetDevice(h->device));
+    DevBatch& d = h->db;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<lcqp_stats_t> st(d.B);
+    HIPCHK(hipMemcpy(st.data(), d.stats, sizeof(lcqp_stats_t) * (size_t)d.B, hipMemcpyDeviceToHost));
+    std::vector<int> list;
+    for (int b = 0; b < d.B; b++) if (st[b].returnValue == LCQP_SUBPROBLEM_SOLVER_ERROR && st[b].qpSolverExitFlag == 1) list.push_back(b);
+    if (list.empty()) return 0;
+    if (!h->rerunList && dev_alloc(h, &h->rerunList, (size_t)d.B, false)) return LCQP_HIP_ERROR;
+    HIPCHK(hipMemcpy(h->rerunList, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice));
+    DISPATCH_NCH(h, k_lcqp_rerun, (int)list.size(), d, (const int*)h->rerunList);
+    HIPCHK(hipGetLastError());
+    *count = (int)list.size();
     return 0;
 }
 catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
