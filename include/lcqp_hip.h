@@ -91,7 +91,10 @@ void lcqp_hip_qp_destroy(lcqp_hip_qp_t* qp);
 /* SubsolverQPOASES::setOptions, src/SubsolverQPOASES.cpp:120-131 (takes effect at the next initial solve) */
 int  lcqp_hip_qp_set_options(lcqp_hip_qp_t* qp, const lcqp_options_t* opt);
 /* SubsolverBase::solve, include/SubsolverBase.hpp:52-56 / src/SubsolverQPOASES.cpp:134-169.
- * Returns LCQP_SUCCESSFUL_RETURN or LCQP_SUBPROBLEM_SOLVER_ERROR; *exit_flag != 0 on failure.
+ * Returns LCQP_SUCCESSFUL_RETURN or LCQP_SUBPROBLEM_SOLVER_ERROR; *exit_flag != 0 on failure (the reference stores
+ * qpOASES' raw status there, src/LCQProblem.cpp:1122, and its tests only require "non-zero on failure"):
+ *   1 the subsolver gave up after maxRounds rounds, 2 lbA > ubA or lb > ub, 3 the setup factorisations failed,
+ *   4 certified primal infeasible, 5 certified unbounded (OSQP's certificates on the ADMM iterates), -1 HIP error.
  * lbA/ubA/lb/ub/x0/y0 may be NULL as in the reference. */
 int  lcqp_hip_qp_solve(lcqp_hip_qp_t* qp, int initialSolve, int* iterations, int* exit_flag,
                        const double* g, const double* lbA, const double* ubA,

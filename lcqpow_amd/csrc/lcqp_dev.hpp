@@ -15,7 +15,7 @@ namespace lcqp {
 enum { V_G, V_GPHI, V_GTIL, V_XK, V_PK, V_XNEW, V_GK, V_QX, V_CX, V_QP, V_CP, V_STATK, V_TMP,
        V_XQ, V_XA, V_XT, V_R1, V_C, V_DU, V_W, V_RHS, V_LB, V_UB, V_X0, V_R1S, V_GS, V_ATY, V_NUM };
 // per-instance vectors of length mEcap (rows of E = [A; L; R; box rows])
-enum { M_L, M_U, M_RHOV, M_YQ, M_YA, M_ZA, M_YT, M_EX, M_COEF, M_EXS, M_NUM };
+enum { M_L, M_U, M_RHOV, M_YQ, M_YA, M_ZA, M_YT, M_EX, M_COEF, M_EXS, M_DY, M_NUM };   // M_DY: change of ya in the last ADMM iteration
 enum { I_ST, I_STT, I_DEP, I_PRIO, I_NUM };   // I_DEP: row flagged dependent by the last factorisation of S; I_PRIO: promotion stamp (0: none)
 enum { S_R2, S_DY, S_D0, S_NUM };
 
@@ -116,7 +116,7 @@ __device__ __forceinline__ void qp_admm(Ctx<NCH>& c, const double* g, int n_it)
     const int t = threadIdx.x, mE = c.mE;
     const double alpha = o.admmAlpha, sigma = c.info->sigma;
     double *xa = c.V(V_XA), *rhs = c.V(V_RHS), *w = c.V(V_W);
-    double *ya = c.M(M_YA), *za = c.M(M_ZA), *rhov = c.M(M_RHOV), *coef = c.M(M_COEF), *ex = c.M(M_EX);
+    double *ya = c.M(M_YA), *za = c.M(M_ZA), *rhov = c.M(M_RHOV), *coef = c.M(M_COEF), *ex = c.M(M_EX), *dyl = c.M(M_DY);
     const double *l = c.M(M_L), *u = c.M(M_U);
     PROF(c, P_MISC);
     for (int it = 0; it < n_it; it++) {
@@ -128,24 +128,79 @@ __device__ __forceinline__ void qp_admm(Ctx<NCH>& c, const double* g, int n_it)
         wg_trsv(c.FK, np, c.nblk, rhs, true, c.lds);
         wg_trsv(c.FK, np, c.nblk, rhs, false, c.lds);       // rhs = xt
         wg_rows<NCH>(c.E, nullptr, mE, rhs, ex, nullptr, c.lds, [](int, double) {});   // ex = E xt
+        const bool last = (it == n_it - 1);      // the change of (ya, xa) in the last iteration feeds qp_certificate
         for (int r = t; r < mE; r += WG) {
             const double zr = alpha * ex[r] + (1.0 - alpha) * za[r];
             const double rv = rhov[r];
+            const double yold = ya[r];
+            double yn;
             if (rv > 0.0) {
-                const double zn = clipd(zr + ya[r] / rv, l[r], u[r]);
-                ya[r] += rv * (zr - zn);
+                const double zn = clipd(zr + yold / rv, l[r], u[r]);
+                yn = yold + rv * (zr - zn);
                 za[r] = zn;
             } else {
                 za[r] = zr;
-                ya[r] = 0.0;
+                yn = 0.0;
             }
+            ya[r] = yn;
+            if (last) dyl[r] = yn - yold;
         }
-        for (int i = t; i < np; i += WG) xa[i] = alpha * rhs[i] + (1.0 - alpha) * xa[i];
+        for (int i = t; i < np; i += WG) {
+            const double xold = xa[i], xn = alpha * rhs[i] + (1.0 - alpha) * xold;
+            xa[i] = xn;
+            if (last) w[i] = xn - xold;
+        }
         __syncthreads();
         c.cAdmm++;
     }
     PROF(c, P_ADMM);
-    (void)w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// OSQP's certificates from the last ADMM step (Stellato et al., Math. Prog. Comp. 12, 2020, section 3.4; oracle:
+// qp_certificate), relative tolerance 1e-4: primal infeasibility from dy = y_k - y_{k-1} (M_DY), unboundedness from
+// dx = x_k - x_{k-1} (V_W).  Returns the exit flag 4 (infeasible), 5 (unbounded) or 0, uniform.
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+__device__ __forceinline__ int qp_certificate(Ctx<NCH>& c, const double* g)
+{
+    constexpr int np = 128 * NCH;
+    constexpr double eps = 1e-4;
+    const int t = threadIdx.x, mE = c.mE;
+    const double *dy = c.M(M_DY), *dx = c.V(V_W), *l = c.M(M_L), *u = c.M(M_U);
+    double *tv = c.V(V_RHS), *ex = c.M(M_EX);
+    const double ny = wg_maxabs(dy, mE, c.lds);
+    if (ny > 1e-30) {
+        double sup = 0.0; int bad = 0;
+        for (int r = t; r < mE; r += WG) {
+            const double d = dy[r];
+            if (d > 0.0) { if (!isfinite(u[r])) bad |= (d > eps * ny); else sup += u[r] * d; }
+            else if (d < 0.0) { if (!isfinite(l[r])) bad |= (-d > eps * ny); else sup += l[r] * d; }
+        }
+        sup = block_sum(sup, c.lds);
+        bad = block_or(bad, c.lds);
+        if (!bad && sup <= -eps * ny) {
+            wg_rows<NCH>(c.E, nullptr, mE, nullptr, nullptr, dy, c.lds, [&](int i, double s) { tv[i] = s; });   // E' dy
+            if (wg_maxabs(tv, np, c.lds) <= eps * ny) return 4;
+        }
+    }
+    const double nx = wg_maxabs(dx, np, c.lds);
+    if (nx > 1e-30) {
+        const double gd = wg_dot(g, dx, np, c.lds);
+        if (gd <= -eps * nx) {
+            wg_symv<NCH>(c.Q, nullptr, c.n, dx, nullptr, tv, nullptr, nullptr, nullptr, c.lds);                 // Q dx
+            if (wg_maxabs(tv, c.n, c.lds) <= eps * nx) {
+                wg_rows<NCH>(c.E, nullptr, mE, dx, ex, nullptr, c.lds, [](int, double) {});                      // E dx
+                int viol = 0;
+                for (int r = t; r < mE; r += WG) {
+                    const double e = ex[r];
+                    viol |= (isfinite(u[r]) && e > eps * nx) || (isfinite(l[r]) && e < -eps * nx);
+                }
+                if (!block_or(viol, c.lds)) return 5;
+            }
+        }
+    }
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -441,7 +496,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
     __syncthreads();
     int n_admm = initial ? o.admmFirst : o.admmHot;
     const int use_stored = (!initial && c.info->haveSolution && n_admm == 0);
-    int solved = 0, admm_ready = 0;   // za = clip(E xa) is only needed once ADMM runs
+    int solved = 0, admm_ready = 0, certificate = 0;   // za = clip(E xa) is only needed once ADMM runs
     for (int round = 0; round < o.maxRounds && !solved; round++) {
         if (!admm_ready && (n_admm > 0 || !(round == 0 && use_stored))) {
             wg_rows<NCH>(c.E, nullptr, mE, xa, ex, nullptr, c.lds, [](int, double) {});
@@ -471,12 +526,16 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         for (int i = t; i < np; i += WG) xt[i] = xa[i];
         __syncthreads();
         if (qp_polish<NCH, ROBUST>(c, g, round == 0 && use_stored)) { solved = 1; break; }
+        if (round >= 2) {    // at least 20 ADMM iterations behind us: is the QP infeasible or unbounded?
+            certificate = qp_certificate<NCH>(c, g);
+            if (certificate) break;
+        }
         n_admm = 2 * n_admm;
         if (n_admm < 10) n_admm = 10;
         if (n_admm > 400) n_admm = 400;
     }
     *iterations = (c.cTrials - trials0) + (c.cAdmm - admm0);
-    if (!solved) return 1;
+    if (!solved) return certificate ? certificate : 1;
     for (int i = t; i < np; i += WG) xq[i] = xt[i];
     for (int r = t; r < mE; r += WG) { yq[r] = yt[r]; st[r] = stt[r]; }
     if (t == 0) c.info->haveSolution = 1;

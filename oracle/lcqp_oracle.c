@@ -242,6 +242,7 @@ struct orc_qp {
     double *w_n1, *w_n2, *w_n3, *w_m1, *T, *S, *w_a1, *w_a2;
     double *r1_last, *ex_last, *g_last; /* residual, E x and linear term of the last verified solution */
     int *idx, *newst, *idx_new;
+    double *dy_last, *dx_last; /* change of (ya, xa) in the last ADMM iteration: OSQP's infeasibility certificates */
     /* dependent-row rules of the single-QP path (SubsolverHIP / k_qp_solve); the batched homotopy kernel runs without them */
     int robust;
     int *dep;      /* per row: 1 = flagged linearly dependent by the last factorisation of S, 2 = left because of it */
@@ -274,6 +275,7 @@ static void qp_free_setup(orc_qp_t* q)
     free(q->boxidx); free(q->E); free(q->Et); free(q->l); free(q->u); free(q->rhov);
     free(q->L1); free(q->LK); free(q->x); free(q->y); free(q->st); free(q->xa); free(q->ya); free(q->za);
     free(q->w_n1); free(q->w_n2); free(q->w_n3); free(q->w_m1); free(q->T); free(q->S); free(q->w_a1); free(q->w_a2);
+    free(q->dy_last); free(q->dx_last); q->dy_last = q->dx_last = NULL;
     free(q->idx); free(q->newst); free(q->idx_new); free(q->dep); free(q->prio); q->dep = q->prio = NULL; free(q->r1_last); free(q->ex_last); free(q->g_last);
     q->idx_new = NULL; q->r1_last = q->ex_last = q->g_last = NULL;
     q->boxidx = NULL; q->E = q->Et = q->l = q->u = q->rhov = q->L1 = q->LK = q->x = q->y = NULL;
@@ -384,6 +386,7 @@ static int qp_setup(orc_qp_t* q, const double* lbA, const double* ubA, const dou
     q->w_a1 = dalloc(q->cap_na); q->w_a2 = dalloc(q->cap_na);
     q->idx = (int*)calloc(q->cap_na ? q->cap_na : 1, sizeof(int));
     q->newst = (int*)calloc(mE ? mE : 1, sizeof(int));
+    q->dy_last = dalloc(mE); q->dx_last = dalloc(n);
     q->dep = (int*)calloc(mE ? mE : 1, sizeof(int));
     q->prio = (int*)calloc(mE ? mE : 1, sizeof(int));
     q->prio_ctr = 0;
@@ -452,6 +455,7 @@ static void qp_admm(orc_qp_t* q, const double* g, int n_it)
             for (int i = 0; i < n; i++) zt += e[i] * rhs[i];
             double zr = alpha * zt + (1.0 - alpha) * q->za[r];
             double rv = q->rhov[r];
+            const double yold = q->ya[r];
             if (rv > 0.0) {
                 double zn = clipd(zr + q->ya[r] / rv, q->l[r], q->u[r]);
                 q->ya[r] += rv * (zr - zn);
@@ -460,10 +464,75 @@ static void qp_admm(orc_qp_t* q, const double* g, int n_it)
                 q->za[r] = zr;
                 q->ya[r] = 0.0;
             }
+            if (it == n_it - 1) q->dy_last[r] = q->ya[r] - yold;
         }
-        for (int i = 0; i < n; i++) q->xa[i] = alpha * rhs[i] + (1.0 - alpha) * q->xa[i];
+        for (int i = 0; i < n; i++) {
+            const double xold = q->xa[i];
+            q->xa[i] = alpha * rhs[i] + (1.0 - alpha) * q->xa[i];
+            if (it == n_it - 1) q->dx_last[i] = q->xa[i] - xold;
+        }
         q->c_admm++;
     }
+}
+
+/* OSQP's certificates from the last ADMM step (Stellato et al., Math. Prog. Comp. 12, 2020, section 3.4), relative
+ * tolerance 1e-4 (OSQP's default): primal infeasibility from dy = y_k - y_{k-1}, unboundedness from dx = x_k - x_{k-1}.
+ * Returns 4 (infeasible), 5 (unbounded) -- the exit flags -- or 0. */
+#define ORC_CERT_EPS 1e-4
+static int qp_certificate(orc_qp_t* q, const double* g)
+{
+    const int n = q->nV, mE = q->mE;
+    const double eps = ORC_CERT_EPS;
+    double ny = 0;
+    for (int r = 0; r < mE; r++) if (fabs(q->dy_last[r]) > ny) ny = fabs(q->dy_last[r]);
+    if (ny > 1e-30) {
+        double sup = 0; int bad = 0;
+        for (int r = 0; r < mE; r++) {
+            const double d = q->dy_last[r];
+            if (d > 0) { if (!isfinite(q->u[r])) { if (d > eps * ny) bad = 1; } else sup += q->u[r] * d; }
+            else if (d < 0) { if (!isfinite(q->l[r])) { if (-d > eps * ny) bad = 1; } else sup += q->l[r] * d; }
+        }
+        if (!bad && sup <= -eps * ny) {
+            double* t = q->w_n2;
+            for (int i = 0; i < n; i++) t[i] = 0;
+            for (int r = 0; r < mE; r++) {
+                const double d = q->dy_last[r];
+                if (d == 0) continue;
+                const double* e = q->E + (size_t)r * n;
+                for (int i = 0; i < n; i++) t[i] += e[i] * d;
+            }
+            double na = 0;
+            for (int i = 0; i < n; i++) if (fabs(t[i]) > na) na = fabs(t[i]);
+            if (na <= eps * ny) return 4;
+        }
+    }
+    double nx = 0;
+    for (int i = 0; i < n; i++) if (fabs(q->dx_last[i]) > nx) nx = fabs(q->dx_last[i]);
+    if (nx > 1e-30) {
+        double gd = 0;
+        for (int i = 0; i < n; i++) gd += g[i] * q->dx_last[i];
+        if (gd <= -eps * nx) {
+            double nq = 0;
+            for (int i = 0; i < n; i++) {
+                const double* qr = q->Q + (size_t)i * n;
+                double sdot = 0;
+                for (int k = 0; k < n; k++) sdot += qr[k] * q->dx_last[k];
+                if (fabs(sdot) > nq) nq = fabs(sdot);
+            }
+            if (nq <= eps * nx) {
+                int ok = 1;
+                for (int r = 0; r < mE; r++) {
+                    const double* e = q->E + (size_t)r * n;
+                    double sdot = 0;
+                    for (int k = 0; k < n; k++) sdot += e[k] * q->dx_last[k];
+                    if (isfinite(q->u[r]) && sdot > eps * nx) ok = 0;
+                    if (isfinite(q->l[r]) && sdot < -eps * nx) ok = 0;
+                }
+                if (ok) return 5;
+            }
+        }
+    }
+    return 0;
 }
 
 /* active-set guess from an ADMM iterate (the rule OSQP's polish uses) */
@@ -691,7 +760,7 @@ int orc_qp_solve(orc_qp_t* q, int initialSolve, int* iterations, int* exit_flag,
     double* xt = (double*)malloc(sizeof(double) * (n ? n : 1));
     double* yt = (double*)malloc(sizeof(double) * (mE ? mE : 1));
     int* stt = (int*)malloc(sizeof(int) * (mE ? mE : 1));
-    int solved = 0;
+    int solved = 0, certificate = 0;
     for (int round = 0; round < o->maxRounds && !solved; round++) {
         if (!admm_ready && (n_admm > 0 || !(round == 0 && use_stored_set))) {
             for (int r = 0; r < mE; r++) {
@@ -713,12 +782,16 @@ int orc_qp_solve(orc_qp_t* q, int initialSolve, int* iterations, int* exit_flag,
         memcpy(xt, q->xa, sizeof(double) * n);
         for (int r = 0; r < mE; r++) yt[r] = (stt[r] != ST_INACT) ? q->ya[r] : 0.0;
         if (qp_polish(q, g, xt, yt, stt, round == 0 && use_stored_set)) { solved = 1; break; }
+        if (round >= 2) {    /* at least 20 ADMM iterations behind us: is the QP infeasible or unbounded? */
+            certificate = qp_certificate(q, g);
+            if (certificate) break;
+        }
         n_admm = 2 * n_admm;
         if (n_admm < 10) n_admm = 10;
         if (n_admm > 400) n_admm = 400;
     }
     *iterations = (q->c_trials - trials0) + (q->c_admm - admm0);
-    if (!solved) { free(xt); free(yt); free(stt); *exit_flag = 1; return ORC_SUBPROBLEM_SOLVER_ERROR; }
+    if (!solved) { free(xt); free(yt); free(stt); *exit_flag = certificate ? certificate : 1; return ORC_SUBPROBLEM_SOLVER_ERROR; }
     memcpy(q->x, xt, sizeof(double) * n);
     memcpy(q->y, yt, sizeof(double) * mE);
     memcpy(q->st, stt, sizeof(int) * mE);
