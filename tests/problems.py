@@ -109,3 +109,21 @@ def kkt_residuals(Q, g, A, lbA, ubA, lb, ub, x, y):
             cs = max(cs, np.abs(np.where(yy > 0, yy * dl, 0.0)).max(initial=0.0))
             cs = max(cs, np.abs(np.where(yy < 0, yy * du, 0.0)).max(initial=0.0))
     return stat, pf, cs
+
+
+def certificate_qps(seed=3, n=24, m=30):
+    """two QPs for the certificates of the subsolver: (infeasible) a feasible polytope plus two rows that contradict each
+    other, x_0 + x_1 >= 1 and x_0 + x_1 <= -1, on different rows so that no bound pair is inconsistent by itself;
+    (unbounded) a singular Hessian whose null space holds a descent direction that no constraint blocks."""
+    r = np.random.default_rng(seed)
+    M = r.standard_normal((n, n)); Q = M.T @ M / n + np.eye(n)
+    A = r.standard_normal((m, n)) / np.sqrt(n); xs = r.standard_normal(n)
+    lbA = A @ xs - r.uniform(0.1, 1, m); ubA = A @ xs + r.uniform(0.1, 1, m)
+    A[0] = 0; A[0, 0] = A[0, 1] = 1; lbA[0] = 1.0; ubA[0] = np.inf
+    A[1] = 0; A[1, 0] = A[1, 1] = 1; lbA[1] = -np.inf; ubA[1] = -1.0
+    infeasible = dict(Q=Q, A=A, g=r.standard_normal(n), lbA=lbA, ubA=ubA)
+    Q2 = Q.copy(); Q2[:, 0] = 0; Q2[0, :] = 0                       # x_0 does not enter the objective's quadratic part
+    A2 = r.standard_normal((m, n)) / np.sqrt(n); A2[:, 0] = 0        # ... nor any constraint
+    g2 = r.standard_normal(n); g2[0] = 1.0                          # ... and decreasing it lowers the objective without bound
+    unbounded = dict(Q=Q2, A=A2, g=g2, lbA=A2 @ xs - 1.0, ubA=A2 @ xs + 1.0)
+    return infeasible, unbounded

@@ -101,6 +101,20 @@ def test_subsolver_matches_oracle_and_kkt(hip, oracle, n, m, seed):
     qh.close()
 
 
+def test_subsolver_certificates(hip, oracle):
+    """exit flags 4 (infeasible) and 5 (unbounded) from the ADMM iterates, same as the oracle"""
+    inf, unb = P.certificate_qps()
+    for d, flag in ((inf, 4), (unb, 5)):
+        n = d["g"].size
+        qh = hip.SubsolverHIP(n, d["A"].shape[0], d["Q"], d["A"])
+        qo = oracle.QP(d["Q"], d["A"])
+        rh = qh.solve(True, d["g"], d["lbA"], d["ubA"], np.zeros(n), None, None, None)
+        ro = qo.solve(True, d["g"], d["lbA"], d["ubA"], np.zeros(n), None, None, None)
+        assert (rh[0], rh[2]) == (ro[0], ro[2]) == (203, flag), (rh, ro)
+        assert rh[1] < 1500
+        qh.close()
+
+
 def test_subsolver_infeasible_bounds(hip):
     """test/RunUnitTests.cpp:463-502 at the subsolver level: lbA > ubA => SUBPROBLEM_SOLVER_ERROR, flag != 0"""
     q = hip.SubsolverHIP(2, 1, 2 * np.eye(2), np.array([[1., 0.]]))

@@ -115,6 +115,17 @@ def test_qp_subsolver_kkt(oracle, n, m, seed):
     assert it2 <= it
 
 
+def test_qp_certificates(oracle):
+    """exit flags 4 / 5: infeasibility and unboundedness are certified from the ADMM iterates after a few rounds instead of
+    running all maxRounds rounds (the reference only requires SUBPROBLEM_SOLVER_ERROR and a non-zero flag,
+    test/RunUnitTests.cpp:492-501)"""
+    inf, unb = P.certificate_qps()
+    for d, flag in ((inf, 4), (unb, 5)):
+        q = oracle.QP(d["Q"], d["A"])
+        ret, it, ef = q.solve(True, d["g"], d["lbA"], d["ubA"], np.zeros(d["g"].size), None, None, None)
+        assert (ret, ef) == (203, flag) and it < 1500, (ret, ef, it)
+
+
 def test_synthetic_golden(oracle):
     for inst in range(2):
         d = oracle.synth_generate(inst, 64, 96, 16)
