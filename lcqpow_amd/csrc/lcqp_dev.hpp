@@ -204,6 +204,60 @@ __device__ __forceinline__ int qp_certificate(Ctx<NCH>& c, const double* g)
 }
 
 // ---------------------------------------------------------------------------------------------
+// OSQP's rho adaptation for the fallback rounds (oracle: qp_adapt_rho): after a failed round, scale all rho_i by
+//   sqrt( (|E xa - za| / max(|E xa|, |za|)) / (|Q xa + g + E'ya| / max(|Q xa|, |E'ya|, |g|)) )   (infinity norms, clipped to
+// [1e-3, 1e3]) when that factor is above 5 or below 1/5, and refactorise K = Q + sigma I + E' diag(rho) E in place (the
+// work k_build_K and k_factor do at setup, here by this workgroup alone).  Returns 1 (uniform) when rho changed.
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+__device__ __forceinline__ int qp_adapt_rho(Ctx<NCH>& c, const double* g)
+{
+    constexpr int np = 128 * NCH;
+    const int t = threadIdx.x, mE = c.mE;
+    double *xa = c.V(V_XA), *tq = c.V(V_RHS), *ty = c.V(V_TMP);
+    double *ya = c.M(M_YA), *za = c.M(M_ZA), *rhov = c.M(M_RHOV), *ex = c.M(M_EX);
+    wg_symv<NCH>(c.Q, nullptr, c.n, xa, nullptr, tq, nullptr, nullptr, nullptr, c.lds);                 // Q xa
+    wg_rows<NCH>(c.E, nullptr, mE, xa, ex, ya, c.lds, [&](int i, double s) { ty[i] = s; });            // E xa, E'ya
+    double rp = 0.0, nax = 0.0, nz = 0.0;
+    for (int r = t; r < mE; r += WG) {
+        rp = fmax(rp, fabs(ex[r] - za[r])); nax = fmax(nax, fabs(ex[r])); nz = fmax(nz, fabs(za[r]));
+    }
+    double rd = 0.0, nq = 0.0, naty = 0.0, gm = 0.0;
+    for (int i = t; i < np; i += WG) {
+        rd = fmax(rd, fabs(tq[i] + g[i] + ty[i])); nq = fmax(nq, fabs(tq[i])); naty = fmax(naty, fabs(ty[i])); gm = fmax(gm, fabs(g[i]));
+    }
+    rp = block_max(rp, c.lds); nax = block_max(nax, c.lds); nz = block_max(nz, c.lds);
+    rd = block_max(rd, c.lds); nq = block_max(nq, c.lds); naty = block_max(naty, c.lds); gm = block_max(gm, c.lds);
+    const double num = rp / fmax(fmax(nax, nz), 1e-30), den = rd / fmax(fmax(fmax(nq, naty), gm), 1e-30);
+    double fac = sqrt(num / fmax(den, 1e-30));
+    fac = fmin(fmax(fac, 1e-3), 1e3);
+    if (!(fac > 5.0 || fac < 0.2)) return 0;
+    for (int r = t; r < mE; r += WG) rhov[r] *= fac;
+    if (t == 0) c.info->rhoAdmm *= fac;
+    __syncthreads();
+    const double sigma = c.info->sigma;
+    for (int I = 0; I < c.nblk; I++)
+        for (int J = 0; J <= I; J++) {
+            double acc[4][4];
+            wg_tile_tn(acc, c.E, np, 64 * I, c.E, np, 64 * J, mE, [=](int r) { return rhov[r]; }, c.lds);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int gi = 64 * I + tile_li(i, j), gj = 64 * J + tile_lj(i, j);
+                    const double v = acc[i][j] + c.Q[(size_t)gi * np + gj] + (gi == gj ? sigma : 0.0);
+                    c.FK[(size_t)gi * np + gj] = v;
+                    if (I != J) c.FK[(size_t)gj * np + gi] = v;     // see k_build_K
+                }
+        }
+    __syncthreads();
+    wg_chol(c.FK, np, c.nblk, c.n, 0.0, c.dscr, nullptr, nullptr, c.lds, 0);
+    __syncthreads();
+    c.cFact++;
+    return 1;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Dependent-row rules of the single-QP kernel (k_qp_solve, ROBUST = true; oracle: q->robust).  k_lcqp_run runs without
 // them: inside the persistent kernel they cost 6 % through register allocation.
 // (1) Rows the last factorisation of S flagged as linearly dependent on the rows before them: the correction neither
@@ -458,7 +512,9 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
 // qp.hotstart (:158).  On success the solution is left in V_XQ / M_YQ / I_ST.
 // Returns 0, or the exit flag (1 max rounds, 2 infeasible bounds, 3 setup failure).
 // ---------------------------------------------------------------------------------------------
-template <int NCH, bool ROBUST>
+// ADAPT: rho adaptation between fallback rounds (qp_adapt_rho).  Only the single-QP kernel carries it: next to the homotopy loop
+// its second Cholesky instantiation pushes the unrolled register tiles of k_lcqp_run / k_lcqp_rerun into scratch (2.7 KB per lane).
+template <int NCH, bool ROBUST, bool ADAPT>
 __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* g, const double* y0ref, int* iterations)
 {
     constexpr int np = 128 * NCH;
@@ -526,6 +582,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         for (int i = t; i < np; i += WG) xt[i] = xa[i];
         __syncthreads();
         if (qp_polish<NCH, ROBUST>(c, g, round == 0 && use_stored)) { solved = 1; break; }
+        if (ADAPT && round >= 1 && n_admm > 0) qp_adapt_rho<NCH>(c, g);
         if (round >= 2) {    // at least 20 ADMM iterations behind us: is the QP infeasible or unbounded?
             certificate = qp_certificate<NCH>(c, g);
             if (certificate) break;
@@ -601,7 +658,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     auto solveQP = [&](int initial) -> int {   // :1115-1148
         const double* y0 = (initial && c.info->hasY0) ? db.y0 + (size_t)c.b * db.nd : nullptr;
         PROF(c, P_LCQP);
-        const int ef = qp_solve<NCH, ROBUST>(c, initial, gk, y0, &qpIter);
+        const int ef = qp_solve<NCH, ROBUST, false>(c, initial, gk, y0, &qpIter);
         PROF(c, P_MISC);
         st.subproblemIter += qpIter;
         st.qpSolverExitFlag = ef;

@@ -21,47 +21,6 @@ using namespace lcqp;
     __shared__ int sh_ired[16];                     \
     Lds lds{sh_arena, sh_red, sh_ired};
 
-// 64x64 tile product, TN form:  acc[i][j] = sum_{r<nrows} wgt(r) * A[r][ca+i] * B[r][cb+j]
-template <class Wgt>
-__device__ __forceinline__ void wg_tile_tn(double (&acc)[4][4], const double* __restrict__ A, int lda, int ca,
-                                           const double* __restrict__ Bm, int ldb, int cb, int nrows, Wgt wgt, Lds lds)
-{
-    constexpr int PL = TILE_PL;
-    double* As = lds.arena;
-    double* Bs = lds.arena + 16 * PL;
-    const int t = threadIdx.x;
-    const int kk = t >> 4, c4 = (t & 15) * 4;
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
-    for (int k0 = 0; k0 < nrows; k0 += 16) {
-        const int r = k0 + kk;
-        double2 a0 = {0.0, 0.0}, a1 = {0.0, 0.0}, b0 = {0.0, 0.0}, b1 = {0.0, 0.0};
-        if (r < nrows) {
-            const double wv = wgt(r);
-            const double* ap = A + (size_t)r * lda + ca + c4;
-            const double* bp = Bm + (size_t)r * ldb + cb + c4;
-            a0 = *reinterpret_cast<const double2*>(ap); a1 = *reinterpret_cast<const double2*>(ap + 2);
-            b0 = *reinterpret_cast<const double2*>(bp); b1 = *reinterpret_cast<const double2*>(bp + 2);
-            a0.x *= wv; a0.y *= wv; a1.x *= wv; a1.y *= wv;
-        }
-        __syncthreads();
-        *reinterpret_cast<double2*>(As + kk * PL + c4) = a0; *reinterpret_cast<double2*>(As + kk * PL + c4 + 2) = a1;
-        *reinterpret_cast<double2*>(Bs + kk * PL + c4) = b0; *reinterpret_cast<double2*>(Bs + kk * PL + c4 + 2) = b1;
-        __syncthreads();
-        tile_panel(acc, As, Bs);
-    }
-    __syncthreads();
-}
-
-// lower-triangular tile index -> (I, J), I >= J
-__device__ __forceinline__ void tri_tile(int tIdx, int& I, int& J)
-{
-    I = 0;
-    while ((I + 1) * (I + 2) / 2 <= tIdx) I++;
-    J = tIdx - I * (I + 1) / 2;
-}
 
 // ---- k_prepare: scales, padding, box rows, ADMM rho vector, phi expressions ----------------------
 template <int NCH>
@@ -316,7 +275,7 @@ __global__ __launch_bounds__(WG, 4) void k_qp_solve(DevBatch db, int initial)
     Ctx<NCH> c = make_ctx<NCH>(db, blockIdx.x, lds);
     const double* y0 = (initial && c.info->hasY0) ? db.y0 + (size_t)c.b * db.nd : nullptr;
     int iters = 0;
-    const int ef = qp_solve<NCH, true>(c, initial, c.V(V_GK), y0, &iters);   // single-QP path: with the dependent-row rules
+    const int ef = qp_solve<NCH, true, true>(c, initial, c.V(V_GK), y0, &iters);   // single-QP path: dependent-row rules and rho adaptation
     if (ef == 0) qp_export<NCH>(c, db.xout + (size_t)c.b * db.n, db.n, db.yout + (size_t)c.b * db.nd);
     if (threadIdx.x == 0) {
         lcqp_stats_t s;

@@ -623,4 +623,47 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
     return minpiv;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 64x64 tile product, TN form:  acc[i][j] = sum_{r<nrows} wgt(r) * A[r][ca+i] * B[r][cb+j]
+template <class Wgt>
+__device__ __forceinline__ void wg_tile_tn(double (&acc)[4][4], const double* __restrict__ A, int lda, int ca,
+                                           const double* __restrict__ Bm, int ldb, int cb, int nrows, Wgt wgt, Lds lds)
+{
+    constexpr int PL = TILE_PL;
+    double* As = lds.arena;
+    double* Bs = lds.arena + 16 * PL;
+    const int t = threadIdx.x;
+    const int kk = t >> 4, c4 = (t & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+    for (int k0 = 0; k0 < nrows; k0 += 16) {
+        const int r = k0 + kk;
+        double2 a0 = {0.0, 0.0}, a1 = {0.0, 0.0}, b0 = {0.0, 0.0}, b1 = {0.0, 0.0};
+        if (r < nrows) {
+            const double wv = wgt(r);
+            const double* ap = A + (size_t)r * lda + ca + c4;
+            const double* bp = Bm + (size_t)r * ldb + cb + c4;
+            a0 = *reinterpret_cast<const double2*>(ap); a1 = *reinterpret_cast<const double2*>(ap + 2);
+            b0 = *reinterpret_cast<const double2*>(bp); b1 = *reinterpret_cast<const double2*>(bp + 2);
+            a0.x *= wv; a0.y *= wv; a1.x *= wv; a1.y *= wv;
+        }
+        __syncthreads();
+        *reinterpret_cast<double2*>(As + kk * PL + c4) = a0; *reinterpret_cast<double2*>(As + kk * PL + c4 + 2) = a1;
+        *reinterpret_cast<double2*>(Bs + kk * PL + c4) = b0; *reinterpret_cast<double2*>(Bs + kk * PL + c4 + 2) = b1;
+        __syncthreads();
+        tile_panel(acc, As, Bs);
+    }
+    __syncthreads();
+}
+
+// lower-triangular tile index -> (I, J), I >= J
+__device__ __forceinline__ void tri_tile(int tIdx, int& I, int& J)
+{
+    I = 0;
+    while ((I + 1) * (I + 2) / 2 <= tIdx) I++;
+    J = tIdx - I * (I + 1) / 2;
+}
+
 }  // namespace lcqp

@@ -245,6 +245,7 @@ struct orc_qp {
     double *dy_last, *dx_last; /* change of (ya, xa) in the last ADMM iteration: OSQP's infeasibility certificates */
     /* dependent-row rules of the single-QP path (SubsolverHIP / k_qp_solve); the batched homotopy kernel runs without them */
     int robust;
+    int adapt;     /* rho adaptation between fallback rounds (qp_adapt_rho): the single-QP path only, like the device */
     int *dep;      /* per row: 1 = flagged linearly dependent by the last factorisation of S, 2 = left because of it */
     int *prio;     /* per row: 0, or the stamp of the trial that promoted the row to the front of the active list */
     int prio_ctr;
@@ -265,6 +266,7 @@ orc_qp_t* orc_qp_create(int nV, int nC, const double* Q, const double* A, const 
     if (nC > 0) memcpy(q->A, A, sizeof(double) * nC * nV);
     if (opt) q->opt = *opt; else orc_options_default(&q->opt);
     q->robust = 1;
+    q->adapt = 1;
     q->xsol = dalloc(nV);
     q->ysol = dalloc((size_t)nV + nC);
     return q;
@@ -535,6 +537,64 @@ static int qp_certificate(orc_qp_t* q, const double* g)
     return 0;
 }
 
+/* OSQP's rho adaptation (Stellato et al. 2020, section 5.2) for the fallback rounds: after a failed round, scale all rho_i by
+ *   sqrt( (|E xa - za| / max(|E xa|, |za|)) / (|Q xa + g + E'ya| / max(|Q xa|, |E'ya|, |g|)) )      (infinity norms, clipped to
+ * [1e-3, 1e3]) when that factor is above 5 or below 1/5, and refactorise K = Q + sigma I + E' diag(rho) E.  A fixed rho makes
+ * ADMM crawl on badly scaled QPs (large penalty parameters, degenerate vertices) and the polish then never gets a usable
+ * working-set guess.  Returns 1 when rho changed. */
+static int qp_adapt_rho(orc_qp_t* q, const double* g)
+{
+    const int n = q->nV, mE = q->mE;
+    double *t = q->w_n2, *t2 = q->w_n3;
+    double rp = 0, rd = 0, nz = 0, nax = 0, nq = 0, naty = 0, gm = 0;
+    for (int i = 0; i < n; i++) {
+        const double* qr = q->Q + (size_t)i * n;
+        double sd = 0;
+        for (int k = 0; k < n; k++) sd += qr[k] * q->xa[k];
+        t[i] = sd; t2[i] = 0;
+        if (fabs(sd) > nq) nq = fabs(sd);
+        if (fabs(g[i]) > gm) gm = fabs(g[i]);
+    }
+    for (int r = 0; r < mE; r++) {
+        const double* e = q->E + (size_t)r * n;
+        double sd = 0;
+        for (int k = 0; k < n; k++) sd += e[k] * q->xa[k];
+        if (fabs(sd - q->za[r]) > rp) rp = fabs(sd - q->za[r]);
+        if (fabs(sd) > nax) nax = fabs(sd);
+        if (fabs(q->za[r]) > nz) nz = fabs(q->za[r]);
+        const double yr = q->ya[r];
+        if (yr != 0.0) for (int k = 0; k < n; k++) t2[k] += e[k] * yr;
+    }
+    for (int i = 0; i < n; i++) {
+        const double v = t[i] + g[i] + t2[i];
+        if (fabs(v) > rd) rd = fabs(v);
+        if (fabs(t2[i]) > naty) naty = fabs(t2[i]);
+    }
+    const double num = rp / fmax(fmax(nax, nz), 1e-30), den = rd / fmax(fmax(fmax(nq, naty), gm), 1e-30);
+    double fac = sqrt(num / fmax(den, 1e-30));
+    if (fac > 1e3) fac = 1e3;
+    if (fac < 1e-3) fac = 1e-3;
+    if (!(fac > 5.0 || fac < 0.2)) return 0;
+    for (int r = 0; r < mE; r++) q->rhov[r] *= fac;
+    q->rho *= fac;
+    memcpy(q->LK, q->Q, sizeof(double) * n * n);
+    for (int i = 0; i < n; i++) q->LK[(size_t)i * n + i] += q->sigma;
+    for (int r = 0; r < mE; r++) {
+        const double rv = q->rhov[r];
+        if (rv == 0.0) continue;
+        const double* e = q->E + (size_t)r * n;
+        for (int i = 0; i < n; i++) {
+            const double ei = rv * e[i];
+            if (ei == 0.0) continue;
+            double* row = q->LK + (size_t)i * n;
+            for (int j = 0; j < n; j++) row[j] += ei * e[j];
+        }
+    }
+    chol_lower(q->LK, n, NULL);
+    q->c_fact++;
+    return 1;
+}
+
 /* active-set guess from an ADMM iterate (the rule OSQP's polish uses) */
 static void qp_guess_from_admm(orc_qp_t* q, int* st)
 {
@@ -782,6 +842,7 @@ int orc_qp_solve(orc_qp_t* q, int initialSolve, int* iterations, int* exit_flag,
         memcpy(xt, q->xa, sizeof(double) * n);
         for (int r = 0; r < mE; r++) yt[r] = (stt[r] != ST_INACT) ? q->ya[r] : 0.0;
         if (qp_polish(q, g, xt, yt, stt, round == 0 && use_stored_set)) { solved = 1; break; }
+        if (q->adapt && round >= 1 && n_admm > 0) qp_adapt_rho(q, g);
         if (round >= 2) {    /* at least 20 ADMM iterations behind us: is the QP infeasible or unbounded? */
             certificate = qp_certificate(q, g);
             if (certificate) break;
@@ -1032,7 +1093,10 @@ int orc_lcqp_solve(int nV, int nC, int nComp,
         p->alphak = 1; p->rho = opt->initialPenaltyParameter;                  /* :999-1004 */
         p->algoStat = ORC_PROBLEM_NOT_SOLVED;
         p->qp = orc_qp_create(nV, m, p->Q, p->A, opt);                          /* :906-907 */
-        p->qp->robust = g_lcqp_robust;   /* 0 mirrors k_lcqp_run; 1 mirrors the host loop over SubsolverHIP (k_qp_solve) */
+        /* 0 mirrors k_lcqp_run; 1 the host loop over SubsolverHIP (k_qp_solve: dependent-row rules and rho adaptation);
+         * 2 the second pass k_lcqp_rerun (dependent-row rules only) */
+        p->qp->robust = g_lcqp_robust != 0;
+        p->qp->adapt = g_lcqp_robust == 1;
 
         /* runSolver :444-560 */
         if (opt->solveZeroPenaltyFirst) memcpy(p->gk, p->g, sizeof(double) * nV);

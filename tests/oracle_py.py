@@ -124,8 +124,8 @@ SEED0 = 0x4C43515000000001
 
 
 def lcqp_set_robust(on):
-    """orc_lcqp_solve mirrors k_lcqp_run (False, default) or the host loop over SubsolverHIP (True)"""
-    lib().orc_lcqp_set_robust(int(bool(on)))
+    """orc_lcqp_solve mirrors k_lcqp_run (0 / False, default), the host loop over SubsolverHIP (1 / True) or k_lcqp_rerun (2)"""
+    lib().orc_lcqp_set_robust(int(on))
 
 
 def synth_generate(instance, n=256, nC=512, nComp=64, seed0=SEED0):

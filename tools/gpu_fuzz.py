@@ -128,9 +128,9 @@ def batch_solve_with_rerun(d):
 def oracle_solve_with_rerun(d):
     ro = P.oracle_solve(O, d, O.default_options(perturbStep=0))
     if ro["ret"] == 203 and ro["stats"]["qpSolverExitFlag"] == 1:
-        O.lcqp_set_robust(True)
+        O.lcqp_set_robust(2)
         ro = P.oracle_solve(O, d, O.default_options(perturbStep=0))
-        O.lcqp_set_robust(False)
+        O.lcqp_set_robust(0)
     return ro
 
 
@@ -139,7 +139,7 @@ def run(count, seed, verbose=True, host=False, rerun=False):
     dependent-row rules) vs the oracle with the same rules; rerun=True: batched loop followed by the second pass for failed
     instances (k_lcqp_rerun) vs the oracle doing the same"""
     O.build(); O.lib()
-    O.lcqp_set_robust(host)
+    O.lcqp_set_robust(1 if host else 0)
     rng = np.random.default_rng(seed)
     rets = {}
     cats = {"same": 0, "same solution, other iterate count": 0, "other stationary point": 0, "return codes differ": 0}
@@ -166,7 +166,7 @@ def run(count, seed, verbose=True, host=False, rerun=False):
         cats[cat] += 1
         if msg and verbose:
             print(f"[{k}] n={d['nV']} nC={d['nC']} nComp={d['nComp']} keys={sorted(set(d) - {'Q', 'g', 'L', 'R', 'nV', 'nC', 'nComp'})}: {cat}: {msg}", flush=True)
-    O.lcqp_set_robust(False)
+    O.lcqp_set_robust(0)
     if verbose:
         print(f"fuzz[{'host loop + SubsolverHIP' if host else 'batched device loop + second pass' if rerun else 'batched device loop'}]: {count} problems (seed {seed}): {cats}; (oracle ret, hip ret) histogram: {dict(sorted(rets.items()))}")
     return cats, rets
