@@ -512,8 +512,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
 // qp.hotstart (:158).  On success the solution is left in V_XQ / M_YQ / I_ST.
 // Returns 0, or the exit flag (1 max rounds, 2 infeasible bounds, 3 setup failure).
 // ---------------------------------------------------------------------------------------------
-// ADAPT: rho adaptation between fallback rounds (qp_adapt_rho).  Only the single-QP kernel carries it: next to the homotopy loop
-// its second Cholesky instantiation pushes the unrolled register tiles of k_lcqp_run / k_lcqp_rerun into scratch (2.7 KB per lane).
+// ADAPT: rho adaptation between fallback rounds (qp_adapt_rho); on in every kernel (the switch stays for A/B builds).
 template <int NCH, bool ROBUST, bool ADAPT>
 __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* g, const double* y0ref, int* iterations)
 {
@@ -658,7 +657,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     auto solveQP = [&](int initial) -> int {   // :1115-1148
         const double* y0 = (initial && c.info->hasY0) ? db.y0 + (size_t)c.b * db.nd : nullptr;
         PROF(c, P_LCQP);
-        const int ef = qp_solve<NCH, ROBUST, false>(c, initial, gk, y0, &qpIter);
+        const int ef = qp_solve<NCH, ROBUST, true>(c, initial, gk, y0, &qpIter);
         PROF(c, P_MISC);
         st.subproblemIter += qpIter;
         st.qpSolverExitFlag = ef;
@@ -678,15 +677,45 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
         for (int i = t; i < np; i += WG) gk[i] = rho * Cx[i] + gtil[i];
         __syncthreads();
     }
-    rc = solveQP(1);
-    if (rc == 0) {
-        st.rhoOpt = rho;   // :473
-        // One sweep over Q and C per iterate: Q*[pk, xk] and C*[pk, xk] (the sweep getOptimalStepLength needs,
-        // :1217-1237).  Q*(xk + alpha pk) at the top of the next pass follows by linearity from these two
-        // direct products (no recurrence over iterates), and A'yk_A + yk_box is taken from the verified KKT
-        // residual of the subproblem (V_ATY), so updateStationarity needs no sweep of its own.
-        wg_symv<NCH>(c.Q, c.C, n, pk, xk, Qp, Cp, Qx, Cx, c.lds);
+    // One call site for the QP subsolver and one for the Q/C sweep (the kernel carries a single copy of each): the pass
+    // below starts with the QP whose linear term gk is current -- the first QP of :452-467, then the hot starts of :545 --
+    // and continues with the top of the reference's loop.
+    // One sweep over Q and C per iterate: Q*[pk, xk] and C*[pk, xk] (the sweep getOptimalStepLength needs,
+    // :1217-1237).  Q*(xk + alpha pk) in updateStep follows by linearity from these two direct products (no
+    // recurrence over iterates), and A'yk_A + yk_box is taken from the verified KKT residual of the subproblem
+    // (V_ATY), so updateStationarity needs no sweep of its own.
+    {
+        int initial = 1;
         for (;;) {
+            rc = solveQP(initial);
+            if (rc != 0) break;
+            if (initial) {
+                st.rhoOpt = rho;   // :473
+            } else if (o.perturbStep) {
+                // perturbStep :1353-1362 (seeded SplitMix64 instead of time-seeded rand())
+                for (int i = t; i < n; i += WG) {
+                    uint64_t z = o.perturbSeed + (perturbCounter + (uint64_t)i + 1ULL) * 0x9E3779B97F4A7C15ULL;
+                    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+                    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+                    z = z ^ (z >> 31);
+                    xk[i] += ((int)(z % 3ULL) - 1) * 2.221e-16;
+                }
+                perturbCounter += (uint64_t)n;
+                __syncthreads();
+            }
+            wg_symv<NCH>(c.Q, c.C, n, pk, xk, Qp, Cp, Qx, Cx, c.lds);
+            if (!initial) {
+                // getOptimalStepLength :1217-1237: qk = pk'Qk pk, lk = pk'(Qk xk + g_tilde)
+                double sq = 0.0, sl = 0.0;
+                for (int i = t; i < n; i += WG) {
+                    sq += pk[i] * (Qp[i] + rho * Cp[i]);
+                    sl += pk[i] * ((Qx[i] + rho * Cx[i]) + gtil[i]);
+                }
+                const double qk = block_sum(sq, c.lds), lk = block_sum(sl, c.lds);
+                alphak = 1.0;
+                if (qk > 0 && lk < 0) alphak = fmin(-lk / qk, 1.0);
+            }
+            initial = 0;
             // updateStep :1240-1243
             for (int i = t; i < np; i += WG) {
                 xk[i] = xk[i] + alphak * pk[i];
@@ -769,30 +798,6 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
             // updateLinearization :1105-1112: gk = rho C xk + g_tilde
             for (int i = t; i < np; i += WG) gk[i] = rho * Cx[i] + gtil[i];
             __syncthreads();
-            rc = solveQP(0);
-            if (rc != 0) break;
-            // perturbStep :1353-1362 (seeded SplitMix64 instead of time-seeded rand())
-            if (o.perturbStep) {
-                for (int i = t; i < n; i += WG) {
-                    uint64_t z = o.perturbSeed + (perturbCounter + (uint64_t)i + 1ULL) * 0x9E3779B97F4A7C15ULL;
-                    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-                    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-                    z = z ^ (z >> 31);
-                    xk[i] += ((int)(z % 3ULL) - 1) * 2.221e-16;
-                }
-                perturbCounter += (uint64_t)n;
-                __syncthreads();
-            }
-            // getOptimalStepLength :1217-1237: qk = pk'Qk pk, lk = pk'(Qk xk + g_tilde)
-            wg_symv<NCH>(c.Q, c.C, n, pk, xk, Qp, Cp, Qx, Cx, c.lds);
-            double sq = 0.0, sl = 0.0;
-            for (int i = t; i < n; i += WG) {
-                sq += pk[i] * (Qp[i] + rho * Cp[i]);
-                sl += pk[i] * ((Qx[i] + rho * Cx[i]) + gtil[i]);
-            }
-            const double qk = block_sum(sq, c.lds), lk = block_sum(sl, c.lds);
-            alphak = 1.0;
-            if (qk > 0 && lk < 0) alphak = fmin(-lk / qk, 1.0);
         }
     }
     st.status = algoStat;

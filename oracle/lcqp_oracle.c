@@ -245,7 +245,6 @@ struct orc_qp {
     double *dy_last, *dx_last; /* change of (ya, xa) in the last ADMM iteration: OSQP's infeasibility certificates */
     /* dependent-row rules of the single-QP path (SubsolverHIP / k_qp_solve); the batched homotopy kernel runs without them */
     int robust;
-    int adapt;     /* rho adaptation between fallback rounds (qp_adapt_rho): the single-QP path only, like the device */
     int *dep;      /* per row: 1 = flagged linearly dependent by the last factorisation of S, 2 = left because of it */
     int *prio;     /* per row: 0, or the stamp of the trial that promoted the row to the front of the active list */
     int prio_ctr;
@@ -266,7 +265,6 @@ orc_qp_t* orc_qp_create(int nV, int nC, const double* Q, const double* A, const 
     if (nC > 0) memcpy(q->A, A, sizeof(double) * nC * nV);
     if (opt) q->opt = *opt; else orc_options_default(&q->opt);
     q->robust = 1;
-    q->adapt = 1;
     q->xsol = dalloc(nV);
     q->ysol = dalloc((size_t)nV + nC);
     return q;
@@ -842,7 +840,7 @@ int orc_qp_solve(orc_qp_t* q, int initialSolve, int* iterations, int* exit_flag,
         memcpy(xt, q->xa, sizeof(double) * n);
         for (int r = 0; r < mE; r++) yt[r] = (stt[r] != ST_INACT) ? q->ya[r] : 0.0;
         if (qp_polish(q, g, xt, yt, stt, round == 0 && use_stored_set)) { solved = 1; break; }
-        if (q->adapt && round >= 1 && n_admm > 0) qp_adapt_rho(q, g);
+        if (round >= 1 && n_admm > 0) qp_adapt_rho(q, g);
         if (round >= 2) {    /* at least 20 ADMM iterations behind us: is the QP infeasible or unbounded? */
             certificate = qp_certificate(q, g);
             if (certificate) break;
@@ -1093,10 +1091,9 @@ int orc_lcqp_solve(int nV, int nC, int nComp,
         p->alphak = 1; p->rho = opt->initialPenaltyParameter;                  /* :999-1004 */
         p->algoStat = ORC_PROBLEM_NOT_SOLVED;
         p->qp = orc_qp_create(nV, m, p->Q, p->A, opt);                          /* :906-907 */
-        /* 0 mirrors k_lcqp_run; 1 the host loop over SubsolverHIP (k_qp_solve: dependent-row rules and rho adaptation);
-         * 2 the second pass k_lcqp_rerun (dependent-row rules only) */
+        /* 0 mirrors k_lcqp_run; non-zero the kernels that also carry the dependent-row rules: k_qp_solve under the host
+         * loop over SubsolverHIP, and the second pass k_lcqp_rerun */
         p->qp->robust = g_lcqp_robust != 0;
-        p->qp->adapt = g_lcqp_robust == 1;
 
         /* runSolver :444-560 */
         if (opt->solveZeroPenaltyFirst) memcpy(p->gk, p->g, sizeof(double) * nV);

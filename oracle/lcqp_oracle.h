@@ -122,9 +122,9 @@ int orc_lcqp_solve(int nV, int nC, int nComp,
                    const orc_options_t* opt, double* xOpt, double* yOpt, orc_stats_t* stats,
                    int traceCap, double* traceScalars /* traceCap x 4 */, double* traceX /* traceCap x nV */, int* traceLen);
 
-/* which QP path orc_lcqp_solve mirrors: 0 (default) the batched homotopy kernel k_lcqp_run; 1 the reference's host loop
- * over SubsolverHIP, whose single-QP kernel applies the dependent-row rules and the rho adaptation of orc_qp_*; 2 the second
- * pass for failed batch instances, k_lcqp_rerun (dependent-row rules only) */
+/* which QP path orc_lcqp_solve mirrors: 0 (default) the batched homotopy kernel k_lcqp_run; non-zero the kernels that also
+ * apply the dependent-row rules of orc_qp_*: k_qp_solve under the reference's host loop over SubsolverHIP, and the second pass
+ * for failed batch instances, k_lcqp_rerun */
 void orc_lcqp_set_robust(int on);
 
 /* ---- synthetic instances (include/lcqp_synth.h) and a threaded batch driver for the CPU baseline ---- */

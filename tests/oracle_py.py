@@ -124,7 +124,7 @@ SEED0 = 0x4C43515000000001
 
 
 def lcqp_set_robust(on):
-    """orc_lcqp_solve mirrors k_lcqp_run (0 / False, default), the host loop over SubsolverHIP (1 / True) or k_lcqp_rerun (2)"""
+    """orc_lcqp_solve mirrors k_lcqp_run (0 / False, default) or the kernels with the dependent-row rules (k_qp_solve, k_lcqp_rerun)"""
     lib().orc_lcqp_set_robust(int(on))
 
 

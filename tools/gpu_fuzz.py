@@ -128,7 +128,7 @@ def batch_solve_with_rerun(d):
 def oracle_solve_with_rerun(d):
     ro = P.oracle_solve(O, d, O.default_options(perturbStep=0))
     if ro["ret"] == 203 and ro["stats"]["qpSolverExitFlag"] == 1:
-        O.lcqp_set_robust(2)
+        O.lcqp_set_robust(1)
         ro = P.oracle_solve(O, d, O.default_options(perturbStep=0))
         O.lcqp_set_robust(0)
     return ro
