@@ -446,3 +446,34 @@ def test_lcqp_second_pass_for_failed_instances(hip, oracle):
     x2, y2, st2 = bt.solution()
     assert np.array_equal(x, x2) and np.array_equal(y, y2)
     bt.close()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(solveZeroPenaltyFirst=0),                              # first QP already carries the penalty (src/LCQProblem.cpp:452-467)
+    dict(nDynamicPenalty=0),                                    # no Leyffer test (:1275-1313)
+    dict(nDynamicPenalty=1, etaDynamicPenalty=0.5),
+    dict(initialPenaltyParameter=1.0, penaltyUpdateFactor=10.0),
+    dict(maxIterations=7),                                      # MAX_ITERATIONS_REACHED (:536-539)
+    dict(maxPenaltyParameter=0.05),                             # MAX_PENALTY_REACHED (:541-543)
+    dict(stationarityTolerance=1e-6, complementarityTolerance=1e-9),
+    dict(perturbStep=1, perturbSeed=12345),
+])
+def test_lcqp_option_sweep(hip, oracle, kw):
+    """every algorithm option of src/Options.cpp:296-333 that changes the control flow of runSolver, HIP batch vs oracle:
+    same return code, same iterate counts (up to one inner cycle), same solution"""
+    base = dict(perturbStep=0)
+    base.update(kw)
+    probs = [oracle.synth_generate(i, 64, 96, 16) for i in range(3)] + [P.circle(20), P.warm_up_binary()]
+    for d in probs:
+        d = dict(d)
+        d.setdefault("nV", d["g"].size)
+        d.setdefault("nComp", d["L"].shape[0] if d["L"].ndim == 2 else d["L"].size // d["nV"])
+        d.setdefault("nC", 0 if d.get("A") is None else d["A"].size // d["nV"])
+        ro = P.oracle_solve(oracle, d, oracle.default_options(**base))
+        rh = P.hip_solve(hip, d, hip.default_options(**base))
+        assert rh["ret"] == ro["ret"], (kw, rh["ret"], ro["ret"])
+        so, sh = ro["stats"], rh["stats"]
+        assert abs(so["iterTotal"] - sh["iterTotal"]) <= 4 and abs(so["iterOuter"] - sh["iterOuter"]) <= 1, (kw, so, sh)
+        if ro["ret"] == 0:
+            assert np.abs(ro["x"] - rh["x"]).max() < 1e-7, kw
+            assert so["status"] == sh["status"]

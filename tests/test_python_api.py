@@ -254,3 +254,44 @@ def test_python_structure_fuzz_host_loop(hip, oracle):
     cats, rets = fz.run(count, seed=7, verbose=False, host=True)
     assert cats["same"] + cats["same solution, other iterate count"] >= count - count // 20, (cats, rets)
     assert rets.get((0, 0), 0) >= count // 2, rets
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(solveZeroPenaltyFirst=0),
+    dict(nDynamicPenalty=0),
+    dict(nDynamicPenalty=1, etaDynamicPenalty=0.5),
+    dict(initialPenaltyParameter=1.0, penaltyUpdateFactor=10.0),
+    dict(maxIterations=7),
+    dict(maxPenaltyParameter=0.05),
+    dict(stationarityTolerance=1e-6, complementarityTolerance=1e-9),
+    dict(perturbStep=1, perturbSeed=12345),
+])
+def test_python_option_sweep_host_loop(hip, oracle, kw):
+    """the option sweep of tests/test_gpu_parity.py::test_lcqp_option_sweep on the host loop (lcqpow_amd/csrc/host/LCQProblem.cpp
+    + SubsolverHIP) through the reference's Options setters, against the oracle running the same subsolver variant"""
+    lcqpow = _lcqpow()
+    setters = dict(solveZeroPenaltyFirst="setSolveZeroPenaltyFirst", nDynamicPenalty="setNDynamicPenalty",
+                   etaDynamicPenalty="setEtaDynamicPenalty", initialPenaltyParameter="setInitialPenaltyParameter",
+                   penaltyUpdateFactor="setPenaltyUpdateFactor", maxIterations="setMaxIterations",
+                   maxPenaltyParameter="setMaxPenaltyParameter", stationarityTolerance="setStationarityTolerance",
+                   complementarityTolerance="setComplementarityTolerance", perturbStep="setPerturbStep", perturbSeed="setPerturbSeed")
+
+    def tweak(o):
+        for k, v in kw.items():
+            assert getattr(o, setters[k])(v) in (None, lcqpow.ReturnValue.SUCCESSFUL_RETURN)
+
+    base = dict(perturbStep=0)
+    base.update(kw)
+    oracle.lcqp_set_robust(1)
+    try:
+        for d in [oracle.synth_generate(i, 64, 96, 16) for i in range(2)] + [P.circle(20), P.warm_up_binary()]:
+            ret, x, y, stats = _solve(lcqpow, d, order="C", tweak=tweak)
+            ro = P.oracle_solve(oracle, d, oracle.default_options(**base))
+            assert int(ret) == ro["ret"], (kw, int(ret), ro["ret"])
+            so = ro["stats"]
+            assert abs(stats.getIterTotal() - so["iterTotal"]) <= 4 and abs(stats.getIterOuter() - so["iterOuter"]) <= 1, (kw, so)
+            if ro["ret"] == 0:
+                assert np.abs(x - ro["x"]).max() < 1e-7 and int(stats.getSolutionStatus()) == so["status"]
+    finally:
+        oracle.lcqp_set_robust(0)
