@@ -47,3 +47,30 @@ def test_no_product_import_of_oracle():
                 assert not re.search(r"#\s*include[^\n]*oracle", txt), f
                 assert not re.search(r"\bimport\s+oracle_py|from\s+oracle_py", txt), f
                 assert "liblcqp_oracle" not in txt and not re.search(r"\borc_[a-z_]+\s*\(", txt), f
+
+
+def test_c_abi_rejects_bad_arguments_without_a_gpu():
+    """argument checks of the C ABI that need no device, and the loud failure of every compute entry when none is visible"""
+    import numpy as np
+    import lcqpow_amd as la
+    from lcqpow_amd import capi
+    L = la.lib()
+    assert L.lcqp_hip_batch_create(0, 4, 1, 1, 0, 0) is None and "invalid" in capi.last_error()
+    assert L.lcqp_hip_batch_create(4, 4, -1, 1, 0, 0) is None
+    assert L.lcqp_hip_batch_create(1, 513, 0, 1, 0, 0) is None and "512" in capi.last_error()
+    Q = np.eye(2); dp = ctypes.POINTER(ctypes.c_double)
+    assert L.lcqp_hip_qp_create(0, 0, Q.ctypes.data_as(dp), None, None, 0) is None
+    assert L.lcqp_hip_qp_create(2, 1, Q.ctypes.data_as(dp), None, None, 0) is None          # nC > 0 without A
+    assert L.lcqp_hip_batch_run(None) != 0 and L.lcqp_hip_batch_setup(None) != 0
+    n = ctypes.c_int(0)
+    assert L.lcqp_hip_batch_rerun_failed(None, ctypes.byref(n)) != 0
+    if la.device_count() == 0:
+        # no GPU here: creating a batch must fail with the HIP error, never fall back to anything
+        assert L.lcqp_hip_batch_create(2, 4, 1, 1, 0, 0) is None and capi.last_error() != ""
+        q = L.lcqp_hip_qp_create(2, 0, Q.ctypes.data_as(dp), None, None, 0)           # host-side object only
+        assert q is not None
+        it, ef = ctypes.c_int(0), ctypes.c_int(0)
+        g = np.zeros(2)
+        rc = L.lcqp_hip_qp_solve(ctypes.c_void_p(q), 1, ctypes.byref(it), ctypes.byref(ef), g.ctypes.data_as(dp), None, None, None, None, None, None)
+        assert rc == capi.SUBPROBLEM_SOLVER_ERROR and ef.value != 0
+        L.lcqp_hip_qp_destroy(ctypes.c_void_p(q))
