@@ -63,3 +63,11 @@ def test_example_programs():
     assert r.returncode == 0 and "xOpt = [" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([os.path.join(bindir, "batch_synthetic"), "64", "64", "96", "16"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "64/64 LCQPs solved" in r.stdout, r.stdout + r.stderr
+    # batch sharding from C++: 4 shards (threads, batch objects, streams) vs one, same instance ids -> same checksum;
+    # on a one-GPU box the shards share the device, which exercises the thread safety of the library
+    outs = []
+    for shards in ("1", "4"):
+        r = subprocess.run([os.path.join(bindir, "multi_gpu_batch"), "128", shards, "64", "96", "16"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "128/128 LCQPs solved" in r.stdout, r.stdout + r.stderr
+        outs.append(float(r.stdout.split("checksum")[1].split(",")[0]))
+    assert abs(outs[0] - outs[1]) <= 1e-10 * abs(outs[0]), outs      # the sum over shards is taken in another order
