@@ -74,3 +74,15 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
         rc = L.lcqp_hip_qp_solve(ctypes.c_void_p(q), 1, ctypes.byref(it), ctypes.byref(ef), g.ctypes.data_as(dp), None, None, None, None, None, None)
         assert rc == capi.SUBPROBLEM_SOLVER_ERROR and ef.value != 0
         L.lcqp_hip_qp_destroy(ctypes.c_void_p(q))
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    """no CPU fallback: without the built HIP library the binding raises instead of computing anything"""
+    import pytest
+    from lcqpow_amd import capi
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "_SO", "/nonexistent/liblcqpow_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        capi.lib()
+    with pytest.raises(RuntimeError):
+        capi.BatchLCQP(1, 2, 0, 1)
