@@ -847,6 +847,9 @@ try {
     if (list.empty()) return 0;
     if (!h->rerunList && dev_alloc(h, &h->rerunList, (size_t)d.B, false)) return LCQP_HIP_ERROR;
     HIPCHK(hipMemcpy(h->rerunList, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice));
+    // the failed pass may have adapted rho and refactorised K for these instances: start again from the setup state
+    // (the setup kernels run over the whole batch, 5 ms; solutions and statistics of the other instances are not touched)
+    { const int rcs = launch_setup(h); if (rcs) return rcs; }
     DISPATCH_NCH(h, k_lcqp_rerun, (int)list.size(), d, (const int*)h->rerunList);
     HIPCHK(hipGetLastError());
     *count = (int)list.size();
