@@ -534,6 +534,7 @@ try {
     if (d.mEcap < 1) d.mEcap = 1;
     int capNa = 2 * nV > 64 ? 2 * nV : 64;      // active rows the Gram factor has room for (qp_polish)
     if (capNa > d.mEcap) capNa = d.mEcap;
+    if (capNa > LCQP_MAX_ACTIVE) capNa = LCQP_MAX_ACTIVE;
     d.capS = ((capNa + 63) / 64) * 64;
     if (d.capS < 64) d.capS = 64;
     d.nd = nV + d.mA;

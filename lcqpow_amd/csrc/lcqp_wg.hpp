@@ -20,6 +20,7 @@ constexpr int WG = 256;          // threads per workgroup
 constexpr int NWAVE = 4;         // waves per workgroup
 constexpr int ARENA = 4512;      // doubles of routine-private LDS (35.25 KiB -> 4 workgroups per CU)
 constexpr int TILE_LD = 65;      // padded leading dimension of the 64x64 LDS tile
+constexpr int LCQP_MAX_ACTIVE = 64 * (ARENA / (5 * 64));   // 896: wg_trsv keeps the vector and four partial copies of it in the arena
 
 enum { ST_INACT = 0, ST_LOWER = 1, ST_UPPER = 2, ST_EQ = 3 };
 
@@ -277,7 +278,7 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
 // dimension 64*nblk): off-diagonal 64x64 blocks hold L (below) and L' (above); the diagonal blocks
 // hold D = inv(L_II) below and D' above.  Forward (L y = b) and backward (L' x = b) both stream
 // 64-wide row segments with lane-local accumulation; no per-row reductions, no sequential 64-step
-// chains.   vec: global, in/out.   LDS: arena[0..nn) b, arena[nn..5nn) partials (nn <= 512).
+// chains.   vec: global, in/out.   LDS: arena[0..nn) b, arena[nn..5nn) partials (nn <= LCQP_MAX_ACTIVE = 896).
 // Algorithmic HBM bytes: 8*N*(N+2) for forward+backward.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wg_trsv(const double* __restrict__ F, int ld, int nblk, double* vec, bool forward, Lds lds)

@@ -477,3 +477,26 @@ def test_lcqp_option_sweep(hip, oracle, kw):
         if ro["ret"] == 0:
             assert np.abs(ro["x"] - rh["x"]).max() < 1e-7, kw
             assert so["status"] == sh["status"]
+
+
+def test_subsolver_active_row_capacity(hip, oracle):
+    """more candidate active rows than the subsolver has room for (LCQP_MAX_ACTIVE = 896: the active-row triangular solves live in
+    the LDS arena): 1000 copies of the row x_0 >= 1 at nV = 500.  The polish must give up cleanly, as the oracle does, instead of
+    running past the arena; ADMM alone cannot verify a KKT point, so both sides report the same failure."""
+    n, m = 500, 1000
+    Q = np.eye(n); A = np.zeros((m, n)); A[:, 0] = 1.0
+    g = np.zeros(n); lbA = np.ones(m); ubA = np.full(m, np.inf)
+    opt_h = hip.default_options(maxRounds=4); opt_o = oracle.default_options(maxRounds=4)
+    qh = hip.SubsolverHIP(n, m, Q, A, opt=opt_h); qo = oracle.QP(Q, A, opt_o)
+    rh = qh.solve(True, g, lbA, ubA, np.zeros(n)); ro = qo.solve(True, g, lbA, ubA, np.zeros(n))
+    assert (rh[0], rh[2]) == (ro[0], ro[2]), (rh, ro)
+    assert rh[0] in (0, 203)
+    qh.close()
+    # the same rows within the capacity: solved, x_0 = 1
+    m2 = 800
+    qh = hip.SubsolverHIP(n, m2, Q, A[:m2]); qo = oracle.QP(Q, A[:m2])
+    rh = qh.solve(True, g, lbA[:m2], ubA[:m2], np.zeros(n)); ro = qo.solve(True, g, lbA[:m2], ubA[:m2], np.zeros(n))
+    assert (rh[0], rh[2]) == (ro[0], ro[2]) == (0, 0)
+    x, y = qh.getSolution()
+    assert abs(x[0] - 1.0) < 1e-9 and np.abs(x[1:]).max() < 1e-12 and abs(y[n:].sum() - 1.0) < 1e-8
+    qh.close()
