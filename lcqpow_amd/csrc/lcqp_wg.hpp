@@ -169,6 +169,7 @@ __device__ __forceinline__ void wg_symv(const double* __restrict__ M0, const dou
                         double* o00, double* o10, double* o01, double* o11, Lds lds)
 {
     constexpr int np = 128 * NCH;
+    static_assert(6 * np <= ARENA, "wg_symv: four partial copies and two staged vectors must fit the LDS arena");
     double* sv0 = lds.arena + 4 * np;
     double* sv1 = lds.arena + 5 * np;
     for (int i = threadIdx.x; i < np; i += WG) {
@@ -225,6 +226,7 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
                         const double* __restrict__ coef, Lds lds, Post post)
 {
     constexpr int np = 128 * NCH;
+    static_assert(5 * np <= ARENA, "wg_rows: four partial copies and the staged vector must fit the LDS arena");
     double* sx = lds.arena + 4 * np;
     if (x) {
         for (int i = threadIdx.x; i < np; i += WG) sx[i] = x[i];
