@@ -489,7 +489,7 @@ struct lcqp_hip_batch {
     hipEvent_t stageDone[2];
     size_t stageBytes;
     std::vector<void*> allocs;
-    bool setupDone, ran;
+    bool setupDone, ran, anyLoaded;
     int* rerunList;     // device buffer of instance ids for k_lcqp_rerun (allocated on first use)
     int nch;
     size_t bytesTotal;
@@ -515,7 +515,7 @@ try {
     HIPCHKN(hipSetDevice(device));
     lcqp_hip_batch* h = new (std::nothrow) lcqp_hip_batch();
     if (!h) { g_err = "out of host memory"; return nullptr; }
-    h->device = device; h->setupDone = false; h->ran = false; h->bytesTotal = 0;
+    h->device = device; h->setupDone = false; h->ran = false; h->anyLoaded = false; h->bytesTotal = 0;
     h->stage[0] = h->stage[1] = nullptr; h->stageBytes = 0;
     h->stream = nullptr; h->ev0 = h->ev1 = h->ev2 = nullptr; h->rerunList = nullptr;
     DevBatch& d = h->db;
@@ -657,7 +657,7 @@ try {
     HIPCHK(hipSetDevice(h->device));
     // a batch mixes instances: keep one setting of "lbL/lbR given" per batch (phi expressions :969-996)
     const int hasL = lbL ? 1 : 0, hasR = lbR ? 1 : 0;
-    if (first == 0) { d.hasLbL = hasL; d.hasLbR = hasR; }
+    if (!h->anyLoaded || first == 0) { d.hasLbL = hasL; d.hasLbR = hasR; h->anyLoaded = true; }   // a (re)load starting at instance 0 or the first load of the object decides
     else if (d.hasLbL != hasL || d.hasLbR != hasR) { g_err = "lbL/lbR must be given for all instances of a batch or for none"; return LCQP_INVALID_ARGUMENT; }
     // pinned staging: [Qp | Ep | nvb | mvb | ybuf | lbuf | rbuf | info | bidx]
     const size_t nQ = (size_t)np * np, nE = (size_t)mE * np, nNV = (size_t)V_NUM * np, nMV = (size_t)M_NUM * mE;
@@ -756,7 +756,7 @@ try {
     HIPCHK(hipSetDevice(h->device));
     DevBatch& d = h->db;
     if (d.nComp * 2 > d.n) { g_err = "synthetic generator needs 2*nComp <= nV"; return LCQP_INVALID_ARGUMENT; }
-    d.hasLbL = d.hasLbR = 0;
+    d.hasLbL = d.hasLbR = 0; h->anyLoaded = true;
     DISPATCH_NCH(h, k_synth_fill, d.B, d, seed0, firstInstance);
     DISPATCH_NCH(h, k_synth_Q, d.B * (d.nblk * (d.nblk + 1) / 2), d);
     HIPCHK(hipGetLastError());
