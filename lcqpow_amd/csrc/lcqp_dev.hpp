@@ -331,7 +331,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
     const double ytol = o.feasTol * gs;
     int na = 0, nblkS = 0, fact_valid = 0;
     int prioCtr = ROBUST ? uniform_i(c.info->prioCtr) : 0;
-    const int capNa = min(min(min(max(2 * c.n, 64), mE), capS), LCQP_MAX_ACTIVE);   // room for the degenerate vertices of small problems
+    const int capNa = min(min(min(max(2 * c.n, 64), mE), capS), max_active(NCH));   // room for the degenerate vertices of small problems
 
     for (int trial = 0; trial < o.maxTrials; trial++) {
         c.cTrials++;

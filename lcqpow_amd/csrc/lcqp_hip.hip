@@ -15,18 +15,19 @@ using namespace lcqp;
 // =================================================================================================
 // device kernels
 // =================================================================================================
-#define LCQP_LDS                                    \
-    __shared__ double sh_arena[ARENA];              \
-    __shared__ double sh_red[16];                   \
-    __shared__ int sh_ired[16];                     \
+#define LCQP_LDS_N(NCHV)                                    \
+    __shared__ double sh_arena[arena_doubles(NCHV)];        \
+    __shared__ double sh_red[16];                           \
+    __shared__ int sh_ired[16];                             \
     Lds lds{sh_arena, sh_red, sh_ired};
+#define LCQP_LDS LCQP_LDS_N(4)
 
 
 // ---- k_prepare: scales, padding, box rows, ADMM rho vector, phi expressions ----------------------
 template <int NCH>
 __global__ __launch_bounds__(WG) void k_prepare(DevBatch db)
 {
-    LCQP_LDS
+    LCQP_LDS_N(NCH)
     constexpr int np = 128 * NCH;
     const int b = blockIdx.x, t = threadIdx.x;
     Ctx<NCH> c = make_ctx<NCH>(db, b, lds);
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(WG) void k_prepare(DevBatch db)
 template <int NCH>
 __global__ __launch_bounds__(WG) void k_build_C(DevBatch db)
 {
-    LCQP_LDS
+    LCQP_LDS_N(NCH)
     constexpr int np = 128 * NCH;
     const int ntile = db.nblk * (db.nblk + 1) / 2;
     const int b = blockIdx.x / ntile, tIdx = blockIdx.x % ntile;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(WG) void k_build_C(DevBatch db)
 template <int NCH>
 __global__ __launch_bounds__(WG) void k_build_K(DevBatch db)
 {
-    LCQP_LDS
+    LCQP_LDS_N(NCH)
     constexpr int np = 128 * NCH;
     const int ntile = db.nblk * (db.nblk + 1) / 2;
     const int b = blockIdx.x / ntile, tIdx = blockIdx.x % ntile;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(WG) void k_build_K(DevBatch db)
 template <int NCH>
 __global__ __launch_bounds__(WG) void k_factor(DevBatch db)
 {
-    LCQP_LDS
+    LCQP_LDS_N(NCH)
     constexpr int np = 128 * NCH;
     const int b = blockIdx.x, t = threadIdx.x;
     Ctx<NCH> c = make_ctx<NCH>(db, b, lds);
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(WG) void k_factor(DevBatch db)
 template <int NCH>
 __global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
 {
-    LCQP_LDS
+    LCQP_LDS_N(NCH)
     constexpr int np = 128 * NCH;
     const int nrb = (db.mEcap + 63) / 64;
     const int b = blockIdx.x / nrb, rb = blockIdx.x % nrb;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
 template <int NCH>
 __global__ __launch_bounds__(WG, LCQP_MINWAVES) void k_lcqp_run(DevBatch db)
 {
-    LCQP_LDS
+    LCQP_LDS_N(NCH)
     Ctx<NCH> c = make_ctx<NCH>(db, blockIdx.x, lds);
     lcqp_run<NCH, false>(c);
 }
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(WG, LCQP_MINWAVES) void k_lcqp_run(DevBatch db)
 template <int NCH>
 __global__ __launch_bounds__(WG, 4) void k_lcqp_rerun(DevBatch db, const int* list)
 {
-    LCQP_LDS
+    LCQP_LDS_N(NCH)
     Ctx<NCH> c = make_ctx<NCH>(db, list[blockIdx.x], lds);
     int *dep = c.I(I_DEP), *prio = c.I(I_PRIO);
     for (int r = threadIdx.x; r < db.mEcap; r += WG) { dep[r] = 0; prio[r] = 0; }
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(WG, 4) void k_lcqp_rerun(DevBatch db, const int* li
 template <int NCH>
 __global__ __launch_bounds__(WG, 4) void k_qp_solve(DevBatch db, int initial)
 {
-    LCQP_LDS
+    LCQP_LDS_N(NCH)
     Ctx<NCH> c = make_ctx<NCH>(db, blockIdx.x, lds);
     const double* y0 = (initial && c.info->hasY0) ? db.y0 + (size_t)c.b * db.nd : nullptr;
     int iters = 0;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(WG, 4) void k_qp_solve(DevBatch db, int initial)
 template <int NCH>
 __global__ __launch_bounds__(WG) void k_synth_fill(DevBatch db, uint64_t seed0, uint64_t first)
 {
-    LCQP_LDS
+    LCQP_LDS_N(NCH)
     constexpr int np = 128 * NCH;
     const int b = blockIdx.x, t = threadIdx.x;
     Ctx<NCH> c = make_ctx<NCH>(db, b, lds);
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(WG) void k_synth_Q(DevBatch db)
 template <int NCH>
 __global__ __launch_bounds__(WG) void k_util_symv(int n, double alpha, const double* A, const double* bv, const double* cv, double* d)
 {
-    LCQP_LDS
+    LCQP_LDS_N(NCH)
     constexpr int np = 128 * NCH;
     const int b = blockIdx.x;
     double* out = d + (size_t)b * np;
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(WG) void k_util_symv(int n, double alpha, const dou
 template <int NCH>
 __global__ __launch_bounds__(WG) void k_util_rows(int m, const double* A, const double* x, double* dots, const double* coef, double* outT)
 {
-    LCQP_LDS
+    LCQP_LDS_N(NCH)
     constexpr int np = 128 * NCH;
     const int b = blockIdx.x;
     double* o = outT ? outT + (size_t)b * np : nullptr;
@@ -511,7 +512,7 @@ static int dev_alloc(lcqp_hip_batch* h, T** p, size_t count, bool zero)
 extern "C" lcqp_hip_batch_t* lcqp_hip_batch_create(int batch, int nV, int nC, int nComp, int withBox, int device)
 try {
     if (batch <= 0 || nV <= 0 || nC < 0 || nComp < 0) { g_err = "invalid dimensions"; return nullptr; }
-    if (nV > 512) { g_err = "nV > 512 is not supported by this build"; return nullptr; }
+    if (nV > 1024) { g_err = "nV > 1024 is not supported by this build"; return nullptr; }
     HIPCHKN(hipSetDevice(device));
     lcqp_hip_batch* h = new (std::nothrow) lcqp_hip_batch();
     if (!h) { g_err = "out of host memory"; return nullptr; }
@@ -527,6 +528,7 @@ try {
     if (e0 != hipSuccess) { set_err("stream/event creation", e0); lcqp_hip_batch_destroy(h); return nullptr; }
     d.B = batch; d.n = nV; d.nC = nC; d.nComp = nComp; d.mA = nC + 2 * nComp;
     h->nch = (nV + 127) / 128;
+    if (h->nch > 4) h->nch = 8;      // 512 < nV <= 1024 runs the np = 1024 instantiation
     d.np = 128 * h->nch;
     d.nblk = d.np / 64;
     d.boxcap = withBox ? nV : 0;
@@ -534,7 +536,7 @@ try {
     if (d.mEcap < 1) d.mEcap = 1;
     int capNa = 2 * nV > 64 ? 2 * nV : 64;      // active rows the Gram factor has room for (qp_polish)
     if (capNa > d.mEcap) capNa = d.mEcap;
-    if (capNa > LCQP_MAX_ACTIVE) capNa = LCQP_MAX_ACTIVE;
+    if (capNa > max_active(h->nch)) capNa = max_active(h->nch);
     d.capS = ((capNa + 63) / 64) * 64;
     if (d.capS < 64) d.capS = 64;
     d.nd = nV + d.mA;
@@ -746,7 +748,8 @@ catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothin
             case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(grid), dim3(WG), 0, (h)->stream, __VA_ARGS__); break; \
             case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(grid), dim3(WG), 0, (h)->stream, __VA_ARGS__); break; \
             case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(grid), dim3(WG), 0, (h)->stream, __VA_ARGS__); break; \
-            default: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(WG), 0, (h)->stream, __VA_ARGS__); break; \
+            case 4: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(WG), 0, (h)->stream, __VA_ARGS__); break; \
+            default: hipLaunchKernelGGL((KERNEL<8>), dim3(grid), dim3(WG), 0, (h)->stream, __VA_ARGS__); break; \
         }                                                                                              \
     } while (0)
 

@@ -18,14 +18,19 @@ namespace lcqp {
 
 constexpr int WG = 256;          // threads per workgroup
 constexpr int NWAVE = 4;         // waves per workgroup
-constexpr int ARENA = 4512;      // doubles of routine-private LDS (35.25 KiB -> 4 workgroups per CU)
+// doubles of routine-private LDS: 35.25 KiB (4 workgroups per CU) up to np = 512; the np = 1024 instantiation (NCH = 8) needs room for
+// six vectors of length np (wg_symv) and takes 48 KiB (3 workgroups per CU)
+constexpr int arena_doubles(int nch) { return 6 * 128 * nch > 4512 ? 6 * 128 * nch : 4512; }
+constexpr int ARENA = arena_doubles(4);
 constexpr int TILE_LD = 65;      // padded leading dimension of the 64x64 LDS tile
-constexpr int LCQP_MAX_ACTIVE = 64 * (ARENA / (5 * 64));   // 896: wg_trsv keeps the vector and four partial copies of it in the arena
+// active rows the subsolver has room for: wg_trsv keeps the vector and four partial copies of it in the arena (896; 1216 at NCH = 8)
+constexpr int max_active(int nch) { return 64 * (arena_doubles(nch) / (5 * 64)); }
+constexpr int LCQP_MAX_ACTIVE = max_active(4);
 
 enum { ST_INACT = 0, ST_LOWER = 1, ST_UPPER = 2, ST_EQ = 3 };
 
 struct Lds {
-    double* arena;  // ARENA doubles
+    double* arena;  // arena_doubles(NCH) doubles
     double* red;    // 16 doubles
     int* ired;      // 16 ints
 };
@@ -169,7 +174,7 @@ __device__ __forceinline__ void wg_symv(const double* __restrict__ M0, const dou
                         double* o00, double* o10, double* o01, double* o11, Lds lds)
 {
     constexpr int np = 128 * NCH;
-    static_assert(6 * np <= ARENA, "wg_symv: four partial copies and two staged vectors must fit the LDS arena");
+    static_assert(6 * np <= arena_doubles(NCH), "wg_symv: four partial copies and two staged vectors must fit the LDS arena");
     double* sv0 = lds.arena + 4 * np;
     double* sv1 = lds.arena + 5 * np;
     for (int i = threadIdx.x; i < np; i += WG) {
@@ -226,7 +231,7 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
                         const double* __restrict__ coef, Lds lds, Post post)
 {
     constexpr int np = 128 * NCH;
-    static_assert(5 * np <= ARENA, "wg_rows: four partial copies and the staged vector must fit the LDS arena");
+    static_assert(5 * np <= arena_doubles(NCH), "wg_rows: four partial copies and the staged vector must fit the LDS arena");
     double* sx = lds.arena + 4 * np;
     if (x) {
         for (int i = threadIdx.x; i < np; i += WG) sx[i] = x[i];

@@ -381,7 +381,8 @@ static int qp_setup(orc_qp_t* q, const double* lbA, const double* ubA, const dou
     q->w_n1 = dalloc(n); q->w_n2 = dalloc(n); q->w_n3 = dalloc(n); q->w_m1 = dalloc(mE);
     q->cap_na = (2 * n > 64) ? 2 * n : 64;   /* room for the degenerate vertices of small problems (many rows, few variables) */
     if (q->cap_na > mE) q->cap_na = mE;
-    if (q->cap_na > 896) q->cap_na = 896;   /* the device keeps the active-row solves in LDS (LCQP_MAX_ACTIVE); only binds for nV > 448 */
+    { const int lim = n > 512 ? 1216 : 896;   /* the device keeps the active-row solves in LDS (max_active(NCH)); binds for nV > 448 only */
+      if (q->cap_na > lim) q->cap_na = lim; }
     q->T = dalloc((size_t)q->cap_na * n);
     q->S = dalloc((size_t)q->cap_na * q->cap_na);
     q->w_a1 = dalloc(q->cap_na); q->w_a2 = dalloc(q->cap_na);

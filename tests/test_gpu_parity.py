@@ -390,10 +390,11 @@ def _csc_np(A):
 
 
 @pytest.mark.parametrize("n,nC,nComp", [(512, 256, 128), (384, 700, 100), (100, 0, 50), (33, 17, 16), (256, 1500, 64),
-                                        (2, 0, 1), (129, 64, 1), (64, 640, 8)])
+                                        (2, 0, 1), (129, 64, 1), (64, 640, 8), (513, 0, 50), (600, 300, 100), (1024, 600, 256)])
 def test_lcqp_shape_sweep(hip, oracle, n, nC, nComp):
-    """every padded-size variant of the kernels (np = 128, 256, 384, 512), nC = 0, more rows than the BASELINE shape"""
-    B = 3
+    """every padded-size variant of the kernels (np = 128, 256, 384, 512 and, for 512 < nV <= 1024, 1024), nC = 0, more rows
+    than the BASELINE shape"""
+    B = 3 if n <= 512 else 2
     bt = hip.BatchLCQP(B, n, nC, nComp, opt=hip.default_options(perturbStep=0))
     bt.generate_synthetic(0)
     bt.run()
