@@ -146,8 +146,9 @@ int  lcqp_hip_batch_last_timing(lcqp_hip_batch_t* b, float* setup_ms, float* sol
  * x[B][nV], y[B][nV+nC+2nComp], stats[B]; returnValue of runSolver is stats[i].returnValue. */
 int  lcqp_hip_batch_get_solution(lcqp_hip_batch_t* b, double* x, double* y, lcqp_stats_t* stats);
 /* per-iterate tracking of one instance when options.storeSteps != 0 (LCQProblem::storeSteps,
- * src/LCQProblem.cpp:1365-1378; OutputStatistics tracking vectors): scalars[len][4] = (|statk|_inf, phi, rho,
- * alphak), x[len][nV] = xk at the top of every pass of the loop; at most cap rows are copied. */
+ * src/LCQProblem.cpp:1365-1378; OutputStatistics tracking vectors, src/OutputStatistics.cpp:131-164): scalars[len][8] =
+ * (|statk|_inf, phi, rho, alphak, objective, merit, |pk|_inf, iterations of the last QP), x[len][nV] = xk at the top of
+ * every pass of the loop; at most cap rows are copied. */
 int  lcqp_hip_batch_get_trace(lcqp_hip_batch_t* b, int instance, int cap, double* scalars, double* x, int* len);
 /* per-instance cycle counters of the homotopy kernel's phases, out[B][16]; all zero unless the library was
  * built with -DLCQP_PROFILE (tools/gpu_phase_profile.py) */

@@ -227,8 +227,8 @@ class BatchLCQP:
         return x, y, [s.asdict() for s in st]
 
     def trace(self, instance, cap=1024):
-        """per-iterate (|statk|inf, phi, rho, alphak) and xk of one instance (needs options.storeSteps)"""
-        sc = np.zeros((cap, 4)); xs = np.zeros((cap, self.nV)); n = C.c_int(0)
+        """per-iterate (|statk|inf, phi, rho, alphak, obj, merit, |pk|inf, QP iterations) and xk of one instance (needs options.storeSteps)"""
+        sc = np.zeros((cap, 8)); xs = np.zeros((cap, self.nV)); n = C.c_int(0)
         _check(lib().lcqp_hip_batch_get_trace(self.h, instance, cap, _p(sc), _p(xs), C.byref(n)), "get_trace")
         return sc[:n.value].copy(), xs[:n.value].copy()
 

@@ -40,7 +40,7 @@ struct DevBatch {
     lcqp_stats_t* stats;
     InstInfo* info;
     unsigned long long* prof;   // [B][16] per-phase cycle counters (filled only by -DLCQP_PROFILE builds)
-    // per-iterate tracking (options.storeSteps, src/LCQProblem.cpp:1365-1378): [B][traceCap][4] = (|statk|inf, phi, rho, alphak)
+    // per-iterate tracking (options.storeSteps, src/LCQProblem.cpp:1365-1378): [B][traceCap][8] = (|statk|inf, phi, rho, alphak, obj, merit, |pk|inf, QP iterations)
     // and [B][traceCap][n] = xk; traceLen[B].  traceCap == 0: not allocated.
     double *traceS, *traceX;
     int* traceLen;
@@ -732,9 +732,18 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
             const double statInf = wg_maxabs(statk, n, c.lds);
             if (db.traceCap > 0 && totalIter < db.traceCap) {   // storeSteps :488-490
                 const double phiNow = getPhi();
-                double* ts = db.traceS + ((size_t)c.b * db.traceCap + totalIter) * 4;
+                // getObj :1161-1169, getMerit :1188-1196 and the step size of updateTrackingVectors (src/OutputStatistics.cpp:131-164)
+                double so = 0.0, sm = 0.0;
+                for (int i = t; i < n; i += WG) { so += g[i] * xk[i] + 0.5 * xk[i] * Qx[i]; sm += 0.5 * rho * xk[i] * Cx[i]; }
+                const double objNow = block_sum(so, c.lds), meritNow = objNow + block_sum(sm, c.lds);
+                const double stepNow = wg_maxabs(pk, n, c.lds);
+                double* ts = db.traceS + ((size_t)c.b * db.traceCap + totalIter) * 8;
                 double* tx = db.traceX + ((size_t)c.b * db.traceCap + totalIter) * n;
-                if (t == 0) { ts[0] = statInf; ts[1] = phiNow; ts[2] = rho; ts[3] = alphak; db.traceLen[c.b] = totalIter + 1; }
+                if (t == 0) {
+                    ts[0] = statInf; ts[1] = phiNow; ts[2] = rho; ts[3] = alphak;
+                    ts[4] = objNow; ts[5] = meritNow; ts[6] = stepNow; ts[7] = (double)qpIter;
+                    db.traceLen[c.b] = totalIter + 1;
+                }
                 for (int i = t; i < n; i += WG) tx[i] = xk[i];
             }
             totalIter++; st.iterTotal++;

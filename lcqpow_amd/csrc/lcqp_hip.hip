@@ -596,7 +596,7 @@ try {
         HIPCHK(hipSetDevice(h->device));
         DevBatch& d = h->db;
         const int cap = opt->maxIterations + 1 < 1024 ? opt->maxIterations + 1 : 1024;
-        if (dev_alloc(h, &d.traceS, (size_t)d.B * cap * 4, true) || dev_alloc(h, &d.traceX, (size_t)d.B * cap * d.n, true) ||
+        if (dev_alloc(h, &d.traceS, (size_t)d.B * cap * 8, true) || dev_alloc(h, &d.traceX, (size_t)d.B * cap * d.n, true) ||
             dev_alloc(h, &d.traceLen, (size_t)d.B, true)) return LCQP_HIP_ERROR;
         d.traceCap = cap;
     }
@@ -619,7 +619,7 @@ try {
     int n = 0;
     HIPCHK(hipMemcpy(&n, d.traceLen + instance, sizeof(int), hipMemcpyDeviceToHost));
     if (n > cap) n = cap;
-    if (scalars && n) HIPCHK(hipMemcpy(scalars, d.traceS + (size_t)instance * d.traceCap * 4, sizeof(double) * 4 * n, hipMemcpyDeviceToHost));
+    if (scalars && n) HIPCHK(hipMemcpy(scalars, d.traceS + (size_t)instance * d.traceCap * 8, sizeof(double) * 8 * n, hipMemcpyDeviceToHost));
     if (x && n) HIPCHK(hipMemcpy(x, d.traceX + (size_t)instance * d.traceCap * d.n, sizeof(double) * (size_t)d.n * n, hipMemcpyDeviceToHost));
     *len = n;
     return 0;

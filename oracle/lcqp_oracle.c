@@ -1110,10 +1110,16 @@ int orc_lcqp_solve(int nV, int nC, int nComp,
                 if (traceCap > 0 && traceLen && *traceLen < traceCap) {
                     int t = *traceLen;
                     if (traceScalars) {
-                        traceScalars[4 * t + 0] = orc_util_maxabs(p->statk, nV);
-                        traceScalars[4 * t + 1] = lcqp_getPhi(p);
-                        traceScalars[4 * t + 2] = p->rho;
-                        traceScalars[4 * t + 3] = p->alphak;
+                        traceScalars[8 * t + 0] = orc_util_maxabs(p->statk, nV);
+                        traceScalars[8 * t + 1] = lcqp_getPhi(p);
+                        traceScalars[8 * t + 2] = p->rho;
+                        traceScalars[8 * t + 3] = p->alphak;
+                        /* getObj :1161-1169, getMerit :1188-1196 (Qk = Q + rho C), step size and QP iterations of
+                         * updateTrackingVectors (src/OutputStatistics.cpp:131-164) */
+                        traceScalars[8 * t + 4] = orc_util_dot(p->g, p->xk, nV) + 0.5 * orc_util_quadform(p->Q, p->xk, nV);
+                        traceScalars[8 * t + 5] = traceScalars[8 * t + 4] + 0.5 * p->rho * orc_util_quadform(p->C, p->xk, nV);
+                        traceScalars[8 * t + 6] = orc_util_maxabs(p->pk, nV);
+                        traceScalars[8 * t + 7] = (double)p->qpIterk;
                     }
                     if (traceX) memcpy(traceX + (size_t)t * nV, p->xk, sizeof(double) * nV);
                     *traceLen = t + 1;

@@ -113,14 +113,15 @@ int       orc_qp_get_sweeps(orc_qp_t* q);   /* trials that swept Q and E (stats.
 
 /* ---- LCQP solve (LCQProblem::loadLCQP dense + runSolver) ----
  * NULL is allowed wherever the reference allows it (lbL,ubL,lbR,ubR,A (nC==0),lbA,ubA,lb,ub,x0,y0).
- * trace (optional, may be NULL): per outer-loop pass, rows of [statk_inf, phi, rho, alphak] and xk. */
+ * trace (optional, may be NULL): per pass of the loop, rows of [statk_inf, phi, rho, alphak, obj, merit, |pk|_inf, QP iterations]
+ * and xk. */
 int orc_lcqp_solve(int nV, int nC, int nComp,
                    const double* Q, const double* g, const double* L, const double* R,
                    const double* lbL, const double* ubL, const double* lbR, const double* ubR,
                    const double* A, const double* lbA, const double* ubA,
                    const double* lb, const double* ub, const double* x0, const double* y0,
                    const orc_options_t* opt, double* xOpt, double* yOpt, orc_stats_t* stats,
-                   int traceCap, double* traceScalars /* traceCap x 4 */, double* traceX /* traceCap x nV */, int* traceLen);
+                   int traceCap, double* traceScalars /* traceCap x 8 */, double* traceX /* traceCap x nV */, int* traceLen);
 
 /* which QP path orc_lcqp_solve mirrors: 0 (default) the batched homotopy kernel k_lcqp_run; non-zero the kernels that also
  * apply the dependent-row rules of orc_qp_*: k_qp_solve under the reference's host loop over SubsolverHIP, and the second pass

@@ -147,7 +147,7 @@ def lcqp_solve(Q, g, L, R, lbL=None, ubL=None, lbR=None, ubR=None, A=None, lbA=N
     opt = opt or default_options()
     x = np.zeros(nV); y = np.zeros(nV + nC + 2 * nComp)
     st = Stats()
-    ts = np.zeros((max(trace, 1), 4)); tx = np.zeros((max(trace, 1), nV)); tl = C.c_int(0)
+    ts = np.zeros((max(trace, 1), 8)); tx = np.zeros((max(trace, 1), nV)); tl = C.c_int(0)
     ret = lib().orc_lcqp_solve(nV, nC, nComp, _p(Q), _p(g), _p(L), _p(R), _p(arrs[0]), _p(arrs[1]), _p(arrs[2]),
                                _p(arrs[3]), _p(A), _p(lbA), _p(ubA), _p(lb), _p(ub), _p(x0), _p(y0), C.byref(opt),
                                _p(x), _p(y), C.byref(st), trace, _p(ts), _p(tx), C.byref(tl))

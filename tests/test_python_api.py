@@ -176,6 +176,13 @@ def test_python_store_steps(hip, oracle):
     assert np.abs(np.array(stats.getPhiVals()) - ts[:, 1]).max() < 1e-9
     assert np.abs(np.array(stats.getStatVals()) - ts[:, 0]).max() < 1e-9
     assert np.abs(stats.getxSteps() - ro["trace_x"]).max() < 1e-7
+    # objective, merit, step size and QP iterations per stored iterate: host loop vs oracle, and the device trace of the batch
+    assert np.abs(np.array(stats.getObjVals()) - ts[:, 4]).max() < 1e-9 and np.abs(np.array(stats.getMeritVals()) - ts[:, 5]).max() < 1e-9
+    assert np.abs(np.array(stats.getStepSize()) - ts[:, 6]).max() < 1e-7
+    rb = P.hip_solve(hip, d, hip.default_options(perturbStep=0, storeSteps=1), trace=True)
+    tb = rb["trace_scalars"]
+    assert tb.shape == ts.shape and np.abs(tb[:, [1, 4, 5]] - ts[:, [1, 4, 5]]).max() < 1e-9 and np.abs(tb[:, 6] - ts[:, 6]).max() < 1e-7
+    assert np.array_equal(tb[:, 2], ts[:, 2]) and np.abs(tb[:, 7] - ts[:, 7]).max() <= 8
 
 
 @pytest.mark.gpu
