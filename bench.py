@@ -51,7 +51,7 @@ def pmc_traffic(B, n, nC, nComp):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
     ap.add_argument("--n", type=int, default=256)
