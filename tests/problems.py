@@ -127,3 +127,33 @@ def certificate_qps(seed=3, n=24, m=30):
     g2 = r.standard_normal(n); g2[0] = 1.0                          # ... and decreasing it lowers the objective without bound
     unbounded = dict(Q=Q2, A=A2, g=g2, lbA=A2 @ xs - 1.0, ubA=A2 @ xs + 1.0)
     return infeasible, unbounded
+
+
+def branch_qp_solution(O, d, x, tol=1e-7):
+    """Independent check of an LCQP solution: fix the complementarity branch x sits on (per pair the side that is at its lower
+    bound becomes an equality, the other keeps its bounds) and solve the resulting convex QP with the oracle's QP solver.  A
+    strongly stationary point of the LCQP is the minimiser of that branch QP when biactive pairs (both sides at their bounds)
+    keep both sides as inequalities -- strong stationarity says exactly that both multipliers are non-negative there.
+    Returns None when x is not complementary or the branch QP cannot be solved."""
+    n, nC, nComp = d["nV"], d["nC"], d["nComp"]
+    lbL = d.get("lbL", np.zeros(nComp)); lbR = d.get("lbR", np.zeros(nComp))
+    ubL = d.get("ubL", np.full(nComp, INF)); ubR = d.get("ubR", np.full(nComp, INF))
+    Lx, Rx = d["L"] @ x - lbL, d["R"] @ x - lbR
+    loL, hiL, loR, hiR = lbL.copy(), ubL.copy(), lbR.copy(), ubR.copy()
+    for i in range(nComp):
+        if Lx[i] <= tol and Rx[i] <= tol:
+            continue
+        if Lx[i] <= tol:
+            hiL[i] = lbL[i]
+        elif Rx[i] <= tol:
+            hiR[i] = lbR[i]
+        else:
+            return None
+    A = d["A"] if nC else np.zeros((0, n))
+    E = np.vstack([A, d["L"], d["R"]])
+    lo = np.concatenate([d["lbA"] if nC else [], loL, loR]); hi = np.concatenate([d["ubA"] if nC else [], hiL, hiR])
+    q = O.QP(d["Q"], E)
+    ret, it, ef = q.solve(True, d["g"], lo, hi, np.array(x, dtype=float), None, d.get("lb"), d.get("ub"))
+    if ret != 0:
+        return None
+    return q.solution()[0]

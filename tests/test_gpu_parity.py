@@ -275,7 +275,7 @@ def test_lcqp_synthetic_golden(hip):
     bt.close()
 
 
-def test_lcqp_full_batch_properties(hip):
+def test_lcqp_full_batch_properties(hip, oracle):
     """BASELINE config C3 at full size (B=1024, n=256, nC=512, nComp=64): size-independent properties --
     every instance terminates successfully, is complementary to the reference tolerance, primal feasible,
     and the returned (transformed) duals satisfy LCQP stationarity  Qx + g - A'y_A - L'y_L - R'y_R = 0."""
@@ -296,6 +296,12 @@ def test_lcqp_full_batch_properties(hip):
         yA = y[b, n:n + nC]; yL = y[b, n + nC:n + nC + nComp]; yR = y[b, n + nC + nComp:]
         stat = d["Q"] @ x[b] + d["g"] - d["A"].T @ yA - d["L"].T @ yL - d["R"].T @ yR - y[b, :n]
         assert np.abs(stat).max() < 1e-8
+        # S-stationary points minimise the convex QP of their complementarity branch (biactive pairs as inequalities);
+        # the branch QP is solved by the QP solver alone, no homotopy involved
+        if st[b]["status"] == 4:
+            dd = dict(d); dd.update(nV=n, nC=nC, nComp=nComp)
+            xb = P.branch_qp_solution(oracle, dd, x[b])
+            assert xb is not None and np.abs(xb - x[b]).max() < 1e-7
     # second run on the same handle reproduces the first bit for bit (determinism with perturbStep = 0)
     bt.run()
     x2, y2, st2 = bt.solution()

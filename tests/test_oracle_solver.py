@@ -126,6 +126,24 @@ def test_qp_certificates(oracle):
         assert (ret, ef) == (203, flag) and it < 1500, (ret, ef, it)
 
 
+def test_lcqp_solution_is_branch_minimiser(oracle):
+    """a property of the domain that does not involve the reference's or the oracle's homotopy: a strongly stationary point
+    without biactive pairs minimises the convex QP of the complementarity branch it lies on (solved here with the QP solver
+    alone, from the LCQP solution as starting point)"""
+    checked = 0
+    probs = [oracle.synth_generate(i, 64, 96, 16) for i in range(6)] + [P.circle(20), P.warm_up_binary(), P.warm_up_w_A()]
+    for d in probs:
+        ro = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0))
+        if ro["ret"] != 0 or ro["stats"]["status"] != 4:
+            continue
+        xb = P.branch_qp_solution(oracle, d, ro["x"])
+        if xb is None:
+            continue
+        assert np.abs(xb - ro["x"]).max() < 1e-7 * (1 + np.abs(ro["x"]).max())
+        checked += 1
+    assert checked >= 6
+
+
 def test_synthetic_golden(oracle):
     for inst in range(2):
         d = oracle.synth_generate(inst, 64, 96, 16)
