@@ -428,6 +428,7 @@ def test_lcqp_structure_fuzz(hip, oracle):
     count = 150
     cats, rets = fz.run(count, seed=5, verbose=False)
     assert cats["same"] + cats["same solution, other iterate count"] >= count - count // 20, (cats, rets)
+    assert cats.get("branch minimiser checked", 0) >= count // 8 and cats.get("NOT a branch minimiser", 0) == 0, cats
     assert rets.get((0, 0), 0) >= count // 2, rets          # the generator is not mostly producing failures
 
 
