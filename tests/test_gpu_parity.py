@@ -508,3 +508,23 @@ def test_subsolver_active_row_capacity(hip, oracle):
     x, y = qh.getSolution()
     assert abs(x[0] - 1.0) < 1e-9 and np.abs(x[1:]).max() < 1e-12 and abs(y[n:].sum() - 1.0) < 1e-8
     qh.close()
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1e3])
+def test_lcqp_objective_scaling(hip, oracle, scale):
+    """scaling the objective (Q, g) together with the penalty parameters and the stationarity tolerance by a constant is the same
+    homotopy in other units: same iterates, same solution, duals scaled.  It holds because the subsolver's own tolerances are
+    relative to max|Q_ii| and |g| (the complementarity tolerance acts on x and stays)."""
+    kw = dict(perturbStep=0, initialPenaltyParameter=0.01 * scale, maxPenaltyParameter=1e8 * scale, stationarityTolerance=1e6 * 2.221e-16 * scale)
+    for d in [oracle.synth_generate(i, 64, 96, 16) for i in range(3)] + [P.circle(20)]:
+        d = dict(d)
+        base = P.hip_solve(hip, d, hip.default_options(perturbStep=0))
+        ds = dict(d); ds["Q"] = scale * d["Q"]; ds["g"] = scale * d["g"]
+        rs = P.hip_solve(hip, ds, hip.default_options(**kw))
+        ro = P.oracle_solve(oracle, ds, oracle.default_options(**kw))
+        assert base["ret"] == rs["ret"] == ro["ret"] == 0
+        assert np.abs(rs["x"] - ro["x"]).max() < 1e-7
+        assert np.abs(rs["x"] - base["x"]).max() < 1e-6 * (1 + np.abs(base["x"]).max())
+        assert abs(rs["stats"]["iterTotal"] - base["stats"]["iterTotal"]) <= 4 and abs(rs["stats"]["rhoOpt"] / scale - base["stats"]["rhoOpt"]) < 1e-9
+        n = d["nV"]
+        assert np.abs(rs["y"][n:] / scale - base["y"][n:]).max() < 1e-5 * (1 + np.abs(base["y"]).max())
