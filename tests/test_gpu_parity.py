@@ -528,3 +528,20 @@ def test_lcqp_objective_scaling(hip, oracle, scale):
         assert abs(rs["stats"]["iterTotal"] - base["stats"]["iterTotal"]) <= 4 and abs(rs["stats"]["rhoOpt"] / scale - base["stats"]["rhoOpt"]) < 1e-9
         n = d["nV"]
         assert np.abs(rs["y"][n:] / scale - base["y"][n:]).max() < 1e-5 * (1 + np.abs(base["y"]).max())
+
+
+def test_lcqp_constraint_row_scaling(hip, oracle):
+    """scaling rows of A together with their bounds by positive factors (0.01 ... 100) describes the same feasible set: same
+    solution, row duals divided by the factors"""
+    rng = np.random.default_rng(11)
+    for d in [oracle.synth_generate(i, 64, 96, 16) for i in range(3)]:
+        base = P.hip_solve(hip, d, hip.default_options(perturbStep=0))
+        f = 10.0 ** rng.uniform(-2, 2, d["nC"])
+        ds = dict(d); ds["A"] = d["A"] * f[:, None]; ds["lbA"] = d["lbA"] * f; ds["ubA"] = d["ubA"] * f
+        rs = P.hip_solve(hip, ds, hip.default_options(perturbStep=0))
+        ro = P.oracle_solve(oracle, ds, oracle.default_options(perturbStep=0))
+        assert base["ret"] == rs["ret"] == ro["ret"] == 0
+        assert np.abs(rs["x"] - ro["x"]).max() < 1e-7
+        assert np.abs(rs["x"] - base["x"]).max() < 1e-6 * (1 + np.abs(base["x"]).max())
+        n, nC = d["nV"], d["nC"]
+        assert np.abs(rs["y"][n:n + nC] * f - base["y"][n:n + nC]).max() < 1e-5 * (1 + np.abs(base["y"]).max())
