@@ -1143,14 +1143,15 @@ static int download_padded(double* dst, const double* src, int batch, int rows, 
             case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(grid), dim3(WG), 0, 0, __VA_ARGS__); break;   \
             case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(grid), dim3(WG), 0, 0, __VA_ARGS__); break;   \
             case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(grid), dim3(WG), 0, 0, __VA_ARGS__); break;   \
-            default: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(WG), 0, 0, __VA_ARGS__); break;  \
+            case 4: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(WG), 0, 0, __VA_ARGS__); break;   \
+            default: hipLaunchKernelGGL((KERNEL<8>), dim3(grid), dim3(WG), 0, 0, __VA_ARGS__); break;  \
         }                                                                                              \
     } while (0)
 
 extern "C" int lcqp_hip_util_symv(int batch, int n, double alpha, const double* A, const double* bv, const double* cv, double* dv)
 try {
-    if (n <= 0 || n > 512 || batch <= 0) return LCQP_HIP_UNSUPPORTED;
-    const int nch = (n + 127) / 128, np = 128 * nch;
+    if (n <= 0 || n > 1024 || batch <= 0) return LCQP_HIP_UNSUPPORTED;
+    const int nch = (n + 127) / 128 > 4 ? 8 : (n + 127) / 128, np = 128 * nch;
     TmpBuf tb;
     double *dA = tb.get((size_t)batch * np * np), *db_ = tb.get((size_t)batch * np), *dc = tb.get((size_t)batch * np), *dd = tb.get((size_t)batch * np);
     if (!dA || !db_ || !dc || !dd) return set_err("hipMalloc", hipErrorOutOfMemory);
@@ -1165,8 +1166,8 @@ catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothin
 
 static int util_rows(int batch, int m, int n, const double* A, const double* x, double* dots, const double* coef, double* outT)
 {
-    if (n <= 0 || n > 512 || batch <= 0 || m <= 0) return LCQP_HIP_UNSUPPORTED;
-    const int nch = (n + 127) / 128, np = 128 * nch;
+    if (n <= 0 || n > 1024 || batch <= 0 || m <= 0) return LCQP_HIP_UNSUPPORTED;
+    const int nch = (n + 127) / 128 > 4 ? 8 : (n + 127) / 128, np = 128 * nch;
     TmpBuf tb;
     double* dA = tb.get((size_t)batch * m * np);
     double* dx = x ? tb.get((size_t)batch * np) : nullptr;
@@ -1337,8 +1338,8 @@ __global__ void k_fill_random(double* p, size_t n, uint64_t seed)
 
 extern "C" int lcqp_hip_bench_rows(int batch, int m, int n, int mode, int repeat, float* ms)
 try {
-    if (n <= 0 || n > 512 || batch <= 0 || m <= 0) return LCQP_HIP_UNSUPPORTED;
-    const int nch = (n + 127) / 128, np = 128 * nch;
+    if (n <= 0 || n > 1024 || batch <= 0 || m <= 0) return LCQP_HIP_UNSUPPORTED;
+    const int nch = (n + 127) / 128 > 4 ? 8 : (n + 127) / 128, np = 128 * nch;
     TmpBuf tb;
     double *dA = tb.get((size_t)batch * m * np, false), *dx = tb.get((size_t)batch * np, false), *dd = tb.get((size_t)batch * m, false);
     double *dcf = tb.get((size_t)batch * m, false), *dout = tb.get((size_t)batch * np, false);
@@ -1368,7 +1369,7 @@ catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothin
 
 extern "C" int lcqp_hip_chol_solve(int batch, int n, const double* K, const double* b, double* x, int repeat, float* ms)
 try {
-    if (n <= 0 || n > 512 || batch <= 0) return LCQP_HIP_UNSUPPORTED;
+    if (n <= 0 || n > LCQP_MAX_ACTIVE || batch <= 0) return LCQP_HIP_UNSUPPORTED;   // k_chol / k_backsolve use the 35 KiB arena
     const int np = ((n + 63) / 64) * 64, nblk = np / 64;
     TmpBuf tb;
     double *dF = tb.get((size_t)batch * np * np), *dscr = tb.get((size_t)batch * 4096), *drhs = tb.get((size_t)batch * np), *dx = tb.get((size_t)batch * np);

@@ -38,7 +38,7 @@ def test_kat_affine_symmetric(hip):               # AffineLinearTransformation :
     assert float(b[0] @ hip.util_symv(1.0, A, b, np.zeros((1, 3)))[0]) == 24
 
 
-@pytest.mark.parametrize("n,m", [(3, 2), (100, 37), (256, 640), (300, 50), (512, 70)])
+@pytest.mark.parametrize("n,m", [(3, 2), (100, 37), (256, 640), (300, 50), (512, 70), (700, 40), (1024, 130)])
 def test_utilities_random(hip, oracle, n, m):
     rng = np.random.default_rng(n)
     A = rng.standard_normal((2, n, n)); A = A + A.transpose(0, 2, 1)
@@ -54,7 +54,7 @@ def test_utilities_random(hip, oracle, n, m):
         assert np.abs(Cm[k] - oracle.util_symm_product(L[k], R[k], m, n).reshape(n, n)).max() < 1e-12 * m
 
 
-@pytest.mark.parametrize("n", [5, 64, 100, 256, 300, 512])
+@pytest.mark.parametrize("n", [5, 64, 100, 256, 300, 512, 896])
 def test_factor_once_backsolve(hip, n):
     rng = np.random.default_rng(n)
     M = rng.standard_normal((3, n, n)); K = np.einsum("bij,bkj->bik", M, M) / n + np.eye(n)
