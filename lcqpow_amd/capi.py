@@ -131,11 +131,20 @@ def _check(rc, what):
         raise RuntimeError(f"{what} failed with code {rc}: {last_error()}")
 
 
+def _sized(name, a, size):
+    """the C side reads exactly `size` doubles through the raw pointer: refuse anything else here"""
+    if a is not None and a.size != size:
+        raise ValueError(f"{name}: expected {size} values, got {a.size} (shape {a.shape})")
+    return a
+
+
 class SubsolverHIP:
     """Python view of the SubsolverBase-shaped QP object (include/SubsolverBase.hpp:28-58)."""
 
     def __init__(self, nV, nC, Q, A, opt=None, device=0):
-        Q = _arr(Q); A = _arr(A)
+        Q = _sized("Q", _arr(Q), nV * nV); A = _sized("A", _arr(A), nC * nV)
+        if Q is None or (nC > 0 and A is None):
+            raise ValueError("Q (and A when nC > 0) must be given")
         self.nV, self.nC = nV, nC
         self.opt = opt or default_options()
         self.h = lib().lcqp_hip_qp_create(nV, nC, _p(Q), _p(A), C.byref(self.opt), device)
@@ -144,7 +153,9 @@ class SubsolverHIP:
 
     def solve(self, initialSolve, g, lbA=None, ubA=None, x0=None, y0=None, lb=None, ub=None):
         it = C.c_int(0); ef = C.c_int(0)
-        a = [_arr(v) for v in (g, lbA, ubA, x0, y0, lb, ub)]
+        n, m = self.nV, self.nC
+        a = [_sized(nm, _arr(v), sz) for nm, v, sz in (("g", g, n), ("lbA", lbA, m), ("ubA", ubA, m), ("x0", x0, n), ("y0", y0, n + m),
+                                                       ("lb", lb, n), ("ub", ub, n))]
         ret = lib().lcqp_hip_qp_solve(self.h, int(bool(initialSolve)), C.byref(it), C.byref(ef), *[_p(v) for v in a])
         return ret, it.value, ef.value
 
@@ -187,7 +198,15 @@ class BatchLCQP:
 
     def load(self, first, count, Q, g, L, R, lbL=None, ubL=None, lbR=None, ubR=None, A=None, lbA=None, ubA=None,
              lb=None, ub=None, x0=None, y0=None):
-        a = [_arr(v) for v in (Q, g, L, R, lbL, ubL, lbR, ubR, A, lbA, ubA, lb, ub, x0, y0)]
+        """lcqp_hip_batch_load for instances [first, first + count).  Returns the reference's ReturnValue code (0, or e.g. 116
+        INVALID_OBJECTIVE_LINEAR_TERM for g = None) like LCQProblem::loadLCQP does; a wrongly sized array raises ValueError."""
+        n, nC, nK = self.nV, self.nC, self.nComp
+        if first < 0 or count <= 0 or first + count > self.B:
+            raise ValueError(f"instances [{first}, {first + count}) outside the batch of {self.B}")
+        sizes = (("Q", Q, n * n), ("g", g, n), ("L", L, nK * n), ("R", R, nK * n), ("lbL", lbL, nK), ("ubL", ubL, nK), ("lbR", lbR, nK),
+                 ("ubR", ubR, nK), ("A", A, nC * n), ("lbA", lbA, nC), ("ubA", ubA, nC), ("lb", lb, n), ("ub", ub, n), ("x0", x0, n),
+                 ("y0", y0, self.nd))
+        a = [_sized(nm, _arr(v), count * sz) for nm, v, sz in sizes]
         return lib().lcqp_hip_batch_load(self.h, first, count, *[_p(v) for v in a])
 
     def generate_synthetic(self, first_instance=0, seed0=SEED0):

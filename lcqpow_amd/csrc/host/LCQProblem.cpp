@@ -7,11 +7,11 @@
 namespace LCQPow {
 
 LCQProblem::LCQProblem()
-    : nV(0), nC(0), nComp(0), nDuals(0), boxDualOffset(0), device(0), loaded(false), sparseSolver(false),
+    : nV(0), nC(0), nComp(0), nDuals(0), boxDualOffset(0), device(0), loaded(false), haveBox(false), sparseSolver(false),
       Q_sparse(0), A_sparse(0), L_sparse(0), R_sparse(0), C_sparse(0) {}
 
 LCQProblem::LCQProblem(int _nV, int _nC, int _nComp)
-    : nV(0), nC(0), nComp(0), nDuals(0), boxDualOffset(0), device(0), loaded(false), sparseSolver(false),
+    : nV(0), nC(0), nComp(0), nDuals(0), boxDualOffset(0), device(0), loaded(false), haveBox(false), sparseSolver(false),
       Q_sparse(0), A_sparse(0), L_sparse(0), R_sparse(0), C_sparse(0)
 {
     // consistency checks of the reference constructor (src/LCQProblem.cpp:43-67)
@@ -59,12 +59,16 @@ ReturnValue LCQProblem::loadLCQP(const double* const _Q, const double* const _g,
     Utilities::MatrixSymmetrizationProduct(L.data(), R.data(), C.data(), nComp, nV);
     lb.assign(nV, -inf); ub.assign(nV, inf);
     for (int i = 0; i < nV; ++i) { if (_lb) lb[i] = _lb[i]; if (_ub) ub[i] = _ub[i]; }
+    haveBox = (_lb != 0) || (_ub != 0);          // lb_tmp / ub_tmp of the reference (src/LCQProblem.cpp:113-121)
     xk.assign(nV, 0.0);
     if (_x0) std::copy(_x0, _x0 + nV, xk.begin());
+    // the dual guess is kept in the layout it is passed in (nV + nC + 2 nComp, include/LCQProblem.ipp:144-155);
+    // initializeSolver lays yk out for the chosen subsolver arm (src/LCQProblem.cpp:888-960)
     nDuals = nV + m; boxDualOffset = nV;
-    yk.assign(nDuals, 0.0);
+    y0Full.assign(nV + m, 0.0);
     haveYk = (_y0 != 0);
-    if (_y0) std::copy(_y0, _y0 + nDuals, yk.begin());
+    if (_y0) std::copy(_y0, _y0 + nV + m, y0Full.begin());
+    yk = y0Full;
     loaded = true;
     return SUCCESSFUL_RETURN;
 }
@@ -211,12 +215,35 @@ void LCQProblem::addRT(const double* y, double* out) const
 ReturnValue LCQProblem::initializeSolver()
 {
     if (!loaded) return LCQPOBJECT_NOT_SETUP;
-    if (options.getQPSolver() != HIP_DENSE) return NOT_YET_IMPLEMENTED;   // qpOASES / OSQP arms need un-vendored code
+    // The four arms of src/LCQProblem.cpp:888-963.  Every arm runs on the HIP subsolver (the reference's qpOASES and OSQP
+    // libraries are not part of this build); what an arm keeps of the reference is its contract: the dense/sparse mode it
+    // insists on, the dual layout, and for OSQP_SPARSE the refusal of box constraints and the missing box duals.
+    const QPSolver arm = options.getQPSolver();
     const int m = nC + 2 * nComp;
+    if (arm == QPOASES_DENSE) {
+        if (sparseSolver) return DENSE_SPARSE_MISSMATCH;                               // :892-894
+        nDuals = nV + m; boxDualOffset = nV;
+    } else if (arm == QPOASES_SPARSE) {
+        if (!sparseSolver) return DENSE_SPARSE_MISSMATCH;                              // :913-915
+        nDuals = nV + m; boxDualOffset = nV;
+    } else if (arm == OSQP_SPARSE) {
+        if (haveBox) return INVALID_OSQP_BOX_CONSTRAINTS;                              // :930-932, :956-958
+        if (!sparseSolver) return DENSE_SPARSE_MISSMATCH;                              // :952-954
+        nDuals = m; boxDualOffset = 0;                                                 // :934-935
+    } else if (arm == HIP_DENSE) {
+        nDuals = nV + m; boxDualOffset = nV;     // new arm: dense kernels, problem held in either mode
+    } else {
+        return NOT_YET_IMPLEMENTED;
+    }
+    // dual guess in the arm's layout; the OSQP arm drops the box part (:938-949 -- the reference shifts by nV too, but its
+    // memcpy counts bytes, not doubles; the intent is restated here)
+    yk.assign(nDuals, 0.0);
+    for (int i = 0; i < nDuals; ++i) yk[i] = y0Full[(nV - boxDualOffset) + i];
+    ysub.assign(nV + m, 0.0);
     if (sparseSolver) {
-        // CSC problem data: the loop below runs on the CSC Utilities; the device subsolver of this round is dense,
-        // so it receives dense copies of Q and [A;L;R] (the reference's QPOASES_SPARSE arm hands the CSC arrays to
-        // qpOASES instead, src/LCQProblem.cpp:908-927; its dual layout -- box duals first -- is the one used here)
+        // CSC problem data: the loop below runs on the CSC Utilities; the device subsolver of this arm is dense,
+        // so it receives dense copies of Q and [A;L;R] (the reference hands the CSC arrays to qpOASES / OSQP instead,
+        // src/LCQProblem.cpp:908-927,960)
         double *q = Utilities::csc_to_dns(Q_sparse), *a = Utilities::csc_to_dns(A_sparse);
         if (!q || !a) { delete[] q; delete[] a; return FAILED_SWITCH_TO_DENSE; }
         Subsolver tmp(nV, m, q, a, HIP_DENSE, device);
@@ -301,14 +328,28 @@ void LCQProblem::updateLinearization()
 
 ReturnValue LCQProblem::solveQPSubproblem(bool initialSolve)
 {
+    // the subsolver speaks the qpOASES layout (box duals first); the OSQP arm has no box part
+    // (boxDualOffset = 0, src/SubsolverOSQP.cpp:186-200): its guess is placed behind nV zeros and its result read from there
+    const bool osqpArm = (boxDualOffset == 0);
+    const int m = nC + 2 * nComp;
+    const double* y0 = 0;
+    if (haveYk) {
+        if (osqpArm) { std::fill(ysub.begin(), ysub.begin() + nV, 0.0); std::copy(yk.begin(), yk.end(), ysub.begin() + nV); y0 = ysub.data(); }
+        else y0 = yk.data();
+    }
     ReturnValue ret = subsolver.solve(initialSolve, qpIterk, qpSolverExitFlag, gk.data(), lbA.data(), ubA.data(), xk.data(),
-                                      haveYk ? yk.data() : 0, lb.data(), ub.data());
+                                      y0, osqpArm ? 0 : lb.data(), osqpArm ? 0 : ub.data());
     stats.updateSubproblemIter(qpIterk);
     stats.updateQPSolverExitFlag(qpSolverExitFlag);
     haveYk = true;
     if (ret != SUCCESSFUL_RETURN) return ret;
-    subsolver.getSolution(xnew.data(), yk.data());
-    for (int i = 0; i < nC + 2 * nComp; ++i) ykA[i] = yk[boxDualOffset + i];
+    if (osqpArm) {
+        subsolver.getSolution(xnew.data(), ysub.data());
+        for (int i = 0; i < m; ++i) yk[i] = ysub[nV + i];
+    } else {
+        subsolver.getSolution(xnew.data(), yk.data());
+    }
+    for (int i = 0; i < m; ++i) ykA[i] = yk[boxDualOffset + i];
     Utilities::WeightedVectorAdd(1, xnew.data(), -1, xk.data(), pk.data(), nV);
     return SUCCESSFUL_RETURN;
 }
@@ -355,7 +396,8 @@ void LCQProblem::updateStationarity()
 {
     mulQ(xk.data(), Qx.data()); mulC(xk.data(), Cx.data());
     mulAT(ykA.data(), constrStatk.data());
-    for (int i = 0; i < nV; ++i) statk[i] = ((Qx[i] + rho * Cx[i]) + gTilde[i]) - constrStatk[i] - yk[i];
+    // the box term only on the arms that carry box duals (src/LCQProblem.cpp:1262-1269: lb / ub are null on the OSQP arm)
+    for (int i = 0; i < nV; ++i) statk[i] = ((Qx[i] + rho * Cx[i]) + gTilde[i]) - constrStatk[i] - (boxDualOffset > 0 ? yk[i] : 0.0);
 }
 
 bool LCQProblem::leyfferCheckPositive()

@@ -81,7 +81,8 @@ class LCQProblem {
     void clearSparse();
 
     int nV, nC, nComp, nDuals, boxDualOffset, device;
-    bool loaded, haveYk, haveLbL, haveLbR, sparseSolver;
+    bool loaded, haveYk, haveLbL, haveLbR, haveBox, sparseSolver;
+    std::vector<double> y0Full, ysub;   // y0 as loaded (reference layout nV + nC + 2 nComp); subsolver dual vector (box duals first)
     csc *Q_sparse, *A_sparse, *L_sparse, *R_sparse, *C_sparse;
     std::vector<double> Q, g, L, R, A, lbA, ubA, lb, ub, lbL, lbR, C, Qk;
     std::vector<double> gTilde, gPhi, xk, yk, ykA, gk, xnew, pk, statk, constrStatk, lkTmp, Qx, Cx, Qp, Cp;

@@ -637,7 +637,10 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     const double phiConst = c.info->phiConst;
     uint64_t perturbCounter = 0;
     double* hist = c.info->hist;
-    if (t == 0) c.info->work[0] = c.info->work[1] = c.info->work[2] = c.info->work[3] = 0.0;
+    if (t == 0) {
+        c.info->work[0] = c.info->work[1] = c.info->work[2] = c.info->work[3] = 0.0;
+        if (db.traceCap > 0) db.traceLen[c.b] = 0;     // a run that records nothing leaves an empty trace, not the last run's
+    }
 
     // xk = x0, g_tilde = g   (setInitialGuess .ipp:133-158, :966-967)
     for (int i = t; i < np; i += WG) { xk[i] = c.V(V_X0)[i]; gtil[i] = g[i]; }

@@ -1,0 +1,426 @@
+// lcqp_kernels.hpp -- the kernels that are instantiated once per padded size np = 128*NCH, and their launcher.
+// Each instantiation is its own translation unit (lcqp_nch.hip compiled with -DLCQP_TU_NCH=1,2,3,4,8): the five builds run in
+// parallel, and the register allocation of one size cannot perturb another's (cdna_hip_programming.md §5.4 rule 19).
+#pragma once
+#include "lcqp_dev.hpp"
+#include "lcqp_launch.hpp"
+#include "../../include/lcqp_synth.h"
+
+using namespace lcqp;
+
+#define LCQP_LDS_N(NCHV)                                    \
+    __shared__ double sh_arena[arena_doubles(NCHV)];        \
+    __shared__ double sh_red[16];                           \
+    __shared__ int sh_ired[16];                             \
+    Lds lds{sh_arena, sh_red, sh_ired};
+#define LCQP_LDS LCQP_LDS_N(4)
+
+
+// ---- k_prepare: scales, padding, box rows, ADMM rho vector, phi expressions ----------------------
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_prepare(DevBatch db)
+{
+    LCQP_LDS_N(NCH)
+    constexpr int np = 128 * NCH;
+    const int b = blockIdx.x, t = threadIdx.x;
+    Ctx<NCH> c = make_ctx<NCH>(db, b, lds);
+    const int n = db.n, mA = db.mA, nC = db.nC, nComp = db.nComp;
+    double dmax = 0.0;
+    for (int i = t; i < n; i += WG) dmax = fmax(dmax, fabs(c.Q[(size_t)i * np + i]));
+    double scale = block_max(dmax, lds);
+    if (!(scale > 1e-300)) scale = 1.0;
+    for (int i = n + t; i < np; i += WG) c.Q[(size_t)i * np + i] = 1.0;
+    const int nfin = c.info->nfin;
+    const int mE = mA + nfin;
+    double *l = c.M(M_L), *u = c.M(M_U), *rhov = c.M(M_RHOV);
+    for (int k = 0; k < nfin; k++) {
+        double* row = c.E + (size_t)(mA + k) * np;
+        const int bi = c.boxidx[k];
+        for (int i = t; i < np; i += WG) row[i] = (i == bi) ? 1.0 : 0.0;
+        if (t == 0) { l[mA + k] = c.V(V_LB)[bi]; u[mA + k] = c.V(V_UB)[bi]; }
+    }
+    __syncthreads();
+    const double rho = db.opt.admmRho * scale;
+    for (int r = t; r < mE; r += WG) {
+        const double lo = l[r], hi = u[r];
+        double rv = rho;
+        if (isinf(lo) && isinf(hi)) rv = 0.0;
+        else if (lo == hi) rv = rho * db.opt.rhoEqMult;
+        rhov[r] = rv;
+    }
+    // phi expressions, src/LCQProblem.cpp:969-996
+    double phiConst = 0.0;
+    double* gphi = c.V(V_GPHI);
+    if (db.hasLbL || db.hasLbR) {
+        const double* lbL = db.lbL + (size_t)b * nComp;
+        const double* lbR = db.lbR + (size_t)b * nComp;
+        double s = 0.0;
+        for (int i = t; i < nComp; i += WG) s += lbL[i] * lbR[i];
+        phiConst = block_sum(s, lds);
+        double* coef = c.M(M_COEF);
+        for (int r = t; r < mA; r += WG) {
+            double v = 0.0;
+            if (r >= nC && r < nC + nComp) v = lbR[r - nC];          // L' * lbR
+            else if (r >= nC + nComp) v = lbL[r - nC - nComp];       // R' * lbL
+            coef[r] = v;
+        }
+        __syncthreads();
+        wg_rows<NCH>(c.E, nullptr, mA, nullptr, nullptr, coef, lds, [&](int i, double sum) { gphi[i] = -sum; });
+    } else {
+        wg_fill(gphi, 0.0, np);
+    }
+    {   // no dependent-row flags or promotions survive a new setup (qp_polish<ROBUST>)
+        int *dep = c.I(I_DEP), *prio = c.I(I_PRIO);
+        for (int r = t; r < db.mEcap; r += WG) { dep[r] = 0; prio[r] = 0; }
+    }
+    if (t == 0) {
+        c.info->prioCtr = 0;
+        c.info->ndep = 0;
+        c.info->mE = mE;
+        c.info->scale = scale;
+        c.info->sigma = db.opt.admmSigma * scale;
+        c.info->rhoAdmm = rho;
+        c.info->phiConst = phiConst;
+        c.info->haveSolution = 0;
+        c.info->cacheNa = -1;
+        c.info->setupFail = 0;
+        c.info->isSetup = 1;
+    }
+}
+
+// ---- k_build_C: C = L'R + R'L (Utilities::MatrixSymmetrizationProduct, src/Utilities.cpp:104-116) ----
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_build_C(DevBatch db)
+{
+    LCQP_LDS_N(NCH)
+    constexpr int np = 128 * NCH;
+    const int ntile = db.nblk * (db.nblk + 1) / 2;
+    const int b = blockIdx.x / ntile, tIdx = blockIdx.x % ntile;
+    int I, J;
+    tri_tile(tIdx, I, J);
+    const double* Lm = db.E + (size_t)b * db.mEcap * np + (size_t)db.nC * np;
+    const double* Rm = Lm + (size_t)db.nComp * np;
+    double* C = db.C + (size_t)b * np * np;
+    double a1[4][4], a2[4][4];
+    auto one = [](int) { return 1.0; };
+    wg_tile_tn(a1, Lm, np, 64 * I, Rm, np, 64 * J, db.nComp, one, lds);
+    wg_tile_tn(a2, Rm, np, 64 * I, Lm, np, 64 * J, db.nComp, one, lds);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int gi = 64 * I + tile_li(i, j), gj = 64 * J + tile_lj(i, j);
+            const double v = a1[i][j] + a2[i][j];
+            C[(size_t)gi * np + gj] = v;
+            C[(size_t)gj * np + gi] = v;
+        }
+}
+
+// ---- k_build_K: FK = Q + sigma I + E' diag(rho) E  (lower tiles, mirrored) -------------------------
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_build_K(DevBatch db)
+{
+    LCQP_LDS_N(NCH)
+    constexpr int np = 128 * NCH;
+    const int ntile = db.nblk * (db.nblk + 1) / 2;
+    const int b = blockIdx.x / ntile, tIdx = blockIdx.x % ntile;
+    int I, J;
+    tri_tile(tIdx, I, J);
+    const double* E = db.E + (size_t)b * db.mEcap * np;
+    const double* Q = db.Q + (size_t)b * np * np;
+    double* FK = db.FK + (size_t)b * np * np;
+    const double* rhov = db.mv + (size_t)b * M_NUM * db.mEcap + (size_t)M_RHOV * db.mEcap;
+    const InstInfo* info = db.info + b;
+    double acc[4][4];
+    wg_tile_tn(acc, E, np, 64 * I, E, np, 64 * J, info->mE, [=](int r) { return rhov[r]; }, lds);
+    const double sigma = info->sigma;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int gi = 64 * I + tile_li(i, j), gj = 64 * J + tile_lj(i, j);
+            const double v = acc[i][j] + Q[(size_t)gi * np + gj] + (gi == gj ? sigma : 0.0);
+            FK[(size_t)gi * np + gj] = v;
+            // mirror only off-diagonal tiles: inside a diagonal tile (i,j) and (j,i) are both computed, and
+            // (rho*e_i)*e_j != (rho*e_j)*e_i in the last bit -- mirroring there would be a write race
+            if (I != J) FK[(size_t)gj * np + gi] = v;
+        }
+}
+
+// ---- k_factor: the two constant factorisations (L1 of Q + sp I, LK of K) ---------------------------
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_factor(DevBatch db)
+{
+    LCQP_LDS_N(NCH)
+    constexpr int np = 128 * NCH;
+    const int b = blockIdx.x, t = threadIdx.x;
+    Ctx<NCH> c = make_ctx<NCH>(db, b, lds);
+    const double scale = c.info->scale;
+    __shared__ int sfail;
+    int failed = 0;
+    double spv = 0.0;
+    for (int pass = 0; pass < 2; pass++) {
+        spv = (pass == 0 ? db.opt.proxSmall : db.opt.proxBig) * scale;
+        for (int e = t; e < np * np; e += WG) {
+            const int i = e / np, j = e - i * np;
+            c.F1[e] = c.Q[e] + (i == j ? spv : 0.0);
+        }
+        if (t == 0) sfail = 0;
+        __syncthreads();
+        // D1 keeps every inverted diagonal block (dense lower) for the TRSM that forms Et
+        double minpiv = INFINITY;
+        {
+            // factor block column by block column so each D block lands in its own slot of D1
+            minpiv = wg_chol(c.F1, np, c.nblk, c.n, 0.0, c.D1, nullptr, &sfail, lds, 4096);
+        }
+        __syncthreads();
+        failed = sfail;
+        __syncthreads();   // every thread has read the flag before thread 0 of the retry pass clears it
+        if (!failed && (pass == 1 || minpiv >= db.opt.pivotThreshold * scale)) break;
+        if (pass == 1) break;
+    }
+    if (t == 0) sfail = 0;
+    __syncthreads();
+    wg_chol(c.FK, np, c.nblk, c.n, 0.0, c.dscr, nullptr, &sfail, lds, 0);
+    __syncthreads();
+    if (t == 0) {
+        c.info->spv = spv;
+        if (failed || sfail) c.info->setupFail = 3;
+    }
+}
+
+// ---- k_trsm: Et = E L1^-T, 64 rows of E per workgroup ----------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
+{
+    LCQP_LDS_N(NCH)
+    constexpr int np = 128 * NCH;
+    const int nrb = (db.mEcap + 63) / 64;
+    const int b = blockIdx.x / nrb, rb = blockIdx.x % nrb;
+    const InstInfo* info = db.info + b;
+    if (64 * rb >= info->mE) return;
+    const double* E = db.E + (size_t)b * db.mEcap * np + (size_t)(64 * rb) * np;
+    double* Et = db.Et + (size_t)b * db.mEcap * np + (size_t)(64 * rb) * np;
+    const double* F1 = db.F1 + (size_t)b * np * np;
+    const double* D1 = db.D1 + (size_t)b * db.nblk * 4096;
+    const int rows = min(64, db.mEcap - 64 * rb);
+    auto rowok = [=](int r) { return (long)(r < rows ? r : -1); };
+    auto ident = [](int r) { return (long)r; };
+    for (int J = 0; J < db.nblk; J++) {
+        double acc[4][4];
+        if (J > 0) wg_tile_nt(acc, Et, np, rowok, F1 + (size_t)(64 * J) * np, np, ident, 64 * J, lds);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int li = tile_li(i, j), gj = 64 * J + tile_lj(i, j);
+                if (li < rows) Et[(size_t)li * np + gj] = E[(size_t)li * np + gj] - acc[i][j];
+            }
+        __syncthreads();
+        double acc2[4][4];
+        wg_tile_nt(acc2, Et + 64 * J, np, rowok, D1 + (size_t)J * 4096, 64, ident, 64, lds);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int li = tile_li(i, j), gj = 64 * J + tile_lj(i, j);
+                if (li < rows) Et[(size_t)li * np + gj] = acc2[i][j];
+            }
+        __syncthreads();
+    }
+}
+
+// ---- the homotopy megakernel: one persistent workgroup per LCQP -----------------------------------
+#ifndef LCQP_MINWAVES
+#define LCQP_MINWAVES 4      // waves per SIMD the register allocation is held to (4 workgroups per CU)
+#endif
+template <int NCH>
+__global__ __launch_bounds__(WG, LCQP_MINWAVES) void k_lcqp_run(DevBatch db)
+{
+    LCQP_LDS_N(NCH)
+    Ctx<NCH> c = make_ctx<NCH>(db, blockIdx.x, lds);
+    lcqp_run<NCH, false>(c);
+}
+
+// ---- second chance for instances whose QP subsolver gave up: the same homotopy with the dependent-row rules --------
+// (a separate kernel, so that the rules cost the first pass nothing; oracle counterpart: the robust switch of its LCQP loop)
+template <int NCH>
+__global__ __launch_bounds__(WG, 4) void k_lcqp_rerun(DevBatch db, const int* list)
+{
+    LCQP_LDS_N(NCH)
+    Ctx<NCH> c = make_ctx<NCH>(db, list[blockIdx.x], lds);
+    int *dep = c.I(I_DEP), *prio = c.I(I_PRIO);
+    for (int r = threadIdx.x; r < db.mEcap; r += WG) { dep[r] = 0; prio[r] = 0; }
+    if (threadIdx.x == 0) { c.info->haveSolution = 0; c.info->cacheNa = -1; c.info->prioCtr = 0; c.info->ndep = 0; }
+    __syncthreads();
+    lcqp_run<NCH, true>(c);
+}
+
+// ---- one QP per workgroup with the SubsolverBase semantics ----------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(WG, 4) void k_qp_solve(DevBatch db, int initial)
+{
+    LCQP_LDS_N(NCH)
+    Ctx<NCH> c = make_ctx<NCH>(db, blockIdx.x, lds);
+    const double* y0 = (initial && c.info->hasY0) ? db.y0 + (size_t)c.b * db.nd : nullptr;
+    int iters = 0;
+    const int ef = qp_solve<NCH, true, true>(c, initial, c.V(V_GK), y0, &iters);   // single-QP path: dependent-row rules and rho adaptation
+    if (ef == 0) qp_export<NCH>(c, db.xout + (size_t)c.b * db.n, db.n, db.yout + (size_t)c.b * db.nd);
+    if (threadIdx.x == 0) {
+        lcqp_stats_t s;
+        memset(&s, 0, sizeof(s));
+        s.subproblemIter = iters;
+        s.qpSolverExitFlag = ef;
+        s.returnValue = ef ? LCQP_SUBPROBLEM_SOLVER_ERROR : 0;
+        s.admmIter = c.cAdmm; s.trials = c.cTrials; s.factorizations = c.cFact; s.corrections = c.cCorr; s.qpSolves = 1; s.reserved = c.cSweeps;
+        db.stats[c.b] = s;
+    }
+}
+
+// ---- synthetic instances directly in HBM (include/lcqp_synth.h) ---------------------
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_synth_fill(DevBatch db, uint64_t seed0, uint64_t first)
+{
+    LCQP_LDS_N(NCH)
+    constexpr int np = 128 * NCH;
+    const int b = blockIdx.x, t = threadIdx.x;
+    Ctx<NCH> c = make_ctx<NCH>(db, b, lds);
+    const int n = db.n, nC = db.nC, nComp = db.nComp, mA = db.mA;
+    const uint64_t st = lcqp_synth_state(seed0, first + (uint64_t)b);
+    double* Mm = c.F1;   // scratch: M, consumed by k_synth_Q
+    for (int e = t; e < np * np; e += WG) {
+        const int i = e / np, j = e - i * np;
+        Mm[e] = (i < n && j < n) ? lcqp_synth_M(st, n, i, j) : 0.0;
+    }
+    double* xs = c.V(V_TMP);
+    for (int i = t; i < np; i += WG) {
+        c.V(V_G)[i] = (i < n) ? lcqp_synth_g(st, n, nC, nComp, i) : 0.0;
+        xs[i] = (i < n) ? lcqp_synth_xstar(st, n, nC, nComp, i) : 0.0;
+        c.V(V_X0)[i] = 0.0;
+        c.V(V_LB)[i] = -INFINITY;
+        c.V(V_UB)[i] = INFINITY;
+    }
+    const double sn = sqrt((double)n);
+    for (int r = 0; r < mA; r++) {
+        double* row = c.E + (size_t)r * np;
+        for (int j = t; j < np; j += WG) {
+            double v = 0.0;
+            if (j < n) {
+                if (r < nC) v = lcqp_synth_Araw(st, n, nC, nComp, r, j) / sn;
+                else if (r < nC + nComp) v = (j == r - nC) ? 1.0 : 0.0;
+                else v = (j == nComp + (r - nC - nComp)) ? 1.0 : 0.0;
+            }
+            row[j] = v;
+        }
+    }
+    __syncthreads();
+    double *l = c.M(M_L), *u = c.M(M_U);
+    for (int r = t; r < mA; r += WG) {
+        if (r < nC) {
+            // A x* summed left to right with separately rounded products, as the host generator does
+            const double* row = c.E + (size_t)r * np;
+            double ax = 0.0;
+            for (int j = 0; j < n; j++) {
+#pragma clang fp contract(off)
+                const double pr = row[j] * xs[j];
+                ax = ax + pr;
+            }
+            l[r] = ax - lcqp_synth_slo(st, n, nC, nComp, r);
+            u[r] = ax + lcqp_synth_shi(st, n, nC, nComp, r);
+        } else { l[r] = 0.0; u[r] = INFINITY; }
+    }
+    if (t == 0) { c.info->nfin = 0; c.info->hasY0 = 0; c.info->isSetup = 0; }
+}
+
+// Q = M'M/n + I in exactly the arithmetic of the host generator (oracle: orc_synth_generate): every element is the sum over
+// k ascending of separately rounded products (no FMA contraction), then one division and one addition -- so the instances
+// generated in HBM are bit-identical to the ones the CPU oracle generates.  One 64x64 tile of the lower triangle per
+// workgroup, a 4x4 block per thread; the generator runs before the timed region of bench.py.
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_synth_Q(DevBatch db)
+{
+    constexpr int np = 128 * NCH;
+    const int ntile = db.nblk * (db.nblk + 1) / 2;
+    const int b = blockIdx.x / ntile, tIdx = blockIdx.x % ntile, t = threadIdx.x;
+    int I, J;
+    tri_tile(tIdx, I, J);
+    const double* Mm = db.F1 + (size_t)b * np * np;
+    double* Q = db.Q + (size_t)b * np * np;
+    const int gi0 = 64 * I + 4 * (t >> 4), gj0 = 64 * J + 4 * (t & 15);
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+    for (int k = 0; k < db.n; k++) {
+#pragma clang fp contract(off)      // separately rounded product and sum (plain operators: the pragma does not reach into __dmul_rn)
+        const double* mk = Mm + (size_t)k * np;
+        double mi[4], mj[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { mi[i] = mk[gi0 + i]; mj[i] = mk[gj0 + i]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const double pr = mi[i] * mj[j]; acc[i][j] = acc[i][j] + pr; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int gi = gi0 + i, gj = gj0 + j;
+            double v = 0.0;
+            if (gi < db.n && gj < db.n) v = acc[i][j] / (double)db.n + (gi == gj ? 1.0 : 0.0);   // a quotient plus 0 or 1: nothing to fuse
+            Q[(size_t)gi * np + gj] = v;
+            Q[(size_t)gj * np + gi] = v;
+        }
+}
+
+// ---- building-block kernels for tests / micro-benchmarks ------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_util_symv(int n, double alpha, const double* A, const double* bv, const double* cv, double* d)
+{
+    LCQP_LDS_N(NCH)
+    constexpr int np = 128 * NCH;
+    const int b = blockIdx.x;
+    double* out = d + (size_t)b * np;
+    wg_symv<NCH>(A + (size_t)b * np * np, nullptr, n, bv + (size_t)b * np, nullptr, out, nullptr, nullptr, nullptr, lds);
+    for (int i = threadIdx.x; i < np; i += WG) out[i] = alpha * out[i] + cv[(size_t)b * np + i];
+}
+
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_util_rows(int m, const double* A, const double* x, double* dots, const double* coef, double* outT)
+{
+    LCQP_LDS_N(NCH)
+    constexpr int np = 128 * NCH;
+    const int b = blockIdx.x;
+    double* o = outT ? outT + (size_t)b * np : nullptr;
+    wg_rows<NCH>(A + (size_t)b * m * np, nullptr, m, x ? x + (size_t)b * np : nullptr, dots ? dots + (size_t)b * m : nullptr,
+                 coef ? coef + (size_t)b * m : nullptr, lds, [&](int i, double s) { if (o) o[i] = s; });
+}
+
+// ---- launcher of this translation unit's instantiation (declared in lcqp_launch.hpp) -----------------------------------------
+template <int NCH>
+static void launch_impl(int kid, int grid, hipStream_t s, const LaunchArgs& a)
+{
+    switch (kid) {
+        case ID_k_prepare:    hipLaunchKernelGGL((k_prepare<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
+        case ID_k_build_C:    hipLaunchKernelGGL((k_build_C<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
+        case ID_k_build_K:    hipLaunchKernelGGL((k_build_K<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
+        case ID_k_factor:     hipLaunchKernelGGL((k_factor<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
+        case ID_k_trsm:       hipLaunchKernelGGL((k_trsm<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
+        case ID_k_lcqp_run:   hipLaunchKernelGGL((k_lcqp_run<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
+        case ID_k_lcqp_rerun: hipLaunchKernelGGL((k_lcqp_rerun<NCH>), dim3(grid), dim3(WG), 0, s, a.db, a.list); break;
+        case ID_k_qp_solve:   hipLaunchKernelGGL((k_qp_solve<NCH>), dim3(grid), dim3(WG), 0, s, a.db, a.initial); break;
+        case ID_k_synth_fill: hipLaunchKernelGGL((k_synth_fill<NCH>), dim3(grid), dim3(WG), 0, s, a.db, a.seed0, a.first); break;
+        case ID_k_synth_Q:    hipLaunchKernelGGL((k_synth_Q<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
+        case ID_k_util_symv:  hipLaunchKernelGGL((k_util_symv<NCH>), dim3(grid), dim3(WG), 0, s, a.n, a.alpha, a.A, a.b, a.c, a.d); break;
+        case ID_k_util_rows:  hipLaunchKernelGGL((k_util_rows<NCH>), dim3(grid), dim3(WG), 0, s, a.m, a.A, a.x, a.dots, a.coef, a.outT); break;
+        default: break;
+    }
+}

@@ -1,0 +1,12 @@
+// lcqp_nch.hip -- one instantiation of the per-size kernels: compile with -DLCQP_TU_NCH=k, k in {1,2,3,4,8}.
+#include "lcqp_kernels.hpp"
+
+#ifndef LCQP_TU_NCH
+#error "compile lcqp_nch.hip with -DLCQP_TU_NCH=1|2|3|4|8"
+#endif
+#define LCQP_CAT2(a, b) a##b
+#define LCQP_CAT(a, b) LCQP_CAT2(a, b)
+
+namespace lcqp {
+void LCQP_CAT(lcqp_launch_, LCQP_TU_NCH)(int kid, int grid, hipStream_t s, const LaunchArgs& a) { launch_impl<LCQP_TU_NCH>(kid, grid, s, a); }
+}

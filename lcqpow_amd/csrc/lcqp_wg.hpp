@@ -168,52 +168,74 @@ __device__ __forceinline__ void wg_combine(const double (&acc)[2 * NCH], Lds lds
 // two vectors.  Any of M1, v1, outputs may be nullptr (workgroup-uniform).
 // LDS: arena[0..4np) combine, arena[4np..6np) the vectors.
 // ---------------------------------------------------------------------------------------------
-template <int NCH>
-__device__ __forceinline__ void wg_symv(const double* __restrict__ M0, const double* __restrict__ M1, int n,
+// Rows in flight: a wave keeps ROWS_IN_FLIGHT rows (2 KiB each at np = 256) of every swept matrix outstanding before it
+// consumes the oldest one.  The kernel is bound by the bytes it keeps in flight, not by issue (4 waves per SIMD, 84 % of the
+// wave cycles parked on memory with one row per wave outstanding -- profiles/round1/final/pmc_sq.txt), so the sweeps
+// load LCQP_DEPTH rows, then consume them.  Rows beyond n are read from the zero padding (np is a multiple of 128).
+#ifndef LCQP_DEPTH
+#define LCQP_DEPTH 4
+#endif
+template <int NCH, bool TWO_M, bool TWO_V>
+__device__ __forceinline__ void wg_symv_t(const double* __restrict__ M0, const double* __restrict__ M1, int n,
                         const double* __restrict__ v0, const double* __restrict__ v1,
                         double* o00, double* o10, double* o01, double* o11, Lds lds)
 {
     constexpr int np = 128 * NCH;
+    constexpr int D = (TWO_M ? (LCQP_DEPTH >= 2 ? LCQP_DEPTH / 2 : 1) : LCQP_DEPTH) * (NCH > 4 ? 1 : 1);
     static_assert(6 * np <= arena_doubles(NCH), "wg_symv: four partial copies and two staged vectors must fit the LDS arena");
     double* sv0 = lds.arena + 4 * np;
     double* sv1 = lds.arena + 5 * np;
     for (int i = threadIdx.x; i < np; i += WG) {
-        sv0[i] = v0[i];
-        sv1[i] = v1 ? v1[i] : 0.0;
+        sv0[i] = (i < n) ? v0[i] : 0.0;
+        sv1[i] = (TWO_V && i < n) ? v1[i] : 0.0;
     }
     __syncthreads();
     const int l = lane_id(), w = wave_id();
     double a00[2 * NCH], a10[2 * NCH], a01[2 * NCH], a11[2 * NCH];
 #pragma unroll
     for (int k = 0; k < 2 * NCH; k++) a00[k] = a10[k] = a01[k] = a11[k] = 0.0;
-    const bool two_m = (M1 != nullptr), two_v = (v1 != nullptr);
-    for (int r = w; r < n; r += NWAVE) {
-        const double x0 = sv0[r], x1 = sv1[r];
-        const double2* row0 = reinterpret_cast<const double2*>(M0 + (size_t)r * np) + l;
-        double2 m0[NCH];
+    const int nR = min(np, ((n + NWAVE * D - 1) / (NWAVE * D)) * (NWAVE * D));   // rows n..nR-1: zero padding times a zero of sv
+    for (int r0 = w; r0 < nR; r0 += NWAVE * D) {
+        double2 m0[D][NCH], m1[D][NCH];
 #pragma unroll
-        for (int k = 0; k < NCH; k++) m0[k] = row0[64 * k];
-        if (two_m) {
-            const double2* row1 = reinterpret_cast<const double2*>(M1 + (size_t)r * np) + l;
-            double2 m1[NCH];
+        for (int d = 0; d < D; d++) {
+            const double2* row0 = reinterpret_cast<const double2*>(M0 + (size_t)(r0 + NWAVE * d) * np) + l;
 #pragma unroll
-            for (int k = 0; k < NCH; k++) m1[k] = row1[64 * k];
+            for (int k = 0; k < NCH; k++) m0[d][k] = row0[64 * k];
+            if (TWO_M) {
+                const double2* row1 = reinterpret_cast<const double2*>(M1 + (size_t)(r0 + NWAVE * d) * np) + l;
 #pragma unroll
-            for (int k = 0; k < NCH; k++) {
-                a10[2 * k] += m1[k].x * x0; a10[2 * k + 1] += m1[k].y * x0;
-                if (two_v) { a11[2 * k] += m1[k].x * x1; a11[2 * k + 1] += m1[k].y * x1; }
+                for (int k = 0; k < NCH; k++) m1[d][k] = row1[64 * k];
             }
         }
 #pragma unroll
-        for (int k = 0; k < NCH; k++) {
-            a00[2 * k] += m0[k].x * x0; a00[2 * k + 1] += m0[k].y * x0;
-            if (two_v) { a01[2 * k] += m0[k].x * x1; a01[2 * k + 1] += m0[k].y * x1; }
+        for (int d = 0; d < D; d++) {
+            const double x0 = sv0[r0 + NWAVE * d], x1 = sv1[r0 + NWAVE * d];
+#pragma unroll
+            for (int k = 0; k < NCH; k++) {
+                a00[2 * k] += m0[d][k].x * x0; a00[2 * k + 1] += m0[d][k].y * x0;
+                if (TWO_V) { a01[2 * k] += m0[d][k].x * x1; a01[2 * k + 1] += m0[d][k].y * x1; }
+                if (TWO_M) {
+                    a10[2 * k] += m1[d][k].x * x0; a10[2 * k + 1] += m1[d][k].y * x0;
+                    if (TWO_V) { a11[2 * k] += m1[d][k].x * x1; a11[2 * k + 1] += m1[d][k].y * x1; }
+                }
+            }
         }
     }
     if (o00) wg_combine<NCH>(a00, lds, [&](int c, double s) { o00[c] = s; });
-    if (two_m && o10) wg_combine<NCH>(a10, lds, [&](int c, double s) { o10[c] = s; });
-    if (two_v && o01) wg_combine<NCH>(a01, lds, [&](int c, double s) { o01[c] = s; });
-    if (two_m && two_v && o11) wg_combine<NCH>(a11, lds, [&](int c, double s) { o11[c] = s; });
+    if (TWO_M && o10) wg_combine<NCH>(a10, lds, [&](int c, double s) { o10[c] = s; });
+    if (TWO_V && o01) wg_combine<NCH>(a01, lds, [&](int c, double s) { o01[c] = s; });
+    if (TWO_M && TWO_V && o11) wg_combine<NCH>(a11, lds, [&](int c, double s) { o11[c] = s; });
+}
+
+// the one-matrix, one-vector sweep (Q x of the QP residual, C x): any of the outputs may be nullptr
+template <int NCH>
+__device__ __forceinline__ void wg_symv(const double* __restrict__ M0, const double* __restrict__ M1, int n,
+                        const double* __restrict__ v0, const double* __restrict__ v1,
+                        double* o00, double* o10, double* o01, double* o11, Lds lds)
+{
+    if (M1 != nullptr || v1 != nullptr) wg_symv_t<NCH, true, true>(M0, M1, n, v0, v1, o00, o10, o01, o11, lds);
+    else wg_symv_t<NCH, false, false>(M0, nullptr, n, v0, nullptr, o00, nullptr, nullptr, nullptr, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -246,6 +268,7 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
         acc[2 * k] = acc[2 * k + 1] = 0.0;
     }
     const int nchunk = (m + 15) >> 4;
+    constexpr int D = LCQP_DEPTH;     // rows a wave keeps in flight (see wg_symv_t)
     for (int ch = w; ch < nchunk; ch += NWAVE) {
         const int a0 = ch << 4;
         const int mya = a0 + l;
@@ -254,24 +277,37 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
         double mycoef = (mine && coef) ? coef[mya] : 0.0;
         double mydot = 0.0;
         const int cnt = min(16, m - a0);
-        for (int j = 0; j < cnt; j++) {
-            const int row = wave_bcast_i(myrow, j);
-            const double cf = wave_bcast(mycoef, j);
-            if (row < 0) continue;  // padded list entry (uniform)
-            const double2* rp = reinterpret_cast<const double2*>(Mx + (size_t)row * np) + l;
-            double2 mm[NCH];
+        for (int j0 = 0; j0 < cnt; j0 += D) {
+            double2 mm[D][NCH];
+            int rows[D];
+            double cfs[D];
 #pragma unroll
-            for (int k = 0; k < NCH; k++) mm[k] = rp[64 * k];
-            if (x) {
-                double d = 0.0;
+            for (int d = 0; d < D; d++) {
+                // lanes >= 16 hold row -1: entries beyond the chunk and padded list entries load nothing and contribute nothing
+                rows[d] = wave_bcast_i(myrow, (j0 + d) & 63);
+                cfs[d] = wave_bcast(mycoef, (j0 + d) & 63);
+                if (rows[d] >= 0) {
+                    const double2* rp = reinterpret_cast<const double2*>(Mx + (size_t)rows[d] * np) + l;
 #pragma unroll
-                for (int k = 0; k < NCH; k++) d += mm[k].x * xr[2 * k] + mm[k].y * xr[2 * k + 1];
-                d = wave_sum(d);
-                if (l == j) mydot = d;
+                    for (int k = 0; k < NCH; k++) mm[d][k] = rp[64 * k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NCH; k++) mm[d][k] = double2{0.0, 0.0};
+                }
             }
-            if (coef && cf != 0.0) {
 #pragma unroll
-                for (int k = 0; k < NCH; k++) { acc[2 * k] += cf * mm[k].x; acc[2 * k + 1] += cf * mm[k].y; }
+            for (int d = 0; d < D; d++) {
+                if (x) {
+                    double dsum = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NCH; k++) dsum += mm[d][k].x * xr[2 * k] + mm[d][k].y * xr[2 * k + 1];
+                    dsum = wave_sum(dsum);
+                    if (l == j0 + d) mydot = dsum;
+                }
+                if (coef && cfs[d] != 0.0) {
+#pragma unroll
+                    for (int k = 0; k < NCH; k++) { acc[2 * k] += cfs[d] * mm[d][k].x; acc[2 * k + 1] += cfs[d] * mm[d][k].y; }
+                }
             }
         }
         if (mine && dots) dots[mya] = mydot;

@@ -82,9 +82,11 @@ class PrintLevel(enum.IntEnum):
 
 
 class QPSolver(enum.IntEnum):
-    """include/Utilities.hpp:125-129 plus the backend this build adds.  The three reference values are accepted by
-    setQPSolver (the range check is the reference's, extended by one) but only HIP_DENSE can run: the other arms
-    need qpOASES / OSQP, which are not vendored, and runSolver returns NOT_YET_IMPLEMENTED for them."""
+    """include/Utilities.hpp:125-129 plus the backend this build adds.  Every value runs on the HIP subsolver (qpOASES
+    and OSQP are not vendored); the three reference values keep their contracts from src/LCQProblem.cpp:888-963:
+    QPOASES_DENSE needs dense problem data and QPOASES_SPARSE / OSQP_SPARSE sparse data (DENSE_SPARSE_MISSMATCH
+    otherwise), OSQP_SPARSE refuses box constraints (INVALID_OSQP_BOX_CONSTRAINTS) and returns nC + 2 nComp duals
+    without the box part; HIP_DENSE takes the problem in either mode."""
     QPOASES_DENSE = 0
     QPOASES_SPARSE = 1
     OSQP_SPARSE = 2
@@ -300,7 +302,7 @@ class LCQProblem:
         self._h = _host().lcqp_host_problem_create(int(nV), int(nC), int(nComp))
         if not self._h:
             raise MemoryError("lcqp_host_problem_create")
-        self._nV = int(nV)
+        self._nV, self._nC, self._nComp = int(nV), int(nC), int(nComp)
         _host().lcqp_host_problem_set_device(self._h, int(device))
 
     def __del__(self):
@@ -328,6 +330,16 @@ class LCQProblem:
         vecs = [_vec(v) for v in (lbL, ubL, lbR, ubR, lbA, ubA, lb, ub, x0, y0)]
         vlbL, vubL, vlbR, vubR, vlbA, vubA, vlb, vub, vx0, vy0 = vecs
         vg = _vec(g)
+        # the C side reads nV, nC, nComp-sized blocks through raw pointers: a wrongly shaped array is an error here, not an
+        # out-of-bounds read there
+        n, nC, nK = self._nV, self._nC, self._nComp
+
+        def sized(name, a, size):
+            if a is not None and a.size != size:
+                raise ValueError(f"loadLCQP: {name} has {a.size} values, expected {size}")
+        for nm, a, sz in (("g", vg, n), ("lbL", vlbL, nK), ("ubL", vubL, nK), ("lbR", vlbR, nK), ("ubR", vubR, nK), ("lbA", vlbA, nC),
+                          ("ubA", vubA, nC), ("lb", vlb, n), ("ub", vub, n), ("x0", vx0, n), ("y0", vy0, n + nC + 2 * nK)):
+            sized(nm, a, sz)
         if isinstance(Q, cscWrapper):
             for M in (L, R):
                 if not isinstance(M, cscWrapper):
@@ -338,6 +350,8 @@ class LCQProblem:
                                                     _ptr(vubL), _ptr(vlbR), _ptr(vubR), C.byref(aA) if aA is not None else None,
                                                     _ptr(vlbA), _ptr(vubA), _ptr(vlb), _ptr(vub), _ptr(vx0), _ptr(vy0)))
         mQ, mL, mR, mA = (_mat(M, order) for M in (Q, L, R, A))
+        for nm, a, sz in (("Q", mQ, n * n), ("L", mL, nK * n), ("R", mR, nK * n), ("A", mA, nC * n)):
+            sized(nm, a, sz)
         return _rv(H.lcqp_host_problem_load_dense(self._h, _ptr(mQ), _ptr(vg), _ptr(mL), _ptr(mR), _ptr(vlbL), _ptr(vubL),
                                                   _ptr(vlbR), _ptr(vubR), _ptr(mA), _ptr(vlbA), _ptr(vubA), _ptr(vlb), _ptr(vub),
                                                   _ptr(vx0), _ptr(vy0)))

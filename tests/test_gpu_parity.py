@@ -193,7 +193,10 @@ def test_lcqp_iterate_level_match(hip, oracle, name):
     so, sh = ro["trace_scalars"], rh["trace_scalars"]
     assert len(so) == len(sh) == ro["stats"]["iterTotal"] == rh["stats"]["iterTotal"]
     assert np.array_equal(so[:, 2], sh[:, 2])                                   # rho per iterate
-    tol = 1e-7 if name in ("circle", "example_data") else 1e-9                  # PSD Hessians: flat directions
+    # Every iterate is a QP solution verified to resTol * (1 + |gk|_inf) = 1e-12 * (1 + rho |C xk| + ...) on both sides, so with
+    # rho up to 1e3 on these problems two correct solvers may differ by 1e-9 in an intermediate xk (the final x is compared at
+    # 1e-9 elsewhere: at convergence the complementarity pairs are exact zeros).  PSD Hessians (flat directions): 1e-7.
+    tol = 1e-7 if name in ("circle", "example_data") else 1e-8
     assert np.abs(ro["trace_x"] - rh["trace_x"]).max() < tol
     assert np.abs(so[:, 1] - sh[:, 1]).max() < 10 * tol                         # complementarity per iterate
     assert np.abs(so[:, 0] - sh[:, 0]).max() < 10 * tol                         # stationarity per iterate

@@ -190,15 +190,7 @@ def test_python_sparse_and_mode_switch(hip, oracle):
     """warm_up_sparse.py restated with explicit cscWrapper inputs (LCQProblem.cpp:118-148) + switchToDenseMode"""
     lcqpow = _lcqpow()
 
-    def csc(M):
-        m, n = M.shape
-        p, i, x = [0], [], []
-        for c in range(n):
-            for r in range(m):
-                if M[r, c] != 0:
-                    i.append(r); x.append(M[r, c])
-            p.append(len(i))
-        return lcqpow.cscWrapper(m, n, len(x), np.array(x, dtype=float), i, p)
+    csc = lambda M: _csc(lcqpow, M)
 
     d = P.circle(10)
     ro = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0))
@@ -242,9 +234,74 @@ def test_python_max_penalty_and_infeasible(hip):
     assert ret == lcqpow.ReturnValue.MAX_PENALTY_REACHED
     ret, x, y, stats = _solve(lcqpow, P.infeasible())
     assert ret == lcqpow.ReturnValue.SUBPROBLEM_SOLVER_ERROR and stats.getQPSolverExitFlag() != 0
-    # a reference solver arm that needs un-vendored code is refused, not silently replaced
-    ret, x, y, stats = _solve(lcqpow, P.warm_up(), tweak=lambda o: o.setQPSolver(lcqpow.QPSolver.QPOASES_DENSE))
-    assert ret == lcqpow.ReturnValue.NOT_YET_IMPLEMENTED
+
+
+def _csc(lcqpow, M):
+    m, n = M.shape
+    p, i, x = [0], [], []
+    for c in range(n):
+        for r in range(m):
+            if M[r, c] != 0:
+                i.append(r); x.append(M[r, c])
+        p.append(len(i))
+    return lcqpow.cscWrapper(m, n, len(x), np.array(x, dtype=float), i, p)
+
+
+@pytest.mark.gpu
+def test_python_reference_solver_arms(hip, oracle):
+    """The option sequences of the reference's own examples run unchanged: warm_up.py:24 (QPOASES_DENSE), warm_up_sparse.py:21
+    (QPOASES_SPARSE), warm_up_osqp.py:34 and OptimizeOnCircle.py:20 (OSQP_SPARSE).  Contracts of src/LCQProblem.cpp:888-963:
+    dense/sparse mismatch, OSQP's refusal of box constraints, dual layout nV + nC + 2 nComp against nC + 2 nComp."""
+    lcqpow = _lcqpow()
+    RV, QS = lcqpow.ReturnValue, lcqpow.QPSolver
+
+    def run(d, solver, sparse, perturb=False, box=False):
+        lcqp = lcqpow.LCQProblem(nV=d["nV"], nC=d["nC"], nComp=d["nComp"])
+        options = lcqpow.Options()
+        options.setPrintLevel(lcqpow.PrintLevel.NONE)
+        options.setQPSolver(solver)
+        options.setPerturbStep(perturb)
+        lcqp.setOptions(options)
+        kw = {k: d[k] for k in ("lbL", "ubL", "lbR", "ubR", "lbA", "ubA", "x0", "y0") if k in d}
+        if box:
+            kw["lb"] = np.full(d["nV"], -10.0); kw["ub"] = np.full(d["nV"], 10.0)
+        if sparse:
+            A = _csc(lcqpow, d["A"]) if d.get("A") is not None else None
+            assert lcqp.loadLCQP(Q=_csc(lcqpow, d["Q"]), g=d["g"], L=_csc(lcqpow, d["L"]), R=_csc(lcqpow, d["R"]), A=A, **kw) == 0
+        else:
+            T = lambda M: None if M is None else M.T
+            assert lcqp.loadLCQP(Q=d["Q"], g=d["g"], L=T(d["L"]), R=T(d["R"]), A=T(d.get("A")), **kw) == 0
+        ret = lcqp.runSolver()
+        return ret, lcqp
+
+    d = P.warm_up_x0()
+    m = d["nC"] + 2 * d["nComp"]
+    # warm_up.py: dense data, QPOASES_DENSE
+    ret, lcqp = run(d, QS.QPOASES_DENSE, sparse=False, perturb=True)
+    assert ret == RV.SUCCESSFUL_RETURN and lcqp.getNumberOfDuals() == d["nV"] + m
+    x = lcqp.getPrimalSolution()
+    assert min(np.abs(x - [1, 0]).max(), np.abs(x - [0, 1]).max()) < 2.2e-10
+    # warm_up_sparse.py: CSC data, QPOASES_SPARSE; warm_up_osqp.py: CSC data, OSQP_SPARSE (no box duals)
+    ret, lcqp = run(d, QS.QPOASES_SPARSE, sparse=True, perturb=True)
+    assert ret == RV.SUCCESSFUL_RETURN and lcqp.getNumberOfDuals() == d["nV"] + m
+    ret, lcqp = run(d, QS.OSQP_SPARSE, sparse=True, perturb=True)
+    assert ret == RV.SUCCESSFUL_RETURN and lcqp.getNumberOfDuals() == m
+    x, y = lcqp.getPrimalSolution(), lcqp.getDualSolution()
+    assert min(np.abs(x - [1, 0]).max(), np.abs(x - [0, 1]).max()) < 2.2e-10
+    dd = P.warm_up()
+    assert np.abs(dd["Q"] @ x + dd["g"] - dd["L"].T @ y[0:1] - dd["R"].T @ y[1:2]).max() < 1e-9    # stationarity without a box term
+    # mode mismatches and OSQP's box refusal
+    assert run(d, QS.QPOASES_DENSE, sparse=True)[0] == RV.DENSE_SPARSE_MISSMATCH
+    assert run(d, QS.QPOASES_SPARSE, sparse=False)[0] == RV.DENSE_SPARSE_MISSMATCH
+    assert run(d, QS.OSQP_SPARSE, sparse=False)[0] == RV.DENSE_SPARSE_MISSMATCH
+    assert run(d, QS.OSQP_SPARSE, sparse=True, box=True)[0] == RV.INVALID_OSQP_BOX_CONSTRAINTS
+    # OptimizeOnCircle.py: OSQP_SPARSE on the circle problem; same solution as the oracle's dense path, duals without the box part
+    c = P.circle(10)
+    ro = P.oracle_solve(oracle, c, oracle.default_options(perturbStep=0))
+    ret, lcqp = run(c, QS.OSQP_SPARSE, sparse=True)
+    assert ret == RV.SUCCESSFUL_RETURN
+    assert np.abs(lcqp.getPrimalSolution() - ro["x"]).max() < 1e-7
+    assert np.abs(lcqp.getDualSolution() - ro["y"][c["nV"]:]).max() < 1e-5
 
 
 @pytest.mark.gpu

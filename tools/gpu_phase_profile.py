@@ -8,14 +8,17 @@ sys.path.insert(0, ROOT)
 so = os.path.join(ROOT, "gpurun_out", "liblcqpow_hip_prof.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]
-if not os.path.exists(so) or "--rebuild" in sys.argv:
+pre = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--so=")]      # a prebuilt -DLCQP_PROFILE library (e.g. under ab_tmp/)
+if pre:
+    so = os.path.abspath(pre[0])
+elif not os.path.exists(so) or "--rebuild" in sys.argv:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DLCQP_PROFILE", *extra,
                            "-Wno-pass-failed", "-o", so, os.path.join(ROOT, "lcqpow_amd", "csrc", "lcqp_hip.hip")])
 import lcqpow_amd.capi as capi
 capi._SO = so
 la = capi
 B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1024
-okw = {a.split("=")[0][2:]: int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--") and "=" in a}
+okw = {a.split("=")[0][2:]: int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--") and "=" in a and not a.startswith("--so=")}
 print("options override:", okw, "defines:", extra)
 bt = la.BatchLCQP(B, 256, 512, 64, opt=la.default_options(perturbStep=0, **okw))
 bt.generate_synthetic(0)
