@@ -141,9 +141,9 @@ def main():
                                f"SplitMix64 seed0=0x4C43515000000001, perturbStep=0, printLevel=NONE)",
                    "global_batch": B * world, "parallelism": f"batch-sharded x{world}, no collective",
                    "solved": n_ok_total, "mean_lcqp_iterates": mean("iterTotal"), "mean_outer": mean("iterOuter"),
-                   "mean_qp_trials": mean("trials"), "mean_residual_sweeps": mean("reserved"), "mean_factorizations": mean("factorizations"),
+                   "mean_qp_trials": mean("trials"), "mean_residual_sweeps": mean("reserved"), "mean_factor_updates": mean("factorizations"),
                    "mean_backsolve_pairs": mean("corrections"), "mean_admm_iters": mean("admmIter"),
-                   "mean_active_rows_per_backsolve": float(ws[0] / n_corr), "mean_active_rows_per_factorization": float(ws[2] / n_fact),
+                   "mean_active_rows_per_backsolve": float(ws[0] / n_corr), "mean_factor_update_kbytes": float(ws[2] / n_fact / 1e3),
                    "setup_ms_per_step": setup_ms / args.steps, "homotopy_kernel_ms_per_step": solve_ms / args.steps},
         "roofline": {"bound": "hbm", "kernel": "k_lcqp_run", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(B, n, nC, nComp),

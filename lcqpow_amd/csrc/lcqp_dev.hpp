@@ -16,22 +16,26 @@ enum { V_G, V_GPHI, V_GTIL, V_XK, V_PK, V_XNEW, V_GK, V_QX, V_CX, V_QP, V_CP, V_
        V_XQ, V_XA, V_XT, V_R1, V_C, V_DU, V_W, V_RHS, V_LB, V_UB, V_X0, V_R1S, V_GS, V_ATY, V_NUM };
 // per-instance vectors of length mEcap (rows of E = [A; L; R; box rows])
 enum { M_L, M_U, M_RHOV, M_YQ, M_YA, M_ZA, M_YT, M_EX, M_COEF, M_EXS, M_DY, M_NUM };   // M_DY: change of ya in the last ADMM iteration
-enum { I_ST, I_STT, I_DEP, I_PRIO, I_NUM };   // I_DEP: row flagged dependent by the last factorisation of S; I_PRIO: promotion stamp (0: none)
-enum { S_R2, S_DY, S_D0, S_NUM };
+enum { I_ST, I_STT, I_DEP, I_PRIO, I_SLOT, I_LIST, I_NUM };   // I_DEP: row is active but linearly dependent on the rows of the factor; I_PRIO: promotion stamp (0: none); I_SLOT: slot of the row in the inverse factor (-1: none); I_LIST: scratch list of rows / slots
+enum { S_R2, S_DY, S_D0, S_SV, S_W, S_NUM };   // slot-space vectors (length capS): S_SV / S_W: column of S and inv(S) times it when a row is appended
 
 struct InstInfo {
-    int mE, nfin, hasY0, setupFail, haveSolution, isSetup, cacheNa, prioCtr;   // cacheNa: active rows the stored factor of S belongs to (-1: none); prioCtr: promotion stamps in use (I_PRIO)
-    int ndep, pad2;                                                            // ndep: rows the stored factor of S flagged as dependent (I_DEP)
+    int mE, nfin, hasY0, setupFail, haveSolution, isSetup, nT, prioCtr;   // nT: rows of the inverse factor Ti (= rows of the working set it holds); prioCtr: promotion stamps in use (I_PRIO)
+    int ndep, ns;                                                         // ndep: active rows flagged dependent (I_DEP); ns: slots of Ti in use (high-water mark, free slots inside count)
     double scale, sigma, spv, rhoAdmm, phiConst;
     double hist[8];
-    double work[4];   // exact work sums for the byte accounting: sum(na), sum(na^2) over corrections; the same over factorisations
+    double work[4];   // exact work sums for the byte accounting: sum(nT), sum(nT*ns) over corrections; bytes of Ti and M moved by working-set updates; number of updates
 };
 
 struct DevBatch {
     int B, n, np, nC, nComp, mA, boxcap, mEcap, capS, nblk, nd;   // nd = n + mA (dual vector, reference layout)
     int hasLbL, hasLbR;
     lcqp_options_t opt;
-    double *Q, *C, *E, *Et, *F1, *FK, *S, *D1, *dscr;   // per-instance matrix blocks
+    double *Q, *C, *E, *Et, *F1, *FK, *S, *D1, *dscr;   // per-instance matrix blocks (S holds the inverse factor Ti, capS x capS)
+    double *S2, *DS;                                     // [B][capS][capS], [B][capS/64][4096]: Cholesky factor of a working-set matrix built in one piece, its inverted diagonal blocks
+    double* MM;                                          // [B][mMld][mMld]: M = Et Et', every entry of every working-set matrix (k_build_M)
+    int mMld;
+    int* crow;                                           // [B][capS]: row of Ti that was appended together with the slot
     double *nv, *mv, *sv;                                // vector pools
     int *mi, *idx, *boxidx;
     double *lbL, *lbR;                                   // [B][nComp]
@@ -52,9 +56,9 @@ struct Ctx {
     static constexpr int np = 128 * NCH;
     const DevBatch* db;
     int b, n, nC, nComp, mA, mE, capS, nblk;
-    double *Q, *C, *E, *Et, *F1, *FK, *S, *D1, *dscr;
+    double *Q, *C, *E, *Et, *F1, *FK, *S, *S2, *DS, *D1, *dscr, *MM;
     double *nv, *mv, *sv;
-    int *mi, *idx, *boxidx;
+    int *mi, *idx, *boxidx, *crow;
     InstInfo* info;
     Lds lds;
     // work counters (uniform)
@@ -79,6 +83,9 @@ __device__ __forceinline__ Ctx<NCH> make_ctx(const DevBatch& db, int b, Lds lds)
     c.E = db.E + (size_t)b * db.mEcap * np; c.Et = db.Et + (size_t)b * db.mEcap * np;
     c.F1 = db.F1 + (size_t)b * np * np; c.FK = db.FK + (size_t)b * np * np;
     c.S = db.S + (size_t)b * db.capS * db.capS;
+    c.MM = db.MM + (size_t)b * db.mMld * db.mMld;
+    c.S2 = db.S2 + (size_t)b * db.capS * db.capS; c.DS = db.DS + (size_t)b * (db.capS / 64) * 4096;
+    c.crow = db.crow + (size_t)b * db.capS;
     c.D1 = db.D1 + (size_t)b * db.nblk * 4096; c.dscr = db.dscr + (size_t)b * 4096;
     c.nv = db.nv + (size_t)b * V_NUM * np; c.mv = db.mv + (size_t)b * M_NUM * db.mEcap;
     c.sv = db.sv + (size_t)b * S_NUM * db.capS;
@@ -308,6 +315,288 @@ __device__ __forceinline__ int polish_promoted_list(const int* st, const int* pr
 }
 
 // ---------------------------------------------------------------------------------------------
+// Inverse factor Ti of the working-set matrix S_W = Et_W Et_W' (oracle: ti_reset / ti_apply / ti_append / ti_delete).
+// The reference's subsolver UPDATES its factors when the working set changes on a hot start (qp.hotstart,
+// src/SubsolverQPOASES.cpp:158); so does this one: Ti (nT rows x ns slots, row-major in c.S, ld = capS) with Ti'Ti = inv(S_W)
+// gains a row when a constraint enters and loses one by a sweep of row rotations when a constraint leaves.  S dy = t is then one
+// fused pass over Ti: dy = Ti'(Ti t) -- no triangular solves, no sequential chains.
+//   slot_row = c.idx[capS] (row of E held by a slot, -1: free), row_slot = I_SLOT[mE], crow = c.crow[capS] (the row of Ti that
+//   was appended together with the slot: column s is zero in the rows above crow[s]).  Entries of S come from M = Et Et'.
+// Slot-space vectors (S_* pool) have capS entries, zero on free slots.
+// ---------------------------------------------------------------------------------------------
+constexpr int TI_FAST_CHUNKS = 4;    // the fused apply keeps up to 256 slots in registers (lane l: slots l, l+64, l+128, l+192)
+
+template <int NCH>
+__device__ __forceinline__ void ti_reset(Ctx<NCH>& c, int& nT, int& ns)
+{
+    int* rslot = c.I(I_SLOT);
+    for (int r = threadIdx.x; r < c.mE; r += WG) rslot[r] = -1;
+    for (int a = threadIdx.x; a < c.capS; a += WG) c.idx[a] = -1;
+    nT = 0; ns = 0;
+    __syncthreads();
+}
+
+// out = Ti' (Ti tv) over the slots [0, ns); tv and out: global, capS entries, tv zero on free slots.  out may alias tv.
+template <int NCH>
+__device__ __forceinline__ void ti_apply(Ctx<NCH>& c, const double* tv, double* out, int nT, int ns)
+{
+    const int ld = c.capS, l = lane_id(), w = wave_id(), t = threadIdx.x;
+    const int nk = (ns + 63) >> 6;
+    const double* Ti = c.S;
+    if (nk <= TI_FAST_CHUNKS) {
+        double* red = c.lds.arena;     // 4 waves x 256 partial sums
+        double tr[TI_FAST_CHUNKS], acc[TI_FAST_CHUNKS];
+#pragma unroll
+        for (int k = 0; k < TI_FAST_CHUNKS; k++) { const int sl = 64 * k + l; tr[k] = (sl < ns) ? tv[sl] : 0.0; acc[k] = 0.0; }
+        constexpr int D = 4;           // rows a wave keeps in flight
+        for (int j0 = w; j0 < nT; j0 += NWAVE * D) {
+            double rv[D][TI_FAST_CHUNKS];
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const int j = j0 + NWAVE * d;
+#pragma unroll
+                for (int k = 0; k < TI_FAST_CHUNKS; k++) {
+                    const int sl = 64 * k + l;
+                    rv[d][k] = (j < nT && sl < ns) ? Ti[(size_t)j * ld + sl] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                double dsum = 0.0;
+#pragma unroll
+                for (int k = 0; k < TI_FAST_CHUNKS; k++) dsum += rv[d][k] * tr[k];
+                const double u = wave_sum(dsum);
+#pragma unroll
+                for (int k = 0; k < TI_FAST_CHUNKS; k++) acc[k] += rv[d][k] * u;
+            }
+        }
+        __syncthreads();               // tv fully read (out may alias it), arena free
+#pragma unroll
+        for (int k = 0; k < TI_FAST_CHUNKS; k++) red[w * 256 + 64 * k + l] = acc[k];
+        __syncthreads();
+        for (int sl = t; sl < 64 * nk; sl += WG) out[sl] = (sl < ns) ? (red[sl] + red[256 + sl]) + (red[512 + sl] + red[768 + sl]) : 0.0;
+        __syncthreads();
+    } else {
+        // wide working sets (more than 256 slots; only after an ADMM round guessed many rows): two passes, u = Ti tv staged in LDS
+        constexpr int MAXK = (max_active(NCH) + 63) / 64;
+        double* ts = c.lds.arena;                 // 64 nk entries
+        double* us = c.lds.arena + 64 * nk;       // nT entries   (64 nk + nT <= 2 capS; the partial sums below reuse the arena)
+        for (int sl = t; sl < 64 * nk; sl += WG) ts[sl] = (sl < ns) ? tv[sl] : 0.0;
+        __syncthreads();
+        for (int j = w; j < nT; j += NWAVE) {
+            double dsum = 0.0;
+#pragma unroll 4
+            for (int k = 0; k < nk; k++) { const int sl = 64 * k + l; dsum += (sl < ns ? Ti[(size_t)j * ld + sl] : 0.0) * ts[sl]; }
+            dsum = wave_sum(dsum);
+            if (l == 0) us[j] = dsum;
+        }
+        __syncthreads();
+        double acc[MAXK];
+#pragma unroll
+        for (int k = 0; k < MAXK; k++) acc[k] = 0.0;
+        for (int j = w; j < nT; j += NWAVE) {
+            const double u = us[j];
+#pragma unroll
+            for (int k = 0; k < MAXK; k++) { const int sl = 64 * k + l; if (k < nk && sl < ns) acc[k] += Ti[(size_t)j * ld + sl] * u; }
+        }
+        __syncthreads();                          // ts / us consumed
+        double* red = c.lds.arena;                // 4 waves x 64 nk partial sums (<= 4 * 64 * MAXK = arena size of the np = 512 build)
+#pragma unroll
+        for (int k = 0; k < MAXK; k++) if (k < nk) red[w * 64 * nk + 64 * k + l] = acc[k];
+        __syncthreads();
+        for (int sl = t; sl < 64 * nk; sl += WG)
+            out[sl] = (sl < ns) ? (red[sl] + red[64 * nk + sl]) + (red[2 * 64 * nk + sl] + red[3 * 64 * nk + sl]) : 0.0;
+        __syncthreads();
+    }
+}
+
+// The inverse factor built in one piece for the ordered row list idx[0..na) (slot a = list position a): S_W gathered from M,
+// blocked Cholesky L (fp64 MFMA tiles, safeguarded pivots, wg_chol), then the blocked inverse Ti = inv(L):
+//   Ti_JJ = D_J (the inverted diagonal blocks wg_chol leaves),  Ti_IJ = -D_I * sum_{K=J}^{I-1} L_IK Ti_KJ   (I > J).
+// Used when the factor is empty or most of it would change (oracle: ti_reset followed by appends in list order -- the same
+// matrix up to rounding, since inv(S_W) = inv(L)' inv(L)).  Rows the factorisation flags as dependent lose their slot and are
+// marked in I_DEP.  Returns the number of flagged rows (uniform).
+template <int NCH>
+__device__ __forceinline__ int ti_bulk(Ctx<NCH>& c, int na, double tau, int& nT, int& ns)
+{
+    const int ld = c.capS, t = threadIdx.x, mMld = c.db->mMld;
+    const int nb = (na + 63) >> 6, nn = 64 * nb;
+    int *idx = c.idx, *rslot = c.I(I_SLOT), *dep = c.I(I_DEP);
+    double *F = c.S2, *Ti = c.S, *DS = c.DS;
+    nT = na; ns = na;
+    if (na == 0) return 0;
+    for (int e = t; e < nn * nn; e += WG) {
+        const int i = e / nn, j = e - i * nn;
+        if (j > i) continue;
+        double v = (i == j) ? 1.0 : 0.0;
+        if (i < na) v = c.MM[(size_t)idx[i] * mMld + idx[j]];
+        F[(size_t)i * ld + j] = v;
+    }
+    __syncthreads();
+    wg_chol(F, ld, nb, na, tau, DS, c.Sv(S_D0), nullptr, c.lds, 4096);
+    // Ti: zero, diagonal blocks D_J (dense lower copies in DS)
+    for (int e = t; e < nn * nn; e += WG) {
+        const int i = e / nn, j = e - i * nn;
+        const int I = i >> 6, J = j >> 6;
+        Ti[(size_t)i * ld + j] = (I == J) ? DS[(size_t)I * 4096 + (i & 63) * 64 + (j & 63)] : 0.0;
+    }
+    __syncthreads();
+    auto ident = [](int r) { return (long)r; };
+    for (int J = 0; J + 1 < nb; J++)
+        for (int I = J + 1; I < nb; I++) {
+            double acc[4][4];
+            // X = sum_K L_IK Ti_KJ: rows 64J .. 64I-1 of the upper part of F hold L_IK' , the same rows of Ti hold Ti_KJ
+            wg_tile_tn(acc, F + (size_t)(64 * J) * ld, ld, 64 * I, Ti + (size_t)(64 * J) * ld, ld, 64 * J, 64 * (I - J), [](int) { return 1.0; }, c.lds);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) c.dscr[tile_lj(i, j) * 64 + tile_li(i, j)] = acc[i][j];       // X'
+            __syncthreads();
+            double acc2[4][4];
+            wg_tile_nt(acc2, DS + (size_t)I * 4096, 64, ident, c.dscr, 64, ident, 64, c.lds);              // D_I X
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) Ti[(size_t)(64 * I + tile_li(i, j)) * ld + 64 * J + tile_lj(i, j)] = -acc2[i][j];
+            __syncthreads();
+        }
+    // slots; rows whose pivot was flagged (stored inverse diagonal 1/1e150) are dependent on the rows before them
+    int nflag = 0;
+    for (int a = t; a < na; a += WG) {
+        const bool flagged = DS[(size_t)(a >> 6) * 4096 + (a & 63) * 65] < 1e-100;
+        const int r = idx[a];
+        c.crow[a] = a;
+        if (flagged) { nflag++; dep[r] = 1; idx[a] = -1; } else { rslot[r] = a; dep[r] = 0; }
+    }
+    nflag = block_sum_i(nflag, c.lds);
+    if (nflag > 0) {
+        // the flagged rows and columns of Ti are ~1e-150 by construction: clear them, the slots are free
+        for (int e = t; e < na * na; e += WG) {
+            const int i = e / na, j = e - i * na;
+            if (idx[i] < 0 || idx[j] < 0) Ti[(size_t)i * ld + j] = 0.0;
+        }
+        __syncthreads();
+    }
+    if (t == 0) c.info->work[2] += 8.0 * 3.0 * (double)na * na;      // S gathered, factor written, inverse written (lower halves: about na^2 / 2 each, read and written)
+    return nflag;
+}
+
+// Row r enters the working set.  With s = S_W,r (entries of M), w = inv(S_W) s and d2 = S_rr - s'w (the Schur complement, i.e.
+// the squared Cholesky pivot of the row behind the rows of W) the new last row of Ti is [-w'/delta, 1/delta], delta = sqrt(d2).
+// d2 <= tau S_rr: the row is linearly dependent on W and stays out of the factor (returns 0).  Returns 1 when appended, -1 when
+// the factor is full.  Uniform.
+template <int NCH>
+__device__ __forceinline__ int ti_append(Ctx<NCH>& c, int r, double tau, int capNa, int& nT, int& ns)
+{
+    const int ld = c.capS, t = threadIdx.x;
+    double *sv = c.Sv(S_SV), *wv = c.Sv(S_W);
+    int *idx = c.idx, *rslot = c.I(I_SLOT);
+    double* Ti = c.S;
+    const double* Mr = c.MM + (size_t)r * c.db->mMld;
+    const int nsp = 64 * ((ns + 63) >> 6);
+    int freeSlot = 1 << 30;
+    for (int sl = t; sl < nsp; sl += WG) {
+        const int rr = (sl < ns) ? idx[sl] : -2;
+        sv[sl] = (rr >= 0) ? Mr[rr] : 0.0;
+        if (rr == -1) freeSlot = min(freeSlot, sl);
+    }
+    __syncthreads();
+    double d2 = Mr[r];
+    const double srr = uniform_d(d2);
+    if (nT > 0) {
+        ti_apply<NCH>(c, sv, wv, nT, ns);
+        double part = 0.0;
+        for (int sl = t; sl < ns; sl += WG) part += sv[sl] * wv[sl];
+        d2 = srr - block_sum(part, c.lds);
+    } else {
+        d2 = srr;
+    }
+    if (t == 0) c.info->work[2] += 8.0 * ((double)nT * ns + 3.0 * ns);
+    int snew = -block_max((double)(-freeSlot), c.lds) + 0.5;      // smallest free slot (exact in double), 2^30: none
+    if (!(d2 > tau * srr) || !(d2 > 0.0)) return 0;
+    if (snew >= ns) {
+        if (ns >= capNa || ns >= c.capS) return -1;
+        snew = ns;
+        ns++;
+        for (int j = t; j < nT; j += WG) Ti[(size_t)j * ld + snew] = 0.0;       // a fresh column
+    }
+    if (nT >= capNa) return -1;
+    const double delta = sqrt(d2);
+    double* row = Ti + (size_t)nT * ld;
+    for (int sl = t; sl < ns; sl += WG) row[sl] = (sl == snew) ? 1.0 / delta : ((idx[sl] >= 0) ? -wv[sl] / delta : 0.0);
+    __syncthreads();
+    if (t == 0) { idx[snew] = r; rslot[r] = snew; c.crow[snew] = nT; }
+    nT++;
+    __syncthreads();
+    return 1;
+}
+
+// The row held by slot p leaves: rotations of neighbouring rows of Ti, from row crow[p] downwards, collect column p in the last
+// row, which is dropped; Ti'Ti then is the inverse of S without row and column p.  The rotations follow from column p alone
+// (rho_j^2 = sum_{i<=j} Ti[i][p]^2), so they are formed first (a prefix sum) and the rows are then swept column by column:
+// thread = column, a lane-local recurrence over the rows, eight rows in flight.
+template <int NCH>
+__device__ __forceinline__ void ti_delete(Ctx<NCH>& c, int p, int& nT, int& ns)
+{
+    const int ld = c.capS, t = threadIdx.x, l = lane_id(), w = wave_id();
+    int *idx = c.idx, *rslot = c.I(I_SLOT), *crow = c.crow;
+    double* Ti = c.S;
+    const int i0 = uniform_i(crow[p]), m = nT - i0;
+    double* b = c.lds.arena;            // m entries each: column p, cosines, sines   (3 capS <= arena)
+    double* cs = b + c.capS;
+    double* sn = cs + c.capS;
+    for (int j = t; j < m; j += WG) b[j] = Ti[(size_t)(i0 + j) * ld + p];
+    __syncthreads();
+    {
+        const int per = (m + WG - 1) / WG, j0 = t * per, j1 = min(m, j0 + per);
+        double loc = 0.0;
+        for (int j = j0; j < j1; j++) loc += b[j] * b[j];
+        double incl = loc;
+#pragma unroll
+        for (int ofs = 1; ofs < 64; ofs <<= 1) { const double v = __shfl_up(incl, ofs, 64); if (l >= ofs) incl += v; }
+        if (l == 63) c.lds.red[8 + w] = incl;
+        __syncthreads();
+        double run = incl - loc;
+        for (int ww = 0; ww < w; ww++) run += c.lds.red[8 + ww];
+        for (int j = j0; j < j1; j++) {
+            const double rp = (j == 1) ? b[0] : sqrt(run);      // rho_0 = Ti[i0][p] carries its sign, rho_j > 0 afterwards
+            run += b[j] * b[j];
+            const double rn = sqrt(run);
+            const bool ok = rn > 0.0;
+            cs[j] = ok ? b[j] / rn : 1.0;
+            sn[j] = ok ? -rp / rn : 0.0;
+        }
+        __syncthreads();
+    }
+    for (int col = t; col < ns; col += WG) {
+        double carry = Ti[(size_t)i0 * ld + col];
+        for (int j = 1; j < m; j += 8) {
+            double rv[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) rv[q] = (j + q < m) ? Ti[(size_t)(i0 + j + q) * ld + col] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (j + q < m) {
+                    const double cc = cs[j + q], ss = sn[j + q];
+                    const double o = cc * carry + ss * rv[q];
+                    carry = cc * rv[q] - ss * carry;
+                    Ti[(size_t)(i0 + j + q - 1) * ld + col] = (col == p) ? 0.0 : o;
+                }
+        }
+    }
+    int top = 0;
+    for (int sl = t; sl < ns; sl += WG) {
+        const int rr = idx[sl];
+        if (sl != p && rr >= 0) { if (crow[sl] > i0) crow[sl]--; top = max(top, sl + 1); }
+    }
+    const int rOut = uniform_i(idx[p]);
+    __syncthreads();
+    if (t == 0) { idx[p] = -1; rslot[rOut] = -1; c.info->work[2] += 16.0 * (double)m * ns; }
+    ns = (int)(block_max((double)top, c.lds) + 0.5);     // free slots at the end are given back
+    nT--;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Primal-dual active-set polish in correction form (oracle: qp_polish).
 // In/out: x = V_XT, multipliers M_YT (OSQP sign, zero on inactive rows), active set I_STT.
 // Returns 1 (uniform) on a verified KKT point.
@@ -325,11 +614,11 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
     const double *l = c.M(M_L), *u = c.M(M_U);
     int* st = c.I(I_STT);
     int *dep = c.I(I_DEP), *prio = c.I(I_PRIO);
-    double *r2 = c.Sv(S_R2), *dy = c.Sv(S_DY), *d0 = c.Sv(S_D0);
+    double *r2 = c.Sv(S_R2), *dy = c.Sv(S_DY);
     int* idx = c.idx;
     const double gs = 1.0 + wg_maxabs(g, c.n, c.lds);
     const double ytol = o.feasTol * gs;
-    int na = 0, nblkS = 0, fact_valid = 0;
+    int na = 0, nsl = 0, fact_valid = 0;
     int prioCtr = ROBUST ? uniform_i(c.info->prioCtr) : 0;
     const int capNa = min(min(min(max(2 * c.n, 64), mE), capS), max_active(NCH));   // room for the degenerate vertices of small problems
 
@@ -398,83 +687,82 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
         }
         if (changed) fact_valid = 0;
         if (!fact_valid) {
-            // ordered list of active rows (ascending row index, as the oracle builds it)
-            const int per = (mE + WG - 1) / WG;
-            const int r0 = t * per, r1e = min(mE, r0 + per);
-            int differs = 0, nprom = 0;
-            if (ROBUST && prioCtr > 0) {
-                // promoted rows come first in the list
-                __syncthreads();
-                const int packed = polish_promoted_list(st, prio, idx, mE, r0, r1e, capNa, c.lds);
-                nprom = packed >> 1; differs = packed & 1;
-                if (nprom > capNa) return 0;
+            // bring the inverse factor to the working set st[]: rows that left are rotated out, rows that entered (and rows flagged
+            // dependent earlier, which may have become independent) are appended in ascending row order (oracle: the same)
+            int nT = uniform_i(c.info->nT), ns = uniform_i(c.info->ns);
+            int* rslot = c.I(I_SLOT);
+            int* list = c.I(I_LIST);
+            int touched = 0, ndepNow = 0;
+            const int ndel = wg_compact(ns, [&](int sl) { const int r = idx[sl]; return r >= 0 && st[r] == ST_INACT; }, list, c.lds);
+            int cntAdd = 0;
+            for (int r = t; r < mE; r += WG) cntAdd += (st[r] != ST_INACT && rslot[r] < 0);
+            const int nadd = block_sum_i(cntAdd, c.lds);
+            // more active rows than variables while the set still changes by more than n/2 rows per trial: the primal-dual update has
+            // overshot (a cold start far from the solution, where every violated row enters at once) and more trials only thrash with
+            // factors at full rank -- give up and let ADMM produce a working set (oracle: the same rule)
+            if (trial >= 2 && nT - ndel + nadd > c.n && ndel + nadd > c.n / 2) return 0;
+            // in one piece when the factor is empty, when most of it would change, or when promotions dictate the order
+            // (oracle: the same rule; there "in one piece" is a reset followed by appends in list order)
+            const bool bulk = (ROBUST && prioCtr > 0) || (nT == 0 && nadd > 0) || (ndel > 0 && ndel >= max(nT / 2, 8)) || nadd >= 16;
+            int naAll = 0;
+            if (bulk) {
+                int cntAct = 0;
+                for (int r = t; r < mE; r += WG) cntAct += (st[r] != ST_INACT);
+                naAll = block_sum_i(cntAct, c.lds);
+                ti_reset<NCH>(c, nT, ns);
             }
-            int cnt = 0;
-            for (int r = r0; r < r1e; r++) cnt += (st[r] != ST_INACT && (!ROBUST || prioCtr == 0 || prio[r] == 0));
-            // exclusive scan over 256 threads
-            int incl = cnt;
-#pragma unroll
-            for (int ofs = 1; ofs < 64; ofs <<= 1) { int v = __shfl_up(incl, ofs, 64); if (lane_id() >= ofs) incl += v; }
-            if (lane_id() == 63) c.lds.ired[8 + wave_id()] = incl;
-            __syncthreads();
-            int base = 0;
-            for (int w = 0; w < wave_id(); w++) base += c.lds.ired[8 + w];
-            na = uniform_i(c.lds.ired[8] + c.lds.ired[9] + c.lds.ired[10] + c.lds.ired[11]) + nprom;
-            __syncthreads();
-            if (na > capNa) return 0;
-            // the factor of S only depends on the list: reuse it when the list is the one it was built for
-            const int cachedNa = c.info->cacheNa;
-            int pos = nprom + base + incl - cnt;
-            differs |= (cachedNa != na);
-            for (int r = r0; r < r1e; r++)
-                if (st[r] != ST_INACT && (!ROBUST || prioCtr == 0 || prio[r] == 0)) { differs |= (idx[pos] != r); idx[pos++] = r; }
-            nblkS = (na + 63) >> 6;
-            for (int a = na + t; a < 64 * nblkS; a += WG) idx[a] = -1;
-            const int rebuild = block_or(differs, c.lds);
-            if (rebuild) {
-            // S = T T' (lower tiles), T = rows idx[] of Et; padded rows get a unit diagonal
-            for (int Ib = 0; Ib < nblkS; Ib++)
-                for (int Jb = 0; Jb <= Ib; Jb++) {
-                    double acc[4][4];
-                    const int* ia = idx + 64 * Ib;
-                    const int* ib = idx + 64 * Jb;
-                    wg_tile_nt(acc, c.Et, np, [=](int r) { return (long)ia[r]; }, c.Et, np, [=](int r) { return (long)ib[r]; }, np, c.lds, na - 64 * Ib);
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int gi = 64 * Ib + tile_li(i, j), gj = 64 * Jb + tile_lj(i, j);
-                            double v = acc[i][j];
-                            if (gi == gj && gi >= na) v = 1.0;
-                            c.S[(size_t)gi * capS + gj] = v;
-                        }
-                    __syncthreads();
+            if (bulk && naAll <= capNa) {
+                int na2 = 0;
+                if (ROBUST)      // latest promotion first (ascending row index within one), then the rest
+                    for (int stamp = prioCtr; stamp >= 1; stamp--)
+                        na2 += wg_compact(mE, [&](int r) { return st[r] != ST_INACT && prio[r] == stamp; }, idx + na2, c.lds);
+                na2 += wg_compact(mE, [&](int r) { return st[r] != ST_INACT && (!ROBUST || prioCtr == 0 || prio[r] == 0); }, idx + na2, c.lds);
+                ndepNow = ti_bulk<NCH>(c, na2, o.depTau, nT, ns);
+                touched = 1;
+                PROF(c, P_GRAM);
+            } else {
+                // row by row: the usual small change -- or more candidate rows than the factor has room for (most of them
+                // dependent, e.g. duplicated constraints): each is tested against the factor and only independent rows take a slot
+                if (!bulk)
+                    for (int k = 0; k < ndel; k++) {
+                        const int sl = uniform_i(list[k]);
+                        ti_delete<NCH>(c, sl, nT, ns);
+                        touched = 1;
+                    }
+                PROF(c, P_GRAM);
+                for (int stamp = (ROBUST && bulk) ? prioCtr : 0; stamp >= 0; stamp--) {
+                    // stamp > 0: the rows of one promotion; stamp == 0: every active row that is not in the factor yet
+                    const int cnt = wg_compact(mE, [&](int r) { return st[r] != ST_INACT && rslot[r] < 0 && (stamp == 0 || prio[r] == stamp); }, list, c.lds);
+                    for (int k = 0; k < cnt; k++) {
+                        const int r = uniform_i(list[k]);
+                        const int rc = ti_append<NCH>(c, r, o.depTau, capNa, nT, ns);
+                        if (rc < 0) { if (t == 0) { c.info->nT = nT; c.info->ns = ns; } __syncthreads(); return 0; }
+                        if (ROBUST && t == 0) dep[r] = (rc == 0);
+                        ndepNow += (rc == 0);
+                        touched = 1;
+                    }
                 }
-            PROF(c, P_GRAM);
-            if (nblkS > 0) wg_chol(c.S, capS, nblkS, na, o.depTau, c.dscr, d0, nullptr, c.lds, 0);
-            PROF(c, P_CHOL);
-            c.cFact++;
+            }
             if (ROBUST) {
-                // rows the safeguarded factorisation flagged as dependent: the diagonal of the stored inverse blocks is 1/l_aa = 1e-150
-                int nflag = 0;
-                for (int a = t; a < na; a += WG) nflag += (c.S[(size_t)a * capS + a] < 1e-100);
-                nflag = block_sum_i(nflag, c.lds);
-                if (nflag > 0 || uniform_i(c.info->ndep) > 0) {
-                    for (int r = t; r < mE; r += WG) dep[r] = 0;
+                if (ndepNow > 0 || uniform_i(c.info->ndep) > 0) {
                     __syncthreads();
-                    for (int a = t; a < na; a += WG) if (c.S[(size_t)a * capS + a] < 1e-100) dep[idx[a]] = 1;
+                    for (int r = t; r < mE; r += WG) if (st[r] == ST_INACT || rslot[r] >= 0) dep[r] = 0;
                 }
-                if (t == 0) c.info->ndep = nflag;
+                if (t == 0) c.info->ndep = ndepNow;
             }
-            if (t == 0) { c.info->cacheNa = na; c.info->work[2] += (double)na; c.info->work[3] += (double)na * na; }
+            PROF(c, P_CHOL);
+            na = nT; nsl = ns;
+            if (touched) { c.cFact++; if (t == 0) c.info->work[3] += 1.0; }
+            if (t == 0) { c.info->nT = nT; c.info->ns = ns; }
             __syncthreads();
-            }   // rebuild
             fact_valid = 1;
         }
-        // correction:  c = L1^-1 r1 ;  S dy = T c - r2 ;  dx = L1^-T (c - T' dy)
-        for (int a = t; a < 64 * nblkS; a += WG) {
+        // correction:  c = L1^-1 r1 ;  S dy = T c - r2 ;  dx = L1^-T (c - T' dy)      (T: the rows of Et in the slots of the factor)
+        const int nsp = 64 * ((nsl + 63) >> 6);
+        for (int a = t; a < nsp; a += WG) {
             double v = 0.0;
-            if (a < na) { const int r = idx[a]; const double bb = (st[r] == ST_UPPER) ? u[r] : l[r]; v = bb - ex[r]; }
+            const int r = (a < nsl) ? idx[a] : -1;
+            if (r >= 0) { const double bb = (st[r] == ST_UPPER) ? u[r] : l[r]; v = bb - ex[r]; }
             r2[a] = v;
         }
         wg_copy(cv, r1, np);
@@ -482,14 +770,13 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
         wg_trsv(c.F1, np, c.nblk, cv, true, c.lds);
         PROF(c, P_CORR_L1);
         if (na > 0) {
-            wg_rows<NCH>(c.Et, idx, na, cv, dy, nullptr, c.lds, [](int, double) {});
-            for (int a = t; a < 64 * nblkS; a += WG) dy[a] = (a < na) ? dy[a] - r2[a] : 0.0;
+            wg_rows<NCH>(c.Et, idx, nsl, cv, dy, nullptr, c.lds, [](int, double) {});
+            for (int a = t; a < nsp; a += WG) dy[a] = (a < nsl && idx[a] >= 0) ? dy[a] - r2[a] : 0.0;
             __syncthreads();
             PROF(c, P_CORR_ROWS);
-            wg_trsv(c.S, capS, nblkS, dy, true, c.lds);
-            wg_trsv(c.S, capS, nblkS, dy, false, c.lds);
+            ti_apply<NCH>(c, dy, dy, na, nsl);
             PROF(c, P_CORR_S);
-            wg_rows<NCH>(c.Et, idx, na, nullptr, nullptr, dy, c.lds, [&](int i, double s) { du[i] = cv[i] - s; });
+            wg_rows<NCH>(c.Et, idx, nsl, nullptr, nullptr, dy, c.lds, [&](int i, double s) { du[i] = cv[i] - s; });
             PROF(c, P_CORR_ROWS);
         } else {
             wg_copy(du, cv, np);
@@ -497,8 +784,8 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
         wg_trsv(c.F1, np, c.nblk, du, false, c.lds);
         PROF(c, P_CORR_L1);
         for (int i = t; i < np; i += WG) x[i] += du[i];
-        for (int a = t; a < na; a += WG) yt[idx[a]] += dy[a];
-        if (t == 0) { c.info->work[0] += (double)na; c.info->work[1] += (double)na * na; }
+        for (int a = t; a < nsl; a += WG) if (idx[a] >= 0) yt[idx[a]] += dy[a];
+        if (t == 0) { c.info->work[0] += (double)na; c.info->work[1] += (double)na * nsl; }
         __syncthreads();
         c.cCorr++;
     }

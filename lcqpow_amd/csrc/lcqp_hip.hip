@@ -189,6 +189,11 @@ try {
     rc |= dev_alloc(h, &d.F1, B * np * np, true);
     rc |= dev_alloc(h, &d.FK, B * np * np, true);
     rc |= dev_alloc(h, &d.S, B * (size_t)d.capS * d.capS, true);
+    d.mMld = ((d.mEcap + 63) / 64) * 64;
+    rc |= dev_alloc(h, &d.MM, B * (size_t)d.mMld * d.mMld, true);
+    rc |= dev_alloc(h, &d.crow, B * (size_t)d.capS, true);
+    rc |= dev_alloc(h, &d.S2, B * (size_t)d.capS * d.capS, true);
+    rc |= dev_alloc(h, &d.DS, B * (size_t)(d.capS / 64) * 4096, true);
     rc |= dev_alloc(h, &d.D1, B * (size_t)d.nblk * 4096, true);
     rc |= dev_alloc(h, &d.dscr, B * 4096, true);
     rc |= dev_alloc(h, &d.nv, B * V_NUM * np, true);
@@ -439,6 +444,7 @@ static int launch_setup(lcqp_hip_batch* h)
     dispatch_db(h, ID_k_build_K, d.B * ntile);
     dispatch_db(h, ID_k_factor, d.B);
     dispatch_db(h, ID_k_trsm, d.B * ((d.mEcap + 63) / 64));
+    { const int nb = d.mMld / 64; dispatch_db(h, ID_k_build_M, d.B * (nb * (nb + 1) / 2)); }
     HIPCHK(hipGetLastError());
     h->setupDone = true;
     return 0;
@@ -528,8 +534,9 @@ catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothin
 
 // Algorithmic HBM bytes of the last run, from the per-instance work counters:
 //   residual evaluation (trial with sweeps, stats.reserved): Q + E once   8*(n*n + m*n)
-//   correction                  : L1 fwd+bwd + 2 sweeps over the active rows of Et + S fwd+bwd
-//   factorisation               : active rows of Et once + S written and read once
+//   correction                  : L1 fwd+bwd + 2 sweeps over the nT active rows of Et + one fused pass over the inverse factor Ti (nT x ns)
+//   working-set update          : the bytes of Ti read and written by row appends and rotations, and the entries of M read (summed
+//                                 exactly by the kernel, InstInfo::work[2])
 //   ADMM iteration              : LK fwd+bwd + two sweeps over E
 //   LCQP iterate                : one sweep over Q and C (Q*[pk,xk], C*[pk,xk])
 extern "C" double lcqp_hip_batch_algorithmic_bytes(lcqp_hip_batch_t* h)
@@ -546,11 +553,11 @@ try {
     const double bs = 8.0 * N * (N + 2.0);
     double total = 0.0;
     for (int b = 0; b < d.B; b++) {
-        // active rows na of each correction / factorisation are summed by the kernel (InstInfo::work), not estimated
-        const double naC = info[b].work[0], na2C = info[b].work[1], naF = info[b].work[2], na2F = info[b].work[3];
+        // the active rows of each correction and the bytes of each working-set update are summed by the kernel (InstInfo::work), not estimated
+        const double naC = info[b].work[0], tiC = info[b].work[1], updBytes = info[b].work[2];
         total += st[b].reserved * 8.0 * (n * n + m * n);   // trials that swept Q and E (hot-start trials reuse the last residual)
-        total += st[b].corrections * bs + 2.0 * 8.0 * naC * n + 8.0 * (na2C + 2.0 * naC);
-        total += 8.0 * naF * n + 8.0 * na2F;
+        total += st[b].corrections * bs + 2.0 * 8.0 * naC * n + 8.0 * (tiC + 2.0 * naC);
+        total += updBytes;
         total += st[b].admmIter * (bs + 2.0 * 8.0 * m * n);
         total += (st[b].iterTotal + 1) * (2.0 * 8.0 * n * n);   // one sweep over Q and C per LCQP iterate
     }

@@ -70,8 +70,9 @@ __global__ __launch_bounds__(WG) void k_prepare(DevBatch db)
         wg_fill(gphi, 0.0, np);
     }
     {   // no dependent-row flags or promotions survive a new setup (qp_polish<ROBUST>)
-        int *dep = c.I(I_DEP), *prio = c.I(I_PRIO);
-        for (int r = t; r < db.mEcap; r += WG) { dep[r] = 0; prio[r] = 0; }
+        int *dep = c.I(I_DEP), *prio = c.I(I_PRIO), *rslot = c.I(I_SLOT);
+        for (int r = t; r < db.mEcap; r += WG) { dep[r] = 0; prio[r] = 0; rslot[r] = -1; }
+        for (int a = t; a < db.capS; a += WG) c.idx[a] = -1;      // the inverse factor of the working-set matrix starts empty
     }
     if (t == 0) {
         c.info->prioCtr = 0;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(WG) void k_prepare(DevBatch db)
         c.info->rhoAdmm = rho;
         c.info->phiConst = phiConst;
         c.info->haveSolution = 0;
-        c.info->cacheNa = -1;
+        c.info->nT = 0; c.info->ns = 0;
         c.info->setupFail = 0;
         c.info->isSetup = 1;
     }
@@ -236,6 +237,35 @@ __global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
     }
 }
 
+// ---- k_build_M: M = Et Et' (lower 64x64 tiles, mirrored): every entry of every working-set matrix S_W = Et_W Et_W' ------------
+// (fp64 MFMA tiles; replaces the Gram products the subsolver used to repeat at every working-set change)
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_build_M(DevBatch db)
+{
+    LCQP_LDS_N(NCH)
+    constexpr int np = 128 * NCH;
+    const int nb = db.mMld / 64, ntile = nb * (nb + 1) / 2;
+    const int b = blockIdx.x / ntile, tIdx = blockIdx.x % ntile;
+    int I, J;
+    tri_tile(tIdx, I, J);
+    const InstInfo* info = db.info + b;
+    const int mE = info->mE;
+    if (64 * J >= mE) return;       // I >= J: both row blocks beyond the rows in use
+    const double* Et = db.Et + (size_t)b * db.mEcap * np;
+    double* M = db.MM + (size_t)b * db.mMld * db.mMld;
+    double acc[4][4];
+    wg_tile_nt(acc, Et, np, [=](int r) { return (long)(64 * I + r < mE ? 64 * I + r : -1); },
+               Et, np, [=](int r) { return (long)(64 * J + r < mE ? 64 * J + r : -1); }, np, lds);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int gi = 64 * I + tile_li(i, j), gj = 64 * J + tile_lj(i, j);
+            M[(size_t)gi * db.mMld + gj] = acc[i][j];
+            if (I != J) M[(size_t)gj * db.mMld + gi] = acc[i][j];      // inside a diagonal tile both (i,j) and (j,i) are computed
+        }
+}
+
 // ---- the homotopy megakernel: one persistent workgroup per LCQP -----------------------------------
 #ifndef LCQP_MINWAVES
 #define LCQP_MINWAVES 4      // waves per SIMD the register allocation is held to (4 workgroups per CU)
@@ -255,9 +285,10 @@ __global__ __launch_bounds__(WG, 4) void k_lcqp_rerun(DevBatch db, const int* li
 {
     LCQP_LDS_N(NCH)
     Ctx<NCH> c = make_ctx<NCH>(db, list[blockIdx.x], lds);
-    int *dep = c.I(I_DEP), *prio = c.I(I_PRIO);
-    for (int r = threadIdx.x; r < db.mEcap; r += WG) { dep[r] = 0; prio[r] = 0; }
-    if (threadIdx.x == 0) { c.info->haveSolution = 0; c.info->cacheNa = -1; c.info->prioCtr = 0; c.info->ndep = 0; }
+    int *dep = c.I(I_DEP), *prio = c.I(I_PRIO), *rslot = c.I(I_SLOT);
+    for (int r = threadIdx.x; r < db.mEcap; r += WG) { dep[r] = 0; prio[r] = 0; rslot[r] = -1; }
+    for (int a = threadIdx.x; a < db.capS; a += WG) c.idx[a] = -1;
+    if (threadIdx.x == 0) { c.info->haveSolution = 0; c.info->nT = 0; c.info->ns = 0; c.info->prioCtr = 0; c.info->ndep = 0; }
     __syncthreads();
     lcqp_run<NCH, true>(c);
 }
@@ -414,6 +445,7 @@ static void launch_impl(int kid, int grid, hipStream_t s, const LaunchArgs& a)
         case ID_k_build_K:    hipLaunchKernelGGL((k_build_K<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_factor:     hipLaunchKernelGGL((k_factor<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_trsm:       hipLaunchKernelGGL((k_trsm<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
+        case ID_k_build_M:    hipLaunchKernelGGL((k_build_M<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_lcqp_run:   hipLaunchKernelGGL((k_lcqp_run<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_lcqp_rerun: hipLaunchKernelGGL((k_lcqp_rerun<NCH>), dim3(grid), dim3(WG), 0, s, a.db, a.list); break;
         case ID_k_qp_solve:   hipLaunchKernelGGL((k_qp_solve<NCH>), dim3(grid), dim3(WG), 0, s, a.db, a.initial); break;

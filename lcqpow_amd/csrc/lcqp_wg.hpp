@@ -117,6 +117,29 @@ __device__ __forceinline__ int block_sum_i(int v, Lds lds)
     return uniform_i(r);
 }
 
+// Ordered compaction: out[0..min(count, cap)) = the indices i in [0, N) with pred(i), ascending; returns count (uniform).
+// Each thread scans a contiguous chunk; exclusive scan over the 256 per-thread counts.  out: global memory.  Ends with a barrier.
+template <class Pred>
+__device__ __forceinline__ int wg_compact(int N, Pred pred, int* out, Lds lds, int cap = 1 << 30)
+{
+    const int per = (N + WG - 1) / WG;
+    const int i0 = threadIdx.x * per, i1 = min(N, i0 + per);
+    int cnt = 0;
+    for (int i = i0; i < i1; i++) cnt += pred(i) ? 1 : 0;
+    int incl = cnt;
+#pragma unroll
+    for (int ofs = 1; ofs < 64; ofs <<= 1) { const int v = __shfl_up(incl, ofs, 64); if (lane_id() >= ofs) incl += v; }
+    if (lane_id() == 63) lds.ired[8 + wave_id()] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave_id(); w++) base += lds.ired[8 + w];
+    const int total = uniform_i(lds.ired[8] + lds.ired[9] + lds.ired[10] + lds.ired[11]);
+    int pos = base + incl - cnt;
+    for (int i = i0; i < i1; i++) if (pred(i)) { if (pos < cap) out[pos] = i; pos++; }     // entries beyond cap are counted, not stored
+    __syncthreads();
+    return total;
+}
+
 // ---------------------------------------------------------------------------------------------
 // small vector helpers (global -> global, length a multiple of nothing in particular)
 // ---------------------------------------------------------------------------------------------

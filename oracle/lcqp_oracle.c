@@ -239,16 +239,25 @@ struct orc_qp {
     /* ADMM state */
     double *xa, *ya, *za;
     /* scratch */
-    double *w_n1, *w_n2, *w_n3, *w_m1, *T, *S, *w_a1, *w_a2;
+    double *w_n1, *w_n2, *w_n3, *w_m1, *w_a1, *w_a2, *w_a3, *w_a4;
+    /* The working-set system S dy = t, S = Et_W Et_W', is solved with an inverse factor that is UPDATED when rows enter or
+     * leave the working set W (what qpOASES does with its factors on a hot start, src/SubsolverQPOASES.cpp:158):
+     *   Ti (nT rows x ns slots) with Ti'Ti = inv(S_W);  slot_row[s] = row of E held by slot s (-1: free), row_slot = its inverse,
+     *   crow[s] = the row of Ti that was appended together with slot s (column s is zero in the rows above it);
+     *   the entries of S are dot products of rows of Et (the device reads them from M = Et Et', built once at setup by k_build_M). */
+    double *Ti;
+    int *slot_row, *row_slot, *crow;
+    int nT, ns;
+    double upd_bytes;   /* bytes of Ti read or written by updates (device byte accounting) */
     double *r1_last, *ex_last, *g_last; /* residual, E x and linear term of the last verified solution */
-    int *idx, *newst, *idx_new;
+    int *newst;
     double *dy_last, *dx_last; /* change of (ya, xa) in the last ADMM iteration: OSQP's infeasibility certificates */
     /* dependent-row rules of the single-QP path (SubsolverHIP / k_qp_solve); the batched homotopy kernel runs without them */
     int robust;
     int *dep;      /* per row: 1 = flagged linearly dependent by the last factorisation of S, 2 = left because of it */
     int *prio;     /* per row: 0, or the stamp of the trial that promoted the row to the front of the active list */
     int prio_ctr;
-    int cap_na, cache_na; /* cache_na: active rows the stored factor of S belongs to (-1: none) */
+    int cap_na;
     /* outputs */
     double *xsol, *ysol;
     /* counters */
@@ -274,13 +283,15 @@ static void qp_free_setup(orc_qp_t* q)
 {
     free(q->boxidx); free(q->E); free(q->Et); free(q->l); free(q->u); free(q->rhov);
     free(q->L1); free(q->LK); free(q->x); free(q->y); free(q->st); free(q->xa); free(q->ya); free(q->za);
-    free(q->w_n1); free(q->w_n2); free(q->w_n3); free(q->w_m1); free(q->T); free(q->S); free(q->w_a1); free(q->w_a2);
+    free(q->w_n1); free(q->w_n2); free(q->w_n3); free(q->w_m1); free(q->w_a1); free(q->w_a2); free(q->w_a3); free(q->w_a4);
+    free(q->Ti); free(q->slot_row); free(q->row_slot); free(q->crow);
+    q->Ti = NULL; q->slot_row = q->row_slot = q->crow = NULL;
     free(q->dy_last); free(q->dx_last); q->dy_last = q->dx_last = NULL;
-    free(q->idx); free(q->newst); free(q->idx_new); free(q->dep); free(q->prio); q->dep = q->prio = NULL; free(q->r1_last); free(q->ex_last); free(q->g_last);
-    q->idx_new = NULL; q->r1_last = q->ex_last = q->g_last = NULL;
+    free(q->newst); free(q->dep); free(q->prio); q->dep = q->prio = NULL; free(q->r1_last); free(q->ex_last); free(q->g_last);
+    q->r1_last = q->ex_last = q->g_last = NULL;
     q->boxidx = NULL; q->E = q->Et = q->l = q->u = q->rhov = q->L1 = q->LK = q->x = q->y = NULL;
-    q->st = NULL; q->xa = q->ya = q->za = q->w_n1 = q->w_n2 = q->w_n3 = q->w_m1 = q->T = q->S = q->w_a1 = q->w_a2 = NULL;
-    q->idx = q->newst = NULL;
+    q->st = NULL; q->xa = q->ya = q->za = q->w_n1 = q->w_n2 = q->w_n3 = q->w_m1 = q->w_a1 = q->w_a2 = q->w_a3 = q->w_a4 = NULL;
+    q->newst = NULL;
     q->is_setup = 0;
 }
 
@@ -383,17 +394,18 @@ static int qp_setup(orc_qp_t* q, const double* lbA, const double* ubA, const dou
     if (q->cap_na > mE) q->cap_na = mE;
     { const int lim = n > 512 ? 1216 : 896;   /* the device keeps the active-row solves in LDS (max_active(NCH)); binds for nV > 448 only */
       if (q->cap_na > lim) q->cap_na = lim; }
-    q->T = dalloc((size_t)q->cap_na * n);
-    q->S = dalloc((size_t)q->cap_na * q->cap_na);
-    q->w_a1 = dalloc(q->cap_na); q->w_a2 = dalloc(q->cap_na);
-    q->idx = (int*)calloc(q->cap_na ? q->cap_na : 1, sizeof(int));
+    q->w_a1 = dalloc(q->cap_na); q->w_a2 = dalloc(q->cap_na); q->w_a3 = dalloc(q->cap_na); q->w_a4 = dalloc(q->cap_na);
     q->newst = (int*)calloc(mE ? mE : 1, sizeof(int));
     q->dy_last = dalloc(mE); q->dx_last = dalloc(n);
     q->dep = (int*)calloc(mE ? mE : 1, sizeof(int));
     q->prio = (int*)calloc(mE ? mE : 1, sizeof(int));
     q->prio_ctr = 0;
-    q->idx_new = (int*)calloc(q->cap_na ? q->cap_na : 1, sizeof(int));
-    q->cache_na = -1;
+    q->Ti = dalloc((size_t)q->cap_na * q->cap_na);
+    q->slot_row = (int*)calloc(q->cap_na ? q->cap_na : 1, sizeof(int));
+    q->crow = (int*)calloc(q->cap_na ? q->cap_na : 1, sizeof(int));
+    q->row_slot = (int*)calloc(mE ? mE : 1, sizeof(int));
+    for (int r = 0; r < mE; r++) q->row_slot[r] = -1;
+    q->nT = q->ns = 0;
     q->r1_last = dalloc(n); q->ex_last = dalloc(mE); q->g_last = dalloc(n);
     q->have_solution = 0;
     q->is_setup = 1;
@@ -608,6 +620,94 @@ static void qp_guess_from_admm(orc_qp_t* q, int* st)
     }
 }
 
+/* ---- inverse factor of the working-set matrix (see struct orc_qp) --------------------------------------------------------- */
+static void ti_reset(orc_qp_t* q)
+{
+    for (int s = 0; s < q->ns; s++) if (q->slot_row[s] >= 0) q->row_slot[q->slot_row[s]] = -1;
+    q->nT = q->ns = 0;
+}
+
+/* dy = Ti' (Ti t) over the slots in use (t is zero on free slots) */
+static void ti_apply(const orc_qp_t* q, const double* t, double* dy)
+{
+    const int ld = q->cap_na, ns = q->ns;
+    for (int s = 0; s < ns; s++) dy[s] = 0.0;
+    for (int j = 0; j < q->nT; j++) {
+        const double* row = q->Ti + (size_t)j * ld;
+        double u = 0;
+        for (int s = 0; s < ns; s++) u += row[s] * t[s];
+        for (int s = 0; s < ns; s++) dy[s] += row[s] * u;
+    }
+}
+
+/* Row r enters: with s = S_W,r (entries of M), w = inv(S_W) s and delta^2 = S_rr - s'w (the Schur complement = the squared
+ * Cholesky pivot of the row behind the rows of W), the new last row of Ti is [-w'/delta, 1/delta].  delta^2 <= tau S_rr: the row
+ * is linearly dependent on W -- it stays out of the factor, its multiplier is not moved and its equation not enforced
+ * (returns 0).  Returns 1 when appended, -1 when the factor is full. */
+static int ti_append(orc_qp_t* q, int r, double tau)
+{
+    const int ld = q->cap_na, n = q->nV;
+    double *sv = q->w_a1, *w = q->w_a3;
+    const double* tr = q->Et + (size_t)r * n;
+    for (int s = 0; s < q->ns; s++) {
+        double sdot = 0;
+        if (q->slot_row[s] >= 0) { const double* ts = q->Et + (size_t)q->slot_row[s] * n; for (int k = 0; k < n; k++) sdot += tr[k] * ts[k]; }
+        sv[s] = sdot;
+    }
+    ti_apply(q, sv, w);
+    double srr = 0;
+    for (int k = 0; k < n; k++) srr += tr[k] * tr[k];
+    double d2 = srr;
+    for (int s = 0; s < q->ns; s++) d2 -= sv[s] * w[s];
+    q->upd_bytes += 8.0 * ((double)q->nT * q->ns + 2.0 * q->ns);
+    if (!(d2 > tau * srr) || !(d2 > 0.0)) return 0;
+    int snew = -1;
+    for (int s = 0; s < q->ns; s++) if (q->slot_row[s] < 0) { snew = s; break; }
+    if (snew < 0) {
+        if (q->ns >= q->cap_na) return -1;
+        snew = q->ns++;
+        for (int j = 0; j < q->nT; j++) q->Ti[(size_t)j * ld + snew] = 0.0;      /* a fresh column */
+    }
+    const double delta = sqrt(d2);
+    double* row = q->Ti + (size_t)q->nT * ld;
+    for (int s = 0; s < q->ns; s++) row[s] = (q->slot_row[s] >= 0) ? -w[s] / delta : 0.0;
+    row[snew] = 1.0 / delta;
+    q->slot_row[snew] = r; q->row_slot[r] = snew; q->crow[snew] = q->nT;
+    q->nT++;
+    return 1;
+}
+
+/* The row held by slot p leaves: rotations of neighbouring rows of Ti, from the row that created the slot downwards, move
+ * column p into the last row, which is dropped (Ti'Ti then is the inverse of S without row and column p).  The rotations
+ * follow from column p alone: rho_j = hypot(rho_{j-1}, Ti[j][p]). */
+static void ti_delete(orc_qp_t* q, int p)
+{
+    const int ld = q->cap_na, ns = q->ns, i0 = q->crow[p], nT = q->nT;
+    double* carry = q->w_a1;
+    memcpy(carry, q->Ti + (size_t)i0 * ld, sizeof(double) * ns);
+    double rho = carry[p];
+    for (int j = i0 + 1; j < nT; j++) {
+        double* rj = q->Ti + (size_t)j * ld;
+        const double b = rj[p], rn = hypot(rho, b);
+        double cs = 1.0, sn = 0.0;
+        if (rn > 0.0) { cs = b / rn; sn = -rho / rn; }
+        double* out = q->Ti + (size_t)(j - 1) * ld;
+        for (int s = 0; s < ns; s++) {
+            const double cv = carry[s], rv = rj[s];
+            out[s] = cs * cv + sn * rv;
+            carry[s] = cs * rv - sn * cv;
+        }
+        out[p] = 0.0;
+        rho = rn;
+    }
+    q->upd_bytes += 8.0 * 2.0 * (double)(nT - i0) * ns;
+    const int r = q->slot_row[p];
+    q->slot_row[p] = -1; q->row_slot[r] = -1;
+    q->nT = nT - 1;
+    for (int s = 0; s < ns; s++) if (q->slot_row[s] >= 0 && q->crow[s] > i0) q->crow[s]--;
+    while (q->ns > 0 && q->slot_row[q->ns - 1] < 0) q->ns--;      /* free slots at the end are given back */
+}
+
 /* Primal-dual active-set polish in correction (iterative refinement) form.
  * Start: x, yfull (OSQP sign, zero on inactive rows), active set st.  Each trial evaluates the true KKT
  * residuals (one pass over Q and E), tests optimality, else updates the active set (all violated rows
@@ -625,7 +725,8 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
     double gmax = 0;
     for (int i = 0; i < n; i++) { double a = fabs(g[i]); if (a > gmax) gmax = a; }
     const double gs = 1.0 + gmax;
-    double *r1 = q->w_n1, *c = q->w_n2, *du = q->w_n3, *Ex = q->w_m1, *r2 = q->w_a1, *dy = q->w_a2;
+    double *r1 = q->w_n1, *c = q->w_n2, *du = q->w_n3, *Ex = q->w_m1;
+    double* dy = q->w_a4;
     int na = 0, fact_valid = 0;
 
     for (int trial = 0; trial < o->maxTrials; trial++) {
@@ -712,68 +813,73 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
             fact_valid = 0;
         }
         if (!fact_valid) {
-            na = 0;
-            /* promoted rows first (latest promotion first, ascending row index within one promotion), then the rest */
-            for (int stamp = robust ? q->prio_ctr : 0; stamp >= 1; stamp--)
-                for (int r = 0; r < mE; r++)
-                    if (st[r] != ST_INACT && q->prio[r] == stamp) {
-                        if (na >= q->cap_na) return 0;
-                        q->idx_new[na++] = r;
-                    }
-            for (int r = 0; r < mE; r++)
-                if (st[r] != ST_INACT && (!robust || q->prio[r] == 0)) {
-                    if (na >= q->cap_na) return 0;
-                    q->idx_new[na++] = r;
-                }
-            /* the factor of S depends only on the ordered list of active rows: reuse it when unchanged */
-            int differs = (q->cache_na != na);
-            for (int a = 0; a < na && !differs; a++) differs = (q->idx[a] != q->idx_new[a]);
-            if (!differs) { fact_valid = 1; }
-        }
-        if (!fact_valid) {
-            memcpy(q->idx, q->idx_new, sizeof(int) * na);
-            q->cache_na = na;
-            for (int a = 0; a < na; a++) memcpy(q->T + (size_t)a * n, q->Et + (size_t)q->idx[a] * n, sizeof(double) * n);
-            for (int a = 0; a < na; a++)
-                for (int b2 = 0; b2 <= a; b2++) {
-                    const double *ta = q->T + (size_t)a * n, *tb = q->T + (size_t)b2 * n;
-                    double s = 0;
-                    for (int k = 0; k < n; k++) s += ta[k] * tb[k];
-                    q->S[(size_t)a * na + b2] = s;
-                }
-            safe_chol(q->S, na, o->depTau);
-            if (robust) {
-                memset(q->dep, 0, sizeof(int) * mE);
-                for (int a = 0; a < na; a++) if (q->S[(size_t)a * na + a] > 1e100) q->dep[q->idx[a]] = 1;
+            /* bring the inverse factor to the working set st[]: rows that left are rotated out, rows that entered (and rows
+             * flagged dependent earlier, which may have become independent) are appended in ascending row order */
+            int touched = 0, ndel = 0, nadd = 0;
+            for (int sl = 0; sl < q->ns; sl++) if (q->slot_row[sl] >= 0 && st[q->slot_row[sl]] == ST_INACT) ndel++;
+            for (int r = 0; r < mE; r++) if (st[r] != ST_INACT && q->row_slot[r] < 0) nadd++;
+            /* more active rows than variables while the set still changes by more than n/2 rows per trial: the primal-dual update has
+             * overshot (a cold start far from the solution, where every violated row enters at once) and more trials only thrash
+             * with factors at full rank -- give up and let ADMM produce a working set */
+            if (trial >= 2 && q->nT - ndel + nadd > n && ndel + nadd > n / 2) return 0;
+            /* from scratch when the factor is empty, when most of it would change, or when promotions dictate the order (the
+             * device builds the factor in one piece then: blocked Cholesky and blocked triangular inverse, ti_bulk) */
+            const int bulk = (robust && q->prio_ctr > 0) || (q->nT == 0 && nadd > 0) || (ndel > 0 && ndel >= (q->nT / 2 > 8 ? q->nT / 2 : 8))
+                             || nadd >= 16;
+            if (bulk) {
+                ti_reset(q); touched = 1;
+                /* promotions: latest first (ascending row index within one), so that a row OTHER than the promoted one is
+                 * found dependent; then the rest in ascending order (the loop below) */
+                for (int stamp = robust ? q->prio_ctr : 0; stamp >= 1; stamp--)
+                    for (int r = 0; r < mE; r++)
+                        if (st[r] != ST_INACT && q->prio[r] == stamp) {
+                            const int rc = ti_append(q, r, o->depTau);
+                            if (rc < 0) return 0;
+                            q->dep[r] = (rc == 0);
+                        }
+            } else {
+                for (int sl = 0; sl < q->ns; sl++)
+                    if (q->slot_row[sl] >= 0 && st[q->slot_row[sl]] == ST_INACT) { ti_delete(q, sl); touched = 1; }
             }
-            q->c_fact++;
+            for (int r = 0; r < mE; r++) {
+                if (st[r] == ST_INACT) { q->dep[r] = (robust && q->dep[r] == 2) ? 2 : 0; continue; }
+                if (q->row_slot[r] >= 0) continue;
+                const int rc = ti_append(q, r, o->depTau);
+                if (rc < 0) return 0;
+                q->dep[r] = (rc == 0);
+                touched = 1;
+            }
+            na = q->nT;
+            if (touched) q->c_fact++;
             fact_valid = 1;
         }
-        /* correction:  c = L1^-1 r1 ;  S dy = T c - r2 ;  dx = L1^-T (c - T' dy) */
-        for (int a = 0; a < na; a++) {
-            int r = q->idx[a];
-            double b = (st[r] == ST_UPPER) ? q->u[r] : q->l[r];
-            r2[a] = b - Ex[r];
-        }
+        /* correction:  c = L1^-1 r1 ;  S dy = T c - r2 ;  dx = L1^-T (c - T' dy)   (T = rows of Et in the slots of the factor) */
+        const int nsl = q->ns;
+        double* tv = q->w_a2;
         memcpy(c, r1, sizeof(double) * n);
         trsv_lower(q->L1, n, c);
-        for (int a = 0; a < na; a++) {
-            const double* ta = q->T + (size_t)a * n;
-            double s = 0;
-            for (int k = 0; k < n; k++) s += ta[k] * c[k];
-            dy[a] = s - r2[a];
+        for (int sl = 0; sl < nsl; sl++) {
+            const int r = q->slot_row[sl];
+            if (r < 0) { tv[sl] = 0.0; continue; }
+            const double bb = (st[r] == ST_UPPER) ? q->u[r] : q->l[r];
+            const double* ta = q->Et + (size_t)r * n;
+            double sdot = 0;
+            for (int k = 0; k < n; k++) sdot += ta[k] * c[k];
+            tv[sl] = sdot - (bb - Ex[r]);
         }
-        if (na > 0) { trsv_lower(q->S, na, dy); trsv_lower_t(q->S, na, dy); }
+        ti_apply(q, tv, dy);
         memcpy(du, c, sizeof(double) * n);
-        for (int a = 0; a < na; a++) {
-            const double* ta = q->T + (size_t)a * n;
-            double v = dy[a];
-            if (v == 0.0) continue;
+        for (int sl = 0; sl < nsl; sl++) {
+            const int r = q->slot_row[sl];
+            if (r < 0 || dy[sl] == 0.0) continue;
+            const double* ta = q->Et + (size_t)r * n;
+            const double v = dy[sl];
             for (int k = 0; k < n; k++) du[k] -= ta[k] * v;
         }
         trsv_lower_t(q->L1, n, du);
         for (int i = 0; i < n; i++) x[i] += du[i];
-        for (int a = 0; a < na; a++) yfull[q->idx[a]] += dy[a];
+        for (int sl = 0; sl < nsl; sl++) if (q->slot_row[sl] >= 0) yfull[q->slot_row[sl]] += dy[sl];
+        (void)na;
         q->c_corr++;
     }
     return 0;

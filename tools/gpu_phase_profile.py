@@ -37,3 +37,8 @@ it = np.array([s["iterTotal"] for s in st], dtype=float)
 print("correlation of cycles with LCQP iterates: %.3f; iterates min/mean/max %d/%.1f/%d" % (np.corrcoef(tot, it)[0, 1], it.min(), it.mean(), it.max()))
 for k, nme in enumerate(names):
     print(f"  {nme:28s} {100 * prof[:, k].astype(float).sum() / tot.sum():6.2f} %")
+order = np.argsort(-tot)[:6]
+for b in order:
+    s = st[b]
+    print(f"  slow instance {b}: cycles {tot[b]:.3e} iter {s['iterTotal']} trials {s['trials']} sweeps {s['reserved']} updates {s['factorizations']} corr {s['corrections']} admm {s['admmIter']} ret {s['returnValue']}"
+          f" | shares: " + " ".join(f"{100 * prof[b, k] / tot[b]:.0f}" for k in range(9)))
