@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- LCQPs/sec of the batched dense penalty-homotopy path on MI355X (BASELINE.json metric).
+"""bench.py -- LCQPs/sec of the batched penalty-homotopy path on MI355X (BASELINE.json metric).
 
-A "step" is one complete solve of one synthetic batch per GPU: B = 1024 dense LCQPs with n = 256,
-nC = 512, nComp = 64 (BASELINE.json configs[2]), generated directly in HBM before the timed region
-(include/lcqp_synth.h).  Every step re-runs everything runSolver does: constant-matrix setup (C, the two
-factorisations, Et) and the homotopy megakernel from x0 = 0.
+Default workload (BASELINE configs[2]): a "step" is one complete solve of one synthetic batch per GPU, B = 1024 dense LCQPs with
+n = 256, nC = 512, nComp = 64, generated directly in HBM before the timed region (include/lcqp_synth.h).  Every step re-runs
+everything runSolver does: constant-matrix setup (C, the two factorisations, Et, M = Et Et') and the homotopy kernel from x0 = 0.
+--workload sparse (BASELINE configs[4]): B sparse LCQPs with n = 4096, nC = 2048, nComp = 512 of one banded pattern
+(tests/problems.py), uploaded before the timed region; a step = KKT factorisation + homotopy for every instance.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): independent instances are sharded over
-the ranks (rank r solves instance ids [r*B, (r+1)*B)); there is no data-path collective, RCCL is used
-only for the barrier and the max-over-ranks of the step time ("scaling": "weak").
+N > 1: independent instances are sharded over the GPUs (GPU r solves instance ids [r*B, (r+1)*B)); there is no data-path
+collective and no RCCL anywhere.  Two ways to get N GPUs:
+  * `python bench.py --gpus N` on its own drives the N devices of the node from this one process (one batch object and stream
+    per device; the C ABI takes the device index) and exits non-zero when fewer than N devices are visible;
+  * under torch.distributed.run (the driver's launcher, one rank per GPU) the ranks meet on a gloo (CPU) process group for the
+    barrier, the max-over-ranks of the step time and the sum of solved counts.
 
 One JSON line is printed by rank 0 (contract in the task description) with two extra objects:
-  roofline      HBM roofline of the dominant kernel (k_lcqp_run), algorithmic bytes from the work
-                counters the kernel keeps, duration from HIP events on the launch stream.
-  cpu_baseline  the CPU oracle (a port of the same algorithm; the reference's qpOASES path cannot be
-                built here) on a bounded sample of the same workload, all host cores.
+  roofline      HBM roofline of the dominant kernel, algorithmic bytes from the work counters the kernel keeps, duration from
+                HIP events on the launch stream.
+  cpu_baseline  the CPU oracle (a port of the same algorithm; the reference's qpOASES / OSQP paths cannot be built here) on a
+                bounded sample of the same workload, all host cores.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -27,6 +32,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+KERNEL_SOURCES = ("lcqp_hip.hip", "lcqp_nch.hip", "lcqp_kernels.hpp", "lcqp_launch.hpp", "lcqp_dev.hpp", "lcqp_wg.hpp", "lcqp_sparse.hip")
 
 
 def shard_range(rank, world, per_rank):
@@ -35,17 +41,49 @@ def shard_range(rank, world, per_rank):
     return first, first + per_rank
 
 
-def pmc_traffic(B, n, nC, nComp):
-    """HBM bytes per k_lcqp_run launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/round1/README.md: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes); counters cannot be
-    read from inside an un-profiled run, so the value is null for any other workload or when the file is absent."""
-    if (B, n, nC, nComp) != (1024, 256, 512, 64):
-        return None
+def kernel_source_hash():
+    """sha256 over the kernel sources: identifies the binary a rocprofv3 PMC pass was taken on (profiles/latest_traffic.json)"""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "lcqpow_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload, B, shape):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes ((2*FETCH_SIZE + WRITE_SIZE)*1024,
+    separate --pmc passes, MI355X_MICROARCH.md §HBM).  Counters cannot be read from inside an un-profiled run, so the value is
+    null unless the committed figure was taken on exactly these kernel sources and this workload."""
     try:
         with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
-            return float(json.load(f)["traffic_bytes_guide_recipe"])
+            t = json.load(f)
+        if t.get("source_hash") == kernel_source_hash() and t.get("workload") == [workload, B] + list(shape):
+            return float(t["traffic_bytes_guide_recipe"])
     except Exception:
-        return None
+        pass
+    return None
+
+
+def run_devices(devices, make_batch, steps, warmup, barrier):
+    """warm-up, then `steps` timed steps on every device of this process (asynchronous launches on one stream per device,
+    then a join); returns (elapsed s, batches, per-device list of (setup ms, solve ms) sums)"""
+    bts = [make_batch(d) for d in devices]
+    for bt in bts:
+        bt.synchronize()
+    for _ in range(warmup):
+        for bt in bts:
+            bt.run()
+    barrier(bts)
+    t0 = time.perf_counter()
+    tsum = [[0.0, 0.0] for _ in bts]
+    for _ in range(steps):
+        for bt in bts:
+            bt.run()                                  # returns after the launches
+        for k, bt in enumerate(bts):
+            s_ms, k_ms = bt.last_timing()             # HIP events on the launch stream (waits for the step)
+            tsum[k][0] += s_ms; tsum[k][1] += k_ms
+    barrier(bts)
+    return time.perf_counter() - t0, bts, tsum
 
 
 def main():
@@ -53,111 +91,145 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
-    ap.add_argument("--n", type=int, default=256)
-    ap.add_argument("--nC", type=int, default=512)
-    ap.add_argument("--nComp", type=int, default=64)
+    ap.add_argument("--workload", choices=("dense", "sparse"), default="dense")
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default 1024 dense, 8192 sparse: one wave per instance, 8 waves per SIMD resident)")
+    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--nC", type=int, default=None)
+    ap.add_argument("--nComp", type=int, default=None)
     ap.add_argument("--cpu-sample", type=int, default=64, help="instances of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-backsolve", action="store_true", help="skip the standalone back-solve kernel measurement")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-batches-in-flight measurement")
+    ap.add_argument("--no-resident", action="store_true", help="skip the 8192-resident-instances measurement")
     args = ap.parse_args()
+    sparse = args.workload == "sparse"
+    B = args.batch or (8192 if sparse else 1024)
+    n = args.n or (4096 if sparse else 256)
+    nC = args.nC if args.nC is not None else (2048 if sparse else 512)
+    nComp = args.nComp or (512 if sparse else 64)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    launched = world_env > 1 or "TORCHELASTIC_RUN_ID" in os.environ
+    if launched and world_env != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
 
     import numpy as np
-    import torch
     import lcqpow_amd as la
 
+    ndev = la.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     dist = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
-        # launched by torch.distributed.run: one rank per GPU over RCCL (backend "nccl" is RCCL on ROCm)
+    if launched:
+        # one rank per GPU; the control plane is a gloo (CPU) group: barrier, max of the step time, sum of the solved counts
+        import torch
         import torch.distributed as dist_
         dist = dist_
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if la.device_count() < 1:
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+        dist.init_process_group(backend="gloo")
+        devices, world = [local_rank], world_env
+        if local_rank >= ndev:
+            raise SystemExit(f"rank {rank}: device {local_rank} requested, {ndev} visible")
+    else:
+        if args.gpus > ndev:
+            raise SystemExit(f"--gpus {args.gpus} requested but only {ndev} device(s) visible: refusing to report a smaller run")
+        devices, world = list(range(args.gpus)), args.gpus
 
-    B, n, nC, nComp = args.batch, args.n, args.nC, args.nComp
     opt = la.default_options(perturbStep=0, printLevel=0)     # defaults except these two
-    bt = la.BatchLCQP(B, n, nC, nComp, device=local_rank, opt=opt)
-    first, _ = shard_range(rank, world, B)
-    bt.generate_synthetic(first)
-    bt.synchronize()
 
-    def barrier():
-        bt.synchronize()
-        torch.cuda.synchronize()
+    if sparse:
+        import problems as P
+        Qpat, Apat = P.sparse_pattern(n, nC, nComp)
+
+        def make_batch(dev):
+            gidx = devices.index(dev) if not launched else rank
+            first, _ = shard_range(gidx, world, B)
+            inst = [P.sparse_instance(first + i, n, nC, nComp) for i in range(B)]
+            sb = la.SparseBatchLCQP(B, n, nC, nComp, Qpat, Apat, device=dev, opt=opt)
+            rc = sb.load(0, B, np.stack([d["Q"].data for d in inst]), np.stack([d["g"] for d in inst]), np.stack([d["E"].data for d in inst]),
+                         lbA=np.stack([d["lbA"] for d in inst]), ubA=np.stack([d["ubA"] for d in inst]))
+            if rc != 0:
+                raise SystemExit(f"sparse load failed: {rc}")
+            return sb
+    else:
+        def make_batch(dev):
+            gidx = devices.index(dev) if not launched else rank
+            first, _ = shard_range(gidx, world, B)
+            bt = la.BatchLCQP(B, n, nC, nComp, device=dev, opt=opt)
+            bt.generate_synthetic(first)
+            return bt
+
+    def barrier(bts):
+        for bt in bts:
+            bt.synchronize()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        bt.run()
-    barrier()
-    t0 = time.perf_counter()
-    setup_ms = solve_ms = 0.0
-    for _ in range(args.steps):
-        bt.run()
-        s_ms, k_ms = bt.last_timing()      # HIP events on the launch stream (also waits for the step)
-        setup_ms += s_ms
-        solve_ms += k_ms
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, bts, tsum = run_devices(devices, make_batch, args.steps, args.warmup, barrier)
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    x, y, st = bt.solution()
-    n_ok = sum(1 for s in st if s["returnValue"] == 0)
-    alg_bytes = bt.algorithmic_bytes()                      # per launch of k_lcqp_run (last step)
-    kernel_s = (solve_ms / args.steps) * 1e-3
-    achieved = alg_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
-    mean = lambda k: float(np.mean([s[k] for s in st]))
-    ws = bt.work_sums()
-    n_corr = max(1, sum(s["corrections"] for s in st)); n_fact = max(1, sum(s["factorizations"] for s in st))
-
+    bt = bts[0]
+    sols = [b_.solution() for b_ in bts]
+    x, y, st = sols[0]
+    n_ok = sum(sum(1 for s in so[2] if s["returnValue"] == 0) for so in sols)
     if dist is not None:
-        ok_t = torch.tensor([n_ok], dtype=torch.int64, device="cuda")
+        import torch
+        ok_t = torch.tensor([n_ok], dtype=torch.int64)
         dist.all_reduce(ok_t, op=dist.ReduceOp.SUM)
-        n_ok_total = int(ok_t.item())
-    else:
-        n_ok_total = n_ok
-
+        n_ok = int(ok_t.item())
+    alg_bytes = bt.algorithmic_bytes()                      # per launch (last step, device 0 of this process)
+    setup_ms, solve_ms = tsum[0][0] / args.steps, tsum[0][1] / args.steps
+    mean = lambda k: float(np.mean([s[k] for s in st]))
     total_units = B * world * args.steps
     value = total_units / elapsed
+    shape = (n, nC, nComp)
+
+    if sparse:
+        kernel_s = (setup_ms + solve_ms) * 1e-3             # setup (the one KKT factorisation) + homotopy: both counted in the bytes
+        kname = "k_sparse_setup + k_sparse_run"
+        cfg_extra = {"kkt_half_bandwidth": bt.bandwidth(), "nnz_Q": bt.nnzQ, "nnz_E": bt.nnzA,
+                     "mean_kkt_factorizations": mean("factorizations"), "mean_band_solves": mean("corrections") + mean("admmIter")}
+        wl = (f"synthetic sparse batch={B}/GPU n={n} nC={nC} nComp={nComp} (BASELINE configs[4]; banded pattern of tests/problems.py, "
+              f"numpy PCG64 seed0=0x4C43515000000005 ^ instance id, perturbStep=0, printLevel=NONE)")
+        metric = f"LCQPs/sec (batched sparse n={n},nC={nC},nComp={nComp}, OSQP-style ADMM KKT + polish)"
+    else:
+        kernel_s = solve_ms * 1e-3
+        kname = "k_lcqp_run"
+        ws = bt.work_sums()
+        n_corr = max(1, sum(s["corrections"] for s in st)); n_fact = max(1, sum(s["factorizations"] for s in st))
+        cfg_extra = {"mean_backsolve_pairs": mean("corrections"), "mean_factor_updates": mean("factorizations"),
+                     "mean_active_rows_per_backsolve": float(ws[0] / n_corr), "mean_factor_update_kbytes": float(ws[2] / n_fact / 1e3)}
+        wl = (f"synthetic dense batch={B}/GPU n={n} nC={nC} nComp={nComp} (BASELINE configs[2]; SplitMix64 seed0=0x4C43515000000001, "
+              f"perturbStep=0, printLevel=NONE)")
+        metric = ("LCQPs/sec (batched dense n=256,nC=512,nComp=64)" if shape == (256, 512, 64)
+                  else f"LCQPs/sec (batched dense n={n},nC={nC},nComp={nComp})")
+    achieved = alg_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
 
     out = {
-        "metric": "LCQPs/sec (batched dense n=256,nC=512,nComp=64)" if (n, nC, nComp) == (256, 512, 64)
-                  else f"LCQPs/sec (batched dense n={n},nC={nC},nComp={nComp})",
-        "value": value, "unit": "LCQPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": metric, "value": value, "unit": "LCQPs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"synthetic dense batch={B}/GPU n={n} nC={nC} nComp={nComp} (BASELINE configs[2]; "
-                               f"SplitMix64 seed0=0x4C43515000000001, perturbStep=0, printLevel=NONE)",
-                   "global_batch": B * world, "parallelism": f"batch-sharded x{world}, no collective",
-                   "solved": n_ok_total, "mean_lcqp_iterates": mean("iterTotal"), "mean_outer": mean("iterOuter"),
-                   "mean_qp_trials": mean("trials"), "mean_residual_sweeps": mean("reserved"), "mean_factor_updates": mean("factorizations"),
-                   "mean_backsolve_pairs": mean("corrections"), "mean_admm_iters": mean("admmIter"),
-                   "mean_active_rows_per_backsolve": float(ws[0] / n_corr), "mean_factor_update_kbytes": float(ws[2] / n_fact / 1e3),
-                   "setup_ms_per_step": setup_ms / args.steps, "homotopy_kernel_ms_per_step": solve_ms / args.steps},
-        "roofline": {"bound": "hbm", "kernel": "k_lcqp_run", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(B, n, nC, nComp),
+        "config": dict({"workload": wl, "global_batch": B * world,
+                        "parallelism": f"batch-sharded x{world}, no collective" + ("" if launched or world == 1 else " (one process drives all devices)"),
+                        "solved": n_ok, "mean_lcqp_iterates": mean("iterTotal"), "mean_outer": mean("iterOuter"),
+                        "mean_qp_trials": mean("trials"), "mean_residual_sweeps": mean("reserved"), "mean_admm_iters": mean("admmIter"),
+                        "setup_ms_per_step": setup_ms, "homotopy_kernel_ms_per_step": solve_ms}, **cfg_extra),
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, B, shape),
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
+    main_proc = (rank == 0)
 
-    if rank == 0 and world == 1 and not args.no_pipelined:
+    if main_proc and world == 1 and not sparse and not args.no_pipelined:
         # not the headline: the same K steps with two batch objects in flight on two streams (step k+1 is launched while step k
         # still runs), so that the launch tail of one step -- its slowest instances -- overlaps with the bulk of the next
-        bt2 = la.BatchLCQP(B, n, nC, nComp, device=local_rank, opt=opt)
-        bt2.generate_synthetic(first)
+        bt2 = make_batch(devices[0])
         bt2.run(); bt2.synchronize()
         pair = (bt, bt2)
-        torch.cuda.synchronize()
         tp = time.perf_counter()
         for k in range(max(2, args.steps)):
             pair[k % 2].run()                 # asynchronous: returns after the launches
@@ -170,45 +242,93 @@ def main():
                             "note": "two independent batches of the same workload in flight on two streams; every step still does setup + homotopy"}
         bt2.close()
 
-    if rank == 0 and not args.no_backsolve:
-        # the factor-once / back-solve-many kernel pair on its own: B factors of order n resident in HBM,
-        # one right-hand side each (bytes_bs(N) = 8 N (N+2))
+    if main_proc and world == 1 and not sparse and not args.no_resident and shape == (256, 512, 64) and B == 1024:
+        # the node-sized job of BASELINE configs[3] (8192 instances) resident on ONE GPU: shows what the tail of a launch that is
+        # exactly one residency wave (B = 1024 = 256 CUs x 4) costs
+        btR = la.BatchLCQP(8192, n, nC, nComp, device=devices[0], opt=opt)
+        btR.generate_synthetic(0)
+        btR.run(); btR.synchronize()
+        tr = time.perf_counter(); btR.run(); btR.synchronize(); dtr = time.perf_counter() - tr
+        _, _, stR = btR.solution()
+        sR, kR = btR.last_timing()
+        out["resident_8192"] = {"batch": 8192, "value": 8192 / dtr, "unit": "LCQPs/s", "ms": 1e3 * dtr, "setup_ms": sR, "homotopy_kernel_ms": kR,
+                                "solved": sum(1 for s_ in stR if s_["returnValue"] == 0),
+                                "roofline_frac": btR.algorithmic_bytes() / (kR * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        btR.close()
+
+    if main_proc and not sparse and not args.no_backsolve:
+        # the factor-once / back-solve-many kernel pair on its own (bytes_bs(N) = 8 N (N+2)), cache-cold: 4096
+        # factors of order n = 2 GiB at n = 256, far beyond the 256 MiB Infinity Cache, one right-hand side each; the in-situ
+        # rate of the same routine inside k_lcqp_run is in profiles/round2 (tools/gpu_phase_profile.py)
         rng = np.random.default_rng(0)
-        nb = min(B, 1024)
-        K = rng.standard_normal((nb, n, n)) * 0.05
-        K = K + K.transpose(0, 2, 1)
-        K[:, np.arange(n), np.arange(n)] += 0.1 * n
+        nb = 4096 if n <= 256 else 1024
+        K0 = rng.standard_normal((64, n, n)) * 0.05
+        K0 = K0 + K0.transpose(0, 2, 1)
+        K0[:, np.arange(n), np.arange(n)] += 0.1 * n
+        K = np.tile(K0, (nb // 64, 1, 1))
         rhs = rng.standard_normal((nb, n))
-        _, ms = la.chol_solve(K, rhs, repeat=20)
+        _, ms = la.chol_solve(K, rhs, repeat=10)
         bs_bytes = nb * 8.0 * n * (n + 2)
         gbs = bs_bytes / (ms * 1e-3) / 1e9
         out["backsolve_kernel"] = {"kernel": "k_backsolve", "batch": nb, "N": n, "ms": ms, "achieved": gbs,
-                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                   "footprint_MiB": nb * n * n * 8 / 2**20,
+                                   "note": "algorithmic bytes 8 N (N+2) per pair; the kernel reads the diagonal 64x64 blocks whole in both passes (8 N (N+64) per pair)"}
         del K, rhs
 
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if main_proc and world == 1 and args.cpu_sample > 0:
         import oracle_py as O
         threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         oopt = O.default_options(perturbStep=0, printLevel=0)
-        cnt = max(args.cpu_sample, threads)      # at least one LCQP per host core
-        tc = time.perf_counter()
-        ok, xo, yo, so = O.synth_batch_solve(0, cnt, n, nC, nComp, opt=oopt, threads=threads)
-        dtc = time.perf_counter() - tc
-        t1 = time.perf_counter()
-        O.synth_batch_solve(0, 4, n, nC, nComp, opt=oopt, threads=1, want_xy=False)     # one core, no contention
-        single = 4 / (time.perf_counter() - t1)
-        dx = float(np.abs(xo[: min(cnt, B)] - x[: min(cnt, B)]).max())
-        out["cpu_baseline"] = {"value": cnt / dtc, "unit": "LCQPs/s", "cores": threads, "kind": "port",
-                               "sample": f"instances 0..{cnt - 1} of the same synthetic workload, CPU oracle "
-                                         f"(oracle/lcqp_oracle.c, same algorithm in scalar C; the reference's qpOASES "
-                                         f"path cannot be built: external/qpOASES is empty), one LCQP per thread, "
-                                         f"{ok}/{cnt} solved in {dtc:.2f} s",
-                               "single_core_value": single, "max_abs_dx_vs_gpu": dx}
-    bt.close()
+        if sparse:
+            import threading
+            import problems as P
+            cnt = min(B, max(args.cpu_sample, threads))
+            inst = [P.sparse_instance(i, n, nC, nComp) for i in range(cnt)]
+            csr = [(d["Q"].tocsr(), d["E"].tocsr()) for d in inst]
+            perm, w = O.kkt_ordering(n, csr[0][0].indptr, csr[0][0].indices, csr[0][1].indptr, csr[0][1].indices)
+            res = [None] * cnt
+
+            def work(lo, hi):
+                for i in range(lo, hi):
+                    d = inst[i]
+                    res[i] = O.sparse_lcqp_solve(n, nC, nComp, csr[i][0], d["g"], csr[i][1], lbA=d["lbA"], ubA=d["ubA"], opt=oopt, perm=perm, w=w)
+            nth = min(threads, cnt)
+            chunks = [(k * cnt // nth, (k + 1) * cnt // nth) for k in range(nth)]
+            O.lib()
+            tc = time.perf_counter()
+            th = [threading.Thread(target=work, args=c_) for c_ in chunks]      # ctypes releases the GIL inside the C solver
+            [t_.start() for t_ in th]; [t_.join() for t_ in th]
+            dtc = time.perf_counter() - tc
+            t1 = time.perf_counter(); work(0, 2); single = 2 / (time.perf_counter() - t1)
+            ok = sum(1 for r_ in res if r_ is not None and r_["ret"] == 0)
+            dx = float(max(np.abs(res[i]["x"] - x[i]).max() for i in range(min(cnt, B))))
+            out["cpu_baseline"] = {"value": cnt / dtc, "unit": "LCQPs/s", "cores": nth, "kind": "port",
+                                   "sample": f"instances 0..{cnt - 1} of the same sparse workload, CPU oracle (oracle/lcqp_oracle_sparse.c, the "
+                                             f"same ADMM-KKT + polish algorithm with band LDL' in scalar C; the reference's OSQP path cannot be "
+                                             f"built: external/osqp is empty), one LCQP per thread, {ok}/{cnt} solved in {dtc:.2f} s",
+                                   "single_core_value": single, "max_abs_dx_vs_gpu": dx}
+        else:
+            cnt = max(args.cpu_sample, threads)      # at least one LCQP per host core
+            tc = time.perf_counter()
+            ok, xo, yo, so = O.synth_batch_solve(0, cnt, n, nC, nComp, opt=oopt, threads=threads)
+            dtc = time.perf_counter() - tc
+            t1 = time.perf_counter()
+            O.synth_batch_solve(0, 4, n, nC, nComp, opt=oopt, threads=1, want_xy=False)     # one core, no contention
+            single = 4 / (time.perf_counter() - t1)
+            dx = float(np.abs(xo[: min(cnt, B)] - x[: min(cnt, B)]).max())
+            out["cpu_baseline"] = {"value": cnt / dtc, "unit": "LCQPs/s", "cores": threads, "kind": "port",
+                                   "sample": f"instances 0..{cnt - 1} of the same synthetic workload, CPU oracle "
+                                             f"(oracle/lcqp_oracle.c, same algorithm in scalar C; the reference's qpOASES "
+                                             f"path cannot be built: external/qpOASES is empty), one LCQP per thread, "
+                                             f"{ok}/{cnt} solved in {dtc:.2f} s",
+                                   "single_core_value": single, "max_abs_dx_vs_gpu": dx}
+    for b_ in bts:
+        b_.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
+    if main_proc:
         print(json.dumps(out))
 
 

@@ -191,6 +191,34 @@ int lcqp_hip_bench_rows(int batch, int m, int n, int mode, int repeat, float* ms
  * per-back-solve kernel time. */
 int lcqp_hip_chol_solve(int batch, int n, const double* K, const double* b, double* x, int repeat, float* ms);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch of B independent SPARSE LCQPs that share one sparsity pattern: the OSQP_SPARSE arm of the reference
+ * (src/LCQProblem.cpp:929-960: no box constraints, nC + 2 nComp duals) on the device -- ADMM on the quasi-definite KKT
+ * matrix + active-set polish (the role of SubsolverOSQP, src/SubsolverOSQP.cpp:124-200), CSR/CSC products, band LDL' in a
+ * reverse Cuthill-McKee ordering computed here once per pattern.  Pattern arrays are the CSC arrays the reference holds
+ * (Q_sparse and the stacked A_sparse = [A; L; R], src/LCQProblem.cpp:629-723; Q full symmetric).  Returns NULL when the
+ * KKT band of the pattern is wider than 63 (lcqp_hip_sparse_last_error() says so): such problems run on the dense kernels.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lcqp_hip_sparse lcqp_hip_sparse_t;
+lcqp_hip_sparse_t* lcqp_hip_sparse_create(int batch, int nV, int nC, int nComp, const int* Qp, const int* Qi,
+                                          const int* Ap, const int* Ai, int device);
+void lcqp_hip_sparse_destroy(lcqp_hip_sparse_t* s);
+const char* lcqp_hip_sparse_last_error(void);
+int  lcqp_hip_sparse_bandwidth(const lcqp_hip_sparse_t* s);              /* half bandwidth of the KKT band */
+int  lcqp_hip_sparse_get_ordering(const lcqp_hip_sparse_t* s, int* perm); /* perm[nV + nC + 2 nComp]: position -> node */
+int  lcqp_hip_sparse_set_options(lcqp_hip_sparse_t* s, const lcqp_options_t* opt);
+/* loadLCQP, sparse overload (src/LCQProblem.cpp:390-441), values only: Qx [count][nnzQ], Ax [count][nnzA] in the CSC order of
+ * the pattern; y0 [count][nC + 2 nComp]; NULL as in the reference */
+int  lcqp_hip_sparse_load(lcqp_hip_sparse_t* s, int first, int count, const double* Qx, const double* g, const double* Ax,
+                          const double* lbA, const double* ubA, const double* lbL, const double* ubL, const double* lbR,
+                          const double* ubR, const double* x0, const double* y0);
+int  lcqp_hip_sparse_run(lcqp_hip_sparse_t* s);                          /* runSolver for every instance (asynchronous) */
+int  lcqp_hip_sparse_synchronize(lcqp_hip_sparse_t* s);
+int  lcqp_hip_sparse_last_timing(lcqp_hip_sparse_t* s, float* setup_ms, float* solve_ms);
+int  lcqp_hip_sparse_get_solution(lcqp_hip_sparse_t* s, double* x, double* y, lcqp_stats_t* stats);   /* y: [B][nC + 2 nComp] */
+double lcqp_hip_sparse_algorithmic_bytes(lcqp_hip_sparse_t* s);
+
 #ifdef __cplusplus
 }
 #endif

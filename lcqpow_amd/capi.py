@@ -343,3 +343,90 @@ class CSCMatrix:
             self.close()
         except Exception:
             pass
+
+
+class SparseBatchLCQP:
+    """B independent sparse LCQPs of one sparsity pattern on one GPU (lcqp_hip_sparse_*): the reference's OSQP_SPARSE arm.
+    Qpat / Apat: scipy-like CSC pattern objects with .indptr / .indices (Q full symmetric nV x nV; A the stacked [A; L; R],
+    (nC + 2 nComp) x nV).  Values are loaded per instance in the CSC order of these patterns."""
+
+    def __init__(self, batch, nV, nC, nComp, Qpat, Apat, device=0, opt=None):
+        ip = C.POINTER(C.c_int)
+        L = lib()
+        L.lcqp_hip_sparse_create.restype = C.c_void_p
+        L.lcqp_hip_sparse_create.argtypes = [C.c_int] * 4 + [ip] * 4 + [C.c_int]
+        L.lcqp_hip_sparse_last_error.restype = C.c_char_p
+        L.lcqp_hip_sparse_destroy.argtypes = [C.c_void_p]
+        L.lcqp_hip_sparse_bandwidth.argtypes = [C.c_void_p]
+        L.lcqp_hip_sparse_get_ordering.argtypes = [C.c_void_p, ip]
+        L.lcqp_hip_sparse_set_options.argtypes = [C.c_void_p, C.POINTER(Options)]
+        L.lcqp_hip_sparse_load.argtypes = [C.c_void_p, C.c_int, C.c_int] + [c_double_p] * 11
+        L.lcqp_hip_sparse_run.argtypes = [C.c_void_p]
+        L.lcqp_hip_sparse_synchronize.argtypes = [C.c_void_p]
+        L.lcqp_hip_sparse_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.lcqp_hip_sparse_get_solution.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_void_p]
+        L.lcqp_hip_sparse_algorithmic_bytes.restype = C.c_double
+        L.lcqp_hip_sparse_algorithmic_bytes.argtypes = [C.c_void_p]
+        self.B, self.nV, self.nC, self.nComp, self.m = batch, nV, nC, nComp, nC + 2 * nComp
+        self._pat = [np.ascontiguousarray(a, dtype=np.int32) for a in (Qpat.indptr, Qpat.indices, Apat.indptr, Apat.indices)]
+        if self._pat[0].size != nV + 1 or self._pat[2].size != nV + 1:
+            raise ValueError("pattern column pointers must have nV + 1 entries (CSC)")
+        self.nnzQ, self.nnzA = int(self._pat[0][-1]), int(self._pat[2][-1])
+        self.h = L.lcqp_hip_sparse_create(batch, nV, nC, nComp, *[a.ctypes.data_as(ip) for a in self._pat], device)
+        if not self.h:
+            raise RuntimeError("lcqp_hip_sparse_create failed: " + L.lcqp_hip_sparse_last_error().decode())
+        if opt is not None:
+            self.set_options(opt)
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with code {rc}: {lib().lcqp_hip_sparse_last_error().decode()}")
+
+    def bandwidth(self):
+        return lib().lcqp_hip_sparse_bandwidth(self.h)
+
+    def ordering(self):
+        perm = np.zeros(self.nV + self.m, dtype=np.int32)
+        self._chk(lib().lcqp_hip_sparse_get_ordering(self.h, perm.ctypes.data_as(C.POINTER(C.c_int))), "get_ordering")
+        return perm
+
+    def set_options(self, opt):
+        self._chk(lib().lcqp_hip_sparse_set_options(self.h, C.byref(opt)), "set_options")
+
+    def load(self, first, count, Qx, g, Ax, lbA=None, ubA=None, lbL=None, ubL=None, lbR=None, ubR=None, x0=None, y0=None):
+        n, nC, nK = self.nV, self.nC, self.nComp
+        sizes = (("Qx", Qx, self.nnzQ), ("g", g, n), ("Ax", Ax, self.nnzA), ("lbA", lbA, nC), ("ubA", ubA, nC), ("lbL", lbL, nK), ("ubL", ubL, nK),
+                 ("lbR", lbR, nK), ("ubR", ubR, nK), ("x0", x0, n), ("y0", y0, self.m))
+        a = [_sized(nm, _arr(v), count * sz) for nm, v, sz in sizes]
+        return lib().lcqp_hip_sparse_load(self.h, first, count, *[_p(v) for v in a])
+
+    def run(self):
+        self._chk(lib().lcqp_hip_sparse_run(self.h), "run")
+
+    def synchronize(self):
+        self._chk(lib().lcqp_hip_sparse_synchronize(self.h), "synchronize")
+
+    def last_timing(self):
+        a = C.c_float(0); b = C.c_float(0)
+        self._chk(lib().lcqp_hip_sparse_last_timing(self.h, C.byref(a), C.byref(b)), "last_timing")
+        return a.value, b.value
+
+    def solution(self):
+        x = np.zeros((self.B, self.nV)); y = np.zeros((self.B, self.m))
+        st = (Stats * self.B)()
+        self._chk(lib().lcqp_hip_sparse_get_solution(self.h, _p(x), _p(y), st), "get_solution")
+        return x, y, [s.asdict() for s in st]
+
+    def algorithmic_bytes(self):
+        return lib().lcqp_hip_sparse_algorithmic_bytes(self.h)
+
+    def close(self):
+        if self.h:
+            lib().lcqp_hip_sparse_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

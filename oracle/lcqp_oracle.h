@@ -136,6 +136,19 @@ void orc_synth_generate(uint64_t seed0, uint64_t instance, int n, int nC, int nC
 int orc_synth_batch_solve(uint64_t seed0, int first, int count, int n, int nC, int nComp, const orc_options_t* opt,
                           int threads, double* xOut, double* yOut, orc_stats_t* statsOut);
 
+
+/* ---- sparse arm (lcqp_oracle_sparse.c): LCQProblem::runSolver with the OSQP_SPARSE conventions of src/LCQProblem.cpp:929-960
+ * (no box constraints, nC + 2 nComp duals) over an OSQP-style subsolver (ADMM on the quasi-definite KKT matrix + active-set
+ * polish).  Q: CSR of the full symmetric matrix; E = [A; L; R]: CSR, nC + 2 nComp rows; y0 / yOpt: nC + 2 nComp entries.
+ * perm[nV + m]: ordering of the KKT matrix [Q E'; E .] (position -> node; node < nV: variable, else row node - nV) with half
+ * bandwidth w -- the factorisations are band LDL'. */
+int orc_sparse_lcqp_solve(int nV, int nC, int nComp,
+                          const int* Qp, const int* Qi, const double* Qx, const double* g,
+                          const int* Ep, const int* Ei, const double* Ex,
+                          const double* lbA, const double* ubA, const double* lbL, const double* ubL, const double* lbR, const double* ubR,
+                          const double* x0, const double* y0, const int* perm, int w,
+                          const orc_options_t* opt, double* xOpt, double* yOpt, orc_stats_t* stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,463 @@
+/*
+ * lcqp_oracle_sparse.c -- CPU restatement of the SPARSE arm of the hot path (TEST INFRASTRUCTURE ONLY, like lcqp_oracle.c:
+ * used by tests/, bench.py's cpu_baseline leg and nothing else).
+ *
+ * What it restates:
+ *   - LCQProblem::runSolver (src/LCQProblem.cpp:444-560) on the OSQP_SPARSE arm of initializeSolver (:929-960): no box
+ *     constraints, nDuals = nC + 2 nComp, boxDualOffset = 0, statk = Qk xk + g_tilde - A'yk_A without a box term (:1246-1272 with
+ *     lb = ub = NULL), the sparse stacking [A; L; R] (:629-723), C xk applied as L'(R xk) + R'(L xk) (C = L'R + R'L, :622-623);
+ *   - the subsolver behind SubsolverOSQP (src/SubsolverOSQP.cpp:124-200): OSQP itself is an un-vendored submodule (external/osqp
+ *     is empty, version unknown) -- PARITY UNPINNED at that boundary.  What stands in its place is OSQP's published algorithm
+ *     (Stellato et al., Math. Prog. Comp. 12, 2020): ADMM on the quasi-definite KKT matrix [Q + sigma I, E'; E, -diag(1/rho)]
+ *     factorised once (LDL'), and a polish on the guessed active set with the regularised KKT matrix
+ *     [Q + delta I, Ea'; Ea, -delta2 I] in iterative-refinement form, run as a primal-dual active-set loop exactly like the dense
+ *     restatement (qp_polish in lcqp_oracle.c) so that LCQPow's tolerances (complementarity 2.2e-13) are met.  Duals are returned
+ *     with the sign flip of src/SubsolverOSQP.cpp:196-199.
+ * The KKT matrices are factorised as band matrices in an ordering handed in by the caller (perm, half bandwidth w); the result
+ * does not depend on the ordering beyond rounding.
+ */
+#include "lcqp_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { SP_INACT = 0, SP_LOWER = 1, SP_UPPER = 2, SP_EQ = 3 };
+
+typedef struct {
+    int N, w;
+    double* B;     /* N x (w+1): B[i*(w+1) + k] = K[i][i-w+k]; after factorisation the unit lower factor, B[i][w] = D_i */
+} band_t;
+
+typedef struct {
+    int n, m, nC, nComp, N, w;
+    const int *Qp, *Qi; const double* Qx;      /* CSR of the symmetric Q */
+    const int *Ep, *Ei; const double* Ex;      /* CSR of E = [A; L; R] */
+    const int *perm; int* iperm;
+    double *l, *u, *rhov;
+    double scale, sigma, delta, delta2;
+    band_t Ka, Kp;
+    int* stf; int stf_valid;                   /* working set the polish factor was built for */
+    double *x, *y; int* st; int have_solution;
+    double *xa, *ya, *za;
+    double *r1, *ex, *wN, *r1_last, *ex_last, *g_last;
+    int* newst;
+    orc_options_t opt;
+    int c_admm, c_trials, c_fact, c_corr, c_sweeps;
+} sqp_t;
+
+static double* dal(size_t n) { return (double*)calloc(n ? n : 1, sizeof(double)); }
+static int* ial(size_t n) { return (int*)calloc(n ? n : 1, sizeof(int)); }
+static double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* ---- sparse products (CSR) ------------------------------------------------------------------------------------------- */
+static void sp_Qx(const sqp_t* q, const double* x, double* out)
+{
+    for (int i = 0; i < q->n; i++) { double s = 0; for (int k = q->Qp[i]; k < q->Qp[i + 1]; k++) s += q->Qx[k] * x[q->Qi[k]]; out[i] = s; }
+}
+static void sp_Ex(const sqp_t* q, const double* x, double* out)
+{
+    for (int r = 0; r < q->m; r++) { double s = 0; for (int k = q->Ep[r]; k < q->Ep[r + 1]; k++) s += q->Ex[k] * x[q->Ei[k]]; out[r] = s; }
+}
+static void sp_ETy_sub(const sqp_t* q, const double* y, double* out)   /* out -= E'y */
+{
+    for (int r = 0; r < q->m; r++) { const double yr = y[r]; if (yr == 0.0) continue; for (int k = q->Ep[r]; k < q->Ep[r + 1]; k++) out[q->Ei[k]] -= q->Ex[k] * yr; }
+}
+
+/* ---- band LDL' (quasi-definite matrix, no pivoting) ---------------------------------------------------------------------- */
+static void band_factor(band_t* f)
+{
+    const int N = f->N, w = f->w, ld = w + 1;
+    for (int i = 0; i < N; i++) {
+        double* ri = f->B + (size_t)i * ld;
+        const int j0 = i - w > 0 ? i - w : 0;
+        for (int j = j0; j < i; j++) {
+            const double* rj = f->B + (size_t)j * ld;
+            const int k0 = j - w > j0 ? j - w : j0;
+            double s = ri[w - (i - j)];
+            for (int k = k0; k < j; k++) s -= ri[w - (i - k)] * f->B[(size_t)k * ld + w] * rj[w - (j - k)];
+            ri[w - (i - j)] = s / rj[w];
+        }
+        double d = ri[w];
+        for (int k = j0; k < i; k++) { const double lik = ri[w - (i - k)]; d -= lik * lik * f->B[(size_t)k * ld + w]; }
+        ri[w] = d;
+    }
+}
+static void band_solve(const band_t* f, double* b)
+{
+    const int N = f->N, w = f->w, ld = w + 1;
+    for (int i = 0; i < N; i++) {
+        const double* ri = f->B + (size_t)i * ld;
+        const int j0 = i - w > 0 ? i - w : 0;
+        double s = b[i];
+        for (int j = j0; j < i; j++) s -= ri[w - (i - j)] * b[j];
+        b[i] = s;
+    }
+    for (int i = 0; i < N; i++) b[i] /= f->B[(size_t)i * ld + w];
+    for (int i = N - 1; i >= 0; i--) {
+        const double* ri = f->B + (size_t)i * ld;
+        const int j0 = i - w > 0 ? i - w : 0;
+        const double xi = b[i];
+        for (int j = j0; j < i; j++) b[j] -= ri[w - (i - j)] * xi;
+    }
+}
+/* K = [Q + dprim I, Ea'; Ea, -diag(ddual)] in the ordering perm; rows with use[r] == 0 are decoupled (diagonal -1) */
+static void kkt_assemble(const sqp_t* q, band_t* f, double dprim, const double* ddual, const int* use)
+{
+    const int n = q->n, m = q->m, w = q->w, ld = w + 1;
+    memset(f->B, 0, sizeof(double) * (size_t)f->N * ld);
+    for (int i = 0; i < n; i++) {
+        const int pi = q->iperm[i];
+        for (int k = q->Qp[i]; k < q->Qp[i + 1]; k++) {
+            const int pj = q->iperm[q->Qi[k]];
+            if (pj <= pi) f->B[(size_t)pi * ld + w - (pi - pj)] += q->Qx[k];
+        }
+        f->B[(size_t)pi * ld + w] += dprim;
+    }
+    for (int r = 0; r < m; r++) {
+        const int pr = q->iperm[n + r];
+        if (use && !use[r]) { f->B[(size_t)pr * ld + w] = -1.0; continue; }
+        f->B[(size_t)pr * ld + w] = -ddual[r];
+        for (int k = q->Ep[r]; k < q->Ep[r + 1]; k++) {
+            const int pc = q->iperm[q->Ei[k]];
+            const int hi = pr > pc ? pr : pc, lo = pr > pc ? pc : pr;
+            f->B[(size_t)hi * ld + w - (hi - lo)] += q->Ex[k];
+        }
+    }
+}
+
+/* ---- subsolver ---------------------------------------------------------------------------------------------------------- */
+static void sqp_free(sqp_t* q)
+{
+    free(q->iperm); free(q->l); free(q->u); free(q->rhov); free(q->Ka.B); free(q->Kp.B); free(q->stf); free(q->x); free(q->y);
+    free(q->st); free(q->xa); free(q->ya); free(q->za); free(q->r1); free(q->ex); free(q->wN); free(q->r1_last); free(q->ex_last);
+    free(q->g_last); free(q->newst);
+}
+
+static int sqp_setup(sqp_t* q, const double* lbE, const double* ubE)
+{
+    const int n = q->n, m = q->m, N = n + m;
+    const orc_options_t* o = &q->opt;
+    q->N = N;
+    q->iperm = ial(N);
+    for (int p = 0; p < N; p++) q->iperm[q->perm[p]] = p;
+    q->l = dal(m); q->u = dal(m); q->rhov = dal(m);
+    memcpy(q->l, lbE, sizeof(double) * m); memcpy(q->u, ubE, sizeof(double) * m);
+    double scale = 0;
+    for (int i = 0; i < n; i++) for (int k = q->Qp[i]; k < q->Qp[i + 1]; k++) if (q->Qi[k] == i && fabs(q->Qx[k]) > scale) scale = fabs(q->Qx[k]);
+    if (!(scale > 1e-300)) scale = 1.0;
+    q->scale = scale;
+    q->sigma = o->admmSigma * scale;
+    q->delta = o->proxBig * scale;          /* primal regularisation of the polish KKT matrix */
+    q->delta2 = 1e-9 / scale;               /* dual regularisation: makes the matrix quasi-definite whatever the rank of Ea */
+    const double rho = o->admmRho * scale;
+    double* dd = dal(m);
+    for (int r = 0; r < m; r++) {
+        if (isinf(q->l[r]) && isinf(q->u[r])) q->rhov[r] = 1e-6 * rho;          /* OSQP's RHO_MIN for unconstrained rows */
+        else if (q->l[r] == q->u[r]) q->rhov[r] = rho * o->rhoEqMult;
+        else q->rhov[r] = rho;
+        dd[r] = 1.0 / q->rhov[r];
+    }
+    q->Ka.N = q->Kp.N = N; q->Ka.w = q->Kp.w = q->w;
+    q->Ka.B = dal((size_t)N * (q->w + 1)); q->Kp.B = dal((size_t)N * (q->w + 1));
+    kkt_assemble(q, &q->Ka, q->sigma, dd, NULL);
+    band_factor(&q->Ka);
+    free(dd);
+    q->stf = ial(m); q->stf_valid = 0;
+    q->x = dal(n); q->y = dal(m); q->st = ial(m);
+    q->xa = dal(n); q->ya = dal(m); q->za = dal(m);
+    q->r1 = dal(n); q->ex = dal(m); q->wN = dal(N); q->r1_last = dal(n); q->ex_last = dal(m); q->g_last = dal(n);
+    q->newst = ial(m);
+    return 0;
+}
+
+/* n_it ADMM iterations (OSQP, KKT form): [Q + sigma I, E'; E, -1/rho][xt; nu] = [sigma x - g; z - y/rho], zt = z + (nu - y)/rho */
+static void sqp_admm(sqp_t* q, const double* g, int n_it)
+{
+    const int n = q->n, m = q->m;
+    const double alpha = q->opt.admmAlpha;
+    double* b = q->wN;
+    for (int it = 0; it < n_it; it++) {
+        for (int i = 0; i < n; i++) b[q->iperm[i]] = q->sigma * q->xa[i] - g[i];
+        for (int r = 0; r < m; r++) b[q->iperm[n + r]] = q->za[r] - q->ya[r] / q->rhov[r];
+        band_solve(&q->Ka, b);
+        for (int r = 0; r < m; r++) {
+            const double rv = q->rhov[r];
+            const double zt = q->za[r] + (b[q->iperm[n + r]] - q->ya[r]) / rv;
+            const double zr = alpha * zt + (1.0 - alpha) * q->za[r];
+            if (isinf(q->l[r]) && isinf(q->u[r])) { q->za[r] = zr; q->ya[r] = 0.0; continue; }
+            const double zn = clipd(zr + q->ya[r] / rv, q->l[r], q->u[r]);
+            q->ya[r] += rv * (zr - zn);
+            q->za[r] = zn;
+        }
+        for (int i = 0; i < n; i++) q->xa[i] = alpha * b[q->iperm[i]] + (1.0 - alpha) * q->xa[i];
+        q->c_admm++;
+    }
+}
+
+/* primal-dual active-set polish in correction form (the sparse twin of qp_polish in lcqp_oracle.c) */
+static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, int reuse)
+{
+    const int n = q->n, m = q->m;
+    const orc_options_t* o = &q->opt;
+    double gmax = 0;
+    for (int i = 0; i < n; i++) if (fabs(g[i]) > gmax) gmax = fabs(g[i]);
+    const double gs = 1.0 + gmax;
+    double *r1 = q->r1, *Ex = q->ex, *b = q->wN;
+    int fact_valid = 0;
+    for (int trial = 0; trial < o->maxTrials; trial++) {
+        q->c_trials++;
+        if (trial == 0 && reuse) {
+            for (int i = 0; i < n; i++) r1[i] = q->r1_last[i] + (q->g_last[i] - g[i]);
+            memcpy(Ex, q->ex_last, sizeof(double) * m);
+        } else {
+            q->c_sweeps++;
+            sp_Qx(q, x, r1);
+            for (int i = 0; i < n; i++) r1[i] = -g[i] - r1[i];
+            sp_ETy_sub(q, y, r1);
+            sp_Ex(q, x, Ex);
+        }
+        double res_stat = 0, res_eq = 0, bmax = 0;
+        for (int i = 0; i < n; i++) if (fabs(r1[i]) > res_stat) res_stat = fabs(r1[i]);
+        int changed = 0, nact = 0;
+        const double ytol = o->feasTol * gs;
+        for (int r = 0; r < m; r++) {
+            int s = st[r], ns = s;
+            if (s == SP_INACT) {
+                const double ftol = o->feasTol * (1.0 + fabs(Ex[r]));
+                if (Ex[r] < q->l[r] - ftol) ns = SP_LOWER;
+                else if (Ex[r] > q->u[r] + ftol) ns = SP_UPPER;
+            } else {
+                const double bb = (s == SP_UPPER) ? q->u[r] : q->l[r];
+                if (fabs(bb - Ex[r]) > res_eq) res_eq = fabs(bb - Ex[r]);
+                if (fabs(bb) > bmax) bmax = fabs(bb);
+                if (s == SP_LOWER && y[r] > ytol) ns = SP_INACT;
+                if (s == SP_UPPER && y[r] < -ytol) ns = SP_INACT;
+            }
+            q->newst[r] = ns;
+            if (ns != s) changed++;
+            nact += (ns != SP_INACT);
+        }
+        if (trial > 0 && !changed && res_stat <= o->resTol * gs && res_eq <= o->resTol * (1.0 + bmax)) {
+            memcpy(q->r1_last, r1, sizeof(double) * n); memcpy(q->ex_last, Ex, sizeof(double) * m); memcpy(q->g_last, g, sizeof(double) * n);
+            return 1;
+        }
+        if (changed && trial > 0) {
+            if (trial >= 2 && nact > n && changed > n / 2) return 0;       /* overshooting cold start: hand over to ADMM */
+            for (int r = 0; r < m; r++) {
+                const int ns = q->newst[r];
+                if (ns == SP_INACT && st[r] != SP_INACT && y[r] != 0.0) {
+                    for (int k = q->Ep[r]; k < q->Ep[r + 1]; k++) r1[q->Ei[k]] += q->Ex[k] * y[r];     /* leaving row: its multiplier leaves the residual */
+                    y[r] = 0.0;
+                }
+                st[r] = ns;
+            }
+            fact_valid = 0;
+        }
+        if (!fact_valid) {
+            int same = q->stf_valid;
+            for (int r = 0; r < m && same; r++) same = ((q->stf[r] != SP_INACT) == (st[r] != SP_INACT));
+            if (!same) {
+                int* use = q->newst;
+                double* d2 = (double*)malloc(sizeof(double) * (m ? m : 1));
+                for (int r = 0; r < m; r++) { use[r] = (st[r] != SP_INACT); d2[r] = q->delta2; }
+                kkt_assemble(q, &q->Kp, q->delta, d2, use);
+                band_factor(&q->Kp);
+                free(d2);
+                memcpy(q->stf, st, sizeof(int) * m); q->stf_valid = 1;
+                q->c_fact++;
+            }
+            fact_valid = 1;
+        }
+        /* correction: [Q + delta I, Ea'; Ea, -delta2 I][dx; dy] = [r1; ba - Ea x] */
+        for (int i = 0; i < n; i++) b[q->iperm[i]] = r1[i];
+        for (int r = 0; r < m; r++) {
+            double v = 0.0;
+            if (st[r] != SP_INACT) v = ((st[r] == SP_UPPER) ? q->u[r] : q->l[r]) - Ex[r];
+            b[q->iperm[n + r]] = v;
+        }
+        band_solve(&q->Kp, b);
+        for (int i = 0; i < n; i++) x[i] += b[q->iperm[i]];
+        for (int r = 0; r < m; r++) if (st[r] != SP_INACT) y[r] += b[q->iperm[n + r]];
+        q->c_corr++;
+    }
+    return 0;
+}
+
+static int sqp_solve(sqp_t* q, int initial, const double* g, const double* x0, const double* y0 /* reference sign, m */, int* iterations, int* flag)
+{
+    const int n = q->n, m = q->m;
+    const orc_options_t* o = &q->opt;
+    const int trials0 = q->c_trials, admm0 = q->c_admm;
+    *iterations = 0; *flag = 0;
+    for (int r = 0; r < m; r++) if (q->l[r] > q->u[r]) { *flag = 2; return ORC_SUBPROBLEM_SOLVER_ERROR; }
+    if (initial) {
+        for (int i = 0; i < n; i++) q->x[i] = x0 ? x0[i] : 0.0;
+        for (int r = 0; r < m; r++) q->y[r] = y0 ? -y0[r] : 0.0;
+    }
+    memcpy(q->xa, q->x, sizeof(double) * n); memcpy(q->ya, q->y, sizeof(double) * m);
+    int n_admm = initial ? o->admmFirst : o->admmHot;
+    const int use_stored = (!initial && q->have_solution && n_admm == 0);
+    int admm_ready = 0, solved = 0;
+    double* xt = dal(n); double* yt = dal(m); int* stt = ial(m);
+    for (int round = 0; round < o->maxRounds && !solved; round++) {
+        if (!admm_ready && (n_admm > 0 || !(round == 0 && use_stored))) {
+            sp_Ex(q, q->xa, q->za);
+            for (int r = 0; r < m; r++) { q->za[r] = clipd(q->za[r], q->l[r], q->u[r]); if (isinf(q->l[r]) && isinf(q->u[r])) q->ya[r] = 0.0; }
+            admm_ready = 1;
+        }
+        if (n_admm > 0) sqp_admm(q, g, n_admm);
+        for (int r = 0; r < m; r++) {
+            int s;
+            if (round == 0 && use_stored) { s = q->st[r]; if (q->l[r] == q->u[r]) s = SP_EQ; }
+            else {
+                const double lo = q->l[r], hi = q->u[r], z = q->za[r], yy = q->ya[r];
+                s = SP_INACT;
+                if (isfinite(lo) && (z - lo < -yy)) s = SP_LOWER;
+                if (isfinite(hi) && (hi - z < yy)) s = SP_UPPER;
+                if (lo == hi) s = SP_EQ;
+            }
+            stt[r] = s;
+            yt[r] = (s != SP_INACT) ? q->ya[r] : 0.0;
+        }
+        memcpy(xt, q->xa, sizeof(double) * n);
+        if (sqp_polish(q, g, xt, yt, stt, round == 0 && use_stored)) { solved = 1; break; }
+        n_admm = 2 * n_admm;
+        if (n_admm < 10) n_admm = 10;
+        if (n_admm > 400) n_admm = 400;
+    }
+    *iterations = (q->c_trials - trials0) + (q->c_admm - admm0);
+    if (solved) { memcpy(q->x, xt, sizeof(double) * n); memcpy(q->y, yt, sizeof(double) * m); memcpy(q->st, stt, sizeof(int) * m); q->have_solution = 1; }
+    free(xt); free(yt); free(stt);
+    if (!solved) { *flag = 1; return ORC_SUBPROBLEM_SOLVER_ERROR; }
+    return ORC_SUCCESSFUL_RETURN;
+}
+
+/* ---- LCQProblem::runSolver on the OSQP_SPARSE arm ----------------------------------------------------------------------- */
+int orc_sparse_lcqp_solve(int nV, int nC, int nComp,
+                          const int* Qp, const int* Qi, const double* Qx, const double* g,
+                          const int* Ep, const int* Ei, const double* Ex,
+                          const double* lbA, const double* ubA, const double* lbL, const double* ubL, const double* lbR, const double* ubR,
+                          const double* x0, const double* y0, const int* perm, int w,
+                          const orc_options_t* opt, double* xOpt, double* yOpt, orc_stats_t* stats)
+{
+    const int n = nV, m = nC + 2 * nComp;
+    memset(stats, 0, sizeof(*stats));
+    sqp_t Q_; memset(&Q_, 0, sizeof(Q_));
+    sqp_t* q = &Q_;
+    q->n = n; q->m = m; q->nC = nC; q->nComp = nComp; q->w = w; q->perm = perm;
+    q->Qp = Qp; q->Qi = Qi; q->Qx = Qx; q->Ep = Ep; q->Ei = Ei; q->Ex = Ex; q->opt = *opt;
+    /* stacked bounds: setConstraints / setComplementarityBounds (src/LCQProblem.cpp:585-608, 726-785) */
+    double *lE = dal(m), *uE = dal(m);
+    for (int i = 0; i < nC; i++) { lE[i] = lbA ? lbA[i] : -INFINITY; uE[i] = ubA ? ubA[i] : INFINITY; }
+    for (int i = 0; i < nComp; i++) {
+        lE[nC + i] = lbL ? lbL[i] : 0.0; uE[nC + i] = ubL ? ubL[i] : INFINITY;
+        lE[nC + nComp + i] = lbR ? lbR[i] : 0.0; uE[nC + nComp + i] = ubR ? ubR[i] : INFINITY;
+    }
+    sqp_setup(q, lE, uE);
+    double *xk = dal(n), *yk = dal(m), *pk = dal(n), *xnew = dal(n), *gk = dal(n), *gtil = dal(n), *gphi = dal(n), *statk = dal(n);
+    double *Qxv = dal(n), *Cxv = dal(n), *Qpv = dal(n), *Cpv = dal(n), *lx = dal(m), *tmp = dal(n);
+    const int hasPhi = (lbL != NULL) || (lbR != NULL);
+    double phiConst = 0.0;
+    if (hasPhi) {       /* :969-996: phi_const = lbL'lbR, g_phi = -(R'lbL + L'lbR) */
+        for (int i = 0; i < nComp; i++) phiConst += (lbL ? lbL[i] : 0.0) * (lbR ? lbR[i] : 0.0);
+        for (int i = 0; i < nComp; i++) {
+            const double a = lbL ? lbL[i] : 0.0, bq = lbR ? lbR[i] : 0.0;
+            for (int k = Ep[nC + nComp + i]; k < Ep[nC + nComp + i + 1]; k++) gphi[Ei[k]] -= Ex[k] * a;      /* R'lbL */
+            for (int k = Ep[nC + i]; k < Ep[nC + i + 1]; k++) gphi[Ei[k]] -= Ex[k] * bq;                    /* L'lbR */
+        }
+    }
+    if (x0) memcpy(xk, x0, sizeof(double) * n);
+    memcpy(gtil, g, sizeof(double) * n);
+    double rho = opt->initialPenaltyParameter, alphak = 1.0;
+    double hist[8]; int histLen = 0, rc = 0, qpIter = 0, flag = 0, totalIter = 0, algoStat = 0;
+    uint64_t perturbCounter = 0;
+#define SP_CPROD(v, out) do { sp_Ex(q, (v), lx); for (int i_ = 0; i_ < n; i_++) (out)[i_] = 0.0;                                       \
+        for (int i_ = 0; i_ < nComp; i_++) {                                                                                          \
+            const double Lv = lx[nC + i_], Rv = lx[nC + nComp + i_];                                                                  \
+            for (int k_ = Ep[nC + i_]; k_ < Ep[nC + i_ + 1]; k_++) (out)[Ei[k_]] += Ex[k_] * Rv;                  /* L'(R v) */       \
+            for (int k_ = Ep[nC + nComp + i_]; k_ < Ep[nC + nComp + i_ + 1]; k_++) (out)[Ei[k_]] += Ex[k_] * Lv; /* R'(L v) */       \
+        } } while (0)
+#define SP_PHI(dst) do { double s_ = 0; for (int i_ = 0; i_ < n; i_++) s_ += (hasPhi ? gphi[i_] * xk[i_] : 0.0) + 0.5 * xk[i_] * Cxv[i_]; (dst) = phiConst + s_; } while (0)
+    if (opt->solveZeroPenaltyFirst) memcpy(gk, g, sizeof(double) * n);
+    else { SP_CPROD(xk, Cxv); for (int i = 0; i < n; i++) gk[i] = rho * Cxv[i] + gtil[i]; }
+    int initial = 1;
+    for (;;) {
+        rc = sqp_solve(q, initial, gk, xk, initial ? y0 : NULL, &qpIter, &flag);            /* :1115-1148 */
+        stats->subproblemIter += qpIter; stats->qpSolverExitFlag = flag; stats->qpSolves++;
+        if (rc != 0) break;
+        memcpy(xnew, q->x, sizeof(double) * n);
+        for (int r = 0; r < m; r++) yk[r] = -q->y[r];                                        /* src/SubsolverOSQP.cpp:196-199 */
+        for (int i = 0; i < n; i++) pk[i] = xnew[i] - xk[i];
+        if (initial) stats->rhoOpt = rho;
+        else if (opt->perturbStep) {
+            for (int i = 0; i < n; i++) {
+                uint64_t z = opt->perturbSeed + (perturbCounter + (uint64_t)i + 1ULL) * 0x9E3779B97F4A7C15ULL;
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z = z ^ (z >> 31);
+                xk[i] += ((int)(z % 3ULL) - 1) * 2.221e-16;
+            }
+            perturbCounter += (uint64_t)n;
+        }
+        sp_Qx(q, pk, Qpv); sp_Qx(q, xk, Qxv); SP_CPROD(pk, Cpv); SP_CPROD(xk, Cxv);
+        if (!initial) {                                                                       /* getOptimalStepLength :1217-1237 */
+            double qk = 0, lk = 0;
+            for (int i = 0; i < n; i++) { qk += pk[i] * (Qpv[i] + rho * Cpv[i]); lk += pk[i] * ((Qxv[i] + rho * Cxv[i]) + gtil[i]); }
+            alphak = 1.0;
+            if (qk > 0 && lk < 0) alphak = fmin(-lk / qk, 1.0);
+        }
+        initial = 0;
+        for (int i = 0; i < n; i++) { xk[i] += alphak * pk[i]; Qxv[i] += alphak * Qpv[i]; Cxv[i] += alphak * Cpv[i]; }      /* updateStep */
+        /* updateStationarity :1246-1272 without the box term (lb = ub = NULL on this arm) */
+        for (int i = 0; i < n; i++) tmp[i] = 0.0;
+        for (int r = 0; r < m; r++) { const double yr = yk[r]; if (yr != 0.0) for (int k = Ep[r]; k < Ep[r + 1]; k++) tmp[Ei[k]] += Ex[k] * yr; }
+        double statInf = 0;
+        for (int i = 0; i < n; i++) { statk[i] = (Qxv[i] + rho * Cxv[i]) + gtil[i] - tmp[i]; if (fabs(statk[i]) > statInf) statInf = fabs(statk[i]); }
+        totalIter++; stats->iterTotal++;
+        int leyffer = 0;                                                                      /* :1275-1313 */
+        const int nd = opt->nDynamicPenalty;
+        if (nd > 0) {
+            double cur; SP_PHI(cur);
+            if (histLen < nd) hist[histLen++] = cur;
+            else {
+                if (!(cur < opt->complementarityTolerance)) { leyffer = 1; for (int i = 0; i < nd; i++) if (cur < opt->etaDynamicPenalty * hist[i]) { leyffer = 0; break; } }
+                for (int i = 0; i + 1 < nd; i++) hist[i] = hist[i + 1];
+                hist[nd - 1] = cur;
+            }
+        }
+#define SP_PENALTY() do { if (nd > 0) histLen = 0; rho *= opt->penaltyUpdateFactor; stats->rhoOpt = rho;                               \
+        if (hasPhi) for (int i_ = 0; i_ < n; i_++) gtil[i_] = g[i_] + rho * gphi[i_]; } while (0)
+        if (leyffer) { SP_PENALTY(); stats->iterOuter++; }
+        if (statInf < opt->stationarityTolerance) {
+            double phi; SP_PHI(phi);
+            if (phi < opt->complementarityTolerance) {
+                sp_Ex(q, xk, lx);
+                int sflag = 1, mflag = 1, wflag = 0;                                          /* :1412-1482 on the untransformed duals */
+                const double ctol = opt->complementarityTolerance;
+                for (int i = 0; i < nComp; i++) {
+                    const double Lx = lx[nC + i], Rx = lx[nC + nComp + i];
+                    if (!(Lx <= ctol && Rx <= ctol)) continue;
+                    const double a = yk[nC + i], bq = yk[nC + nComp + i];
+                    const double dualProd = a * bq, dualMin = fmin(a, bq);
+                    if (dualMin < 0) sflag = 0;
+                    if (fabs(dualProd) >= ctol && dualMin <= 0) { if (dualProd <= ctol) { wflag = 1; break; } mflag = 0; }
+                }
+                algoStat = wflag ? 1 : (sflag ? 4 : (mflag ? 3 : 2));
+                for (int i = 0; i < nComp; i++) { yk[nC + i] -= rho * lx[nC + nComp + i]; yk[nC + nComp + i] -= rho * lx[nC + i]; }   /* transformDuals :1381-1409 */
+                rc = 0;
+                break;
+            }
+            SP_PENALTY(); stats->iterOuter++;
+        }
+        if (totalIter > opt->maxIterations) { rc = ORC_MAX_ITERATIONS_REACHED; break; }
+        if (rho > opt->maxPenaltyParameter) { rc = ORC_MAX_PENALTY_REACHED; break; }
+        for (int i = 0; i < n; i++) gk[i] = rho * Cxv[i] + gtil[i];                          /* updateLinearization :1105-1112 */
+    }
+    stats->status = algoStat; stats->returnValue = rc;
+    stats->admmIter = q->c_admm; stats->trials = q->c_trials; stats->factorizations = q->c_fact; stats->corrections = q->c_corr; stats->reserved = q->c_sweeps;
+    if (xOpt) memcpy(xOpt, xk, sizeof(double) * n);
+    if (yOpt) memcpy(yOpt, yk, sizeof(double) * m);
+    free(xk); free(yk); free(pk); free(xnew); free(gk); free(gtil); free(gphi); free(statk); free(Qxv); free(Cxv); free(Qpv); free(Cpv);
+    free(lx); free(tmp); free(lE); free(uE);
+    sqp_free(q);
+    return rc;
+}

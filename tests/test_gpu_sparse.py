@@ -1,0 +1,86 @@
+"""Sparse arm on the GPU (lcqp_hip_sparse_*, BASELINE configs[4]) against the sparse CPU oracle through the C ABI."""
+import numpy as np
+import pytest
+
+import problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(hip, n, nC, nK, B, **okw):
+    Qp, Ap = P.sparse_pattern(n, nC, nK)
+    inst = [P.sparse_instance(i, n, nC, nK) for i in range(B)]
+    sb = hip.SparseBatchLCQP(B, n, nC, nK, Qp, Ap, opt=hip.default_options(perturbStep=0, printLevel=0, **okw))
+    assert sb.load(0, B, np.stack([d["Q"].data for d in inst]), np.stack([d["g"] for d in inst]), np.stack([d["E"].data for d in inst]),
+                   lbA=np.stack([d["lbA"] for d in inst]), ubA=np.stack([d["ubA"] for d in inst])) == 0
+    sb.run()
+    x, y, st = sb.solution()
+    return sb, inst, x, y, st
+
+
+@pytest.mark.parametrize("shape,B", [((64, 32, 8), 6), ((512, 256, 64), 4), ((4096, 2048, 512), 4)])
+def test_sparse_hip_matches_oracle(hip, oracle, shape, B):
+    """same algorithm, same inputs: solution to 1e-9 / duals 1e-7 (fp64 summation order only), same return code and status,
+    iterate counts equal up to one inner cycle"""
+    n, nC, nK = shape
+    sb, inst, x, y, st = _run(hip, n, nC, nK, B)
+    assert 1 <= sb.bandwidth() <= 63 and sb.algorithmic_bytes() > 0
+    opt = oracle.default_options(perturbStep=0)
+    for b in range(B):
+        d = inst[b]
+        ro = oracle.sparse_lcqp_solve(n, nC, nK, d["Q"].tocsr(), d["g"], d["E"].tocsr(), lbA=d["lbA"], ubA=d["ubA"], opt=opt)
+        assert st[b]["returnValue"] == ro["ret"] == 0
+        assert np.abs(x[b] - ro["x"]).max() < 1e-9 and np.abs(y[b] - ro["y"]).max() < 1e-7
+        assert st[b]["status"] == ro["stats"]["status"] and abs(st[b]["iterTotal"] - ro["stats"]["iterTotal"]) <= 4
+    # second run on the same handle reproduces the first bit for bit
+    sb.run()
+    x2, y2, _ = sb.solution()
+    assert np.array_equal(x, x2) and np.array_equal(y, y2)
+    sb.close()
+
+
+def test_sparse_hip_batch_properties(hip):
+    """a batch at BASELINE size: every instance solved, complementarity exact, stationarity of the returned duals"""
+    n, nC, nK, B = 4096, 2048, 512, 64
+    sb, inst, x, y, st = _run(hip, n, nC, nK, B)
+    assert all(s["returnValue"] == 0 for s in st)
+    for b in range(0, B, 7):
+        d = inst[b]
+        Qc, Ec = d["Q"].tocsr(), d["E"].tocsr()
+        Lx, Rx = x[b][8 * np.arange(nK)], x[b][8 * np.arange(nK) + 4]
+        assert (Lx * Rx).sum() < 2.2e-13
+        assert np.abs(Qc @ x[b] + d["g"] - Ec.T @ y[b]).max() < 1e-8
+    sb.close()
+
+
+def test_sparse_default_options_and_admm_first(hip, oracle):
+    """reference defaults (perturbStep on, seeded) and an ADMM-first cold start (the OSQP route: ADMM iterations, then polish)"""
+    n, nC, nK, B = 512, 256, 64, 3
+    for kw in (dict(perturbStep=1, perturbSeed=7), dict(admmFirst=50)):
+        base = dict(perturbStep=0); base.update(kw)
+        Qp, Ap = P.sparse_pattern(n, nC, nK)
+        inst = [P.sparse_instance(i, n, nC, nK) for i in range(B)]
+        sb = hip.SparseBatchLCQP(B, n, nC, nK, Qp, Ap, opt=hip.default_options(printLevel=0, **base))
+        assert sb.load(0, B, np.stack([d["Q"].data for d in inst]), np.stack([d["g"] for d in inst]), np.stack([d["E"].data for d in inst]),
+                       lbA=np.stack([d["lbA"] for d in inst]), ubA=np.stack([d["ubA"] for d in inst])) == 0
+        sb.run()
+        x, y, st = sb.solution()
+        for b in range(B):
+            d = inst[b]
+            ro = oracle.sparse_lcqp_solve(n, nC, nK, d["Q"].tocsr(), d["g"], d["E"].tocsr(), lbA=d["lbA"], ubA=d["ubA"], opt=oracle.default_options(**base))
+            assert st[b]["returnValue"] == ro["ret"] == 0, (kw, st[b], ro["stats"])
+            assert np.abs(x[b] - ro["x"]).max() < 1e-8
+            if "admmFirst" in kw:
+                assert st[b]["admmIter"] >= 50 and ro["stats"]["admmIter"] >= 50
+        sb.close()
+
+
+def test_sparse_pattern_outside_the_band_engine_is_refused(hip):
+    """the arrow-shaped KKT matrix of examples/OptimizeOnCircle.cpp (one dense constraint row) is not banded: the sparse engine
+    says so, it does not run past its window (the host layer runs this problem on the dense kernels behind the OSQP_SPARSE
+    surface: tests/test_python_api.py::test_python_reference_solver_arms)"""
+    import scipy.sparse as sp
+    d = P.circle(100)
+    Q = sp.csc_matrix(d["Q"]); E = sp.csc_matrix(np.vstack([d["A"], d["L"], d["R"]]))
+    with pytest.raises(RuntimeError, match="bandwidth"):
+        hip.SparseBatchLCQP(1, d["nV"], d["nC"], d["nComp"], Q, E)
