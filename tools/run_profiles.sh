@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round-2 profiles (run on the GPU box from the repo root): kernel trace + stats, FETCH_SIZE / WRITE_SIZE in their own passes.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r2
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+D="--cpu-sample 0 --no-pipelined --no-resident"
+python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
+rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 $D > $O/bench_under_rocprof.json 2>> $O/rocprof.err
+rocprofv3 --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $D > /dev/null 2>> $O/rocprof.err
+rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $D > /dev/null 2>> $O/rocprof.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY -d $O/sq --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $D --no-backsolve > /dev/null 2>> $O/rocprof.err
+python3 $R/bench.py --workload sparse --steps 2 --warmup 1 > $O/bench_sparse.json 2> $O/bench_sparse.err
+rocprofv3 --kernel-trace --stats -d $O/trace_sparse --output-format csv -- python3 $R/bench.py --workload sparse --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>> $O/rocprof.err
+find $O -name "*.csv" | head -50 > $O/files.txt
+ls -la $O >> $O/files.txt
