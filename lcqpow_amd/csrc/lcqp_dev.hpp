@@ -336,6 +336,44 @@ __device__ __forceinline__ void ti_reset(Ctx<NCH>& c, int& nT, int& ns)
     __syncthreads();
 }
 
+// The fused pass for up to 64*NK slots: a wave takes rows j = w, w+4, ..., keeps D rows (D*NK loads of 512 bytes) in flight, and
+// for each row forms u = row.t (one wavefront reduction) and accumulates u*row -- the row is read once.
+template <int NK, int D>
+__device__ __forceinline__ void ti_apply_fast(const double* __restrict__ Ti, int ld, const double* tv, double* out, int nT, int ns, double* red)
+{
+    const int l = lane_id(), w = wave_id(), t = threadIdx.x;
+    double tr[NK], acc[NK];
+#pragma unroll
+    for (int k = 0; k < NK; k++) { const int sl = 64 * k + l; tr[k] = (sl < ns) ? tv[sl] : 0.0; acc[k] = 0.0; }
+    for (int j0 = w; j0 < nT; j0 += NWAVE * D) {
+        double rv[D][NK];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const int j = j0 + NWAVE * d;
+#pragma unroll
+            for (int k = 0; k < NK; k++) {
+                const int sl = 64 * k + l;
+                rv[d][k] = (j < nT && sl < ns) ? Ti[(size_t)j * ld + sl] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            double dsum = 0.0;
+#pragma unroll
+            for (int k = 0; k < NK; k++) dsum += rv[d][k] * tr[k];
+            const double u = wave_sum(dsum);
+#pragma unroll
+            for (int k = 0; k < NK; k++) acc[k] += rv[d][k] * u;
+        }
+    }
+    __syncthreads();               // tv fully read (out may alias it), arena free
+#pragma unroll
+    for (int k = 0; k < NK; k++) red[w * 256 + 64 * k + l] = acc[k];
+    __syncthreads();
+    for (int sl = t; sl < 64 * NK; sl += WG) out[sl] = (sl < ns) ? (red[sl] + red[256 + sl]) + (red[512 + sl] + red[768 + sl]) : 0.0;
+    __syncthreads();
+}
+
 // out = Ti' (Ti tv) over the slots [0, ns); tv and out: global, capS entries, tv zero on free slots.  out may alias tv.
 template <int NCH>
 __device__ __forceinline__ void ti_apply(Ctx<NCH>& c, const double* tv, double* out, int nT, int ns)
@@ -345,37 +383,10 @@ __device__ __forceinline__ void ti_apply(Ctx<NCH>& c, const double* tv, double* 
     const double* Ti = c.S;
     if (nk <= TI_FAST_CHUNKS) {
         double* red = c.lds.arena;     // 4 waves x 256 partial sums
-        double tr[TI_FAST_CHUNKS], acc[TI_FAST_CHUNKS];
-#pragma unroll
-        for (int k = 0; k < TI_FAST_CHUNKS; k++) { const int sl = 64 * k + l; tr[k] = (sl < ns) ? tv[sl] : 0.0; acc[k] = 0.0; }
-        constexpr int D = 4;           // rows a wave keeps in flight
-        for (int j0 = w; j0 < nT; j0 += NWAVE * D) {
-            double rv[D][TI_FAST_CHUNKS];
-#pragma unroll
-            for (int d = 0; d < D; d++) {
-                const int j = j0 + NWAVE * d;
-#pragma unroll
-                for (int k = 0; k < TI_FAST_CHUNKS; k++) {
-                    const int sl = 64 * k + l;
-                    rv[d][k] = (j < nT && sl < ns) ? Ti[(size_t)j * ld + sl] : 0.0;
-                }
-            }
-#pragma unroll
-            for (int d = 0; d < D; d++) {
-                double dsum = 0.0;
-#pragma unroll
-                for (int k = 0; k < TI_FAST_CHUNKS; k++) dsum += rv[d][k] * tr[k];
-                const double u = wave_sum(dsum);
-#pragma unroll
-                for (int k = 0; k < TI_FAST_CHUNKS; k++) acc[k] += rv[d][k] * u;
-            }
-        }
-        __syncthreads();               // tv fully read (out may alias it), arena free
-#pragma unroll
-        for (int k = 0; k < TI_FAST_CHUNKS; k++) red[w * 256 + 64 * k + l] = acc[k];
-        __syncthreads();
-        for (int sl = t; sl < 64 * nk; sl += WG) out[sl] = (sl < ns) ? (red[sl] + red[256 + sl]) + (red[512 + sl] + red[768 + sl]) : 0.0;
-        __syncthreads();
+        if (nk <= 1) ti_apply_fast<1, 16>(Ti, ld, tv, out, nT, ns, red);
+        else if (nk == 2) ti_apply_fast<2, 8>(Ti, ld, tv, out, nT, ns, red);
+        else if (nk == 3) ti_apply_fast<3, 6>(Ti, ld, tv, out, nT, ns, red);
+        else ti_apply_fast<4, 4>(Ti, ld, tv, out, nT, ns, red);
     } else {
         // wide working sets (more than 256 slots; only after an ADMM round guessed many rows): two passes, u = Ti tv staged in LDS
         constexpr int MAXK = (max_active(NCH) + 63) / 64;
@@ -534,7 +545,7 @@ __device__ __forceinline__ int ti_append(Ctx<NCH>& c, int r, double tau, int cap
 // The row held by slot p leaves: rotations of neighbouring rows of Ti, from row crow[p] downwards, collect column p in the last
 // row, which is dropped; Ti'Ti then is the inverse of S without row and column p.  The rotations follow from column p alone
 // (rho_j^2 = sum_{i<=j} Ti[i][p]^2), so they are formed first (a prefix sum) and the rows are then swept column by column:
-// thread = column, a lane-local recurrence over the rows, eight rows in flight.
+// thread = column, a lane-local recurrence over the rows, sixteen rows in flight.
 template <int NCH>
 __device__ __forceinline__ void ti_delete(Ctx<NCH>& c, int p, int& nT, int& ns)
 {
@@ -570,12 +581,12 @@ __device__ __forceinline__ void ti_delete(Ctx<NCH>& c, int p, int& nT, int& ns)
     }
     for (int col = t; col < ns; col += WG) {
         double carry = Ti[(size_t)i0 * ld + col];
-        for (int j = 1; j < m; j += 8) {
-            double rv[8];
+        for (int j = 1; j < m; j += 16) {
+            double rv[16];
 #pragma unroll
-            for (int q = 0; q < 8; q++) rv[q] = (j + q < m) ? Ti[(size_t)(i0 + j + q) * ld + col] : 0.0;
+            for (int q = 0; q < 16; q++) rv[q] = (j + q < m) ? Ti[(size_t)(i0 + j + q) * ld + col] : 0.0;
 #pragma unroll
-            for (int q = 0; q < 8; q++)
+            for (int q = 0; q < 16; q++)
                 if (j + q < m) {
                     const double cc = cs[j + q], ss = sn[j + q];
                     const double o = cc * carry + ss * rv[q];
@@ -697,10 +708,10 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             int cntAdd = 0;
             for (int r = t; r < mE; r += WG) cntAdd += (st[r] != ST_INACT && rslot[r] < 0);
             const int nadd = block_sum_i(cntAdd, c.lds);
-            // more active rows than variables while the set still changes by more than n/2 rows per trial: the primal-dual update has
+            // more active rows than variables while the set still changes by more than max(n/2, 32) rows per trial: the primal-dual update has
             // overshot (a cold start far from the solution, where every violated row enters at once) and more trials only thrash with
             // factors at full rank -- give up and let ADMM produce a working set (oracle: the same rule)
-            if (trial >= 2 && nT - ndel + nadd > c.n && ndel + nadd > c.n / 2) return 0;
+            if (trial >= 2 && nT - ndel + nadd > c.n && ndel + nadd > max(c.n / 2, 32)) return 0;
             // in one piece when the factor is empty, when most of it would change, or when promotions dictate the order
             // (oracle: the same rule; there "in one piece" is a reset followed by appends in list order)
             const bool bulk = (ROBUST && prioCtr > 0) || (nT == 0 && nadd > 0) || (ndel > 0 && ndel >= max(nT / 2, 8)) || nadd >= 16;

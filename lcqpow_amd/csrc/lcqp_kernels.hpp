@@ -275,11 +275,12 @@ __global__ __launch_bounds__(WG, LCQP_MINWAVES) void k_lcqp_run(DevBatch db)
 {
     LCQP_LDS_N(NCH)
     Ctx<NCH> c = make_ctx<NCH>(db, blockIdx.x, lds);
-    lcqp_run<NCH, false>(c);
+    lcqp_run<NCH, true>(c);      // with the dependent-row rules: since the factor is updated instead of rebuilt they cost nothing here
+                                 // (A/B 73.0 vs 72.0 ms, profiles/round2), so the batched loop and the per-QP path are ONE algorithm
 }
 
-// ---- second chance for instances whose QP subsolver gave up: the same homotopy with the dependent-row rules --------
-// (a separate kernel, so that the rules cost the first pass nothing; oracle counterpart: the robust switch of its LCQP loop)
+// ---- repeat the instances whose QP subsolver gave up (same algorithm as k_lcqp_run since round 2, from a clean subsolver state;
+// kept for the C ABI: lcqp_hip_batch_rerun_failed) -----------------------------------------------------------------------
 template <int NCH>
 __global__ __launch_bounds__(WG, 4) void k_lcqp_rerun(DevBatch db, const int* list)
 {

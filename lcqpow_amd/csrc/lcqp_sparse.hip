@@ -373,7 +373,7 @@ __device__ __forceinline__ int sp_polish(SpCtx& c, const double* g, int reuse)
             return 1;
         }
         if (changed && trial > 0) {
-            if (trial >= 2 && nact > n && changed > n / 2) return 0;       // overshooting cold start: hand over to ADMM
+            if (trial >= 2 && nact > n && changed > max(n / 2, 32)) return 0;       // overshooting cold start: hand over to ADMM
             // leaving rows: their multipliers leave the residual (r1 += E_r' y_r), then the new working set takes over
             double* ytmp = c.M(MV_LX);
             for (int r = t; r < m; r += WGS) ytmp[r] = (newst[r] == ST_INACT && st[r] != ST_INACT) ? -yt[r] : 0.0;

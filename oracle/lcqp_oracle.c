@@ -818,10 +818,10 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
             int touched = 0, ndel = 0, nadd = 0;
             for (int sl = 0; sl < q->ns; sl++) if (q->slot_row[sl] >= 0 && st[q->slot_row[sl]] == ST_INACT) ndel++;
             for (int r = 0; r < mE; r++) if (st[r] != ST_INACT && q->row_slot[r] < 0) nadd++;
-            /* more active rows than variables while the set still changes by more than n/2 rows per trial: the primal-dual update has
+            /* more active rows than variables while the set still changes by more than max(n/2, 32) rows per trial: the primal-dual update has
              * overshot (a cold start far from the solution, where every violated row enters at once) and more trials only thrash
              * with factors at full rank -- give up and let ADMM produce a working set */
-            if (trial >= 2 && q->nT - ndel + nadd > n && ndel + nadd > n / 2) return 0;
+            if (trial >= 2 && q->nT - ndel + nadd > n && ndel + nadd > (n / 2 > 32 ? n / 2 : 32)) return 0;
             /* from scratch when the factor is empty, when most of it would change, or when promotions dictate the order (the
              * device builds the factor in one piece then: blocked Cholesky and blocked triangular inverse, ti_bulk) */
             const int bulk = (robust && q->prio_ctr > 0) || (q->nT == 0 && nadd > 0) || (ndel > 0 && ndel >= (q->nT / 2 > 8 ? q->nT / 2 : 8))
@@ -1117,7 +1117,7 @@ static void lcqp_determineStationarityType(lcqp_t* p)
     p->algoStat = ORC_C_STATIONARY;
 }
 
-static int g_lcqp_robust = 0;
+static int g_lcqp_robust = 1;   /* every kernel carries the dependent-row rules since round 2 (k_lcqp_run, k_lcqp_rerun, k_qp_solve) */
 void orc_lcqp_set_robust(int on) { g_lcqp_robust = on; }
 
 int orc_lcqp_solve(int nV, int nC, int nComp,

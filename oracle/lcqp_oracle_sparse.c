@@ -243,7 +243,7 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
             return 1;
         }
         if (changed && trial > 0) {
-            if (trial >= 2 && nact > n && changed > n / 2) return 0;       /* overshooting cold start: hand over to ADMM */
+            if (trial >= 2 && nact > n && changed > (n / 2 > 32 ? n / 2 : 32)) return 0;       /* overshooting cold start: hand over to ADMM */
             for (int r = 0; r < m; r++) {
                 const int ns = q->newst[r];
                 if (ns == SP_INACT && st[r] != SP_INACT && y[r] != 0.0) {

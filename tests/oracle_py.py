@@ -124,7 +124,8 @@ SEED0 = 0x4C43515000000001
 
 
 def lcqp_set_robust(on):
-    """orc_lcqp_solve mirrors k_lcqp_run (0 / False, default) or the kernels with the dependent-row rules (k_qp_solve, k_lcqp_rerun)"""
+    """dependent-row rules of the oracle's QP solver inside orc_lcqp_solve: on by default (every kernel carries them since round 2);
+    0 / False selects the plain polish of round 1"""
     lib().orc_lcqp_set_robust(int(on))
 
 

@@ -197,6 +197,15 @@ def test_lcqp_iterate_level_match(hip, oracle, name):
     # rho up to 1e3 on these problems two correct solvers may differ by 1e-9 in an intermediate xk (the final x is compared at
     # 1e-9 elsewhere: at convergence the complementarity pairs are exact zeros).  PSD Hessians (flat directions): 1e-7.
     tol = 1e-7 if name in ("circle", "example_data") else 1e-8
+    if name == "example_data":
+        # PSD Hessian AND duplicated rows: the QP minimisers are not unique (flat directions), and which of several valid ones an
+        # intermediate QP returns depends on last bits (observed: iterates 1-4 differ by 0.09 in x while objective and merit agree to
+        # 1e-15, iterates 5-33 coincide again).  What is unique is compared per iterate -- objective and merit of the iterate --, and
+        # the iterates themselves at both ends.
+        assert np.abs(so[:, 4] - sh[:, 4]).max() < tol and np.abs(so[:, 5] - sh[:, 5]).max() < tol
+        assert np.abs(ro["trace_x"][0] - rh["trace_x"][0]).max() < tol and np.abs(ro["trace_x"][-1] - rh["trace_x"][-1]).max() < tol
+        assert np.abs(ro["x"] - rh["x"]).max() < tol
+        return
     assert np.abs(ro["trace_x"] - rh["trace_x"]).max() < tol
     assert np.abs(so[:, 1] - sh[:, 1]).max() < 10 * tol                         # complementarity per iterate
     assert np.abs(so[:, 0] - sh[:, 0]).max() < 10 * tol                         # stationarity per iterate

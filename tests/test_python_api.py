@@ -358,4 +358,4 @@ def test_python_option_sweep_host_loop(hip, oracle, kw):
             if ro["ret"] == 0:
                 assert np.abs(x - ro["x"]).max() < 1e-7 and int(stats.getSolutionStatus()) == so["status"]
     finally:
-        oracle.lcqp_set_robust(0)
+        oracle.lcqp_set_robust(1)

@@ -130,7 +130,7 @@ def oracle_solve_with_rerun(d):
     if ro["ret"] == 203 and ro["stats"]["qpSolverExitFlag"] == 1:
         O.lcqp_set_robust(1)
         ro = P.oracle_solve(O, d, O.default_options(perturbStep=0))
-        O.lcqp_set_robust(0)
+        O.lcqp_set_robust(1)
     return ro
 
 
@@ -139,7 +139,7 @@ def run(count, seed, verbose=True, host=False, rerun=False):
     dependent-row rules) vs the oracle with the same rules; rerun=True: batched loop followed by the second pass for failed
     instances (k_lcqp_rerun) vs the oracle doing the same"""
     O.build(); O.lib()
-    O.lcqp_set_robust(1 if host else 0)
+    O.lcqp_set_robust(1)      # every kernel carries the dependent-row rules since round 2
     rng = np.random.default_rng(seed)
     rets = {}
     cats = {"same": 0, "same solution, other iterate count": 0, "other stationary point": 0, "return codes differ": 0}
@@ -179,7 +179,7 @@ def run(count, seed, verbose=True, host=False, rerun=False):
                         print(f"[{k}] S-stationary point is not the minimiser of its branch QP: {np.abs(xb - rh['x']).max():.2e}", flush=True)
         if msg and verbose:
             print(f"[{k}] n={d['nV']} nC={d['nC']} nComp={d['nComp']} keys={sorted(set(d) - {'Q', 'g', 'L', 'R', 'nV', 'nC', 'nComp'})}: {cat}: {msg}", flush=True)
-    O.lcqp_set_robust(0)
+    O.lcqp_set_robust(1)
     if verbose:
         print(f"fuzz[{'host loop + SubsolverHIP' if host else 'batched device loop + second pass' if rerun else 'batched device loop'}]: {count} problems (seed {seed}): {cats}; (oracle ret, hip ret) histogram: {dict(sorted(rets.items()))}")
     return cats, rets
