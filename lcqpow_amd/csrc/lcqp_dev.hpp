@@ -13,7 +13,7 @@ namespace lcqp {
 
 // per-instance vectors of length np (padded nV)
 enum { V_G, V_GPHI, V_GTIL, V_XK, V_PK, V_XNEW, V_GK, V_QX, V_CX, V_QP, V_CP, V_STATK, V_TMP,
-       V_XQ, V_XA, V_XT, V_R1, V_C, V_DU, V_W, V_RHS, V_LB, V_UB, V_X0, V_R1S, V_GS, V_ATY, V_NUM };
+       V_XQ, V_XA, V_XT, V_R1, V_C, V_DU, V_W, V_RHS, V_LB, V_UB, V_X0, V_R1S, V_GS, V_ATY, V_QXN, V_NUM };   // V_QXN: Q x at the last verified QP solution
 // per-instance vectors of length mEcap (rows of E = [A; L; R; box rows])
 enum { M_L, M_U, M_RHOV, M_YQ, M_YA, M_ZA, M_YT, M_EX, M_COEF, M_EXS, M_DY, M_NUM };   // M_DY: change of ya in the last ADMM iteration
 enum { I_ST, I_STT, I_DEP, I_PRIO, I_SLOT, I_LIST, I_NUM };   // I_DEP: row is active but linearly dependent on the rows of the factor; I_PRIO: promotion stamp (0: none); I_SLOT: slot of the row in the inverse factor (-1: none); I_LIST: scratch list of rows / slots
@@ -22,6 +22,7 @@ enum { S_R2, S_DY, S_D0, S_SV, S_W, S_NUM };   // slot-space vectors (length cap
 struct InstInfo {
     int mE, nfin, hasY0, setupFail, haveSolution, isSetup, nT, prioCtr;   // nT: rows of the inverse factor Ti (= rows of the working set it holds); prioCtr: promotion stamps in use (I_PRIO)
     int ndep, ns;                                                         // ndep: active rows flagged dependent (I_DEP); ns: slots of Ti in use (high-water mark, free slots inside count)
+    int cNnz, pad3;                                                       // cNnz: non-zeros of C held in compressed rows (k_compress_C), -1: C is swept as a dense matrix
     double scale, sigma, spv, rhoAdmm, phiConst;
     double hist[8];
     double work[4];   // exact work sums for the byte accounting: sum(nT), sum(nT*ns) over corrections; bytes of Ti and M moved by working-set updates; number of updates
@@ -36,6 +37,7 @@ struct DevBatch {
     double* MM;                                          // [B][mMld][mMld]: M = Et Et', every entry of every working-set matrix (k_build_M)
     int mMld;
     int* crow;                                           // [B][capS]: row of Ti that was appended together with the slot
+    int *Cp, *Ci; double* Cv; int capC;                  // C in compressed rows when it is sparse: [B][np+1], [B][capC], [B][capC]
     double *nv, *mv, *sv;                                // vector pools
     int *mi, *idx, *boxidx;
     double *lbL, *lbR;                                   // [B][nComp]
@@ -691,7 +693,8 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
         if (trial > 0 && !changed && res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) {
             double *r1s = c.V(V_R1S), *gs0 = c.V(V_GS), *exs = c.M(M_EXS), *aty = c.V(V_ATY);
             // A'y_A + y_box = -E'y = g + Qx + r1 at the verified point (all three are direct sums of this trial)
-            for (int i = t; i < np; i += WG) { r1s[i] = r1[i]; gs0[i] = g[i]; aty[i] = g[i] + qx[i] + r1[i]; }
+            double* qxn = c.V(V_QXN);
+            for (int i = t; i < np; i += WG) { r1s[i] = r1[i]; gs0[i] = g[i]; aty[i] = g[i] + qx[i] + r1[i]; qxn[i] = qx[i]; }
             for (int r = t; r < mE; r += WG) exs[r] = ex[r];
             __syncthreads();
             return 1;
@@ -987,6 +990,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     // (V_ATY), so updateStationarity needs no sweep of its own.
     {
         int initial = 1;
+        wg_symv<NCH>(c.Q, c.C, n, xk, nullptr, Qx, Cx, nullptr, nullptr, c.lds);      // Q x0, C x0: the one sweep over Q and C of the homotopy
         for (;;) {
             rc = solveQP(initial);
             if (rc != 0) break;
@@ -1004,7 +1008,28 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
                 perturbCounter += (uint64_t)n;
                 __syncthreads();
             }
-            wg_symv<NCH>(c.Q, c.C, n, pk, xk, Qp, Cp, Qx, Cx, c.lds);
+            // Q pk and C pk (the products getOptimalStepLength needs, :1217-1237).  Q x_new is the direct product the subsolver formed when
+            // it verified its solution (V_QXN), so Q pk = Q x_new - Q xk needs no sweep; C is applied from its compressed rows when it is
+            // sparse (one-hot L, R: 2 nComp non-zeros), else swept.  Q xk and C xk follow from the step (updateStep below).
+            {
+                const double* qxn = c.V(V_QXN);
+                for (int i = t; i < np; i += WG) Qp[i] = qxn[i] - Qx[i];
+                const int cnz = uniform_i(c.info->cNnz);
+                if (cnz >= 0) {
+                    const int* cp = db.Cp + (size_t)c.b * (np + 1);
+                    const int* ci = db.Ci + (size_t)c.b * db.capC;
+                    const double* cv = db.Cv + (size_t)c.b * db.capC;
+                    for (int i = t; i < np; i += WG) {
+                        double sdot = 0.0;
+                        if (i < n) for (int k = cp[i]; k < cp[i + 1]; k++) sdot += cv[k] * pk[ci[k]];
+                        Cp[i] = sdot;
+                    }
+                    __syncthreads();
+                } else {
+                    __syncthreads();
+                    wg_symv<NCH>(c.C, nullptr, n, pk, nullptr, Cp, nullptr, nullptr, nullptr, c.lds);
+                }
+            }
             if (!initial) {
                 // getOptimalStepLength :1217-1237: qk = pk'Qk pk, lk = pk'(Qk xk + g_tilde)
                 double sq = 0.0, sl = 0.0;

@@ -192,6 +192,10 @@ try {
     d.mMld = ((d.mEcap + 63) / 64) * 64;
     rc |= dev_alloc(h, &d.MM, B * (size_t)d.mMld * d.mMld, true);
     rc |= dev_alloc(h, &d.crow, B * (size_t)d.capS, true);
+    d.capC = 8 * d.np;                                     // C goes into compressed rows when it has at most 8 non-zeros per row on average
+    rc |= dev_alloc(h, &d.Cp, B * (np + 1), true);
+    rc |= dev_alloc(h, &d.Ci, B * (size_t)d.capC, true);
+    rc |= dev_alloc(h, &d.Cv, B * (size_t)d.capC, true);
     rc |= dev_alloc(h, &d.S2, B * (size_t)d.capS * d.capS, true);
     rc |= dev_alloc(h, &d.DS, B * (size_t)(d.capS / 64) * 4096, true);
     rc |= dev_alloc(h, &d.D1, B * (size_t)d.nblk * 4096, true);
@@ -440,7 +444,7 @@ static int launch_setup(lcqp_hip_batch* h)
     DevBatch& d = h->db;
     const int ntile = d.nblk * (d.nblk + 1) / 2;
     dispatch_db(h, ID_k_prepare, d.B);
-    if (d.nComp > 0) dispatch_db(h, ID_k_build_C, d.B * ntile);
+    if (d.nComp > 0) { dispatch_db(h, ID_k_build_C, d.B * ntile); dispatch_db(h, ID_k_compress_C, d.B); }
     dispatch_db(h, ID_k_build_K, d.B * ntile);
     dispatch_db(h, ID_k_factor, d.B);
     dispatch_db(h, ID_k_trsm, d.B * ((d.mEcap + 63) / 64));
@@ -538,7 +542,8 @@ catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothin
 //   working-set update          : the bytes of Ti read and written by row appends and rotations, and the entries of M read (summed
 //                                 exactly by the kernel, InstInfo::work[2])
 //   ADMM iteration              : LK fwd+bwd + two sweeps over E
-//   LCQP iterate                : one sweep over Q and C (Q*[pk,xk], C*[pk,xk])
+//   LCQP                        : one sweep over Q and C (Q x0, C x0); per iterate C pk from compressed rows (12 B per non-zero) or by a
+//                                 sweep over C; Q pk comes from the subsolver's verified residual
 extern "C" double lcqp_hip_batch_algorithmic_bytes(lcqp_hip_batch_t* h)
 try {
     if (!h) return 0.0;
@@ -559,7 +564,8 @@ try {
         total += st[b].corrections * bs + 2.0 * 8.0 * naC * n + 8.0 * (tiC + 2.0 * naC);
         total += updBytes;
         total += st[b].admmIter * (bs + 2.0 * 8.0 * m * n);
-        total += (st[b].iterTotal + 1) * (2.0 * 8.0 * n * n);   // one sweep over Q and C per LCQP iterate
+        total += 2.0 * 8.0 * n * n;                                                   // Q x0, C x0: the one sweep over Q and C
+        total += (st[b].iterTotal + 1) * (info[b].cNnz >= 0 ? 12.0 * info[b].cNnz : 8.0 * n * n);   // C pk per LCQP iterate: compressed rows or a sweep
     }
     return total;
 }

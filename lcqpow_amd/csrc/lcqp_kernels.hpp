@@ -83,7 +83,7 @@ __global__ __launch_bounds__(WG) void k_prepare(DevBatch db)
         c.info->rhoAdmm = rho;
         c.info->phiConst = phiConst;
         c.info->haveSolution = 0;
-        c.info->nT = 0; c.info->ns = 0;
+        c.info->nT = 0; c.info->ns = 0; c.info->cNnz = -1;
         c.info->setupFail = 0;
         c.info->isSetup = 1;
     }
@@ -115,6 +115,59 @@ __global__ __launch_bounds__(WG) void k_build_C(DevBatch db)
             C[(size_t)gi * np + gj] = v;
             C[(size_t)gj * np + gi] = v;
         }
+}
+
+// ---- k_compress_C: C in compressed rows when it is sparse (one-hot L, R give 2 nComp non-zeros) ------------------------------------
+// The homotopy applies C to one vector per iterate; from compressed rows that costs 12 bytes per non-zero instead of a sweep over
+// np x np doubles.  More than capC non-zeros: cNnz = -1 and C stays a dense sweep.
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_compress_C(DevBatch db)
+{
+    LCQP_LDS_N(NCH)
+    constexpr int np = 128 * NCH;
+    const int b = blockIdx.x, t = threadIdx.x, l = lane_id(), w = wave_id();
+    const double* C = db.C + (size_t)b * np * np;
+    int* cp = db.Cp + (size_t)b * (np + 1);
+    int* ci = db.Ci + (size_t)b * db.capC;
+    double* cv = db.Cv + (size_t)b * db.capC;
+    int* cnt = reinterpret_cast<int*>(lds.arena);        // np row counts, then row starts
+    const int n = db.n;
+    for (int r = w; r < np; r += NWAVE) {
+        int k = 0;
+        if (r < n) for (int c0 = 0; c0 < np; c0 += 64) k += __popcll(__ballot(C[(size_t)r * np + c0 + l] != 0.0));
+        if (l == 0) cnt[r] = k;
+    }
+    __syncthreads();
+    {   // exclusive scan of the np counts: each thread a contiguous chunk
+        constexpr int per = (np + WG - 1) / WG;
+        const int r0 = t * per;
+        int loc = 0;
+        for (int q = 0; q < per; q++) if (r0 + q < np) loc += cnt[r0 + q];
+        int incl = loc;
+#pragma unroll
+        for (int ofs = 1; ofs < 64; ofs <<= 1) { const int v = __shfl_up(incl, ofs, 64); if (l >= ofs) incl += v; }
+        if (l == 63) lds.ired[8 + w] = incl;
+        __syncthreads();
+        int run = incl - loc;
+        for (int ww = 0; ww < w; ww++) run += lds.ired[8 + ww];
+        const int total = lds.ired[8] + lds.ired[9] + lds.ired[10] + lds.ired[11];
+        __syncthreads();
+        for (int q = 0; q < per; q++) if (r0 + q < np) { const int k = cnt[r0 + q]; cnt[r0 + q] = run; run += k; }
+        __syncthreads();
+        if (total > db.capC) { if (t == 0) db.info[b].cNnz = -1; return; }
+        if (t == 0) { db.info[b].cNnz = total; cp[np] = total; }
+    }
+    for (int r = w; r < np; r += NWAVE) {
+        int pos = cnt[r];
+        if (l == 0) cp[r] = pos;
+        if (r < n)
+            for (int c0 = 0; c0 < np; c0 += 64) {
+                const double v = C[(size_t)r * np + c0 + l];
+                const unsigned long long mask = __ballot(v != 0.0);
+                if (v != 0.0) { const int o = pos + __popcll(mask & ((1ULL << l) - 1ULL)); ci[o] = c0 + l; cv[o] = v; }
+                pos += __popcll(mask);
+            }
+    }
 }
 
 // ---- k_build_K: FK = Q + sigma I + E' diag(rho) E  (lower tiles, mirrored) -------------------------
@@ -443,6 +496,7 @@ static void launch_impl(int kid, int grid, hipStream_t s, const LaunchArgs& a)
     switch (kid) {
         case ID_k_prepare:    hipLaunchKernelGGL((k_prepare<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_build_C:    hipLaunchKernelGGL((k_build_C<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
+        case ID_k_compress_C: hipLaunchKernelGGL((k_compress_C<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_build_K:    hipLaunchKernelGGL((k_build_K<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_factor:     hipLaunchKernelGGL((k_factor<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_trsm:       hipLaunchKernelGGL((k_trsm<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;

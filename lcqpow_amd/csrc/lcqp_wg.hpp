@@ -257,7 +257,9 @@ __device__ __forceinline__ void wg_symv(const double* __restrict__ M0, const dou
                         const double* __restrict__ v0, const double* __restrict__ v1,
                         double* o00, double* o10, double* o01, double* o11, Lds lds)
 {
-    if (M1 != nullptr || v1 != nullptr) wg_symv_t<NCH, true, true>(M0, M1, n, v0, v1, o00, o10, o01, o11, lds);
+    if (M1 != nullptr && v1 != nullptr) wg_symv_t<NCH, true, true>(M0, M1, n, v0, v1, o00, o10, o01, o11, lds);
+    else if (M1 != nullptr) wg_symv_t<NCH, true, false>(M0, M1, n, v0, nullptr, o00, o10, nullptr, nullptr, lds);
+    else if (v1 != nullptr) wg_symv_t<NCH, false, true>(M0, nullptr, n, v0, v1, o00, nullptr, o01, nullptr, lds);
     else wg_symv_t<NCH, false, false>(M0, nullptr, n, v0, nullptr, o00, nullptr, nullptr, nullptr, lds);
 }
 

@@ -326,7 +326,8 @@ def test_lcqp_full_batch_properties(hip, oracle):
     tot = lambda k: float(sum(s[k] for s in st2))
     # ws = (sum of active rows nT, sum of nT * slots, bytes moved by working-set updates, number of updates)
     expect = (tot("reserved") * 8.0 * (n * n + m * n) + tot("corrections") * bs + 16.0 * ws[0] * n + 8.0 * (ws[1] + 2.0 * ws[0])
-              + ws[2] + tot("admmIter") * (bs + 16.0 * m * n) + (tot("iterTotal") + B) * 16.0 * n * n)
+              + ws[2] + tot("admmIter") * (bs + 16.0 * m * n) + B * 16.0 * n * n + (tot("iterTotal") + B) * 12.0 * (2 * nComp))
+    # (LCQP level: one sweep over Q and C per homotopy; C pk per iterate from the 2 nComp non-zeros of C = L'R + R'L for one-hot L, R)
     assert abs(bt.algorithmic_bytes() - expect) <= 1e-9 * expect
     assert 64 < ws[0] / tot("corrections") < n and ws[1] >= ws[0] ** 2 / tot("corrections")      # mean active rows; slots >= rows
     assert ws[3] == tot("factorizations") and ws[2] > 0
