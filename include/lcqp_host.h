@@ -56,6 +56,9 @@ typedef struct lcqp_host_problem lcqp_host_problem_t;
 lcqp_host_problem_t* lcqp_host_problem_create(int nV, int nC, int nComp);        /* LCQProblem(int,int,int) src/LCQProblem.cpp:43-84 */
 void lcqp_host_problem_destroy(lcqp_host_problem_t* p);
 void lcqp_host_problem_set_device(lcqp_host_problem_t* p, int device);           /* which GPU runs the subsolver (no reference analogue) */
+/* HIP_DENSE runs the whole homotopy on the device (batch of one); hostLoop != 0 keeps the reference's host loop (src/LCQProblem.cpp:444-560)
+ * over the SubsolverHIP plugin for it as well -- the reference's three solver values always use the host loop */
+void lcqp_host_problem_set_host_loop(lcqp_host_problem_t* p, int hostLoop);
 void lcqp_host_problem_set_options(lcqp_host_problem_t* p, const lcqp_host_options_t* o);   /* include/LCQProblem.hpp:242 */
 
 /* dense loadLCQP, src/LCQProblem.cpp:87-144 */

@@ -7,11 +7,11 @@
 namespace LCQPow {
 
 LCQProblem::LCQProblem()
-    : nV(0), nC(0), nComp(0), nDuals(0), boxDualOffset(0), device(0), loaded(false), haveBox(false), sparseSolver(false),
+    : nV(0), nC(0), nComp(0), nDuals(0), boxDualOffset(0), device(0), loaded(false), haveBox(false), sparseSolver(false), hostLoop(false),
       Q_sparse(0), A_sparse(0), L_sparse(0), R_sparse(0), C_sparse(0) {}
 
 LCQProblem::LCQProblem(int _nV, int _nC, int _nComp)
-    : nV(0), nC(0), nComp(0), nDuals(0), boxDualOffset(0), device(0), loaded(false), haveBox(false), sparseSolver(false),
+    : nV(0), nC(0), nComp(0), nDuals(0), boxDualOffset(0), device(0), loaded(false), haveBox(false), sparseSolver(false), hostLoop(false),
       Q_sparse(0), A_sparse(0), L_sparse(0), R_sparse(0), C_sparse(0)
 {
     // consistency checks of the reference constructor (src/LCQProblem.cpp:43-67)
@@ -212,7 +212,7 @@ void LCQProblem::addRT(const double* y, double* out) const
     else Utilities::AddTransponsedMatrixMultiplication(R.data(), y, out, nComp, nV, 1);
 }
 
-ReturnValue LCQProblem::initializeSolver()
+ReturnValue LCQProblem::initializeSolver(bool needSubsolver)
 {
     if (!loaded) return LCQPOBJECT_NOT_SETUP;
     // The four arms of src/LCQProblem.cpp:888-963.  Every arm runs on the HIP subsolver (the reference's qpOASES and OSQP
@@ -240,7 +240,9 @@ ReturnValue LCQProblem::initializeSolver()
     yk.assign(nDuals, 0.0);
     for (int i = 0; i < nDuals; ++i) yk[i] = y0Full[(nV - boxDualOffset) + i];
     ysub.assign(nV + m, 0.0);
-    if (sparseSolver) {
+    if (!needSubsolver) {
+        // the loop runs on the device: no per-QP plugin object
+    } else if (sparseSolver) {
         // CSC problem data: the loop below runs on the CSC Utilities; the device subsolver of this arm is dense,
         // so it receives dense copies of Q and [A;L;R] (the reference hands the CSC arrays to qpOASES / OSQP instead,
         // src/LCQProblem.cpp:908-927,960)
@@ -253,7 +255,7 @@ ReturnValue LCQProblem::initializeSolver()
         Subsolver tmp(nV, m, Q.data(), A.data(), HIP_DENSE, device);
         subsolver = tmp;
     }
-    subsolver.setOptions(options.getHIPOptions());
+    if (needSubsolver) subsolver.setOptions(options.getHIPOptions());
     gTilde = g;
     phiConst = 0.0;
     gPhi.clear();
@@ -279,10 +281,111 @@ ReturnValue LCQProblem::initializeSolver()
     return SUCCESSFUL_RETURN;
 }
 
+// per-iterate outputs of a device run: the tracking vectors of OutputStatistics (src/OutputStatistics.cpp:131-164) and the
+// iteration table of printIteration (src/LCQProblem.cpp:1528-1576), rebuilt from the device trace
+// (scalars: |statk|inf, phi, rho, alphak, objective, merit, |pk|inf, QP iterations)
+void LCQProblem::finishFromTrace(const std::vector<double>& sc, const std::vector<double>& xs, int len)
+{
+    const PrintLevel pl = options.getPrintLevel();
+    int outer = 0, inner = 0;
+    for (int k = 0; k < len; ++k) {
+        const double* s = &sc[(size_t)k * 8];
+        if (k > 0 && s[2] != sc[(size_t)(k - 1) * 8 + 2]) { outer++; inner = 0; }      // a penalty update in the previous pass
+        if (options.getStoreSteps())
+            stats.updateTrackingVectors(&xs[(size_t)k * nV], inner, (int)s[7], s[3], s[6], s[0], s[4], s[1], s[5], nV);
+        if (pl != NONE && !(pl == OUTER_LOOP_ITERATES && inner > 0)) {
+            const bool in = pl >= INNER_LOOP_ITERATES;
+            if ((in && inner % 10 == 0) || (!in && outer % 10 == 0))
+                std::printf(in ? " outer |  inner |   station  |   complem  |     rho    |   norm p   |    alpha   | sub it\n"
+                               : " outer |   station  |   complem  |     rho    |   norm p\n");
+            std::printf("%6d", outer);
+            if (in) std::printf(" | %6d", inner);
+            std::printf(" | %10.3g | %10.3g | %10.3g | %10.3g", s[0], s[1], s[2], s[6]);
+            if (in) std::printf(" | %10.3g | %6d", s[3], (int)s[7]);
+            std::printf(" \n");
+        }
+        inner++;
+    }
+}
+
+ReturnValue LCQProblem::runOnDevice()
+{
+    const int m = nC + 2 * nComp;
+    double *q = 0, *a = 0, *l = 0, *r = 0;
+    if (sparseSolver) {
+        q = Utilities::csc_to_dns(Q_sparse); a = Utilities::csc_to_dns(A_sparse); l = Utilities::csc_to_dns(L_sparse); r = Utilities::csc_to_dns(R_sparse);
+        if (!q || !a || !l || !r) { delete[] q; delete[] a; delete[] l; delete[] r; return FAILED_SWITCH_TO_DENSE; }
+    }
+    const double *Qd = sparseSolver ? q : Q.data(), *Ad = sparseSolver ? a : A.data(), *Ld = sparseSolver ? l : L.data(), *Rd = sparseSolver ? r : R.data();
+    lcqp_hip_batch_t* bt = lcqp_hip_batch_create(1, nV, nC, nComp, haveBox ? 1 : 0, device);
+    ReturnValue ret = SUBPROBLEM_SOLVER_ERROR;
+    if (bt) {
+        lcqp_options_t o = options.getHIPOptions();
+        const bool wantTrace = o.storeSteps != 0 || o.printLevel != 0;
+        o.storeSteps = wantTrace ? 1 : 0;
+        int rc = lcqp_hip_batch_set_options(bt, &o);
+        if (!rc) rc = lcqp_hip_batch_load(bt, 0, 1, Qd, g.data(), Ld, Rd, haveLbL ? lbL.data() : 0, &ubA[nC], haveLbR ? lbR.data() : 0, &ubA[nC + nComp],
+                                          nC > 0 ? Ad : 0, lbA.data(), ubA.data(), haveBox ? lb.data() : 0, haveBox ? ub.data() : 0, xk.data(),
+                                          haveYk ? y0Full.data() : 0);
+        if (!rc) rc = lcqp_hip_batch_run(bt);
+        lcqp_stats_t st;
+        std::memset(&st, 0, sizeof(st));
+        yk.assign(nV + m, 0.0);
+        if (!rc) rc = lcqp_hip_batch_get_solution(bt, xk.data(), yk.data(), &st);
+        if (!rc) {
+            stats.updateIterTotal(st.iterTotal); stats.updateIterOuter(st.iterOuter); stats.updateSubproblemIter(st.subproblemIter);
+            stats.updateRhoOpt(st.rhoOpt); stats.updateQPSolverExitFlag(st.qpSolverExitFlag);
+            algoStat = (AlgorithmStatus)st.status;
+            stats.updateSolutionStatus(algoStat);
+            if (wantTrace) {
+                const int cap = std::min(st.iterTotal + 1, 1024);
+                std::vector<double> sc((size_t)cap * 8), xs((size_t)cap * nV);
+                int len = 0;
+                if (!lcqp_hip_batch_get_trace(bt, 0, cap, sc.data(), xs.data(), &len)) finishFromTrace(sc, xs, len);
+            }
+            ret = (ReturnValue)st.returnValue;
+        }
+        lcqp_hip_batch_destroy(bt);
+    }
+    delete[] q; delete[] a; delete[] l; delete[] r;
+    return ret;
+}
+
+// OSQP_SPARSE arm with CSC data: the sparse engine (lcqp_hip_sparse_*, band LDL' of the KKT matrix) when the pattern is banded and
+// no per-iterate output is asked for (the sparse kernel keeps no trace); otherwise the caller falls back to the host loop over the
+// dense kernels.
+bool LCQProblem::runSparseOnDevice(ReturnValue& ret)
+{
+    if (!sparseSolver || options.getStoreSteps() || options.getPrintLevel() != NONE) return false;
+    lcqp_hip_sparse_t* sb = lcqp_hip_sparse_create(1, nV, nC, nComp, Q_sparse->p, Q_sparse->i, A_sparse->p, A_sparse->i, device);
+    if (!sb) return false;                        // not a banded pattern (lcqp_hip_sparse_last_error says so)
+    const int m = nC + 2 * nComp;
+    int rc = lcqp_hip_sparse_set_options(sb, &options.getHIPOptions());
+    if (!rc) rc = lcqp_hip_sparse_load(sb, 0, 1, Q_sparse->x, g.data(), A_sparse->x, lbA.data(), ubA.data(), haveLbL ? lbL.data() : 0, &ubA[nC],
+                                       haveLbR ? lbR.data() : 0, &ubA[nC + nComp], xk.data(), haveYk ? yk.data() : 0);
+    if (!rc) rc = lcqp_hip_sparse_run(sb);
+    lcqp_stats_t st;
+    std::memset(&st, 0, sizeof(st));
+    yk.assign(m, 0.0);
+    if (!rc) rc = lcqp_hip_sparse_get_solution(sb, xk.data(), yk.data(), &st);
+    lcqp_hip_sparse_destroy(sb);
+    if (rc) { ret = SUBPROBLEM_SOLVER_ERROR; return true; }
+    stats.updateIterTotal(st.iterTotal); stats.updateIterOuter(st.iterOuter); stats.updateSubproblemIter(st.subproblemIter);
+    stats.updateRhoOpt(st.rhoOpt); stats.updateQPSolverExitFlag(st.qpSolverExitFlag);
+    algoStat = (AlgorithmStatus)st.status;
+    stats.updateSolutionStatus(algoStat);
+    ret = (ReturnValue)st.returnValue;
+    return true;
+}
+
 ReturnValue LCQProblem::runSolver()
 {
-    ReturnValue ret = initializeSolver();
+    const QPSolver arm = options.getQPSolver();
+    const bool deviceLoop = (arm == HIP_DENSE && !hostLoop);
+    ReturnValue ret = initializeSolver(!deviceLoop);
     if (ret != SUCCESSFUL_RETURN) return ret;
+    if (deviceLoop) return runOnDevice();
+    if (arm == OSQP_SPARSE && !hostLoop && runSparseOnDevice(ret)) return ret;
     if (options.getSolveZeroPenaltyFirst()) gk = g;
     else updateLinearization();
     ret = solveQPSubproblem(true);

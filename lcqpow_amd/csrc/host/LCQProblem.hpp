@@ -52,9 +52,15 @@ class LCQProblem {
     void getOutputStatistics(OutputStatistics& stats_) const { stats_ = stats; }
     void setOptions(const Options& options_) { options = options_; }
     void setDevice(int device_) { device = device_; }
+    // HIP_DENSE runs the whole homotopy on the device (a batch of one through lcqp_hip_batch_*); the reference's three solver values keep
+    // the reference's host loop over the subsolver plugin.  hostLoop = true forces the host loop for HIP_DENSE too.
+    void setHostLoop(bool hostLoop_) { hostLoop = hostLoop_; }
 
   private:
-    ReturnValue initializeSolver();
+    ReturnValue initializeSolver(bool needSubsolver = true);
+    ReturnValue runOnDevice();                 // HIP_DENSE: LCQProblem::runSolver as one batch-of-one launch of k_lcqp_run
+    bool runSparseOnDevice(ReturnValue& ret);  // OSQP_SPARSE with a banded pattern: k_sparse_run; false when the pattern is not banded
+    void finishFromTrace(const std::vector<double>& sc, const std::vector<double>& xs, int len);
     ReturnValue solveQPSubproblem(bool initialSolve);
     void updateLinearization();
     void updateStationarity();
@@ -81,7 +87,7 @@ class LCQProblem {
     void clearSparse();
 
     int nV, nC, nComp, nDuals, boxDualOffset, device;
-    bool loaded, haveYk, haveLbL, haveLbR, haveBox, sparseSolver;
+    bool loaded, haveYk, haveLbL, haveLbR, haveBox, sparseSolver, hostLoop;
     std::vector<double> y0Full, ysub;   // y0 as loaded (reference layout nV + nC + 2 nComp); subsolver dual vector (box duals first)
     csc *Q_sparse, *A_sparse, *L_sparse, *R_sparse, *C_sparse;
     std::vector<double> Q, g, L, R, A, lbA, ubA, lb, ub, lbL, lbR, C, Qk;

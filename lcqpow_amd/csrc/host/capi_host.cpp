@@ -106,6 +106,7 @@ catch (...) { return nullptr; }   // nothing throws across the C boundary
 void lcqp_host_problem_destroy(lcqp_host_problem_t* p) { delete p; }
 
 void lcqp_host_problem_set_device(lcqp_host_problem_t* p, int device) { if (p) p->lcqp.setDevice(device); }
+void lcqp_host_problem_set_host_loop(lcqp_host_problem_t* p, int hostLoop) { if (p) p->lcqp.setHostLoop(hostLoop != 0); }
 
 void lcqp_host_problem_set_options(lcqp_host_problem_t* p, const lcqp_host_options_t* o)
 {

@@ -137,6 +137,7 @@ def _host():
         L.lcqp_host_problem_create.argtypes = [C.c_int] * 3
         L.lcqp_host_problem_destroy.argtypes = [vp]
         L.lcqp_host_problem_set_device.argtypes = [vp, C.c_int]
+        L.lcqp_host_problem_set_host_loop.argtypes = [vp, C.c_int]
         L.lcqp_host_problem_set_options.argtypes = [vp, vp]
         L.lcqp_host_problem_load_dense.argtypes = [vp] + [_dp] * 15
         cp = C.POINTER(_CscArg)
@@ -312,6 +313,11 @@ class LCQProblem:
 
     def setOptions(self, options):
         _host().lcqp_host_problem_set_options(self._h, options._h)
+
+    def setHostLoop(self, host_loop=True):
+        """QPSolver.HIP_DENSE runs the whole homotopy on the device; True keeps the reference's host loop over the SubsolverHIP plugin
+        for it too (no reference analogue; the reference's three solver values always use the host loop)"""
+        _host().lcqp_host_problem_set_host_loop(self._h, int(bool(host_loop)))
 
     def loadLCQP(self, Q=None, g=None, L=None, R=None, lbL=None, ubL=None, lbR=None, ubR=None, A=None, lbA=None, ubA=None,
                  lb=None, ub=None, x0=None, y0=None, *, order="F",

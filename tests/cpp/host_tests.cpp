@@ -194,7 +194,7 @@ static void test_examples()
       CHECK((int)st.getxStepsStdVec().size() == st.getIterTotal() && (int)st.getPhiValsStdVec().size() == st.getIterTotal()); }
 }
 
-static void test_circle(bool print)
+static void test_circle(bool print, bool hostLoop = false, double* xOut = 0, int* itOut = 0)
 {   // examples/OptimizeOnCircle.cpp:32-99, dense path (BASELINE config C2)
     const int N = 100, nV = 2 + 2 * N, nC = N + 1, nComp = N;
     std::vector<double> Q(nV * nV, 0.0), g(nV, 0.0), L(nComp * nV, 0.0), R(nComp * nV, 0.0), A(nC * nV, 0.0), lbA(nC, 1.0), ubA(nC, 1.0), x0(nV, 0.0);
@@ -211,14 +211,40 @@ static void test_circle(bool print)
     LCQProblem lcqp(nV, nC, nComp);
     Options options; options.setPrintLevel(print ? INNER_LOOP_ITERATES : NONE); options.setPerturbStep(false);
     lcqp.setOptions(options);
+    lcqp.setHostLoop(hostLoop);
     CHECK(lcqp.loadLCQP(Q.data(), g.data(), L.data(), R.data(), 0, 0, 0, 0, A.data(), lbA.data(), ubA.data(), 0, 0, x0.data()) == SUCCESSFUL_RETURN);
     CHECK(lcqp.runSolver() == SUCCESSFUL_RETURN);
     std::vector<double> x(nV), y(nV + nC + 2 * nComp);
     lcqp.getPrimalSolution(x.data()); lcqp.getDualSolution(y.data());
     OutputStatistics st; lcqp.getOutputStatistics(st);
-    std::printf("circle xOpt = [ %.10g, %.10g ]; i = %d; k = %d; rho = %g; WSR = %d; status = %d\n", x[0], x[1], st.getIterTotal(), st.getIterOuter(), st.getRhoOpt(), st.getSubproblemIter(), (int)st.getSolutionStatus());
+    if (xOut) { xOut[0] = x[0]; xOut[1] = x[1]; }
+    if (itOut) { itOut[0] = st.getIterTotal(); itOut[1] = st.getIterOuter(); }
+    std::printf("%scircle xOpt = [ %.10g, %.10g ]; i = %d; k = %d; rho = %g; WSR = %d; status = %d\n", hostLoop ? "host-loop " : "", x[0], x[1], st.getIterTotal(), st.getIterOuter(), st.getRhoOpt(), st.getSubproblemIter(), (int)st.getSolutionStatus());
     const bool glob = std::fabs(x[0] - 0.1811) < 1e-4 && std::fabs(x[1] + 0.9835) < 1e-4, loc = std::fabs(x[0] - 0.9764) < 1e-4 && std::fabs(x[1] + 0.2183) < 1e-4;
     CHECK(glob || loc);   // examples/OptimizeOnCircle.cpp:144-145
+}
+
+static void test_loops_agree()
+{   // runSolver with the homotopy on the device (HIP_DENSE default: a batch of one through k_lcqp_run) and with the reference's host
+    // loop over the SubsolverHIP plugin (setHostLoop) take the same path: same iterate counts, same minimiser
+    double xd[2], xh[2]; int itd[2], ith[2];
+    test_circle(false, false, xd, itd);
+    test_circle(false, true, xh, ith);
+    CHECK(itd[0] == ith[0] && itd[1] == ith[1]);
+    CHECK(std::fabs(xd[0] - xh[0]) < 1e-8 && std::fabs(xd[1] - xh[1]) < 1e-8);
+    Options options; options.setPrintLevel(NONE); options.setPerturbStep(false);
+    double xw[2][2];
+    for (int hl = 0; hl < 2; hl++) {
+        LCQProblem p(2, 0, 1); p.setOptions(options); p.setHostLoop(hl != 0);
+        double x0[2] = {1, 1}, y0[4] = {0, 0, 0, 0};
+        CHECK(p.loadLCQP(Qw, gw, Lw, Rw, 0, 0, 0, 0, 0, 0, 0, 0, 0, x0, y0) == SUCCESSFUL_RETURN);
+        CHECK(p.runSolver() == SUCCESSFUL_RETURN);
+        p.getPrimalSolution(xw[hl]);
+        CHECK(std::fabs(xw[hl][0] * xw[hl][1]) <= options.getComplementarityTolerance());
+        OutputStatistics st; p.getOutputStatistics(st);
+        CHECK(st.getSolutionStatus() >= W_STATIONARY_SOLUTION);
+    }
+    CHECK(std::fabs(xw[0][0] - xw[1][0]) < 1e-9 && std::fabs(xw[0][1] - xw[1][1]) < 1e-9);
 }
 
 static void test_batch()
@@ -272,6 +298,7 @@ int main(int argc, char** argv)
         test_examples();
         test_dense_to_sparse();
         test_circle(argc > 2);
+        test_loops_agree();
         test_batch();
     }
     std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED%.0d\n", failures);

@@ -28,7 +28,7 @@ def test_host_library_exports_declared_symbols():
     src = open(os.path.join(ROOT, "include", "lcqp_host.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = sorted(set(re.findall(r"\b(lcqp_host_[a-z_0-9]+)\s*\(", src)))
-    assert len(names) == 24, names
+    assert len(names) == 25, names
     L = ctypes.CDLL(os.path.join(ROOT, "lcqpow_amd", "liblcqpow_host.so"))
     for n in names:
         assert hasattr(L, n), n
@@ -97,9 +97,11 @@ def test_load_argument_checks_and_layout():
 
 # ------------------------------------------------------------------------------------------------ GPU
 
-def _solve(lcqpow, d, order="F", tweak=None, files=None):
-    """the call sequence of interfaces/python/examples/warm_up.py:20-47"""
+def _solve(lcqpow, d, order="F", tweak=None, files=None, host_loop=False):
+    """the call sequence of interfaces/python/examples/warm_up.py:20-47.  HIP_DENSE runs the whole homotopy on the device (a batch
+    of one); host_loop=True keeps the reference's host loop over the SubsolverHIP plugin"""
     lcqp = lcqpow.LCQProblem(nV=d["nV"], nC=d["nC"], nComp=d["nComp"])
+    lcqp.setHostLoop(host_loop)
     options = lcqpow.Options()
     options.setPrintLevel(lcqpow.PrintLevel.NONE)
     options.setQPSolver(lcqpow.QPSolver.HIP_DENSE)
@@ -137,29 +139,36 @@ def test_python_warm_up(hip):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("host_loop", [False, True])
 @pytest.mark.parametrize("name,order", [("warm_up_w_A", "F"), ("warm_up_binary", "F"), ("circle", "F"), ("circle", "C")])
-def test_python_examples_match_oracle(hip, oracle, name, order):
-    """warm_up_w_A.py, warm_up_binary.py, OptimizeOnCircle.py (L.T, R.T, A.T as at :76) vs the oracle"""
+def test_python_examples_match_oracle(hip, oracle, name, order, host_loop):
+    """warm_up_w_A.py, warm_up_binary.py, OptimizeOnCircle.py (L.T, R.T, A.T as at :76) vs the oracle -- with the whole homotopy on
+    the device (HIP_DENSE default: a batch of one through k_lcqp_run) and with the reference's host loop over SubsolverHIP"""
     lcqpow = _lcqpow()
     d = getattr(P, name)()
-    ret, x, y, stats = _solve(lcqpow, d, order=order)
+    ret, x, y, stats = _solve(lcqpow, d, order=order, host_loop=host_loop)
     ro = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0))
     assert int(ret) == ro["ret"] == 0
     assert np.abs(x - ro["x"]).max() < 1e-7
     assert np.abs(y - ro["y"]).max() < 1e-5
     so = ro["stats"]
-    assert (stats.getIterTotal(), stats.getIterOuter(), stats.getRhoOpt(), int(stats.getSolutionStatus())) == \
-        (so["iterTotal"], so["iterOuter"], so["rhoOpt"], so["status"])
+    assert (stats.getIterOuter(), stats.getRhoOpt(), int(stats.getSolutionStatus())) == (so["iterOuter"], so["rhoOpt"], so["status"])
+    # warm_up_w_A walks down the symmetric ray x1 = x2 to the saddle point at the origin (29 penalty updates, rho = 5.4e6); every other
+    # inner step there is round-off (|p| ~ 1e-16), and its stationarity residual (~ rho * eps) sits at the tolerance: the tree
+    # reductions of the device loop may take one such step more or less than the sequential sums of the oracle / host loop
+    assert abs(stats.getIterTotal() - so["iterTotal"]) <= (1 if (name == "warm_up_w_A" and not host_loop) else 0)
     if name == "circle":          # examples/OptimizeOnCircle.cpp:144
         assert np.abs(x[:2] - [0.1811, -0.9835]).max() < 1e-4
 
 
 @pytest.mark.gpu
-def test_python_store_steps(hip, oracle):
-    """OptimizeOnCircleStoreSteps.py: tracking vectors of OutputStatistics (src/OutputStatistics.cpp:131-164)"""
+@pytest.mark.parametrize("host_loop", [False, True])
+def test_python_store_steps(hip, oracle, host_loop):
+    """OptimizeOnCircleStoreSteps.py: tracking vectors of OutputStatistics (src/OutputStatistics.cpp:131-164), filled by the host loop
+    or rebuilt from the device trace when the loop runs on the device"""
     lcqpow = _lcqpow()
     d = P.circle(20)
-    ret, x, y, stats = _solve(lcqpow, d, tweak=lambda o: o.setStoreSteps(True))
+    ret, x, y, stats = _solve(lcqpow, d, tweak=lambda o: o.setStoreSteps(True), host_loop=host_loop)
     assert ret == 0
     n = len(stats.getInnerIters())
     assert n == stats.getIterTotal() + 1 or n == stats.getIterTotal()
@@ -350,7 +359,7 @@ def test_python_option_sweep_host_loop(hip, oracle, kw):
     oracle.lcqp_set_robust(1)
     try:
         for d in [oracle.synth_generate(i, 64, 96, 16) for i in range(2)] + [P.circle(20), P.warm_up_binary()]:
-            ret, x, y, stats = _solve(lcqpow, d, order="C", tweak=tweak)
+            ret, x, y, stats = _solve(lcqpow, d, order="C", tweak=tweak, host_loop=True)
             ro = P.oracle_solve(oracle, d, oracle.default_options(**base))
             assert int(ret) == ro["ret"], (kw, int(ret), ro["ret"])
             so = ro["stats"]
