@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=("dense", "sparse"), default="dense")
-    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default 1024 dense, 8192 sparse: one wave per instance, 8 waves per SIMD resident)")
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default 1024 dense; 16384 sparse: 8 instances per wavefront, 2 wavefronts per SIMD resident)")
     ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--nC", type=int, default=None)
     ap.add_argument("--nComp", type=int, default=None)
@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--no-resident", action="store_true", help="skip the 8192-resident-instances measurement")
     args = ap.parse_args()
     sparse = args.workload == "sparse"
-    B = args.batch or (8192 if sparse else 1024)
+    B = args.batch or (16384 if sparse else 1024)
     n = args.n or (4096 if sparse else 256)
     nC = args.nC if args.nC is not None else (2048 if sparse else 512)
     nComp = args.nComp or (512 if sparse else 64)

@@ -206,6 +206,7 @@ lcqp_hip_sparse_t* lcqp_hip_sparse_create(int batch, int nV, int nC, int nComp, 
 void lcqp_hip_sparse_destroy(lcqp_hip_sparse_t* s);
 const char* lcqp_hip_sparse_last_error(void);
 int  lcqp_hip_sparse_bandwidth(const lcqp_hip_sparse_t* s);              /* half bandwidth of the KKT band */
+int  lcqp_hip_sparse_lanes(const lcqp_hip_sparse_t* s);                  /* lanes of a wavefront per instance: 8, 16, 32 or 64 */
 int  lcqp_hip_sparse_get_ordering(const lcqp_hip_sparse_t* s, int* perm); /* perm[nV + nC + 2 nComp]: position -> node */
 int  lcqp_hip_sparse_set_options(lcqp_hip_sparse_t* s, const lcqp_options_t* opt);
 /* loadLCQP, sparse overload (src/LCQProblem.cpp:390-441), values only: Qx [count][nnzQ], Ax [count][nnzA] in the CSC order of
@@ -218,6 +219,8 @@ int  lcqp_hip_sparse_synchronize(lcqp_hip_sparse_t* s);
 int  lcqp_hip_sparse_last_timing(lcqp_hip_sparse_t* s, float* setup_ms, float* solve_ms);
 int  lcqp_hip_sparse_get_solution(lcqp_hip_sparse_t* s, double* x, double* y, lcqp_stats_t* stats);   /* y: [B][nC + 2 nComp] */
 double lcqp_hip_sparse_algorithmic_bytes(lcqp_hip_sparse_t* s);
+/* mean clock ticks per instance in 8 phases of the last run; LCQP_HIP_UNSUPPORTED unless the library was built with -DLCQP_PROFILE */
+int  lcqp_hip_sparse_read_profile(lcqp_hip_sparse_t* s, double* out);
 
 #ifdef __cplusplus
 }

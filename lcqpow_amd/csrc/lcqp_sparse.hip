@@ -1,5 +1,6 @@
-// lcqp_sparse.hip -- the SPARSE arm of the hot path on gfx950: B independent LCQPs that share one sparsity pattern, one persistent
-// wavefront (64-thread workgroup) per instance (k_sparse_run), behind lcqp_hip_sparse_* (include/lcqp_hip.h).
+// lcqp_sparse.hip -- the SPARSE arm of the hot path on gfx950: B independent LCQPs that share one sparsity pattern, behind
+// lcqp_hip_sparse_* (include/lcqp_hip.h).  G lanes of a wavefront per instance (G = 8, 16, 32 or 64: the smallest power of two
+// above the half bandwidth of the KKT band), 64 / G instances per wavefront, one wavefront per workgroup (k_sparse_run).
 //
 // Restates, with the conventions of the reference's OSQP_SPARSE arm (src/LCQProblem.cpp:929-960: no box constraints, nC + 2 nComp
 // duals, no box term in the stationarity :1246-1272, dual sign of src/SubsolverOSQP.cpp:196-199):
@@ -10,8 +11,10 @@
 //     and an active-set polish on [Q + delta I, Ea'; Ea, -delta2 I] in iterative-refinement form, refactorised only when the
 //     working set changes.  oracle/lcqp_oracle_sparse.c is the same algorithm in scalar C.
 // The KKT matrices are factorised as BAND matrices in a reverse Cuthill-McKee ordering computed once per pattern on the host
-// (all instances of a batch share it): LDL' with a sliding (w+1) x (w+1) window in LDS (half bandwidth w <= 63), triangular
-// solves by one wave that keeps the 64 pending rows in its lanes (axpy form both ways, no reductions in the chain).
+// (all instances of a batch share it): LDL' with a sliding G x G window in LDS (half bandwidth w <= G - 1 <= 63), triangular
+// solves that keep the G pending rows of an instance in its G lanes (axpy form both ways, no reductions in the chain; the finished
+// entry is broadcast inside the lane group by DPP).  A group of lanes behaves like a small workgroup of its own: every branch
+// condition is uniform inside a group, groups of one wavefront diverge through the execution mask, there are no workgroup barriers.
 // Patterns whose KKT band is wider (e.g. the arrow-shaped circle example) are refused here; the host layer runs them on the
 // dense kernels behind the same OSQP_SPARSE surface.
 #include "lcqp_wg.hpp"
@@ -19,6 +22,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <queue>
@@ -30,11 +34,13 @@ using namespace lcqp;
 namespace {
 
 constexpr int SP_WMAX = 63;
-constexpr int WGS = 64;      // ONE wave per instance: the factorisation and the triangular solves are chains a single wave runs; many
-                             // instances per CU (up to 32 waves) hide their latencies instead of three idle partner waves
+constexpr int WGS = 64;      // one wavefront per workgroup; 64 / G instances in it
+#ifndef SP_WAVES_PER_SIMD
+#define SP_WAVES_PER_SIMD 2  // register budget of k_sparse_run: 512 / SP_WAVES_PER_SIMD per lane
+#endif
 enum { NV_G, NV_GTIL, NV_GPHI, NV_XK, NV_PK, NV_XNEW, NV_GK, NV_QX, NV_CX, NV_QP, NV_CP, NV_TMP, NV_XQ, NV_XA, NV_XT, NV_R1, NV_R1S, NV_GS,
        NV_X0, NV_NUM };
-enum { MV_L, MV_U, MV_RHOV, MV_YQ, MV_YA, MV_ZA, MV_YT, MV_EX, MV_EXS, MV_YK, MV_Y0, MV_LX, MV_NUM };
+enum { MV_L, MV_U, MV_RHOV, MV_YQ, MV_YA, MV_ZA, MV_YT, MV_EX, MV_EXS, MV_YK, MV_Y0, MV_LX, MV_LX2, MV_NUM };
 enum { MI_ST, MI_STT, MI_STF, MI_NEW, MI_NUM };
 
 struct SpInfo {
@@ -42,17 +48,23 @@ struct SpInfo {
     double scale, sigma, delta, delta2, phiConst;
     double hist[8];
     double bytes;        // algorithmic bytes counted by the kernel
+    double prof[8];      // -DLCQP_PROFILE: clock ticks per phase (SP_* below)
 };
+enum { SP_PRODUCTS, SP_ASSEMBLE, SP_FACTOR, SP_FORWARD, SP_BACKWARD, SP_VECTORS, SP_LCQP, SP_RHS, SP_NPHASE };
+
+struct EllMat { const int *eidx, *epos, *ptr, *cidx, *cmap; int rows, W, tails; };   // see g_ell
 
 struct SpBatch {
-    int B, n, m, nC, nComp, N, Np, w, ld, nnzQ, nnzE;     // Np: N rounded up to a multiple of 64 (padding rows of the band arrays: unit diagonal)
+    int B, n, m, nC, nComp, N, Np, w, ld, nnzQ, nnzE, G;  // Np: N rounded up to a multiple of 64 (padding rows: zero coefficients)
     int hasLbL, hasLbR;
     lcqp_options_t opt;
     const int *Qp, *Qi, *Ep, *Ei, *ETp, *ETi, *ETmap, *iperm, *bandQ, *bandE;
+    EllMat ellQ, ellE, ellT; // rows of Q, rows of E, columns of E in ELL slabs
     double *Qx, *Ex;         // [B][nnzQ], [B][nnzE] (CSR order)
-    double *Ka, *KaC, *KaD;  // ADMM KKT factor: rows [B][N*ld], columns [B][N*w], 1/D [B][N]
-    double *Kp, *KpC, *KpD;  // polish KKT factor
-    double *nv, *mv, *Nv;    // [B][NV_NUM][n], [B][MV_NUM][m], [B][2][N]
+    double *Kb;              // [B][N*ld] assembled band rows (input of a factorisation): Kb[i*ld + k] = K[i][i-w+k]
+    double *KaF, *KaB, *KaD; // ADMM KKT factor in the two folded layouts of band_sweep [B][Np*G] each, 1/D [B][Np]
+    double *KpF, *KpB, *KpD; // polish KKT factor
+    double *nv, *mv, *Nv;    // [B][NV_NUM][n], [B][MV_NUM][m], [B][2][Np]
     double *lbL, *lbR;       // [B][nComp]
     int* mi;                 // [B][MI_NUM][m]
     SpInfo* info;
@@ -60,246 +72,538 @@ struct SpBatch {
     double *xout, *yout;     // [B][n], [B][m]
 };
 
+// ---- addressing: uniform base pointer + 32-bit lane offset -------------------------------------------------------------------------
+// Every per-instance array is reached as (base of the wave's first instance: uniform, SGPRs) + (byte offset of the lane's instance
+// inside the wave's block + element offset: 32 bits, one VGPR) -- the global_load saddr form.  Per-lane 64-bit pointers would cost two
+// VGPRs for each of the ~40 vectors of an instance (the compiler hoists them) and 64-bit VALU address arithmetic at every access.
+typedef double dv2 __attribute__((ext_vector_type(2)));
+template <class T> struct GRef {
+    T* base; unsigned boff;
+    __device__ __forceinline__ operator T() const { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)boff); }
+    __device__ __forceinline__ T operator=(T v) const { *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (size_t)boff) = v; return v; }
+    __device__ __forceinline__ T operator=(const GRef& o) const { return *this = (T)o; }
+    __device__ __forceinline__ T operator+=(T v) const { return *this = (T)(*this) + v; }
+    __device__ __forceinline__ T operator-=(T v) const { return *this = (T)(*this) - v; }
+};
+template <class T> struct GP {
+    T* base; unsigned off;                       // uniform base; byte offset of this lane's data
+    __device__ __forceinline__ GRef<T> operator[](int i) const { return GRef<T>{base, off + (unsigned)i * (unsigned)sizeof(T)}; }
+    __device__ __forceinline__ T ld(int i) const { return (T)(*this)[i]; }
+    __device__ __forceinline__ GP<T> operator+(int i) const { return GP<T>{base, off + (unsigned)i * (unsigned)sizeof(T)}; }
+    __device__ __forceinline__ dv2 ld2(int i) const { return *reinterpret_cast<const dv2*>(reinterpret_cast<const char*>(base) + (size_t)(off + (unsigned)i * 8u)); }
+};
+typedef GP<double> GD;
+typedef GP<int> GI;
+// the value type behind what a load lambda returns (a lambda that returns x[i] returns the reference proxy, not the value)
+template <class X> struct val_of { typedef X type; };
+template <class T> struct val_of<GRef<T>> { typedef T type; };
+
+template <int G>
 struct SpCtx {
     const SpBatch* db;
-    int b, n, m, nC, nComp, N, w, ld;
-    const double *Qx, *Ex;
-    double *Ka, *KaC, *KaD, *Kp, *KpC, *KpD, *nv, *mv, *Nv;
-    int* mi;
+    int b, gl;               // instance, lane inside the group
+    unsigned gi;             // group (instance) inside the wave
+    int w0;                  // first instance of the wave (uniform)
     SpInfo* info;
-    Lds lds;
-    double* win;     // LDS: (w+1)^2 window + staging
+    double* win;             // LDS of this group: G x G window + 16 staged rows
     int cAdmm, cTrials, cFact, cCorr, cSweeps;
     double bytes;
-    __device__ __forceinline__ double* V(int k) const { return nv + (size_t)k * n; }
-    __device__ __forceinline__ double* M(int k) const { return mv + (size_t)k * m; }
-    __device__ __forceinline__ int* I(int k) const { return mi + (size_t)k * m; }
+#ifdef LCQP_PROFILE
+    unsigned long long tprev, prof[SP_NPHASE];
+#endif
+    // per-instance arrays: block of the wave's first instance (uniform) + this instance's offset inside it
+    template <class T> __device__ __forceinline__ GP<T> arr(T* p, size_t perInst, unsigned extra = 0) const
+    { return GP<T>{p + ((size_t)w0 * perInst + extra), gi * (unsigned)perInst * (unsigned)sizeof(T)}; }    // vectors differ in the (SGPR) base only
+    __device__ __forceinline__ GD V(int k) const { return arr(db->nv, (size_t)NV_NUM * db->n, (unsigned)k * db->n); }
+    __device__ __forceinline__ GD M(int k) const { return arr(db->mv, (size_t)MV_NUM * db->m, (unsigned)k * db->m); }
+    __device__ __forceinline__ GI I(int k) const { return arr(db->mi, (size_t)MI_NUM * db->m, (unsigned)k * db->m); }
+    __device__ __forceinline__ GD Qx() const { return arr(db->Qx, db->nnzQ); }
+    __device__ __forceinline__ GD Ex() const { return arr(db->Ex, db->nnzE); }
+    __device__ __forceinline__ GD Nv() const { return arr(db->Nv, (size_t)2 * db->Np); }
+    __device__ __forceinline__ GD Kb() const { return arr(db->Kb, (size_t)db->N * db->ld); }
+    __device__ __forceinline__ GD KF(bool admm) const { return arr(admm ? db->KaF : db->KpF, (size_t)db->Np * G); }
+    __device__ __forceinline__ GD KB(bool admm) const { return arr(admm ? db->KaB : db->KpB, (size_t)db->Np * G); }
+    __device__ __forceinline__ GD KD(bool admm) const { return arr(admm ? db->KaD : db->KpD, db->Np); }
 };
 
+#ifdef LCQP_PROFILE
+#define SPROF(c, P) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); (c).prof[P] += t_ - (c).tprev; (c).tprev = t_; } while (0)
+#else
+#define SPROF(c, P) do { } while (0)
+#endif
 
-__device__ __forceinline__ double sp_sum(double v) { return uniform_d(wave_sum(v)); }
-__device__ __forceinline__ double sp_max(double v) { return uniform_d(wave_max(v)); }
-__device__ __forceinline__ int sp_any(int v) { return __any(v) ? 1 : 0; }
-__device__ __forceinline__ int sp_sum_i(int v)
+// ---- lane-group collectives (every lane of the group takes part; results are uniform inside the group) ------------------------
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return uniform_i(v);
+    const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
-
-// ---- sparse products: thread per row (CSR) / per column (CSC); rows carry 3-8 entries, the vectors stay in L2 ----------------
-__device__ __forceinline__ void sp_Qx(const SpCtx& c, const double* x, double* out)
+// DPP controls: 0xB1 = quad_perm[1,0,3,2], 0x4E = quad_perm[2,3,0,1], 0x141 = row_half_mirror (lane j <- 7 - j of its 8), 0x140 = row_mirror
+template <int G> __device__ __forceinline__ double g_sum(double v)
 {
-    const int* Qp = c.db->Qp; const int* Qi = c.db->Qi;
-    for (int i = threadIdx.x; i < c.n; i += WGS) {
-        double s = 0.0;
-        for (int k = Qp[i]; k < Qp[i + 1]; k++) s += c.Qx[k] * x[Qi[k]];
-        out[i] = s;
-    }
-    __syncthreads();
+    v += dpp_d<0xB1>(v);
+    v += dpp_d<0x4E>(v);
+    v += dpp_d<0x141>(v);
+    if (G >= 16) v += dpp_d<0x140>(v);
+    if (G >= 32) v += __shfl_xor(v, 16, 64);
+    if (G >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
 }
-__device__ __forceinline__ void sp_Ex(const SpCtx& c, const double* x, double* out)
+template <int G> __device__ __forceinline__ double g_max(double v)
 {
-    const int* Ep = c.db->Ep; const int* Ei = c.db->Ei;
-    for (int r = threadIdx.x; r < c.m; r += WGS) {
-        double s = 0.0;
-        for (int k = Ep[r]; k < Ep[r + 1]; k++) s += c.Ex[k] * x[Ei[k]];
-        out[r] = s;
-    }
-    __syncthreads();
+    v = fmax(v, dpp_d<0xB1>(v));
+    v = fmax(v, dpp_d<0x4E>(v));
+    v = fmax(v, dpp_d<0x141>(v));
+    if (G >= 16) v = fmax(v, dpp_d<0x140>(v));
+    if (G >= 32) v = fmax(v, __shfl_xor(v, 16, 64));
+    if (G >= 64) v = fmax(v, __shfl_xor(v, 32, 64));
+    return v;
 }
-// out[i] = base(i) - (E'y)[i]   (column gather over the CSC of E; rows r0 <= r < r1 only)
-template <class Base>
-__device__ __forceinline__ void sp_ETy(const SpCtx& c, const double* y, double* out, Base base, int r0 = 0, int r1 = 1 << 30)
+template <int G> __device__ __forceinline__ int g_sum_i(int v)
 {
-    const int *Tp = c.db->ETp, *Ti = c.db->ETi, *Tm = c.db->ETmap;
-    for (int i = threadIdx.x; i < c.n; i += WGS) {
-        double s = 0.0;
-        for (int k = Tp[i]; k < Tp[i + 1]; k++) { const int r = Ti[k]; if (r >= r0 && r < r1) s += c.Ex[Tm[k]] * y[r]; }
-        out[i] = base(i) - s;
-    }
-    __syncthreads();
+    v += dpp_i<0xB1>(v);
+    v += dpp_i<0x4E>(v);
+    v += dpp_i<0x141>(v);
+    if (G >= 16) v += dpp_i<0x140>(v);
+    if (G >= 32) v += __shfl_xor(v, 16, 64);
+    if (G >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
 }
-// C v = L'(R v) + R'(L v): lx = E v (rows of L: nC .. nC+nComp, of R: nC+nComp ..), then a column gather with swapped coefficients
-__device__ __forceinline__ void sp_Cx(const SpCtx& c, const double* v, double* out)
+template <int G> __device__ __forceinline__ bool g_any(int v)
 {
-    double* lx = c.M(MV_LX);
-    sp_Ex(c, v, lx);
-    const int *Tp = c.db->ETp, *Ti = c.db->ETi, *Tm = c.db->ETmap;
-    const int nC = c.nC, nK = c.nComp;
-    for (int i = threadIdx.x; i < c.n; i += WGS) {
-        double s = 0.0;
-        for (int k = Tp[i]; k < Tp[i + 1]; k++) {
-            const int r = Ti[k];
-            if (r >= nC + nK) s += c.Ex[Tm[k]] * lx[r - nK];          // R' (L v)
-            else if (r >= nC) s += c.Ex[Tm[k]] * lx[r + nK];          // L' (R v)
+    const unsigned long long mk = __ballot(v != 0);
+    if (G == 64) return mk != 0ull;
+    const int sh = threadIdx.x & ~(G - 1);
+    return ((mk >> sh) & ((1ull << (G & 63)) - 1ull)) != 0ull;
+}
+// value of lane k of the group (k is a compile-time constant after unrolling)
+template <int G> __device__ __forceinline__ double g_bcast(double v, int k)
+{
+    if (G == 64) return wave_bcast(v, k);
+    if (G == 8) {
+        double t;
+        switch (k & 3) {
+            case 0: t = dpp_d<0x00>(v); break;
+            case 1: t = dpp_d<0x55>(v); break;
+            case 2: t = dpp_d<0xAA>(v); break;
+            default: t = dpp_d<0xFF>(v); break;
         }
-        out[i] = s;
+        const double u = dpp_d<0x141>(t);
+        return ((((int)threadIdx.x >> 2) & 1) == (k >> 2)) ? t : u;
     }
-    __syncthreads();
+    return __shfl(v, k, G);
 }
-__device__ __forceinline__ double sp_maxabs(const double* a, int n)
-{
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += WGS) s = fmax(s, fabs(a[i]));
-    return sp_max(s);
-}
-
-// ---- KKT assembly into band storage: Kb[i*ld + k] = K[i][i-w+k] in the ordering iperm ----------------------------------------
-// variables: Q + dprim I; row r: -(use ? ddual(r) : 1) on the diagonal, its entries of E only when used
-template <class Dd, class Use>
-__device__ __forceinline__ void sp_assemble(SpCtx& c, double* Kb, double dprim, Dd ddual, Use use)
-{
-    const SpBatch& db = *c.db;
-    const int t = threadIdx.x, ld = c.ld, w = c.w;
-    for (int e = t; e < c.N * ld; e += WGS) Kb[e] = 0.0;
-    __syncthreads();
-    for (int k = t; k < db.nnzQ; k += WGS) { const int o = db.bandQ[k]; if (o >= 0) Kb[o] = c.Qx[k]; }
-    for (int r = t; r < c.m; r += WGS) {
-        const bool on = use(r);
-        if (on) for (int k = db.Ep[r]; k < db.Ep[r + 1]; k++) Kb[db.bandE[k]] = c.Ex[k];
-        Kb[(size_t)db.iperm[c.n + r] * ld + w] = on ? -ddual(r) : -1.0;
-    }
-    __syncthreads();
-    for (int i = t; i < c.n; i += WGS) Kb[(size_t)db.iperm[i] * ld + w] += dprim;
-    __syncthreads();
-    c.bytes += 8.0 * ((double)c.N * ld + db.nnzQ + db.nnzE) + 4.0 * (db.nnzQ + db.nnzE);
-}
-
-// LDS traffic of one wave is in order; this keeps the compiler from moving LDS accesses across the point and waits for them
+// LDS traffic of one wave is in order; this keeps the compiler from moving LDS accesses across the point
 __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-
-// ---- band LDL' with a sliding (w+1)^2 window in LDS -------------------------------------------------------------------------------
-// The elimination is a chain of N column steps with O(w^2) work each: one wave runs it wave-synchronously (no workgroup barriers
-// inside the chain), the rows that enter the window are fetched 16 columns ahead.
-// in: Kb assembled band; out: Kb = unit lower factor by rows (diagonal slot: D), Kc[j*w + a-1] = L[j+a][j], Kd = 1/D
-__device__ __forceinline__ void sp_factor(SpCtx& c, double* Kb, double* Kc, double* Kd)
+// global memory written by one lane of the group and read by another: wait for the stores (no barrier: the group is inside one wave)
+__device__ __forceinline__ void g_sync()
 {
-    const int N = c.N, w = c.w, ld = c.ld, W1 = w + 1, l = lane_id();
-    double* win = c.win;                  // W1 * W1
-    double* stage = win + W1 * W1;        // 16 rows x W1
-    double* lvec = stage + 16 * W1;       // w
-    {
-        for (int e = l; e < W1 * W1; e += 64) {
-            const int r = e / W1, k = e - r * W1, cc = r - w + k;
-            if (r < N && cc >= 0) win[(r % W1) * W1 + (cc % W1)] = Kb[(size_t)r * ld + k];
-        }
-        double pre[16];                    // rows j0 + w + 1 .. j0 + w + 16 of the NEXT block of columns, one band entry per lane and row
-#pragma unroll
-        for (int q = 0; q < 16; q++) { const int rn = w + 1 + q; pre[q] = (l <= w && rn < N) ? Kb[(size_t)rn * ld + l] : 0.0; }
-        for (int j0 = 0; j0 < N; j0 += 16) {
-#pragma unroll
-            for (int q = 0; q < 16; q++) if (l <= w) stage[q * W1 + l] = pre[q];
-#pragma unroll
-            for (int q = 0; q < 16; q++) { const int rn = j0 + 16 + w + 1 + q; pre[q] = (l <= w && rn < N) ? Kb[(size_t)rn * ld + l] : 0.0; }
-            wave_sync();
-            const int j1 = min(N, j0 + 16);
-            for (int j = j0; j < j1; j++) {
-                const int jm = j % W1;
-                const double d = win[jm * W1 + jm];
-                if (l < w) {
-                    const int r = j + l + 1;
-                    double la = 0.0;
-                    if (r < N) { la = win[(r % W1) * W1 + jm] / d; Kb[(size_t)r * ld + (w - l - 1)] = la; }
-                    Kc[(size_t)j * w + l] = la;
-                    lvec[l] = la;
-                }
-                if (l == 0) { Kb[(size_t)j * ld + w] = d; Kd[j] = 1.0 / d; }
-                wave_sync();
-                for (int e = l; e < w * w; e += 64) {
-                    const int a = e / w + 1, bb = e - (a - 1) * w + 1;
-                    if (bb <= a && j + a < N) win[((j + a) % W1) * W1 + ((j + bb) % W1)] -= lvec[a - 1] * d * lvec[bb - 1];
-                }
-                wave_sync();
-                const int rn = j + w + 1;
-                if (l <= w && rn < N) win[(rn % W1) * W1 + ((j + 1 + l) % W1)] = stage[(j - j0) * W1 + l];
-                wave_sync();
-            }
-        }
-    }
-    __syncthreads();
-    c.bytes += 8.0 * (3.0 * (double)N * ld);
-    c.cFact++;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
 }
 
-// ---- band solve K z = b (b in band order, in place): wave 0 keeps the 64 pending rows in its lanes ---------------------------
-// Row r lives in lane r mod 64 (forward) while steps r-63 .. r run; every step broadcasts the finished entry (v_readlane with a
-// constant lane: the 64 steps of a block are unrolled) and every lane subtracts its multiple -- axpy form both ways, no reduction
-// in the chain.  Factor entries are loaded 16 steps ahead, right-hand sides and results move 64 rows at a time (coalesced).
-// The arrays are padded to a multiple of 64 rows (unit diagonal, zero off-diagonal), so no step needs a bounds test.
-__device__ __forceinline__ void sp_solve(SpCtx& c, const double* Kb, const double* Kc, const double* Kd, double* b)
+// ---- loops over the entries of a vector, G lanes per instance ------------------------------------------------------------------
+// One or two wavefronts per SIMD cannot hide a load behind other waves, so every loop is software-pipelined: the loads of the next
+// tile of U*G elements (load(i) returns them by value) are issued before the stores of the current tile (store(i, v)).  Legal for
+// element-wise loops only: store(i, .) must not write what load(j) reads for j != i.
+template <int G, int U, class L, class S>
+__device__ __forceinline__ void g_map(int n, int gl, L load, S store)
 {
-    const int Np = c.db->Np, w = c.w, ld = c.ld, l = lane_id();
-    {
-        // forward: L y = b; z = y / D is what is stored
-        double cur = b[l];
-        for (int blk = 0; blk < Np; blk += 64) {
-            const double nxt = (blk + 64 < Np) ? b[blk + 64 + l] : 0.0;              // this lane's next row
-            const double dl = Kd[blk + l];
-            double res = 0.0;
+    using T = typename val_of<decltype(load(0))>::type;
+    T v[U];
 #pragma unroll
-            for (int s0 = 0; s0 < 64; s0 += 16) {
-                double lk[16];
+    for (int u = 0; u < U; u++) { const int i = gl + u * G; v[u] = load(i < n ? i : 0); }
+    for (int i0 = gl; i0 < n; i0 += U * G) {
+        T w[U];
+        const int i1 = i0 + U * G;
+        if (i1 - gl < n) {
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int a = (l - (s0 + q)) & 63;
-                    lk[q] = (a >= 1 && a <= w) ? Kc[(size_t)(blk + s0 + q) * w + a - 1] : 0.0;
-                }
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const double yj = wave_bcast(cur, s0 + q);
-                    cur -= lk[q] * yj;
-                    if (l == s0 + q) { res = yj; cur = nxt; }
-                }
-            }
-            b[blk + l] = res * dl;
+            for (int u = 0; u < U; u++) { const int i = i1 + u * G; w[u] = load(i < n ? i : 0); }
         }
-        // backward: L' x = z; lane l holds row base - l - 64 q
-        const int base = Np - 1;
-        cur = b[base - l];
-        for (int blk = 0; blk < Np; blk += 64) {
-            const double nxt = (blk + 64 < Np) ? b[base - blk - 64 - l] : 0.0;
-            double res = 0.0;
 #pragma unroll
-            for (int s0 = 0; s0 < 64; s0 += 16) {
-                double lk[16];
+        for (int u = 0; u < U; u++) { const int i = i0 + u * G; if (i < n) store(i, v[u]); }
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int a = (l - (s0 + q)) & 63, i = base - (blk + s0 + q);
-                    lk[q] = (a >= 1 && a <= w && i - a >= 0) ? Kb[(size_t)i * ld + (w - a)] : 0.0;
-                }
+        for (int u = 0; u < U; u++) v[u] = w[u];
+    }
+}
+struct D2 { double a, b; };
+struct D3 { double a, b, c; };
+struct D4 { double a, b, c, d; };
+struct ID { int i; double a; };
+
+// ---- sparse products: lane per row / per column of the pattern, in ELL form ----------------------------------------------------------
+// The pattern is shared by the batch, so the host lays it out once as ELL slabs: eidx[q * rows + i] = index of the q-th entry of row
+// i into the gathered vector, epos[q * rows + i] = its position in the instance's value array (-1: no such entry), q < W (4 or 8);
+// longer rows finish in a scalar tail over the CSR/CSC arrays.  Per tile of U*G rows: the values and the gathered vector entries of
+// the tile and the indices of the NEXT tile are in flight together.  xv(j) returns a D2 (two vectors share one pass over the
+// matrix); pre(i) loads what the consumer needs beside the sums; out(i, s0, s1, pre) consumes.
+
+template <int G, int U, int W, class Xv, class Pre, class Out>
+__device__ __forceinline__ void g_ell(const EllMat& E, int gl, GD vals, Xv xv, Pre pre, Out out)
+{
+    const int rows = E.rows;
+    for (int i0 = gl; i0 < rows; i0 += U * G) {
+        int ci[U][W], ps[U][W];
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const double xi = wave_bcast(cur, s0 + q);
-                    cur -= lk[q] * xi;
-                    if (l == s0 + q) { res = xi; cur = nxt; }
-                }
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int q = 0; q < W; q++) {
+                const int i = i0 + u * G; const bool ok = i < rows;
+                ci[u][q] = ok ? E.eidx[q * rows + i] : 0;
+                ps[u][q] = ok ? E.epos[q * rows + i] : -1;
             }
-            b[base - blk - l] = res;
+        double a[U][W]; D2 xs[U][W];
+        typename val_of<decltype(pre(0))>::type pv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int q = 0; q < W; q++) {
+                const bool ok = ps[u][q] >= 0;
+                const double av = vals[ok ? ps[u][q] : 0];
+                const D2 xv2 = xv(ok ? ci[u][q] : 0);
+                a[u][q] = ok ? av : 0.0; xs[u][q].a = ok ? xv2.a : 0.0; xs[u][q].b = ok ? xv2.b : 0.0;
+            }
+            const int i = i0 + u * G;
+            pv[u] = pre(i < rows ? i : 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int q = 0; q < W; q++) { s0 += a[u][q] * xs[u][q].a; s1 += a[u][q] * xs[u][q].b; }
+            const int i = i0 + u * G;
+            if (i < rows) {
+                if (E.tails)
+                    for (int k = E.ptr[i] + W; k < E.ptr[i + 1]; k++) {
+                        const double av = vals[E.cmap ? E.cmap[k] : k]; const D2 xv2 = xv(E.cidx[k]);
+                        s0 += av * xv2.a; s1 += av * xv2.b;
+                    }
+                out(i, s0, s1, pv[u]);
+            }
         }
     }
-    __syncthreads();
-    c.bytes += 8.0 * (2.0 * (double)c.N * w + 4.0 * c.N);
+}
+// dispatch on the slab width of the pattern (4 or 8)
+template <int G, class Xv, class Pre, class Out>
+__device__ __forceinline__ void sp_ell(const EllMat& E, int gl, GD vals, Xv xv, Pre pre, Out out)
+{
+    if (E.W == 4) g_ell<G, 4, 4>(E, gl, vals, xv, pre, out);
+    else g_ell<G, 2, 8>(E, gl, vals, xv, pre, out);
+}
+struct NoPre { };
+
+template <int G> __device__ __forceinline__ void sp_Ex(SpCtx<G>& c, GD x, GD out)
+{
+    SPROF(c, SP_VECTORS);
+    sp_ell<G>(c.db->ellE, c.gl, c.Ex(), [&](int j) { return D2{x[j], 0.0}; }, [](int) { return NoPre{}; }, [&](int r, double s, double, NoPre) { out[r] = s; });
+    g_sync();
+    SPROF(c, SP_PRODUCTS);
+}
+// two vectors through one pass over Q: o0 = Q x0, o1 = Q x1
+template <int G> __device__ __forceinline__ void sp_Qx2(SpCtx<G>& c, GD x0, GD x1, GD o0, GD o1)
+{
+    SPROF(c, SP_VECTORS);
+    sp_ell<G>(c.db->ellQ, c.gl, c.Qx(), [&](int j) { return D2{x0[j], x1[j]}; }, [](int) { return NoPre{}; },
+              [&](int i, double s0, double s1, NoPre) { o0[i] = s0; o1[i] = s1; });
+    g_sync();
+    SPROF(c, SP_PRODUCTS);
+}
+// out[i] = base(pre(i)) - (E'y)[i]   (column gather over the CSC of E); returns max |out| over the group
+template <int G, class Pre, class Base> __device__ __forceinline__ double sp_ETy(SpCtx<G>& c, GD y, GD out, Pre pre, Base base)
+{
+    SPROF(c, SP_VECTORS);
+    double mx = 0.0;
+    sp_ell<G>(c.db->ellT, c.gl, c.Ex(), [&](int r) { return D2{y[r], 0.0}; }, pre,
+              [&](int i, double s, double, typename val_of<decltype(pre(0))>::type pv) { const double v = base(pv) - s; out[i] = v; mx = fmax(mx, fabs(v)); });
+    g_sync();
+    SPROF(c, SP_PRODUCTS);
+    return g_max<G>(mx);
+}
+// the residual of the stationarity condition in one pass over Q and E' (both indexed by the variable):
+// r1[i] = (-g[i] - (Q x)[i]) - (E'y)[i]; returns max |r1|
+template <int G> __device__ __forceinline__ double sp_residual(SpCtx<G>& c, GD g, GD x, GD y, GD r1, GD qx)
+{
+    SPROF(c, SP_VECTORS);
+    sp_ell<G>(c.db->ellQ, c.gl, c.Qx(), [&](int j) { return D2{x[j], 0.0}; }, [](int) { return NoPre{}; }, [&](int i, double s, double, NoPre) { qx[i] = s; });
+    g_sync();
+    double mx = 0.0;
+    sp_ell<G>(c.db->ellT, c.gl, c.Ex(), [&](int r) { return D2{y[r], 0.0}; }, [&](int i) { return D2{g[i], qx[i]}; },
+              [&](int i, double s, double, D2 pv) { const double v = (-pv.a - pv.b) - s; r1[i] = v; mx = fmax(mx, fabs(v)); });
+    g_sync();
+    SPROF(c, SP_PRODUCTS);
+    return g_max<G>(mx);
+}
+// C v = L'(R v) + R'(L v) for two vectors: lx = E v (rows of L: nC .. nC+nComp, of R: nC+nComp ..), then a column gather with
+// swapped coefficients
+template <int G> __device__ __forceinline__ void sp_Cx2(SpCtx<G>& c, GD v0, GD v1, GD o0, GD o1)
+{
+    SPROF(c, SP_VECTORS);
+    GD lx0 = c.M(MV_LX), lx1 = c.M(MV_LX2);
+    sp_ell<G>(c.db->ellE, c.gl, c.Ex(), [&](int j) { return D2{v0[j], v1[j]}; }, [](int) { return NoPre{}; },
+              [&](int r, double s0, double s1, NoPre) { lx0[r] = s0; lx1[r] = s1; });
+    g_sync();
+    const int nC = c.db->nC, nK = c.db->nComp;
+    sp_ell<G>(c.db->ellT, c.gl, c.Ex(),
+              [&](int r) { const int rr = r >= nC + nK ? r - nK : (r >= nC ? r + nK : -1);      // R'(L v) + L'(R v)
+                           return rr >= 0 ? D2{lx0[rr], lx1[rr]} : D2{0.0, 0.0}; },
+              [](int) { return NoPre{}; }, [&](int i, double s0, double s1, NoPre) { o0[i] = s0; o1[i] = s1; });
+    g_sync();
+    SPROF(c, SP_PRODUCTS);
+}
+template <int G> __device__ __forceinline__ double sp_maxabs(const SpCtx<G>& c, GD a, int n)
+{
+    double s = 0.0;
+#pragma unroll 8
+    for (int i = c.gl; i < n; i += G) s = fmax(s, fabs(a[i]));
+    return g_max<G>(s);
+}
+
+// ---- KKT assembly into band storage: Kb[i*ld + k] = K[i][i-w+k] in the ordering iperm ----------------------------------------
+// variables: Q + dprim I; row r: -(use ? ddual(r) : 1) on the diagonal, its entries of E only when used
+template <int G, class Dd, class Use>
+__device__ __forceinline__ void sp_assemble(SpCtx<G>& c, double dprim, Dd ddual, Use use)
+{
+    const SpBatch& db = *c.db;
+    const int t = c.gl, ld = db.ld, w = db.ld - 1, n = db.n, m = db.m;
+    GD Kb = c.Kb();
+    SPROF(c, SP_VECTORS);
+    for (int e = t; e < db.N * ld; e += G) Kb[e] = 0.0;
+    g_sync();
+    for (int k = t; k < db.nnzQ; k += G) { const int o = db.bandQ[k]; if (o >= 0) Kb[o] = c.Qx()[k]; }
+    for (int r = t; r < m; r += G) {
+        const bool on = use(r);
+        if (on) for (int k = db.Ep[r]; k < db.Ep[r + 1]; k++) Kb[db.bandE[k]] = c.Ex()[k];
+        Kb[(size_t)db.iperm[n + r] * ld + w] = on ? -ddual(r) : -1.0;
+    }
+    g_sync();
+    for (int i = t; i < n; i += G) Kb[(size_t)db.iperm[i] * ld + w] += dprim;
+    g_sync();
+    c.bytes += 8.0 * ((double)db.N * ld + db.nnzQ + db.nnzE) + 4.0 * (db.nnzQ + db.nnzE);
+    SPROF(c, SP_ASSEMBLE);
+}
+
+// ---- band LDL' with a sliding G x G window in LDS ---------------------------------------------------------------------------------
+// The elimination is a chain of N column steps with O(w^2) work each, run by the G lanes of the instance without barriers; the rows
+// that enter the window are fetched 16 columns ahead.  Window slot of K[r][c]: win[(r % G) * G + (c % G)].
+// in: Kb assembled band rows; out: the unit lower factor L in the two folded layouts the sweeps stream (band_sweep), Kd = 1/D:
+//     KF[((j / G) * G + r % G) * G + j % G] = L[r][j]          (forward: columns finish in ascending order)
+//     KB[((r'/ G) * G + j'% G) * G + r'% G] = L[r][j],  r' = Np-1-r, j' = Np-1-j   (backward: rows finish in descending order)
+template <int G>
+__device__ __forceinline__ void sp_factor_lds(SpCtx<G>& c, GD KF, GD KB, GD Kd)
+{
+    constexpr int GM = G - 1;
+    const int N = c.db->N, Np = c.db->Np, w = G - 1, ld = G, l = c.gl;
+    GD Kb = c.Kb();
+    double* win = c.win;                  // G * G
+    double* stage = win + G * G;          // 16 rows x G
+    for (int r = 0; r <= w && r < N; r++) {
+        const int cc = r - w + l;
+        if (l <= w && cc >= 0) win[(r & GM) * G + (cc & GM)] = Kb[(size_t)r * ld + l];
+    }
+    double pre[16];                        // rows j0 + w + 1 .. j0 + w + 16 of the NEXT block of columns, one band entry per lane and row
+#pragma unroll
+    for (int q = 0; q < 16; q++) { const int rn = w + 1 + q; pre[q] = (l <= w && rn < N) ? Kb[(size_t)rn * ld + l] : 0.0; }
+    for (int j0 = 0; j0 < N; j0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) stage[q * G + l] = pre[q];
+#pragma unroll
+        for (int q = 0; q < 16; q++) { const int rn = j0 + 16 + w + 1 + q; pre[q] = (l <= w && rn < N) ? Kb[(size_t)rn * ld + l] : 0.0; }
+        wave_sync();
+        const int j1 = min(N, j0 + 16);
+        for (int j = j0; j < j1; j++) {
+            const int jm = j & GM, r = j + l + 1;
+            const double d = win[jm * G + jm];
+            const bool mine = (l < w) && (r < N);
+            double la = 0.0;
+            if (mine) {
+                la = win[(r & GM) * G + jm] / d;
+                KF[((size_t)(j & ~GM) + (r & GM)) * G + jm] = la;
+                const int rr = Np - 1 - r, jr = Np - 1 - j;
+                KB[((size_t)(rr & ~GM) + (jr & GM)) * G + (rr & GM)] = la;
+            }
+            if (l == 0) Kd[j] = 1.0 / d;
+            const double lad = la * d;
+#pragma unroll
+            for (int bb = 1; bb < G; bb++) {
+                const double lb = g_bcast<G>(la, bb - 1);          // L[j + bb][j]
+                if (mine && bb <= l + 1) win[(r & GM) * G + ((j + bb) & GM)] -= lad * lb;
+            }
+            wave_sync();
+            const int rn = j + w + 1;
+            if (l <= w && rn < N) win[(rn & GM) * G + ((j + 1 + l) & GM)] = stage[(j - j0) * G + l];
+            wave_sync();
+        }
+    }
+    c.bytes += 8.0 * (3.0 * (double)N * (c.db->w + 1));
+    c.cFact++;
+    SPROF(c, SP_FACTOR);
+}
+
+// ---- band LDL' with the window in registers (G <= 16) -----------------------------------------------------------------------------
+// Row r of the window lives in lane r % G, its entry of column c in register slot c % G, so that at step j (unrolled G times: u =
+// j % G is static) every lane finds the entry of column j in slot u and the entries it updates, columns j + bb, in slot (u + bb) % G:
+// no indexed register access, no LDS.  The pivot and the multipliers L[j+bb][j] travel inside the lane group by DPP; lane u, whose
+// row is finished at step u, takes over row j + G (fetched two blocks ahead, 8 G bytes per lane, the rows of a group contiguous).
+// Rows >= N are identity rows.  Same arithmetic, in the same order, as the LDS version and the oracle.
+template <int G>
+__device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD KB, GD Kd)
+{
+    constexpr int GM = G - 1;
+    const int N = c.db->N, Np = c.db->Np, l = c.gl;
+    GD Kb = c.Kb();
+    const int NG = (N + GM) & ~GM;
+    auto load_row = [&](double* dst, int r) {              // band row r in band order (entry k: column r - (G-1) + k)
+        if (r < N) {
+#pragma unroll
+            for (int k = 0; k < G; k += 2) { const dv2 v = Kb.ld2(r * G + k); dst[k] = v.x; dst[k + 1] = v.y; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < G; k++) dst[k] = (k == GM) ? 1.0 : 0.0;
+        }
+    };
+    double wr[G], nx[G], nn[G], kf[G];
+    {
+        double tmp[G];
+        load_row(tmp, l);
+#pragma unroll
+        for (int k = 0; k < G; k++) wr[(k + 1) & GM] = 0.0;
+        // row l: entry k is column l - (G-1) + k, slot (l + 1 + k) % G -- lane-dependent here (once): rotate through a select chain
+#pragma unroll
+        for (int k = 0; k < G; k++)
+#pragma unroll
+            for (int sl = 0; sl < G; sl++) if (((l + 1 + k) & GM) == sl) wr[sl] = tmp[k];
+    }
+    load_row(nx, G + l);
+    double rinv = 1.0;
+    for (int j0 = 0; j0 < NG; j0 += G) {
+        load_row(nn, j0 + 2 * G + l);
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const int j = j0 + u;
+            const int ag = (l - u) & GM;                               // this lane holds row j + ag (ag == 0: the pivot row)
+            const double d = g_bcast<G>(wr[u], u);
+            const double la = (ag != 0) ? wr[u] / d : 0.0;               // L[j + ag][j]; zero outside the band
+            kf[u] = la;
+            if (ag == 0) rinv = 1.0 / d;
+            {   // backward layout: finishing row r' = Np-1-r in block (r' & ~GM), lane slot j' % G, column r' % G
+                const int rblk = (l > u) ? j0 : j0 + G;               // block of row r = j + ag
+                if (ag != 0 && rblk + l < Np) KB[((Np - G - rblk) + (GM - u)) * G + (GM - l)] = la;
+            }
+            const double lad = la * d;
+#pragma unroll
+            for (int bb = 1; bb < G; bb++) {
+                const double lb = g_bcast<G>(la, (u + bb) & GM);        // L[j + bb][j]
+                if (ag >= bb) wr[(u + bb) & GM] -= lad * lb;
+            }
+            if (l == u) {                                                // row j is finished: row j + G enters this lane
+#pragma unroll
+                for (int k = 0; k < G; k++) wr[(u + 1 + k) & GM] = nx[k];
+            }
+        }
+        // forward layout: row (j0 + l) of the block holds L[.][j0 + u] in column u (zero on and above this lane's own step)
+#pragma unroll
+        for (int k = 0; k < G; k += 2) { dv2 v; v.x = kf[k]; v.y = kf[k + 1]; *reinterpret_cast<dv2*>(reinterpret_cast<char*>(KF.base) + (size_t)(KF.off + (unsigned)((j0 + l) * G + k) * 8u)) = v; }
+        if (j0 + l < Np) Kd[j0 + l] = rinv;
+#pragma unroll
+        for (int k = 0; k < G; k++) nx[k] = nn[k];
+    }
+    c.bytes += 8.0 * (3.0 * (double)N * (c.db->w + 1));
+    c.cFact++;
+    SPROF(c, SP_FACTOR);
+}
+template <int G>
+__device__ __forceinline__ void sp_factor(SpCtx<G>& c, GD KF, GD KB, GD Kd)
+{
+    if constexpr (G <= 16) sp_factor_reg<G>(c, KF, KB, Kd);
+    else sp_factor_lds<G>(c, KF, KB, Kd);
+}
+
+// ---- band sweeps: L y = b, z = y / D (forward) and L' x = z (backward), in place ----------------------------------------------------
+// Position p (0 .. Np-1 in processing order: row p forward, row Np-1-p backward) is pending in lane p % G of the group while steps
+// p-G+1 .. p run; every step broadcasts the finished entry inside the group and every lane subtracts its multiple -- axpy form, no
+// reduction in the chain.  The folded layouts put the coefficient lane u needs at step s of a block of G steps at K[(blk + u) * G + s]:
+// one 8 G-byte row per lane and block, the rows of a group contiguous (G x G doubles per block), streamed RING chunks ahead of use.
+// Right-hand sides and 1/D for the next 64 positions are loaded while the current 64 run.
+template <int G, bool FWD>
+__device__ __forceinline__ void band_sweep(GD K, GD Kd, GD b, int Np, int gl)
+{
+    constexpr int CH = G < 16 ? G : 16, NCHUNK = 64 / CH, BPS = 64 / G, RING = (G == 8) ? 4 : 2;
+    auto at = [&](int p) -> int { return FWD ? p : Np - 1 - p; };
+    double cf[RING][CH];
+    auto load_chunk = [&](double* dst, int sb, int ck) {
+        const int s0 = ck * CH, bi = s0 / G, so = s0 % G;
+        if (sb < Np) {
+            const int e0 = (sb + bi * G + gl) * G + so;
+#pragma unroll
+            for (int q = 0; q < CH / 2; q++) { const dv2 v = K.ld2(e0 + 2 * q); dst[2 * q] = v.x; dst[2 * q + 1] = v.y; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < CH; q++) dst[q] = 0.0;
+        }
+    };
+    double rh[BPS], dl[BPS], rhN[BPS], dlN[BPS], res[BPS];
+#pragma unroll
+    for (int q = 0; q < BPS; q++) { rh[q] = b[at(q * G + gl)]; dl[q] = FWD ? Kd[q * G + gl] : 1.0; res[q] = 0.0; }
+#pragma unroll
+    for (int ck = 0; ck < RING - 1; ck++) load_chunk(cf[ck], 0, ck);
+    double cur = rh[0];
+    for (int sb = 0; sb < Np; sb += 64) {
+        const bool more = sb + 64 < Np;
+#pragma unroll
+        for (int q = 0; q < BPS; q++) {
+            rhN[q] = more ? b[at(sb + 64 + q * G + gl)] : 0.0;
+            dlN[q] = (FWD && more) ? Kd[sb + 64 + q * G + gl] : 1.0;
+        }
+#pragma unroll
+        for (int ck = 0; ck < NCHUNK; ck++) {
+            { const int nck = ck + RING - 1; load_chunk(cf[nck % RING], sb + 64 * (nck / NCHUNK), nck % NCHUNK); }
+#pragma unroll
+            for (int q = 0; q < CH; q++) {
+                const int s = ck * CH + q, k = s % G, bi = s / G;
+                const double yj = g_bcast<G>(cur, k);
+                cur -= cf[ck % RING][q] * yj;
+                if (gl == k) { res[bi] = yj; cur = (bi + 1 < BPS) ? rh[bi + 1] : rhN[0]; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < BPS; q++) { b[at(sb + q * G + gl)] = FWD ? res[q] * dl[q] : res[q]; rh[q] = rhN[q]; dl[q] = dlN[q]; }
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void sp_solve(SpCtx<G>& c, bool admm, GD b)
+{
+    const int Np = c.db->Np;
+    SPROF(c, SP_VECTORS);
+    band_sweep<G, true>(c.KF(admm), c.KD(admm), b, Np, c.gl);
+    g_sync();
+    SPROF(c, SP_FORWARD);
+    band_sweep<G, false>(c.KB(admm), c.KD(admm), b, Np, c.gl);
+    g_sync();
+    SPROF(c, SP_BACKWARD);
+    c.bytes += 8.0 * (2.0 * (double)c.db->N * c.db->w + 4.0 * c.db->N);
 }
 
 // ---- ADMM iterations (OSQP, KKT form; oracle: sqp_admm) ----------------------------------------------------------------------
-__device__ __forceinline__ void sp_admm(SpCtx& c, const double* g, int n_it)
+template <int G>
+__device__ __forceinline__ void sp_admm(SpCtx<G>& c, GD g, int n_it)
 {
     const SpBatch& db = *c.db;
-    const int t = threadIdx.x, n = c.n, m = c.m;
+    const int t = c.gl, n = db.n, m = db.m;
     const double alpha = db.opt.admmAlpha, sigma = c.info->sigma;
-    double *xa = c.V(NV_XA), *ya = c.M(MV_YA), *za = c.M(MV_ZA), *b = c.Nv;
-    const double *l = c.M(MV_L), *u = c.M(MV_U), *rhov = c.M(MV_RHOV);
+    GD xa = c.V(NV_XA), ya = c.M(MV_YA), za = c.M(MV_ZA), b = c.Nv();
+    GD l = c.M(MV_L), u = c.M(MV_U), rhov = c.M(MV_RHOV);
     for (int it = 0; it < n_it; it++) {
-        for (int i = t; i < n; i += WGS) b[db.iperm[i]] = sigma * xa[i] - g[i];
-        for (int r = t; r < m; r += WGS) b[db.iperm[n + r]] = za[r] - ya[r] / rhov[r];
-        __syncthreads();
-        sp_solve(c, c.Ka, c.KaC, c.KaD, b);
-        for (int r = t; r < m; r += WGS) {
+        for (int i = t; i < n; i += G) b[db.iperm[i]] = sigma * xa[i] - g[i];
+        for (int r = t; r < m; r += G) b[db.iperm[n + r]] = za[r] - ya[r] / rhov[r];
+        g_sync();
+        sp_solve<G>(c, true, b);
+        for (int r = t; r < m; r += G) {
             const double rv = rhov[r];
             const double zt = za[r] + (b[db.iperm[n + r]] - ya[r]) / rv;
             const double zr = alpha * zt + (1.0 - alpha) * za[r];
@@ -308,210 +612,225 @@ __device__ __forceinline__ void sp_admm(SpCtx& c, const double* g, int n_it)
             ya[r] += rv * (zr - zn);
             za[r] = zn;
         }
-        for (int i = t; i < n; i += WGS) xa[i] = alpha * b[db.iperm[i]] + (1.0 - alpha) * xa[i];
-        __syncthreads();
+        for (int i = t; i < n; i += G) xa[i] = alpha * b[db.iperm[i]] + (1.0 - alpha) * xa[i];
+        g_sync();
         c.cAdmm++;
     }
 }
 
 // ---- primal-dual active-set polish in correction form (oracle: sqp_polish) ---------------------------------------------------
-__device__ __forceinline__ int sp_polish(SpCtx& c, const double* g, int reuse)
+struct StRow { int s; double e, lo, hi, y; };
+struct I2 { int a, b; };
+struct I2D { int a, b; double y; };
+struct ID4 { int p, s; double lo, hi, e; };
+struct ID2 { int s; double v, y; };
+
+template <int G>
+__device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
 {
     const SpBatch& db = *c.db;
     const lcqp_options_t& o = db.opt;
-    const int t = threadIdx.x, n = c.n, m = c.m;
-    double *x = c.V(NV_XT), *r1 = c.V(NV_R1), *qx = c.V(NV_TMP), *yt = c.M(MV_YT), *ex = c.M(MV_EX), *b = c.Nv;
-    const double *l = c.M(MV_L), *u = c.M(MV_U);
-    int *st = c.I(MI_STT), *stf = c.I(MI_STF), *newst = c.I(MI_NEW);
-    const double gs = 1.0 + sp_maxabs(g, n);
+    const int t = c.gl, n = db.n, m = db.m;
+    GD x = c.V(NV_XT), r1 = c.V(NV_R1), qx = c.V(NV_TMP), yt = c.M(MV_YT), ex = c.M(MV_EX), b = c.Nv();
+    GD l = c.M(MV_L), u = c.M(MV_U);
+    GI st = c.I(MI_STT), stf = c.I(MI_STF), newst = c.I(MI_NEW);
+    const int* iperm = db.iperm;
+    const double gs = 1.0 + sp_maxabs<G>(c, g, n);
     const double ytol = o.feasTol * gs;
     int fact_valid = 0;
     for (int trial = 0; trial < o.maxTrials; trial++) {
         c.cTrials++;
+        double res_stat;
         if (trial == 0 && reuse) {
-            const double *r1s = c.V(NV_R1S), *gs0 = c.V(NV_GS), *exs = c.M(MV_EXS);
-            for (int i = t; i < n; i += WGS) r1[i] = r1s[i] + (gs0[i] - g[i]);
-            for (int r = t; r < m; r += WGS) ex[r] = exs[r];
-            __syncthreads();
+            GD r1s = c.V(NV_R1S), gs0 = c.V(NV_GS), exs = c.M(MV_EXS);
+            double mx = 0.0;
+            g_map<G, 8>(n, t, [&](int i) { return D3{r1s[i], gs0[i], g[i]}; },
+                        [&](int i, D3 v) { const double r = v.a + (v.b - v.c); r1[i] = r; mx = fmax(mx, fabs(r)); });
+            g_map<G, 8>(m, t, [&](int r) { return exs[r]; }, [&](int r, double v) { ex[r] = v; });
+            g_sync();
+            res_stat = g_max<G>(mx);
         } else {
-            sp_Qx(c, x, qx);
-            sp_ETy(c, yt, r1, [&](int i) { return -g[i] - qx[i]; });
-            sp_Ex(c, x, ex);
+            res_stat = sp_residual<G>(c, g, x, yt, r1, qx);
+            sp_Ex<G>(c, x, ex);
             c.cSweeps++;
             c.bytes += 12.0 * (db.nnzQ + 2.0 * db.nnzE) + 8.0 * (4.0 * n + 2.0 * m);
         }
-        const double res_stat = sp_maxabs(r1, n);
         double res_eq = 0.0, bmax = 0.0;
         int chg = 0, act = 0;
-        for (int r = t; r < m; r += WGS) {
-            const int s = st[r];
-            int ns = s;
-            const double e = ex[r];
-            if (s == ST_INACT) {
-                const double ftol = o.feasTol * (1.0 + fabs(e));
-                if (e < l[r] - ftol) ns = ST_LOWER;
-                else if (e > u[r] + ftol) ns = ST_UPPER;
-            } else {
-                const double bb = (s == ST_UPPER) ? u[r] : l[r];
-                res_eq = fmax(res_eq, fabs(bb - e));
-                bmax = fmax(bmax, fabs(bb));
-                if (s == ST_LOWER && yt[r] > ytol) ns = ST_INACT;
-                if (s == ST_UPPER && yt[r] < -ytol) ns = ST_INACT;
-            }
-            newst[r] = ns;
-            chg += (ns != s);
-            act += (ns != ST_INACT);
-        }
-        const int changed = sp_sum_i(chg), nact = sp_sum_i(act);
-        res_eq = sp_max(res_eq);
-        bmax = sp_max(bmax);
+        g_map<G, 4>(m, t, [&](int r) { return StRow{st[r], ex[r], l[r], u[r], yt[r]}; },
+                    [&](int r, StRow v) {
+                        int ns = v.s;
+                        if (v.s == ST_INACT) {
+                            const double ftol = o.feasTol * (1.0 + fabs(v.e));
+                            if (v.e < v.lo - ftol) ns = ST_LOWER;
+                            else if (v.e > v.hi + ftol) ns = ST_UPPER;
+                        } else {
+                            const double bb = (v.s == ST_UPPER) ? v.hi : v.lo;
+                            res_eq = fmax(res_eq, fabs(bb - v.e));
+                            bmax = fmax(bmax, fabs(bb));
+                            if (v.s == ST_LOWER && v.y > ytol) ns = ST_INACT;
+                            if (v.s == ST_UPPER && v.y < -ytol) ns = ST_INACT;
+                        }
+                        newst[r] = ns;
+                        chg += (ns != v.s);
+                        act += (ns != ST_INACT);
+                    });
+        const int changed = g_sum_i<G>(chg), nact = g_sum_i<G>(act);
+        res_eq = g_max<G>(res_eq);
+        bmax = g_max<G>(bmax);
+        SPROF(c, SP_VECTORS);
         if (trial > 0 && !changed && res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) {
-            double *r1s = c.V(NV_R1S), *gs0 = c.V(NV_GS), *exs = c.M(MV_EXS);
-            for (int i = t; i < n; i += WGS) { r1s[i] = r1[i]; gs0[i] = g[i]; }
-            for (int r = t; r < m; r += WGS) exs[r] = ex[r];
-            __syncthreads();
+            GD r1s = c.V(NV_R1S), gs0 = c.V(NV_GS), exs = c.M(MV_EXS);
+            g_map<G, 8>(n, t, [&](int i) { return D2{r1[i], g[i]}; }, [&](int i, D2 v) { r1s[i] = v.a; gs0[i] = v.b; });
+            g_map<G, 8>(m, t, [&](int r) { return ex[r]; }, [&](int r, double v) { exs[r] = v; });
+            g_sync();
             return 1;
         }
         if (changed && trial > 0) {
             if (trial >= 2 && nact > n && changed > max(n / 2, 32)) return 0;       // overshooting cold start: hand over to ADMM
             // leaving rows: their multipliers leave the residual (r1 += E_r' y_r), then the new working set takes over
-            double* ytmp = c.M(MV_LX);
-            for (int r = t; r < m; r += WGS) ytmp[r] = (newst[r] == ST_INACT && st[r] != ST_INACT) ? -yt[r] : 0.0;
-            __syncthreads();
-            sp_ETy(c, ytmp, r1, [&](int i) { return r1[i]; });             // r1 - E'(-y_leaving) = r1 + E'y_leaving
-            for (int r = t; r < m; r += WGS) { if (ytmp[r] != 0.0) yt[r] = 0.0; st[r] = newst[r]; }
-            __syncthreads();
+            GD ytmp = c.M(MV_LX);
+            g_sync();
+            g_map<G, 8>(m, t, [&](int r) { return I2D{newst[r], st[r], yt[r]}; },
+                        [&](int r, I2D v) { const bool leaves = (v.a == ST_INACT && v.b != ST_INACT); ytmp[r] = leaves ? -v.y : 0.0; st[r] = v.a; if (leaves && v.y != 0.0) yt[r] = 0.0; });
+            g_sync();
+            sp_ETy<G>(c, ytmp, r1, [&](int i) { return r1[i]; }, [](double v) { return v; });             // r1 - E'(-y_leaving) = r1 + E'y_leaving
             fact_valid = 0;
         }
         if (!fact_valid) {
             int diff = (c.info->stfValid == 0);
-            for (int r = t; r < m; r += WGS) diff |= ((stf[r] != ST_INACT) != (st[r] != ST_INACT));
-            if (sp_any(diff)) {
+#pragma unroll 8
+            for (int r = t; r < m; r += G) diff |= ((stf[r] != ST_INACT) != (st[r] != ST_INACT));
+            if (g_any<G>(diff)) {
                 const double d2 = c.info->delta2;
-                sp_assemble(c, c.Kp, c.info->delta, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; });
-                sp_factor(c, c.Kp, c.KpC, c.KpD);
-                for (int r = t; r < m; r += WGS) stf[r] = st[r];
+                sp_assemble<G>(c, c.info->delta, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; });
+                sp_factor<G>(c, c.KF(false), c.KB(false), c.KD(false));
+                g_map<G, 8>(m, t, [&](int r) { return st[r]; }, [&](int r, int v) { stf[r] = v; });
                 if (t == 0) c.info->stfValid = 1;
-                __syncthreads();
+                g_sync();
             }
             fact_valid = 1;
         }
         // correction: [Q + delta I, Ea'; Ea, -delta2 I][dx; dy] = [r1; ba - Ea x]
-        for (int i = t; i < n; i += WGS) b[db.iperm[i]] = r1[i];
-        for (int r = t; r < m; r += WGS) {
-            double v = 0.0;
-            if (st[r] != ST_INACT) v = ((st[r] == ST_UPPER) ? u[r] : l[r]) - ex[r];
-            b[db.iperm[n + r]] = v;
-        }
-        __syncthreads();
-        sp_solve(c, c.Kp, c.KpC, c.KpD, b);
-        for (int i = t; i < n; i += WGS) x[i] += b[db.iperm[i]];
-        for (int r = t; r < m; r += WGS) if (st[r] != ST_INACT) yt[r] += b[db.iperm[n + r]];
-        __syncthreads();
+        SPROF(c, SP_VECTORS);
+        g_map<G, 8>(n, t, [&](int i) { return ID{iperm[i], r1[i]}; }, [&](int, ID v) { b[v.i] = v.a; });
+        g_map<G, 4>(m, t, [&](int r) { return ID4{iperm[n + r], st[r], l[r], u[r], ex[r]}; },
+                    [&](int, ID4 v) { b[v.p] = (v.s != ST_INACT) ? ((v.s == ST_UPPER) ? v.hi : v.lo) - v.e : 0.0; });
+        g_sync();
+        SPROF(c, SP_RHS);
+        sp_solve<G>(c, false, b);
+        g_map<G, 8>(n, t, [&](int i) { return D2{b[iperm[i]], x[i]}; }, [&](int i, D2 v) { x[i] = v.b + v.a; });
+        g_map<G, 8>(m, t, [&](int r) { return ID2{st[r], b[iperm[n + r]], yt[r]}; }, [&](int r, ID2 v) { if (v.s != ST_INACT) yt[r] = v.y + v.v; });
+        g_sync();
         c.cCorr++;
     }
     return 0;
 }
 
 // ---- SubsolverBase::solve on the OSQP arm (oracle: sqp_solve) ------------------------------------------------------------------
-__device__ __forceinline__ int sp_qp_solve(SpCtx& c, int initial, const double* g, int* iterations)
+struct ID3 { int s; double lo, hi, z, y; };
+
+template <int G>
+__device__ __forceinline__ int sp_qp_solve(SpCtx<G>& c, int initial, GD g, int* iterations)
 {
     const SpBatch& db = *c.db;
     const lcqp_options_t& o = db.opt;
-    const int t = threadIdx.x, n = c.n, m = c.m;
+    const int t = c.gl, n = db.n, m = db.m;
     const int trials0 = c.cTrials, admm0 = c.cAdmm;
-    double *xq = c.V(NV_XQ), *xa = c.V(NV_XA), *xt = c.V(NV_XT);
-    double *yq = c.M(MV_YQ), *ya = c.M(MV_YA), *za = c.M(MV_ZA), *yt = c.M(MV_YT);
-    const double *l = c.M(MV_L), *u = c.M(MV_U);
-    int *st = c.I(MI_ST), *stt = c.I(MI_STT);
+    GD xq = c.V(NV_XQ), xa = c.V(NV_XA), xt = c.V(NV_XT);
+    GD yq = c.M(MV_YQ), ya = c.M(MV_YA), za = c.M(MV_ZA), yt = c.M(MV_YT);
+    GD l = c.M(MV_L), u = c.M(MV_U);
+    GI st = c.I(MI_ST), stt = c.I(MI_STT);
     *iterations = 0;
     int bad = 0;
-    for (int r = t; r < m; r += WGS) bad |= (l[r] > u[r]);
-    if (sp_any(bad)) return 2;
+#pragma unroll 8
+    for (int r = t; r < m; r += G) bad |= (l[r] > u[r]);
     if (initial) {
-        const double *x0 = c.V(NV_X0), *y0 = c.M(MV_Y0);
-        for (int i = t; i < n; i += WGS) xq[i] = x0[i];
-        for (int r = t; r < m; r += WGS) yq[r] = c.info->hasY0 ? -y0[r] : 0.0;
-        __syncthreads();
+        GD x0 = c.V(NV_X0), y0 = c.M(MV_Y0);
+        const int hasY0 = c.info->hasY0;
+        g_map<G, 8>(n, t, [&](int i) { return x0[i]; }, [&](int i, double v) { xq[i] = v; xa[i] = v; });
+        g_map<G, 8>(m, t, [&](int r) { return y0[r]; }, [&](int r, double v) { const double yv = hasY0 ? -v : 0.0; yq[r] = yv; ya[r] = yv; });
+    } else {
+        g_map<G, 8>(n, t, [&](int i) { return xq[i]; }, [&](int i, double v) { xa[i] = v; });
+        g_map<G, 8>(m, t, [&](int r) { return yq[r]; }, [&](int r, double v) { ya[r] = v; });
     }
-    for (int i = t; i < n; i += WGS) xa[i] = xq[i];
-    for (int r = t; r < m; r += WGS) ya[r] = yq[r];
-    __syncthreads();
+    g_sync();
     int n_admm = initial ? o.admmFirst : o.admmHot;
     const int use_stored = (!initial && c.info->haveSolution && n_admm == 0);
     int solved = 0, admm_ready = 0;
     for (int round = 0; round < o.maxRounds && !solved; round++) {
         if (!admm_ready && (n_admm > 0 || !(round == 0 && use_stored))) {
-            sp_Ex(c, xa, za);
-            for (int r = t; r < m; r += WGS) { za[r] = fmin(fmax(za[r], l[r]), u[r]); if (isinf(l[r]) && isinf(u[r])) ya[r] = 0.0; }
-            __syncthreads();
+            sp_Ex<G>(c, xa, za);
+            g_map<G, 8>(m, t, [&](int r) { return D3{za[r], l[r], u[r]}; },
+                        [&](int r, D3 v) { za[r] = fmin(fmax(v.a, v.b), v.c); if (isinf(v.b) && isinf(v.c)) ya[r] = 0.0; });
+            g_sync();
             admm_ready = 1;
         }
-        if (n_admm > 0) sp_admm(c, g, n_admm);
-        for (int r = t; r < m; r += WGS) {
-            int s;
-            if (round == 0 && use_stored) { s = st[r]; if (l[r] == u[r]) s = ST_EQ; }
-            else {
-                const double lo = l[r], hi = u[r], z = za[r], y = ya[r];
-                s = ST_INACT;
-                if (isfinite(lo) && (z - lo < -y)) s = ST_LOWER;
-                if (isfinite(hi) && (hi - z < y)) s = ST_UPPER;
-                if (lo == hi) s = ST_EQ;
-            }
-            stt[r] = s;
-            yt[r] = (s != ST_INACT) ? ya[r] : 0.0;
+        if (n_admm > 0) sp_admm<G>(c, g, n_admm);
+        if (round == 0 && use_stored) {
+            g_map<G, 4>(m, t, [&](int r) { return ID3{st[r], l[r], u[r], 0.0, ya[r]}; },
+                        [&](int r, ID3 v) { const int s = (v.lo == v.hi) ? ST_EQ : v.s; stt[r] = s; yt[r] = (s != ST_INACT) ? v.y : 0.0; });
+        } else {
+            g_map<G, 4>(m, t, [&](int r) { return ID3{0, l[r], u[r], za[r], ya[r]}; },
+                        [&](int r, ID3 v) {
+                            int s = ST_INACT;
+                            if (isfinite(v.lo) && (v.z - v.lo < -v.y)) s = ST_LOWER;
+                            if (isfinite(v.hi) && (v.hi - v.z < v.y)) s = ST_UPPER;
+                            if (v.lo == v.hi) s = ST_EQ;
+                            stt[r] = s;
+                            yt[r] = (s != ST_INACT) ? v.y : 0.0;
+                        });
         }
-        for (int i = t; i < n; i += WGS) xt[i] = xa[i];
-        __syncthreads();
-        if (sp_polish(c, g, round == 0 && use_stored)) { solved = 1; break; }
+        g_map<G, 8>(n, t, [&](int i) { return xa[i]; }, [&](int i, double v) { xt[i] = v; });
+        g_sync();
+        if (sp_polish<G>(c, g, round == 0 && use_stored)) { solved = 1; break; }
         n_admm = 2 * n_admm;
         if (n_admm < 10) n_admm = 10;
         if (n_admm > 400) n_admm = 400;
     }
     *iterations = (c.cTrials - trials0) + (c.cAdmm - admm0);
     if (!solved) return 1;
-    for (int i = t; i < n; i += WGS) xq[i] = xt[i];
-    for (int r = t; r < m; r += WGS) { yq[r] = yt[r]; st[r] = stt[r]; }
+    g_map<G, 8>(n, t, [&](int i) { return xt[i]; }, [&](int i, double v) { xq[i] = v; });
+    g_map<G, 8>(m, t, [&](int r) { return ID{stt[r], yt[r]}; }, [&](int r, ID v) { yq[r] = v.a; st[r] = v.i; });
     if (t == 0) c.info->haveSolution = 1;
-    __syncthreads();
+    g_sync();
     return 0;
 }
 
-// ---- setup: scales, rho vector, phi expressions, the ONE factorisation of the ADMM KKT matrix ----------------------------------
-__global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db);
-__global__ __launch_bounds__(WGS) void k_sparse_run(SpBatch db);
+extern __shared__ double sp_dyn_lds[];
 
-#define SP_LDS extern __shared__ double sp_dyn_lds[];  Lds lds{sp_dyn_lds, nullptr, nullptr};
-
-__device__ __forceinline__ SpCtx sp_ctx(const SpBatch& db, int b, Lds lds)
+template <int G>
+__device__ __forceinline__ SpCtx<G> sp_ctx(const SpBatch& db, int b)
 {
-    SpCtx c;
-    c.db = &db; c.b = b; c.n = db.n; c.m = db.m; c.nC = db.nC; c.nComp = db.nComp; c.N = db.N; c.w = db.w; c.ld = db.ld;
-    c.Qx = db.Qx + (size_t)b * db.nnzQ; c.Ex = db.Ex + (size_t)b * db.nnzE;
-    c.Ka = db.Ka + (size_t)b * db.Np * db.ld; c.KaC = db.KaC + (size_t)b * db.Np * db.w; c.KaD = db.KaD + (size_t)b * db.Np;
-    c.Kp = db.Kp + (size_t)b * db.Np * db.ld; c.KpC = db.KpC + (size_t)b * db.Np * db.w; c.KpD = db.KpD + (size_t)b * db.Np;
-    c.nv = db.nv + (size_t)b * NV_NUM * db.n; c.mv = db.mv + (size_t)b * MV_NUM * db.m; c.Nv = db.Nv + (size_t)b * 2 * db.Np;
-    c.mi = db.mi + (size_t)b * MI_NUM * db.m;
+    SpCtx<G> c;
+    c.db = &db; c.b = b; c.gl = threadIdx.x & (G - 1); c.gi = threadIdx.x / G; c.w0 = blockIdx.x * (64 / G);
     c.info = db.info + b;
-    c.lds = lds; c.win = lds.arena;
+    c.win = sp_dyn_lds + (size_t)(threadIdx.x / G) * (G * G + 16 * G);
     c.cAdmm = c.cTrials = c.cFact = c.cCorr = c.cSweeps = 0;
     c.bytes = 0.0;
+#ifdef LCQP_PROFILE
+    for (int k = 0; k < SP_NPHASE; k++) c.prof[k] = 0;
+    c.tprev = __builtin_amdgcn_s_memtime();
+#endif
     return c;
 }
 
+// ---- setup: scales, rho vector, phi expressions, the ONE factorisation of the ADMM KKT matrix ----------------------------------
+template <int G>
 __global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db)
 {
-    SP_LDS
-    SpCtx c = sp_ctx(db, blockIdx.x, lds);
-    const int t = threadIdx.x, n = c.n, m = c.m, nC = c.nC, nK = c.nComp;
+    const int b = blockIdx.x * (64 / G) + threadIdx.x / G;
+    if (b >= db.B) return;
+    SpCtx<G> c = sp_ctx<G>(db, b);
+    const int t = c.gl, n = db.n, m = db.m, nC = db.nC, nK = db.nComp;
     double dmax = 0.0;
-    for (int i = t; i < n; i += WGS)
-        for (int k = db.Qp[i]; k < db.Qp[i + 1]; k++) if (db.Qi[k] == i) dmax = fmax(dmax, fabs(c.Qx[k]));
-    double scale = sp_max(dmax);
+    for (int i = t; i < n; i += G)
+        for (int k = db.Qp[i]; k < db.Qp[i + 1]; k++) if (db.Qi[k] == i) dmax = fmax(dmax, fabs(c.Qx()[k]));
+    double scale = g_max<G>(dmax);
     if (!(scale > 1e-300)) scale = 1.0;
     const double rho = db.opt.admmRho * scale;
-    double *l = c.M(MV_L), *u = c.M(MV_U), *rhov = c.M(MV_RHOV);
-    for (int r = t; r < m; r += WGS) {
+    GD l = c.M(MV_L), u = c.M(MV_U), rhov = c.M(MV_RHOV);
+    for (int r = t; r < m; r += G) {
         double rv = rho;
         if (isinf(l[r]) && isinf(u[r])) rv = 1e-6 * rho;
         else if (l[r] == u[r]) rv = rho * db.opt.rhoEqMult;
@@ -519,40 +838,41 @@ __global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db)
     }
     // phi expressions (src/LCQProblem.cpp:969-996)
     double phiConst = 0.0;
-    double* gphi = c.V(NV_GPHI);
+    GD gphi = c.V(NV_GPHI);
     if (db.hasLbL || db.hasLbR) {
-        const double* lbL = db.lbL + (size_t)c.b * nK;
-        const double* lbR = db.lbR + (size_t)c.b * nK;
+        GD lbL = c.arr(db.lbL, nK), lbR = c.arr(db.lbR, nK);
         double s = 0.0;
-        for (int i = t; i < nK; i += WGS) s += lbL[i] * lbR[i];
-        phiConst = sp_sum(s);
-        double* coef = c.M(MV_LX);
-        for (int r = t; r < m; r += WGS) coef[r] = (r >= nC + nK) ? lbL[r - nC - nK] : ((r >= nC) ? lbR[r - nC] : 0.0);     // R'lbL + L'lbR
-        __syncthreads();
-        sp_ETy(c, coef, gphi, [](int) { return 0.0; });
+        for (int i = t; i < nK; i += G) s += lbL[i] * lbR[i];
+        phiConst = g_sum<G>(s);
+        GD coef = c.M(MV_LX);
+        for (int r = t; r < m; r += G) coef[r] = (r >= nC + nK) ? lbL[r - nC - nK] : ((r >= nC) ? lbR[r - nC] : 0.0);     // R'lbL + L'lbR
+        g_sync();
+        sp_ETy<G>(c, coef, gphi, [](int) { return 0.0; }, [](double v) { return v; });
     } else {
-        for (int i = t; i < n; i += WGS) gphi[i] = 0.0;
+        for (int i = t; i < n; i += G) gphi[i] = 0.0;
     }
     if (t == 0) {
         c.info->scale = scale; c.info->sigma = db.opt.admmSigma * scale; c.info->delta = db.opt.proxBig * scale; c.info->delta2 = 1e-9 / scale;
         c.info->phiConst = phiConst; c.info->haveSolution = 0; c.info->stfValid = 0; c.info->bytes = 0.0;
     }
-    __syncthreads();
-    sp_assemble(c, c.Ka, db.opt.admmSigma * scale, [=](int r) { return 1.0 / rhov[r]; }, [](int) { return true; });
-    sp_factor(c, c.Ka, c.KaC, c.KaD);
+    g_sync();
+    sp_assemble<G>(c, db.opt.admmSigma * scale, [=](int r) { return 1.0 / rhov[r]; }, [](int) { return true; });
+    sp_factor<G>(c, c.KF(true), c.KB(true), c.KD(true));
     if (t == 0) c.info->bytes = c.bytes;
 }
 
 // ---- LCQProblem::runSolver, OSQP_SPARSE arm (oracle: orc_sparse_lcqp_solve) ----------------------------------------------------
-__global__ __launch_bounds__(WGS, 8) void k_sparse_run(SpBatch db)
+template <int G>
+__global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_run(SpBatch db)
 {
-    SP_LDS
-    SpCtx c = sp_ctx(db, blockIdx.x, lds);
+    const int b = blockIdx.x * (64 / G) + threadIdx.x / G;
+    if (b >= db.B) return;
+    SpCtx<G> c = sp_ctx<G>(db, b);
     const lcqp_options_t& o = db.opt;
-    const int t = threadIdx.x, n = c.n, m = c.m, nC = c.nC, nK = c.nComp;
-    double *g = c.V(NV_G), *gtil = c.V(NV_GTIL), *gphi = c.V(NV_GPHI), *xk = c.V(NV_XK), *pk = c.V(NV_PK), *xnew = c.V(NV_XNEW), *gk = c.V(NV_GK);
-    double *Qx = c.V(NV_QX), *Cx = c.V(NV_CX), *Qp = c.V(NV_QP), *Cp = c.V(NV_CP), *tmp = c.V(NV_TMP);
-    double *yk = c.M(MV_YK), *lx = c.M(MV_LX);
+    const int t = c.gl, n = db.n, m = db.m, nC = db.nC, nK = db.nComp;
+    GD g = c.V(NV_G), gtil = c.V(NV_GTIL), gphi = c.V(NV_GPHI), xk = c.V(NV_XK), pk = c.V(NV_PK), xnew = c.V(NV_XNEW), gk = c.V(NV_GK);
+    GD Qx = c.V(NV_QX), Cx = c.V(NV_CX), Qp = c.V(NV_QP), Cp = c.V(NV_CP), tmp = c.V(NV_TMP);
+    GD yk = c.M(MV_YK), lx = c.M(MV_LX);
     const bool hasPhi = db.hasLbL || db.hasLbR;
     const double phiConst = c.info->phiConst;
     double* hist = c.info->hist;
@@ -561,77 +881,84 @@ __global__ __launch_bounds__(WGS, 8) void k_sparse_run(SpBatch db)
     int rc = 0, qpIter = 0, histLen = 0, algoStat = 0, totalIter = 0;
     double alphak = 1.0, rho = o.initialPenaltyParameter;
     uint64_t perturbCounter = 0;
-    for (int i = t; i < n; i += WGS) { xk[i] = c.V(NV_X0)[i]; gtil[i] = g[i]; }
-    __syncthreads();
+    { GD x0 = c.V(NV_X0);
+      g_map<G, 8>(n, t, [&](int i) { return D2{x0[i], g[i]}; }, [&](int i, D2 v) { xk[i] = v.a; gtil[i] = v.b; }); }
+    g_sync();
     auto getPhi = [&]() -> double {
         double s = 0.0;
-        for (int i = t; i < n; i += WGS) s += (hasPhi ? gphi[i] * xk[i] : 0.0) + 0.5 * xk[i] * Cx[i];
-        return phiConst + sp_sum(s);
+#pragma unroll 8
+        for (int i = t; i < n; i += G) s += (hasPhi ? gphi[i] * xk[i] : 0.0) + 0.5 * xk[i] * Cx[i];
+        return phiConst + g_sum<G>(s);
     };
     auto updatePenalty = [&]() {
         if (o.nDynamicPenalty > 0) histLen = 0;
         rho *= o.penaltyUpdateFactor;
         st.rhoOpt = rho;
-        if (hasPhi) { for (int i = t; i < n; i += WGS) gtil[i] = g[i] + rho * gphi[i]; __syncthreads(); }
+        if (hasPhi) { for (int i = t; i < n; i += G) gtil[i] = g[i] + rho * gphi[i]; g_sync(); }
     };
-    if (o.solveZeroPenaltyFirst) { for (int i = t; i < n; i += WGS) gk[i] = g[i]; __syncthreads(); }
-    else { sp_Cx(c, xk, Cx); for (int i = t; i < n; i += WGS) gk[i] = rho * Cx[i] + gtil[i]; __syncthreads(); }
+    if (o.solveZeroPenaltyFirst) { for (int i = t; i < n; i += G) gk[i] = g[i]; g_sync(); }
+    else { sp_Cx2<G>(c, xk, xk, Cx, Cp); for (int i = t; i < n; i += G) gk[i] = rho * Cx[i] + gtil[i]; g_sync(); }
     int initial = 1;
     for (;;) {
-        const int ef = sp_qp_solve(c, initial, gk, &qpIter);
+        SPROF(c, SP_LCQP);
+        const int ef = sp_qp_solve<G>(c, initial, gk, &qpIter);
+        SPROF(c, SP_VECTORS);
         st.subproblemIter += qpIter; st.qpSolverExitFlag = ef; st.qpSolves++;
         if (ef != 0) { rc = LCQP_SUBPROBLEM_SOLVER_ERROR; break; }
         {
-            const double *xq = c.V(NV_XQ), *yq = c.M(MV_YQ);
-            for (int i = t; i < n; i += WGS) { xnew[i] = xq[i]; pk[i] = xq[i] - xk[i]; }
-            for (int r = t; r < m; r += WGS) yk[r] = -yq[r];                         // src/SubsolverOSQP.cpp:196-199
-            __syncthreads();
+            GD xq = c.V(NV_XQ), yq = c.M(MV_YQ);
+            g_map<G, 8>(n, t, [&](int i) { return D2{xq[i], xk[i]}; }, [&](int i, D2 v) { xnew[i] = v.a; pk[i] = v.a - v.b; });
+            g_map<G, 8>(m, t, [&](int r) { return yq[r]; }, [&](int r, double v) { yk[r] = -v; });     // src/SubsolverOSQP.cpp:196-199
+            g_sync();
         }
         if (initial) st.rhoOpt = rho;
         else if (o.perturbStep) {
-            for (int i = t; i < n; i += WGS) {
+            for (int i = t; i < n; i += G) {
                 uint64_t z = o.perturbSeed + (perturbCounter + (uint64_t)i + 1ULL) * 0x9E3779B97F4A7C15ULL;
                 z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z = z ^ (z >> 31);
                 xk[i] += ((int)(z % 3ULL) - 1) * 2.221e-16;
             }
             perturbCounter += (uint64_t)n;
-            __syncthreads();
+            g_sync();
         }
-        sp_Qx(c, pk, Qp); sp_Qx(c, xk, Qx); sp_Cx(c, pk, Cp); sp_Cx(c, xk, Cx);
+        sp_Qx2<G>(c, pk, xk, Qp, Qx); sp_Cx2<G>(c, pk, xk, Cp, Cx);
         c.bytes += 2.0 * 12.0 * db.nnzQ + 4.0 * 12.0 * db.nnzE;
         if (!initial) {
             double sq = 0.0, sl = 0.0;
-            for (int i = t; i < n; i += WGS) { sq += pk[i] * (Qp[i] + rho * Cp[i]); sl += pk[i] * ((Qx[i] + rho * Cx[i]) + gtil[i]); }
-            const double qk = sp_sum(sq), lk = sp_sum(sl);
+#pragma unroll 4
+            for (int i = t; i < n; i += G) { sq += pk[i] * (Qp[i] + rho * Cp[i]); sl += pk[i] * ((Qx[i] + rho * Cx[i]) + gtil[i]); }
+            const double qk = g_sum<G>(sq), lk = g_sum<G>(sl);
             alphak = 1.0;
             if (qk > 0 && lk < 0) alphak = fmin(-lk / qk, 1.0);
         }
         initial = 0;
-        for (int i = t; i < n; i += WGS) { xk[i] += alphak * pk[i]; Qx[i] += alphak * Qp[i]; Cx[i] += alphak * Cp[i]; }
-        __syncthreads();
+        { struct D6 { double a, b, c, d, e, f; };
+          g_map<G, 4>(n, t, [&](int i) { return D6{xk[i], pk[i], Qx[i], Qp[i], Cx[i], Cp[i]}; },
+                      [&](int i, D6 v) { xk[i] = v.a + alphak * v.b; Qx[i] = v.c + alphak * v.d; Cx[i] = v.e + alphak * v.f; }); }
+        g_sync();
         // updateStationarity without a box term: statk = Qk xk + g_tilde - E'yk
-        sp_ETy(c, yk, tmp, [&](int i) { return (Qx[i] + rho * Cx[i]) + gtil[i]; });
-        const double statInf = sp_maxabs(tmp, n);
+        const double statMax = sp_ETy<G>(c, yk, tmp, [&](int i) { return D3{Qx[i], Cx[i], gtil[i]}; }, [&](D3 v) { return (v.a + rho * v.b) + v.c; });
+        const double statInf = statMax;
         totalIter++; st.iterTotal++;
         bool leyffer = false;
         const int nd = o.nDynamicPenalty;
         if (nd > 0) {
             const double cur = getPhi();
-            if (histLen < nd) { if (t == 0) hist[histLen] = cur; histLen++; __syncthreads(); }
+            if (histLen < nd) { if (t == 0) hist[histLen] = cur; histLen++; g_sync(); }
             else {
                 if (!(cur < o.complementarityTolerance)) {
                     leyffer = true;
                     for (int i = 0; i < nd; i++) if (cur < o.etaDynamicPenalty * hist[i]) { leyffer = false; break; }
                 }
-                __syncthreads();
+                g_sync();
                 if (t == 0) { for (int i = 0; i + 1 < nd; i++) hist[i] = hist[i + 1]; hist[nd - 1] = cur; }
-                __syncthreads();
+                g_sync();
             }
         }
         if (leyffer) { updatePenalty(); st.iterOuter++; }
         if (statInf < o.stationarityTolerance) {
             if (getPhi() < o.complementarityTolerance) {
-                sp_Ex(c, xk, lx);
+                sp_Ex<G>(c, xk, lx);
                 int sflag = 1, mflag = 1, wflag = 0;
                 const double ctol = o.complementarityTolerance;
                 for (int i = 0; i < nK; i++) {
@@ -643,9 +970,9 @@ __global__ __launch_bounds__(WGS, 8) void k_sparse_run(SpBatch db)
                     if (fabs(dualProd) >= ctol && dualMin <= 0) { if (dualProd <= ctol) { wflag = 1; break; } mflag = 0; }
                 }
                 algoStat = wflag ? 1 : (sflag ? 4 : (mflag ? 3 : 2));
-                __syncthreads();
-                for (int i = t; i < nK; i += WGS) { const double Lx = lx[nC + i], Rx = lx[nC + nK + i]; yk[nC + i] -= rho * Rx; yk[nC + nK + i] -= rho * Lx; }
-                __syncthreads();
+                g_sync();
+                for (int i = t; i < nK; i += G) { const double Lx = lx[nC + i], Rx = lx[nC + nK + i]; yk[nC + i] -= rho * Rx; yk[nC + nK + i] -= rho * Lx; }
+                g_sync();
                 rc = 0;
                 break;
             }
@@ -653,14 +980,28 @@ __global__ __launch_bounds__(WGS, 8) void k_sparse_run(SpBatch db)
         }
         if (totalIter > o.maxIterations) { rc = LCQP_MAX_ITERATIONS_REACHED; break; }
         if (rho > o.maxPenaltyParameter) { rc = LCQP_MAX_PENALTY_REACHED; break; }
-        for (int i = t; i < n; i += WGS) gk[i] = rho * Cx[i] + gtil[i];
-        __syncthreads();
+        g_map<G, 8>(n, t, [&](int i) { return D2{Cx[i], gtil[i]}; }, [&](int i, D2 v) { gk[i] = rho * v.a + v.b; });
+        g_sync();
     }
     st.status = algoStat; st.returnValue = rc;
     st.admmIter = c.cAdmm; st.trials = c.cTrials; st.factorizations = c.cFact; st.corrections = c.cCorr; st.reserved = c.cSweeps;
-    for (int i = t; i < n; i += WGS) db.xout[(size_t)c.b * n + i] = xk[i];
-    for (int r = t; r < m; r += WGS) db.yout[(size_t)c.b * m + r] = yk[r];
+    for (int i = t; i < n; i += G) db.xout[(size_t)c.b * n + i] = xk[i];
+    for (int r = t; r < m; r += G) db.yout[(size_t)c.b * m + r] = yk[r];
     if (t == 0) { db.stats[c.b] = st; c.info->bytes += c.bytes; }
+#ifdef LCQP_PROFILE
+    SPROF(c, SP_LCQP);
+    if (t == 0) for (int k = 0; k < SP_NPHASE; k++) c.info->prof[k] = (double)c.prof[k];
+#endif
+}
+
+template <int G>
+static void sp_launch(const SpBatch& db, hipStream_t stream, hipEvent_t mid)
+{
+    const int ipw = 64 / G, grid = (db.B + ipw - 1) / ipw;
+    const size_t ldsBytes = G <= 16 ? 0 : sizeof(double) * (size_t)ipw * (G * G + 16 * G);       // LDS window of sp_factor_lds: per group G x G and 16 staged rows
+    hipLaunchKernelGGL(k_sparse_setup<G>, dim3(grid), dim3(WGS), ldsBytes, stream, db);
+    (void)hipEventRecord(mid, stream);
+    hipLaunchKernelGGL(k_sparse_run<G>, dim3(grid), dim3(WGS), ldsBytes, stream, db);
 }
 
 }  // namespace
@@ -754,10 +1095,13 @@ try {
         return nullptr;
     }
     if (w < 1) w = 1;
-    const int ld = w + 1;
+    // lanes per instance: the smallest of 8, 16, 32, 64 above the half bandwidth (LCQP_SPARSE_LANES raises it: test hook)
+    int G = w < 8 ? 8 : (w < 16 ? 16 : (w < 32 ? 32 : 64));
+    if (const char* e = std::getenv("LCQP_SPARSE_LANES")) { const int v = std::atoi(e); if ((v == 16 || v == 32 || v == 64) && v > G) G = v; }
+    const int ld = G, wS = G - 1;          // band rows are stored G wide: entry k of row i is K[i][i - (G-1) + k] (zero outside the true band)
     std::vector<int> bandQ(nnzQ, -1), bandE(nnzA);
-    for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) { const int pi = iperm[i], pj = iperm[Qi[k]]; if (pj <= pi) bandQ[k] = pi * ld + w - (pi - pj); }
-    for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { const int pr = iperm[n + r], pc = iperm[Ei[k]]; const int hi = std::max(pr, pc), lo = std::min(pr, pc); bandE[k] = hi * ld + w - (hi - lo); }
+    for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) { const int pi = iperm[i], pj = iperm[Qi[k]]; if (pj <= pi) bandQ[k] = pi * ld + wS - (pi - pj); }
+    for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { const int pr = iperm[n + r], pc = iperm[Ei[k]]; const int hi = std::max(pr, pc), lo = std::min(pr, pc); bandE[k] = hi * ld + wS - (hi - lo); }
     if (hipSetDevice(device) != hipSuccess) { g_sp_err = "hipSetDevice failed"; return nullptr; }
     lcqp_hip_sparse* h = new (std::nothrow) lcqp_hip_sparse();
     if (!h) return nullptr;
@@ -765,7 +1109,7 @@ try {
     h->stream = nullptr; h->ev0 = h->ev1 = h->ev2 = nullptr;
     SpBatch& d = h->db;
     memset(&d, 0, sizeof(d));
-    d.B = batch; d.n = n; d.m = m; d.nC = nC; d.nComp = nComp; d.N = N; d.Np = ((N + 63) / 64) * 64; d.w = w; d.ld = ld; d.nnzQ = nnzQ; d.nnzE = nnzA;
+    d.B = batch; d.n = n; d.m = m; d.nC = nC; d.nComp = nComp; d.N = N; d.Np = ((N + 63) / 64) * 64; d.w = w; d.ld = ld; d.nnzQ = nnzQ; d.nnzE = nnzA; d.G = G;
     const size_t Np = d.Np;
     lcqp_hip_options_default(&d.opt);
     bool ok = hipStreamCreate(&h->stream) == hipSuccess && hipEventCreate(&h->ev0) == hipSuccess && hipEventCreate(&h->ev1) == hipSuccess &&
@@ -775,9 +1119,23 @@ try {
          (d.Ei = sp_alloc<int>(h, nnzA, Ei.data())) && (d.ETp = sp_alloc<int>(h, n + 1, ETp.data())) && (d.ETi = sp_alloc<int>(h, nnzA, ETi.data())) &&
          (d.ETmap = sp_alloc<int>(h, nnzA, ETmap.data())) && (d.iperm = sp_alloc<int>(h, N, iperm.data())) &&
          (d.bandQ = sp_alloc<int>(h, nnzQ, bandQ.data())) && (d.bandE = sp_alloc<int>(h, nnzA, bandE.data()));
+    // ELL slabs of the three gathers (g_ell): rows of Q, rows of E, columns of E
+    auto make_ell = [&](EllMat& e, int rows, const std::vector<int>& ptr, const std::vector<int>& idx, const int* map, const int* dptr, const int* didx, const int* dmap) {
+        int mx = 0;
+        for (int i = 0; i < rows; i++) mx = std::max(mx, ptr[i + 1] - ptr[i]);
+        const int W = mx <= 4 ? 4 : 8;
+        std::vector<int> ei((size_t)W * rows, 0), ep((size_t)W * rows, -1);
+        for (int i = 0; i < rows; i++)
+            for (int q = 0; q < W && ptr[i] + q < ptr[i + 1]; q++) { const int k = ptr[i] + q; ei[(size_t)q * rows + i] = idx[k]; ep[(size_t)q * rows + i] = map ? map[k] : k; }
+        e.rows = rows; e.W = W; e.tails = mx > W ? 1 : 0; e.ptr = dptr; e.cidx = didx; e.cmap = dmap;
+        return (e.eidx = sp_alloc<int>(h, ei.size(), ei.data())) && (e.epos = sp_alloc<int>(h, ep.size(), ep.data()));
+    };
+    ok = ok && make_ell(d.ellQ, n, std::vector<int>(Qp, Qp + n + 1), std::vector<int>(Qi, Qi + nnzQ), nullptr, d.Qp, d.Qi, nullptr) &&
+         make_ell(d.ellE, m, Ep, Ei, nullptr, d.Ep, d.Ei, nullptr) && make_ell(d.ellT, n, ETp, ETi, ETmap.data(), d.ETp, d.ETi, d.ETmap);
     ok = ok && (d.Qx = sp_alloc<double>(h, B * nnzQ)) && (d.Ex = sp_alloc<double>(h, B * nnzA)) &&
-         (d.Ka = sp_alloc<double>(h, B * Np * ld)) && (d.KaC = sp_alloc<double>(h, B * Np * w)) && (d.KaD = sp_alloc<double>(h, B * Np)) &&
-         (d.Kp = sp_alloc<double>(h, B * Np * ld)) && (d.KpC = sp_alloc<double>(h, B * Np * w)) && (d.KpD = sp_alloc<double>(h, B * Np)) &&
+         (d.Kb = sp_alloc<double>(h, B * N * ld)) &&
+         (d.KaF = sp_alloc<double>(h, B * Np * G)) && (d.KaB = sp_alloc<double>(h, B * Np * G)) && (d.KaD = sp_alloc<double>(h, B * Np)) &&
+         (d.KpF = sp_alloc<double>(h, B * Np * G)) && (d.KpB = sp_alloc<double>(h, B * Np * G)) && (d.KpD = sp_alloc<double>(h, B * Np)) &&
          (d.nv = sp_alloc<double>(h, B * NV_NUM * n)) && (d.mv = sp_alloc<double>(h, B * MV_NUM * m)) && (d.Nv = sp_alloc<double>(h, B * 2 * Np)) &&
          (d.lbL = sp_alloc<double>(h, B * nComp)) && (d.lbR = sp_alloc<double>(h, B * nComp)) && (d.mi = sp_alloc<int>(h, B * MI_NUM * m)) &&
          (d.info = sp_alloc<SpInfo>(h, B)) && (d.stats = sp_alloc<lcqp_stats_t>(h, B)) && (d.xout = sp_alloc<double>(h, B * n)) &&
@@ -802,6 +1160,7 @@ try {
 catch (...) { }
 
 extern "C" int lcqp_hip_sparse_bandwidth(const lcqp_hip_sparse_t* h) { return h ? h->db.w : -1; }
+extern "C" int lcqp_hip_sparse_lanes(const lcqp_hip_sparse_t* h) { return h ? h->db.G : -1; }
 extern "C" int lcqp_hip_sparse_get_ordering(const lcqp_hip_sparse_t* h, int* perm)
 {
     if (!h || !perm) return LCQP_INVALID_ARGUMENT;
@@ -869,11 +1228,12 @@ try {
     if (!h || !h->loaded) return LCQP_LCQPOBJECT_NOT_SETUP;
     SPCHK(hipSetDevice(h->device));
     SPCHK(hipEventRecord(h->ev0, h->stream));
-    const int W1 = h->db.w + 1;
-    const size_t ldsBytes = sizeof(double) * (size_t)(W1 * W1 + 16 * W1 + W1 + 8);       // window, 16 staged rows, one column
-    hipLaunchKernelGGL(k_sparse_setup, dim3(h->db.B), dim3(WGS), ldsBytes, h->stream, h->db);
-    SPCHK(hipEventRecord(h->ev1, h->stream));
-    hipLaunchKernelGGL(k_sparse_run, dim3(h->db.B), dim3(WGS), ldsBytes, h->stream, h->db);
+    switch (h->db.G) {
+        case 8: sp_launch<8>(h->db, h->stream, h->ev1); break;
+        case 16: sp_launch<16>(h->db, h->stream, h->ev1); break;
+        case 32: sp_launch<32>(h->db, h->stream, h->ev1); break;
+        default: sp_launch<64>(h->db, h->stream, h->ev1); break;
+    }
     SPCHK(hipGetLastError());
     SPCHK(hipEventRecord(h->ev2, h->stream));
     h->ran = true;
@@ -910,6 +1270,26 @@ extern "C" int lcqp_hip_sparse_get_solution(lcqp_hip_sparse_t* h, double* x, dou
     if (stats) SPCHK(hipMemcpy(stats, d.stats, sizeof(lcqp_stats_t) * (size_t)d.B, hipMemcpyDeviceToHost));
     return 0;
 }
+
+// -DLCQP_PROFILE builds (tools/gpu_phase_profile.py --sparse): mean clock ticks per instance and phase of the last run
+// (products, assembly, factorisation, forward sweeps, backward sweeps, vector operations, LCQP level, -)
+extern "C" int lcqp_hip_sparse_read_profile(lcqp_hip_sparse_t* h, double* out)
+try {
+#if defined(LCQP_PROFILE) || defined(SP_DEBUG)
+    if (!h || !out) return LCQP_INVALID_ARGUMENT;
+    SpBatch& d = h->db;
+    SPCHK(hipSetDevice(h->device));
+    SPCHK(hipStreamSynchronize(h->stream));
+    std::vector<SpInfo> info(d.B);
+    SPCHK(hipMemcpy(info.data(), d.info, sizeof(SpInfo) * (size_t)d.B, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; k++) { out[k] = 0.0; for (auto& i : info) out[k] += i.prof[k] / d.B; }
+    return 0;
+#else
+    (void)h; (void)out;
+    return LCQP_HIP_UNSUPPORTED;
+#endif
+}
+catch (...) { return LCQP_HIP_ERROR; }
 
 // algorithmic bytes of the last run (setup + homotopy), counted by the kernels: CSR values and indices of every sparse product,
 // band storage read and written by every assembly, factorisation and solve

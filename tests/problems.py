@@ -163,16 +163,16 @@ def branch_qp_solution(O, d, x, tol=1e-7):
 SPARSE_SEED0 = 0x4C43515000000005
 
 
-def sparse_pattern(n=4096, nC=2048, nComp=512):
-    """Pattern of the sparse synthetic LCQPs: Q tridiagonal; row r of A touches the 6 variables around 2 r (n = 2 nC);
+def sparse_pattern(n=4096, nC=2048, nComp=512, span=6):
+    """Pattern of the sparse synthetic LCQPs: Q tridiagonal; row r of A touches the `span` (6) variables around 2 r (n = 2 nC);
     complementarity pairs L_i = e_{8 i}, R_i = e_{8 i + 4} (n = 8 nComp).  Returns scipy CSC matrices of ones (Q, stacked [A; L; R])."""
     import scipy.sparse as sp
-    assert n >= 2 * nC and n >= 8 * nComp and n >= 8
+    assert n >= 2 * nC and n >= 8 * nComp and n >= max(8, span)
     qi = np.concatenate([np.arange(n), np.arange(n - 1), np.arange(1, n)])
     qj = np.concatenate([np.arange(n), np.arange(1, n), np.arange(n - 1)])
     Q = sp.csc_matrix((np.ones(qi.size), (qi, qj)), shape=(n, n))
-    c0 = np.clip(2 * np.arange(nC) - 2, 0, n - 6)
-    ai = np.repeat(np.arange(nC), 6); aj = (c0[:, None] + np.arange(6)[None, :]).ravel()
+    c0 = np.clip(2 * np.arange(nC) - 2, 0, n - span)
+    ai = np.repeat(np.arange(nC), span); aj = (c0[:, None] + np.arange(span)[None, :]).ravel()
     li = nC + np.arange(nComp); lj = 8 * np.arange(nComp)
     ri = nC + nComp + np.arange(nComp); rj = 8 * np.arange(nComp) + 4
     A = sp.csc_matrix((np.ones(ai.size + 2 * nComp), (np.concatenate([ai, li, ri]), np.concatenate([aj, lj, rj]))), shape=(nC + 2 * nComp, n))
@@ -180,7 +180,7 @@ def sparse_pattern(n=4096, nC=2048, nComp=512):
     return Q, A
 
 
-def sparse_instance(inst, n=4096, nC=2048, nComp=512, seed0=SPARSE_SEED0):
+def sparse_instance(inst, n=4096, nC=2048, nComp=512, seed0=SPARSE_SEED0, span=6):
     """Values of instance `inst` (numpy PCG64 seeded with seed0 ^ inst): Q = B'B + I with B upper bidiagonal (SPD, tridiagonal),
     g in U(-1,1), A values U(-1,1)/sqrt(6), bounds strictly feasible around a point x* that satisfies the complementarities.
     Returns dict(Q, E (scipy CSR/CSC with values), g, lbA, ubA, nV, nC, nComp)."""
@@ -195,9 +195,9 @@ def sparse_instance(inst, n=4096, nC=2048, nComp=512, seed0=SPARSE_SEED0):
     coin = rng.integers(0, 2, nComp)
     xs[8 * np.arange(nComp)] = np.where(coin == 0, 0.0, rng.uniform(0, 1, nComp))
     xs[8 * np.arange(nComp) + 4] = np.where(coin == 0, rng.uniform(0, 1, nComp), 0.0)
-    c0 = np.clip(2 * np.arange(nC) - 2, 0, n - 6)
-    av = rng.uniform(-1, 1, (nC, 6)) / np.sqrt(6.0)
-    ai = np.repeat(np.arange(nC), 6); aj = (c0[:, None] + np.arange(6)[None, :]).ravel()
+    c0 = np.clip(2 * np.arange(nC) - 2, 0, n - span)
+    av = rng.uniform(-1, 1, (nC, span)) / np.sqrt(float(span))
+    ai = np.repeat(np.arange(nC), span); aj = (c0[:, None] + np.arange(span)[None, :]).ravel()
     A = sp.csr_matrix((av.ravel(), (ai, aj)), shape=(nC, n))
     ax = A @ xs
     lbA = ax - rng.uniform(0.1, 1.0, nC); ubA = ax + rng.uniform(0.1, 1.0, nC)

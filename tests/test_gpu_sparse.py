@@ -7,9 +7,9 @@ import problems as P
 pytestmark = pytest.mark.gpu
 
 
-def _run(hip, n, nC, nK, B, **okw):
-    Qp, Ap = P.sparse_pattern(n, nC, nK)
-    inst = [P.sparse_instance(i, n, nC, nK) for i in range(B)]
+def _run(hip, n, nC, nK, B, span=6, **okw):
+    Qp, Ap = P.sparse_pattern(n, nC, nK, span=span)
+    inst = [P.sparse_instance(i, n, nC, nK, span=span) for i in range(B)]
     sb = hip.SparseBatchLCQP(B, n, nC, nK, Qp, Ap, opt=hip.default_options(perturbStep=0, printLevel=0, **okw))
     assert sb.load(0, B, np.stack([d["Q"].data for d in inst]), np.stack([d["g"] for d in inst]), np.stack([d["E"].data for d in inst]),
                    lbA=np.stack([d["lbA"] for d in inst]), ubA=np.stack([d["ubA"] for d in inst])) == 0
@@ -36,6 +36,40 @@ def test_sparse_hip_matches_oracle(hip, oracle, shape, B):
     sb.run()
     x2, y2, _ = sb.solution()
     assert np.array_equal(x, x2) and np.array_equal(y, y2)
+    sb.close()
+
+
+@pytest.mark.parametrize("lanes", [16, 32, 64])
+def test_sparse_lane_group_widths(hip, oracle, monkeypatch, lanes):
+    """the engine gives every instance G lanes of a wavefront, G the smallest of 8, 16, 32, 64 above the half bandwidth (here 7 -> 8);
+    LCQP_SPARSE_LANES forces the wider groups (register window at 16, LDS window at 32 and 64) on the same problems; a batch
+    that does not fill its last wavefront"""
+    monkeypatch.setenv("LCQP_SPARSE_LANES", str(lanes))
+    n, nC, nK, B = 512, 256, 64, 5
+    sb, inst, x, y, st = _run(hip, n, nC, nK, B)
+    assert sb.lanes() == lanes and sb.bandwidth() == 7
+    opt = oracle.default_options(perturbStep=0)
+    for b in range(B):
+        d = inst[b]
+        ro = oracle.sparse_lcqp_solve(n, nC, nK, d["Q"].tocsr(), d["g"], d["E"].tocsr(), lbA=d["lbA"], ubA=d["ubA"], opt=opt)
+        assert st[b]["returnValue"] == ro["ret"] == 0
+        assert np.abs(x[b] - ro["x"]).max() < 1e-9 and np.abs(y[b] - ro["y"]).max() < 1e-7
+    sb.close()
+
+
+@pytest.mark.parametrize("span", [10, 18])
+def test_sparse_wider_bands(hip, oracle, span):
+    """constraint rows over 10 / 18 variables: half bandwidths beyond 7 select wider lane groups by themselves"""
+    n, nC, nK, B = 512, 256, 64, 9
+    sb, inst, x, y, st = _run(hip, n, nC, nK, B, span=span)
+    assert sb.bandwidth() > 7 and sb.lanes() in (16, 32, 64) and sb.bandwidth() < sb.lanes() <= 2 * sb.bandwidth() + 2
+    opt = oracle.default_options(perturbStep=0)
+    for b in range(B):
+        d = inst[b]
+        ro = oracle.sparse_lcqp_solve(n, nC, nK, d["Q"].tocsr(), d["g"], d["E"].tocsr(), lbA=d["lbA"], ubA=d["ubA"], opt=opt)
+        assert st[b]["returnValue"] == ro["ret"], (b, st[b], ro["stats"])
+        if ro["ret"] == 0:
+            assert np.abs(x[b] - ro["x"]).max() < 1e-8 and np.abs(y[b] - ro["y"]).max() < 1e-6
     sb.close()
 
 
