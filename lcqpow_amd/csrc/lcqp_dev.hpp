@@ -122,7 +122,7 @@ __device__ __forceinline__ void qp_admm(Ctx<NCH>& c, const double* g, int n_it)
 {
     constexpr int np = 128 * NCH;
     const lcqp_options_t& o = c.db->opt;
-    const int t = threadIdx.x, mE = c.mE;
+    const int t = tid_here(), mE = c.mE;
     const double alpha = o.admmAlpha, sigma = c.info->sigma;
     double *xa = c.V(V_XA), *rhs = c.V(V_RHS), *w = c.V(V_W);
     double *ya = c.M(M_YA), *za = c.M(M_ZA), *rhov = c.M(M_RHOV), *coef = c.M(M_COEF), *ex = c.M(M_EX), *dyl = c.M(M_DY);
@@ -175,7 +175,7 @@ __device__ __forceinline__ int qp_certificate(Ctx<NCH>& c, const double* g)
 {
     constexpr int np = 128 * NCH;
     constexpr double eps = 1e-4;
-    const int t = threadIdx.x, mE = c.mE;
+    const int t = tid_here(), mE = c.mE;
     const double *dy = c.M(M_DY), *dx = c.V(V_W), *l = c.M(M_L), *u = c.M(M_U);
     double *tv = c.V(V_RHS), *ex = c.M(M_EX);
     const double ny = wg_maxabs(dy, mE, c.lds);
@@ -222,7 +222,7 @@ template <int NCH>
 __device__ __forceinline__ int qp_adapt_rho(Ctx<NCH>& c, const double* g)
 {
     constexpr int np = 128 * NCH;
-    const int t = threadIdx.x, mE = c.mE;
+    const int t = tid_here(), mE = c.mE;
     double *xa = c.V(V_XA), *tq = c.V(V_RHS), *ty = c.V(V_TMP);
     double *ya = c.M(M_YA), *za = c.M(M_ZA), *rhov = c.M(M_RHOV), *ex = c.M(M_EX);
     wg_symv<NCH>(c.Q, nullptr, c.n, xa, nullptr, tq, nullptr, nullptr, nullptr, c.lds);                 // Q xa
@@ -281,7 +281,7 @@ __device__ __forceinline__ int polish_dependent_rows(int* st, const int* dep, in
                                                      const double* u, int mE, double feasTol, int stamp)
 {
     int chg = 0;
-    for (int r = threadIdx.x; r < mE; r += WG) {
+    for (int r = tid_here(); r < mE; r += WG) {
         const int s = st[r];
         if (s == ST_INACT || !dep[r]) continue;
         const double e = ex[r], ftol = feasTol * (1.0 + fabs(e));
@@ -332,8 +332,8 @@ template <int NCH>
 __device__ __forceinline__ void ti_reset(Ctx<NCH>& c, int& nT, int& ns)
 {
     int* rslot = c.I(I_SLOT);
-    for (int r = threadIdx.x; r < c.mE; r += WG) rslot[r] = -1;
-    for (int a = threadIdx.x; a < c.capS; a += WG) c.idx[a] = -1;
+    for (int r = tid_here(); r < c.mE; r += WG) rslot[r] = -1;
+    for (int a = tid_here(); a < c.capS; a += WG) c.idx[a] = -1;
     nT = 0; ns = 0;
     __syncthreads();
 }
@@ -343,7 +343,7 @@ __device__ __forceinline__ void ti_reset(Ctx<NCH>& c, int& nT, int& ns)
 template <int NK, int D>
 __device__ __forceinline__ void ti_apply_fast(const double* __restrict__ Ti, int ld, const double* tv, double* out, int nT, int ns, double* red)
 {
-    const int l = lane_id(), w = wave_id(), t = threadIdx.x;
+    const int l = lane_id(), w = wave_id(), t = tid_here();
     double tr[NK], acc[NK];
 #pragma unroll
     for (int k = 0; k < NK; k++) { const int sl = 64 * k + l; tr[k] = (sl < ns) ? tv[sl] : 0.0; acc[k] = 0.0; }
@@ -380,7 +380,7 @@ __device__ __forceinline__ void ti_apply_fast(const double* __restrict__ Ti, int
 template <int NCH>
 __device__ __forceinline__ void ti_apply(Ctx<NCH>& c, const double* tv, double* out, int nT, int ns)
 {
-    const int ld = c.capS, l = lane_id(), w = wave_id(), t = threadIdx.x;
+    const int ld = c.capS, l = lane_id(), w = wave_id(), t = tid_here();
     const int nk = (ns + 63) >> 6;
     const double* Ti = c.S;
     if (nk <= TI_FAST_CHUNKS) {
@@ -432,7 +432,7 @@ __device__ __forceinline__ void ti_apply(Ctx<NCH>& c, const double* tv, double* 
 template <int NCH>
 __device__ __forceinline__ int ti_bulk(Ctx<NCH>& c, int na, double tau, int& nT, int& ns)
 {
-    const int ld = c.capS, t = threadIdx.x, mMld = c.db->mMld;
+    const int ld = c.capS, t = tid_here(), mMld = c.db->mMld;
     const int nb = (na + 63) >> 6, nn = 64 * nb;
     int *idx = c.idx, *rslot = c.I(I_SLOT), *dep = c.I(I_DEP);
     double *F = c.S2, *Ti = c.S, *DS = c.DS;
@@ -501,7 +501,7 @@ __device__ __forceinline__ int ti_bulk(Ctx<NCH>& c, int na, double tau, int& nT,
 template <int NCH>
 __device__ __forceinline__ int ti_append(Ctx<NCH>& c, int r, double tau, int capNa, int& nT, int& ns)
 {
-    const int ld = c.capS, t = threadIdx.x;
+    const int ld = c.capS, t = tid_here();
     double *sv = c.Sv(S_SV), *wv = c.Sv(S_W);
     int *idx = c.idx, *rslot = c.I(I_SLOT);
     double* Ti = c.S;
@@ -551,7 +551,7 @@ __device__ __forceinline__ int ti_append(Ctx<NCH>& c, int r, double tau, int cap
 template <int NCH>
 __device__ __forceinline__ void ti_delete(Ctx<NCH>& c, int p, int& nT, int& ns)
 {
-    const int ld = c.capS, t = threadIdx.x, l = lane_id(), w = wave_id();
+    const int ld = c.capS, t = tid_here(), l = lane_id(), w = wave_id();
     int *idx = c.idx, *rslot = c.I(I_SLOT), *crow = c.crow;
     double* Ti = c.S;
     const int i0 = uniform_i(crow[p]), m = nT - i0;
@@ -621,7 +621,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
 {
     constexpr int np = 128 * NCH;
     const lcqp_options_t& o = c.db->opt;
-    const int t = threadIdx.x, mE = c.mE, capS = c.capS;
+    const int t = tid_here(), mE = c.mE, capS = c.capS;
     double *x = c.V(V_XT), *r1 = c.V(V_R1), *cv = c.V(V_C), *du = c.V(V_DU), *qx = c.V(V_TMP);
     double *yt = c.M(M_YT), *ex = c.M(M_EX), *coef = c.M(M_COEF);
     const double *l = c.M(M_L), *u = c.M(M_U);
@@ -819,7 +819,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
 {
     constexpr int np = 128 * NCH;
     const lcqp_options_t& o = c.db->opt;
-    const int t = threadIdx.x, mE = c.mE, n = c.n, nC = c.mA;
+    const int t = tid_here(), mE = c.mE, n = c.n, nC = c.mA;
     const int trials0 = c.cTrials, admm0 = c.cAdmm;
     *iterations = 0;
     if (c.info->setupFail) return 3;
@@ -904,7 +904,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
 template <int NCH>
 __device__ __forceinline__ void qp_export(Ctx<NCH>& c, double* xdst /*np or n*/, int xlen, double* yref /*n + mA*/)
 {
-    const int t = threadIdx.x, n = c.n, nC = c.mA;
+    const int t = tid_here(), n = c.n, nC = c.mA;
     const double *xq = c.V(V_XQ), *yq = c.M(M_YQ);
     for (int i = t; i < xlen; i += WG) xdst[i] = xq[i];
     for (int i = t; i < n + nC; i += WG) yref[i] = (i < n) ? 0.0 : -yq[i - n];
@@ -924,7 +924,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     constexpr int np = 128 * NCH;
     const DevBatch& db = *c.db;
     const lcqp_options_t& o = db.opt;
-    const int t = threadIdx.x, n = c.n, nC = c.nC, nComp = c.nComp, mA = c.mA;
+    const int t = tid_here(), n = c.n, nC = c.nC, nComp = c.nComp, mA = c.mA;
     double *g = c.V(V_G), *gphi = c.V(V_GPHI), *gtil = c.V(V_GTIL), *xk = c.V(V_XK), *pk = c.V(V_PK), *xnew = c.V(V_XNEW);
     double *gk = c.V(V_GK), *Qx = c.V(V_QX), *Cx = c.V(V_CX), *Qp = c.V(V_QP), *Cp = c.V(V_CP), *statk = c.V(V_STATK);
     double* yk = db.yk + (size_t)c.b * db.nd;

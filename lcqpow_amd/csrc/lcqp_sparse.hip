@@ -38,6 +38,9 @@ constexpr int WGS = 64;      // one wavefront per workgroup; 64 / G instances in
 #ifndef SP_WAVES_PER_SIMD
 #define SP_WAVES_PER_SIMD 2  // register budget of k_sparse_run: 512 / SP_WAVES_PER_SIMD per lane
 #endif
+#ifndef SP_SWEEP_RING
+#define SP_SWEEP_RING 4      // coefficient chunks (8 steps each) of a band sweep in flight at G = 8
+#endif
 enum { NV_G, NV_GTIL, NV_GPHI, NV_XK, NV_PK, NV_XNEW, NV_GK, NV_QX, NV_CX, NV_QP, NV_CP, NV_TMP, NV_XQ, NV_XA, NV_XT, NV_R1, NV_R1S, NV_GS,
        NV_X0, NV_NUM };
 enum { MV_L, MV_U, MV_RHOV, MV_YQ, MV_YA, MV_ZA, MV_YT, MV_EX, MV_EXS, MV_YK, MV_Y0, MV_LX, MV_LX2, MV_NUM };
@@ -132,6 +135,11 @@ struct SpCtx {
 #define SPROF(c, P) do { } while (0)
 #endif
 
+// Everything a lane computes from its lane number and uniform values is invariant in every loop of the kernel, and the compiler
+// hoists it all to the top (hundreds of 64-bit addresses, spilled to scratch at once).  An empty volatile asm cannot be hoisted:
+// what is derived from the laundered lane number stays inside the routine that uses it.
+__device__ __forceinline__ int here(int lane) { asm volatile("" : "+v"(lane)); return lane; }
+
 // ---- lane-group collectives (every lane of the group takes part; results are uniform inside the group) ------------------------
 template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
 template <int CTRL> __device__ __forceinline__ double dpp_d(double v)
@@ -216,17 +224,20 @@ __device__ __forceinline__ void g_map(int n, int gl, L load, S store)
 {
     using T = typename val_of<decltype(load(0))>::type;
     T v[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) { const int i = gl + u * G; v[u] = load(i < n ? i : 0); }
-    for (int i0 = gl; i0 < n; i0 += U * G) {
+    gl = here(gl);
+    // the first trip only loads (tile 0): keeping these loads inside the loop keeps their addresses from being hoisted to the top
+    // of the kernel as loop invariants of the outer loops (one 64-bit address per vector and tile element, hundreds of registers)
+    for (int i0 = gl - U * G; i0 < n; i0 += U * G) {
         T w[U];
         const int i1 = i0 + U * G;
         if (i1 - gl < n) {
 #pragma unroll
             for (int u = 0; u < U; u++) { const int i = i1 + u * G; w[u] = load(i < n ? i : 0); }
         }
+        if (i0 >= 0) {
 #pragma unroll
-        for (int u = 0; u < U; u++) { const int i = i0 + u * G; if (i < n) store(i, v[u]); }
+            for (int u = 0; u < U; u++) { const int i = i0 + u * G; if (i < n) store(i, v[u]); }
+        }
 #pragma unroll
         for (int u = 0; u < U; u++) v[u] = w[u];
     }
@@ -247,6 +258,7 @@ template <int G, int U, int W, class Xv, class Pre, class Out>
 __device__ __forceinline__ void g_ell(const EllMat& E, int gl, GD vals, Xv xv, Pre pre, Out out)
 {
     const int rows = E.rows;
+    gl = here(gl);
     for (int i0 = gl; i0 < rows; i0 += U * G) {
         int ci[U][W], ps[U][W];
 #pragma unroll
@@ -358,8 +370,9 @@ template <int G> __device__ __forceinline__ void sp_Cx2(SpCtx<G>& c, GD v0, GD v
 template <int G> __device__ __forceinline__ double sp_maxabs(const SpCtx<G>& c, GD a, int n)
 {
     double s = 0.0;
+    const int gl = here(c.gl);
 #pragma unroll 8
-    for (int i = c.gl; i < n; i += G) s = fmax(s, fabs(a[i]));
+    for (int i = gl; i < n; i += G) s = fmax(s, fabs(a[i]));
     return g_max<G>(s);
 }
 
@@ -454,7 +467,7 @@ template <int G>
 __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD KB, GD Kd)
 {
     constexpr int GM = G - 1;
-    const int N = c.db->N, Np = c.db->Np, l = c.gl;
+    const int N = c.db->N, Np = c.db->Np, l = here(c.gl);
     GD Kb = c.Kb();
     const int NG = (N + GM) & ~GM;
     auto load_row = [&](double* dst, int r) {              // band row r in band order (entry k: column r - (G-1) + k)
@@ -532,7 +545,8 @@ __device__ __forceinline__ void sp_factor(SpCtx<G>& c, GD KF, GD KB, GD Kd)
 template <int G, bool FWD>
 __device__ __forceinline__ void band_sweep(GD K, GD Kd, GD b, int Np, int gl)
 {
-    constexpr int CH = G < 16 ? G : 16, NCHUNK = 64 / CH, BPS = 64 / G, RING = (G == 8) ? 4 : 2;
+    constexpr int CH = G < 16 ? G : 16, NCHUNK = 64 / CH, BPS = 64 / G, RING = (G == 8) ? SP_SWEEP_RING : 2;
+    gl = here(gl);
     auto at = [&](int p) -> int { return FWD ? p : Np - 1 - p; };
     double cf[RING][CH];
     auto load_chunk = [&](double* dst, int sb, int ck) {
@@ -546,19 +560,18 @@ __device__ __forceinline__ void band_sweep(GD K, GD Kd, GD b, int Np, int gl)
             for (int q = 0; q < CH; q++) dst[q] = 0.0;
         }
     };
-    double rh[BPS], dl[BPS], rhN[BPS], dlN[BPS], res[BPS];
+    // rh[q], dl[q]: right-hand side and 1/D of this lane's position in block q of the current 64 positions; a slot is refilled for
+    // the next 64 as soon as it has been consumed
+    double rh[BPS], dl[BPS];
 #pragma unroll
-    for (int q = 0; q < BPS; q++) { rh[q] = b[at(q * G + gl)]; dl[q] = FWD ? Kd[q * G + gl] : 1.0; res[q] = 0.0; }
+    for (int q = 0; q < BPS; q++) { rh[q] = b[at(q * G + gl)]; dl[q] = FWD ? Kd.ld(q * G + gl) : 1.0; }
 #pragma unroll
     for (int ck = 0; ck < RING - 1; ck++) load_chunk(cf[ck], 0, ck);
     double cur = rh[0];
+    if (64 < Np) rh[0] = b[at(64 + gl)];
     for (int sb = 0; sb < Np; sb += 64) {
-        const bool more = sb + 64 < Np;
-#pragma unroll
-        for (int q = 0; q < BPS; q++) {
-            rhN[q] = more ? b[at(sb + 64 + q * G + gl)] : 0.0;
-            dlN[q] = (FWD && more) ? Kd[sb + 64 + q * G + gl] : 1.0;
-        }
+        const bool more = sb + 64 < Np, more2 = sb + 128 < Np;
+        double res = 0.0;
 #pragma unroll
         for (int ck = 0; ck < NCHUNK; ck++) {
             { const int nck = ck + RING - 1; load_chunk(cf[nck % RING], sb + 64 * (nck / NCHUNK), nck % NCHUNK); }
@@ -567,11 +580,15 @@ __device__ __forceinline__ void band_sweep(GD K, GD Kd, GD b, int Np, int gl)
                 const int s = ck * CH + q, k = s % G, bi = s / G;
                 const double yj = g_bcast<G>(cur, k);
                 cur -= cf[ck % RING][q] * yj;
-                if (gl == k) { res[bi] = yj; cur = (bi + 1 < BPS) ? rh[bi + 1] : rhN[0]; }
+                if (gl == k) { res = yj; cur = rh[(bi + 1) % BPS]; }      // block bi+1 of these 64, or block 0 of the next 64 (already refilled)
+                if (k == G - 1) {                                          // block bi is complete: store it, refill its slots
+                    b[at(sb + bi * G + gl)] = FWD ? res * dl[bi] : res;
+                    if (bi + 1 < BPS) { if (more) { rh[bi + 1] = b[at(sb + 64 + (bi + 1) * G + gl)]; } }
+                    else if (more2) rh[0] = b[at(sb + 128 + gl)];
+                    if (FWD && more) dl[bi] = Kd.ld(sb + 64 + bi * G + gl);
+                }
             }
         }
-#pragma unroll
-        for (int q = 0; q < BPS; q++) { b[at(sb + q * G + gl)] = FWD ? res[q] * dl[q] : res[q]; rh[q] = rhN[q]; dl[q] = dlN[q]; }
     }
 }
 

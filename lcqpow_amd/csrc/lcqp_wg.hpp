@@ -35,8 +35,12 @@ struct Lds {
     int* ired;      // 16 ints
 };
 
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+// Everything a thread computes from its thread number and uniform values is invariant in every loop of a kernel, and the compiler
+// hoists it all to the top of the kernel (hundreds of addresses and masks, spilled to scratch at once).  An empty volatile asm cannot
+// be hoisted: what is derived from the laundered thread number stays inside the routine that uses it.
+__device__ __forceinline__ int tid_here() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+__device__ __forceinline__ int lane_id() { return tid_here() & 63; }
+__device__ __forceinline__ int wave_id() { return tid_here() >> 6; }
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -123,7 +127,7 @@ template <class Pred>
 __device__ __forceinline__ int wg_compact(int N, Pred pred, int* out, Lds lds, int cap = 1 << 30)
 {
     const int per = (N + WG - 1) / WG;
-    const int i0 = threadIdx.x * per, i1 = min(N, i0 + per);
+    const int i0 = tid_here() * per, i1 = min(N, i0 + per);
     int cnt = 0;
     for (int i = i0; i < i1; i++) cnt += pred(i) ? 1 : 0;
     int incl = cnt;
@@ -145,24 +149,24 @@ __device__ __forceinline__ int wg_compact(int N, Pred pred, int* out, Lds lds, i
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wg_copy(double* dst, const double* src, int n)
 {
-    for (int i = threadIdx.x; i < n; i += WG) dst[i] = src[i];
+    for (int i = tid_here(); i < n; i += WG) dst[i] = src[i];
     __syncthreads();
 }
 __device__ __forceinline__ void wg_fill(double* dst, double v, int n)
 {
-    for (int i = threadIdx.x; i < n; i += WG) dst[i] = v;
+    for (int i = tid_here(); i < n; i += WG) dst[i] = v;
     __syncthreads();
 }
 __device__ __forceinline__ double wg_dot(const double* a, const double* b, int n, Lds lds)
 {
     double s = 0;
-    for (int i = threadIdx.x; i < n; i += WG) s += a[i] * b[i];
+    for (int i = tid_here(); i < n; i += WG) s += a[i] * b[i];
     return block_sum(s, lds);
 }
 __device__ __forceinline__ double wg_maxabs(const double* a, int n, Lds lds)
 {
     double s = 0;
-    for (int i = threadIdx.x; i < n; i += WG) s = fmax(s, fabs(a[i]));
+    for (int i = tid_here(); i < n; i += WG) s = fmax(s, fabs(a[i]));
     return block_max(s, lds);
 }
 
@@ -180,7 +184,7 @@ __device__ __forceinline__ void wg_combine(const double (&acc)[2 * NCH], Lds lds
         red[w * np + 128 * k + 2 * l + 1] = acc[2 * k + 1];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < np; c += WG) post(c, red[c] + red[np + c] + red[2 * np + c] + red[3 * np + c]);
+    for (int c = tid_here(); c < np; c += WG) post(c, red[c] + red[np + c] + red[2 * np + c] + red[3 * np + c]);
     __syncthreads();
 }
 
@@ -208,7 +212,7 @@ __device__ __forceinline__ void wg_symv_t(const double* __restrict__ M0, const d
     static_assert(6 * np <= arena_doubles(NCH), "wg_symv: four partial copies and two staged vectors must fit the LDS arena");
     double* sv0 = lds.arena + 4 * np;
     double* sv1 = lds.arena + 5 * np;
-    for (int i = threadIdx.x; i < np; i += WG) {
+    for (int i = tid_here(); i < np; i += WG) {
         sv0[i] = (i < n) ? v0[i] : 0.0;
         sv1[i] = (TWO_V && i < n) ? v1[i] : 0.0;
     }
@@ -281,7 +285,7 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
     static_assert(5 * np <= arena_doubles(NCH), "wg_rows: four partial copies and the staged vector must fit the LDS arena");
     double* sx = lds.arena + 4 * np;
     if (x) {
-        for (int i = threadIdx.x; i < np; i += WG) sx[i] = x[i];
+        for (int i = tid_here(); i < np; i += WG) sx[i] = x[i];
     }
     __syncthreads();
     const int l = lane_id(), w = wave_id();
@@ -354,7 +358,7 @@ __device__ __forceinline__ void wg_trsv(const double* __restrict__ F, int ld, in
     const int nn = 64 * nblk;
     double* b = lds.arena;
     double* red = lds.arena + nn;
-    for (int i = threadIdx.x; i < nn; i += WG) b[i] = vec[i];
+    for (int i = tid_here(); i < nn; i += WG) b[i] = vec[i];
     __syncthreads();
     const int l = lane_id(), w = wave_id();
     for (int s = 0; s < nblk; s++) {
@@ -374,7 +378,7 @@ __device__ __forceinline__ void wg_trsv(const double* __restrict__ F, int ld, in
             red[w * 64 + l] = acc;
         }
         __syncthreads();
-        if (threadIdx.x < 64) b[64 * I + threadIdx.x] = red[l] + red[64 + l] + red[128 + l] + red[192 + l];
+        if (tid_here() < 64) b[64 * I + tid_here()] = red[l] + red[64 + l] + red[128 + l] + red[192 + l];
         __syncthreads();
         const int cb0 = forward ? I + 1 : 0, cb1 = forward ? nblk : I;
         if (cb1 > cb0) {
@@ -389,12 +393,12 @@ __device__ __forceinline__ void wg_trsv(const double* __restrict__ F, int ld, in
                 red[w * nn + 64 * cb + l] = acc;
             }
             __syncthreads();
-            for (int c = 64 * cb0 + threadIdx.x; c < 64 * cb1; c += WG)
+            for (int c = 64 * cb0 + tid_here(); c < 64 * cb1; c += WG)
                 b[c] -= red[c] + red[nn + c] + red[2 * nn + c] + red[3 * nn + c];
             __syncthreads();
         }
     }
-    for (int i = threadIdx.x; i < nn; i += WG) vec[i] = b[i];
+    for (int i = tid_here(); i < nn; i += WG) vec[i] = b[i];
     __syncthreads();
 }
 
@@ -414,7 +418,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int tile_li(int a, int b)
 {
 #ifdef LCQP_TILE_VALU
-    (void)b; return 4 * (threadIdx.x >> 4) + a;
+    (void)b; return 4 * (tid_here() >> 4) + a;
 #else
     (void)a; return 16 * wave_id() + (lane_id() >> 4) + 4 * b;
 #endif
@@ -422,7 +426,7 @@ __device__ __forceinline__ int tile_li(int a, int b)
 __device__ __forceinline__ int tile_lj(int a, int b)
 {
 #ifdef LCQP_TILE_VALU
-    (void)a; return 4 * (threadIdx.x & 15) + b;
+    (void)a; return 4 * (tid_here() & 15) + b;
 #else
     (void)b; return 16 * a + (lane_id() & 15);
 #endif
@@ -432,7 +436,7 @@ __device__ __forceinline__ int tile_lj(int a, int b)
 __device__ __forceinline__ void tile_panel(double (&acc)[4][4], const double* As, const double* Bs)
 {
 #ifdef LCQP_TILE_VALU
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int ty = tid_here() >> 4, tx = tid_here() & 15;
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
         const double2 av0 = *reinterpret_cast<const double2*>(As + kk * TILE_PL + 4 * ty);
@@ -480,7 +484,7 @@ __device__ __forceinline__ void wg_tile_nt(double (&acc)[4][4], const double* __
     constexpr int PL = TILE_PL;
     double* As = lds.arena;
     double* Bs = lds.arena + 16 * PL;
-    const int t = threadIdx.x;
+    const int t = tid_here();
     const int lr = t >> 2, kq = (t & 3) * 4;   // loader: row lr, k-quad kq
     const long ra = rowA(lr), rb = rowB(lr);
     const double* ap = (ra >= 0) ? A + (size_t)ra * lda + kq : nullptr;
@@ -516,7 +520,7 @@ __device__ __forceinline__ void wg_tile_nt(double (&acc)[4][4], const double* __
 __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal, double tau, double* dscr0, double* d0,
                           int* info_fail, Lds lds, int dscrStride)
 {
-    const int t = threadIdx.x;
+    const int t = tid_here();
     double* tile = lds.arena;
     double* dl = lds.arena + 64 * TILE_LD;
     double minpiv = INFINITY;
@@ -701,7 +705,7 @@ __device__ __forceinline__ void wg_tile_tn(double (&acc)[4][4], const double* __
     constexpr int PL = TILE_PL;
     double* As = lds.arena;
     double* Bs = lds.arena + 16 * PL;
-    const int t = threadIdx.x;
+    const int t = tid_here();
     const int kk = t >> 4, c4 = (t & 15) * 4;
 #pragma unroll
     for (int i = 0; i < 4; i++)
