@@ -65,8 +65,8 @@ struct SpBatch {
     EllMat ellQ, ellE, ellT; // rows of Q, rows of E, columns of E in ELL slabs
     double *Qx, *Ex;         // [B][nnzQ], [B][nnzE] (CSR order)
     double *Kb;              // [B][N*ld] assembled band rows (input of a factorisation): Kb[i*ld + k] = K[i][i-w+k]
-    double *KaF, *KaB, *KaD; // ADMM KKT factor in the two folded layouts of band_sweep [B][Np*G] each, 1/D [B][Np]
-    double *KpF, *KpB, *KpD; // polish KKT factor
+    double *KaF, *KaD;       // ADMM KKT factor in the folded layout of band_sweep [B][Np*G], 1/D [B][Np]
+    double *KpF, *KpD;       // polish KKT factor
     double *nv, *mv, *Nv;    // [B][NV_NUM][n], [B][MV_NUM][m], [B][2][Np]
     double *lbL, *lbR;       // [B][nComp]
     int* mi;                 // [B][MI_NUM][m]
@@ -125,7 +125,6 @@ struct SpCtx {
     __device__ __forceinline__ GD Nv() const { return arr(db->Nv, (size_t)2 * db->Np); }
     __device__ __forceinline__ GD Kb() const { return arr(db->Kb, (size_t)db->N * db->ld); }
     __device__ __forceinline__ GD KF(bool admm) const { return arr(admm ? db->KaF : db->KpF, (size_t)db->Np * G); }
-    __device__ __forceinline__ GD KB(bool admm) const { return arr(admm ? db->KaB : db->KpB, (size_t)db->Np * G); }
     __device__ __forceinline__ GD KD(bool admm) const { return arr(admm ? db->KaD : db->KpD, db->Np); }
 };
 
@@ -405,9 +404,8 @@ __device__ __forceinline__ void sp_assemble(SpCtx<G>& c, double dprim, Dd ddual,
 // that enter the window are fetched 16 columns ahead.  Window slot of K[r][c]: win[(r % G) * G + (c % G)].
 // in: Kb assembled band rows; out: the unit lower factor L in the two folded layouts the sweeps stream (band_sweep), Kd = 1/D:
 //     KF[((j / G) * G + r % G) * G + j % G] = L[r][j]          (forward: columns finish in ascending order)
-//     KB[((r'/ G) * G + j'% G) * G + r'% G] = L[r][j],  r' = Np-1-r, j' = Np-1-j   (backward: rows finish in descending order)
 template <int G>
-__device__ __forceinline__ void sp_factor_lds(SpCtx<G>& c, GD KF, GD KB, GD Kd)
+__device__ __forceinline__ void sp_factor_lds(SpCtx<G>& c, GD KF, GD Kd)
 {
     constexpr int GM = G - 1;
     const int N = c.db->N, Np = c.db->Np, w = G - 1, ld = G, l = c.gl;
@@ -436,8 +434,6 @@ __device__ __forceinline__ void sp_factor_lds(SpCtx<G>& c, GD KF, GD KB, GD Kd)
             if (mine) {
                 la = win[(r & GM) * G + jm] / d;
                 KF[((size_t)(j & ~GM) + (r & GM)) * G + jm] = la;
-                const int rr = Np - 1 - r, jr = Np - 1 - j;
-                KB[((size_t)(rr & ~GM) + (jr & GM)) * G + (rr & GM)] = la;
             }
             if (l == 0) Kd[j] = 1.0 / d;
             const double lad = la * d;
@@ -464,7 +460,7 @@ __device__ __forceinline__ void sp_factor_lds(SpCtx<G>& c, GD KF, GD KB, GD Kd)
 // row is finished at step u, takes over row j + G (fetched two blocks ahead, 8 G bytes per lane, the rows of a group contiguous).
 // Rows >= N are identity rows.  Same arithmetic, in the same order, as the LDS version and the oracle.
 template <int G>
-__device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD KB, GD Kd)
+__device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd)
 {
     constexpr int GM = G - 1;
     const int N = c.db->N, Np = c.db->Np, l = here(c.gl);
@@ -503,10 +499,6 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD KB, GD Kd)
             const double la = (ag != 0) ? wr[u] / d : 0.0;               // L[j + ag][j]; zero outside the band
             kf[u] = la;
             if (ag == 0) rinv = 1.0 / d;
-            {   // backward layout: finishing row r' = Np-1-r in block (r' & ~GM), lane slot j' % G, column r' % G
-                const int rblk = (l > u) ? j0 : j0 + G;               // block of row r = j + ag
-                if (ag != 0 && rblk + l < Np) KB[((Np - G - rblk) + (GM - u)) * G + (GM - l)] = la;
-            }
             const double lad = la * d;
 #pragma unroll
             for (int bb = 1; bb < G; bb++) {
@@ -530,10 +522,10 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD KB, GD Kd)
     SPROF(c, SP_FACTOR);
 }
 template <int G>
-__device__ __forceinline__ void sp_factor(SpCtx<G>& c, GD KF, GD KB, GD Kd)
+__device__ __forceinline__ void sp_factor(SpCtx<G>& c, GD KF, GD Kd)
 {
-    if constexpr (G <= 16) sp_factor_reg<G>(c, KF, KB, Kd);
-    else sp_factor_lds<G>(c, KF, KB, Kd);
+    if constexpr (G <= 16) sp_factor_reg<G>(c, KF, Kd);
+    else sp_factor_lds<G>(c, KF, Kd);
 }
 
 // ---- band sweeps: L y = b, z = y / D (forward) and L' x = z (backward), in place ----------------------------------------------------
@@ -552,9 +544,23 @@ __device__ __forceinline__ void band_sweep(GD K, GD Kd, GD b, int Np, int gl)
     auto load_chunk = [&](double* dst, int sb, int ck) {
         const int s0 = ck * CH, bi = s0 / G, so = s0 % G;
         if (sb < Np) {
-            const int e0 = (sb + bi * G + gl) * G + so;
+            if (FWD) {
+                const int e0 = (sb + bi * G + gl) * G + so;
 #pragma unroll
-            for (int q = 0; q < CH / 2; q++) { const dv2 v = K.ld2(e0 + 2 * q); dst[2 * q] = v.x; dst[2 * q + 1] = v.y; }
+                for (int q = 0; q < CH / 2; q++) { const dv2 v = K.ld2(e0 + 2 * q); dst[2 * q] = v.x; dst[2 * q + 1] = v.y; }
+            } else {
+                // the same array read the other way: at step k of a block (row r = Np-1-(pb+k) finishes) the lane whose pending
+                // row is i needs L[r][i] = K[((i / G) * G + r % G) * G + i % G]; i % G = G-1-gl, r % G = G-1-k, and i lies in the
+                // row block of r for gl > k, in the one below for gl < k.  One double per lane and step, a group reads 8 G bytes
+                // of one or two rows.
+                const int pb = sb + bi * G;
+#pragma unroll
+                for (int q = 0; q < CH; q++) {
+                    const int k = so + q;
+                    const int iblk = Np - G - pb - (gl < k ? G : 0);
+                    dst[q] = (iblk >= 0) ? K.ld((iblk + (G - 1 - k)) * G + (G - 1 - gl)) : 0.0;
+                }
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < CH; q++) dst[q] = 0.0;
@@ -600,7 +606,7 @@ __device__ __forceinline__ void sp_solve(SpCtx<G>& c, bool admm, GD b)
     band_sweep<G, true>(c.KF(admm), c.KD(admm), b, Np, c.gl);
     g_sync();
     SPROF(c, SP_FORWARD);
-    band_sweep<G, false>(c.KB(admm), c.KD(admm), b, Np, c.gl);
+    band_sweep<G, false>(c.KF(admm), c.KD(admm), b, Np, c.gl);
     g_sync();
     SPROF(c, SP_BACKWARD);
     c.bytes += 8.0 * (2.0 * (double)c.db->N * c.db->w + 4.0 * c.db->N);
@@ -721,7 +727,7 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
             if (g_any<G>(diff)) {
                 const double d2 = c.info->delta2;
                 sp_assemble<G>(c, c.info->delta, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; });
-                sp_factor<G>(c, c.KF(false), c.KB(false), c.KD(false));
+                sp_factor<G>(c, c.KF(false), c.KD(false));
                 g_map<G, 8>(m, t, [&](int r) { return st[r]; }, [&](int r, int v) { stf[r] = v; });
                 if (t == 0) c.info->stfValid = 1;
                 g_sync();
@@ -874,7 +880,7 @@ __global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db)
     }
     g_sync();
     sp_assemble<G>(c, db.opt.admmSigma * scale, [=](int r) { return 1.0 / rhov[r]; }, [](int) { return true; });
-    sp_factor<G>(c, c.KF(true), c.KB(true), c.KD(true));
+    sp_factor<G>(c, c.KF(true), c.KD(true));
     if (t == 0) c.info->bytes = c.bytes;
 }
 
@@ -1151,8 +1157,8 @@ try {
          make_ell(d.ellE, m, Ep, Ei, nullptr, d.Ep, d.Ei, nullptr) && make_ell(d.ellT, n, ETp, ETi, ETmap.data(), d.ETp, d.ETi, d.ETmap);
     ok = ok && (d.Qx = sp_alloc<double>(h, B * nnzQ)) && (d.Ex = sp_alloc<double>(h, B * nnzA)) &&
          (d.Kb = sp_alloc<double>(h, B * N * ld)) &&
-         (d.KaF = sp_alloc<double>(h, B * Np * G)) && (d.KaB = sp_alloc<double>(h, B * Np * G)) && (d.KaD = sp_alloc<double>(h, B * Np)) &&
-         (d.KpF = sp_alloc<double>(h, B * Np * G)) && (d.KpB = sp_alloc<double>(h, B * Np * G)) && (d.KpD = sp_alloc<double>(h, B * Np)) &&
+         (d.KaF = sp_alloc<double>(h, B * Np * G)) && (d.KaD = sp_alloc<double>(h, B * Np)) &&
+         (d.KpF = sp_alloc<double>(h, B * Np * G)) && (d.KpD = sp_alloc<double>(h, B * Np)) &&
          (d.nv = sp_alloc<double>(h, B * NV_NUM * n)) && (d.mv = sp_alloc<double>(h, B * MV_NUM * m)) && (d.Nv = sp_alloc<double>(h, B * 2 * Np)) &&
          (d.lbL = sp_alloc<double>(h, B * nComp)) && (d.lbR = sp_alloc<double>(h, B * nComp)) && (d.mi = sp_alloc<int>(h, B * MI_NUM * m)) &&
          (d.info = sp_alloc<SpInfo>(h, B)) && (d.stats = sp_alloc<lcqp_stats_t>(h, B)) && (d.xout = sp_alloc<double>(h, B * n)) &&
