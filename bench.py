@@ -273,7 +273,7 @@ def main():
         out["backsolve_kernel"] = {"kernel": "k_backsolve", "batch": nb, "N": n, "ms": ms, "achieved": gbs,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                    "footprint_MiB": nb * n * n * 8 / 2**20,
-                                   "note": "algorithmic bytes 8 N (N+2) per pair; the kernel reads the diagonal 64x64 blocks whole in both passes (8 N (N+64) per pair)"}
+                                   "note": "algorithmic bytes 8 N (N+2) per pair; of the diagonal 64x64 blocks only the triangle each pass needs is fetched"}
         del K, rhs
 
     if main_proc and world == 1 and args.cpu_sample > 0:

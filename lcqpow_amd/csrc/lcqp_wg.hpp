@@ -367,7 +367,15 @@ __device__ __forceinline__ void wg_trsv(const double* __restrict__ F, int ld, in
             const double* Fd = F + (size_t)(64 * I) * ld + 64 * I;
             double f[16];
 #pragma unroll
-            for (int cc = 0; cc < 16; cc++) f[cc] = Fd[(size_t)(16 * w + cc) * ld + l];
+            for (int cc = 0; cc < 16; cc++) {      // only the triangle is fetched: lanes outside it issue no load (LCQP_TRSV_FULL_DIAG: all)
+                const int c = 16 * w + cc;
+#ifdef LCQP_TRSV_FULL_DIAG
+                f[cc] = Fd[(size_t)c * ld + l];
+#else
+                f[cc] = 0.0;
+                if (forward ? (c <= l) : (c >= l)) f[cc] = Fd[(size_t)c * ld + l];
+#endif
+            }
             double acc = 0.0;
 #pragma unroll
             for (int cc = 0; cc < 16; cc++) {
