@@ -57,8 +57,9 @@ def pmc_traffic(workload, B, shape):
     try:
         with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
             t = json.load(f)
-        if t.get("source_hash") == kernel_source_hash() and t.get("workload") == [workload, B] + list(shape):
-            return float(t["traffic_bytes_guide_recipe"])
+        for e in t.get("entries", [t]):
+            if e.get("source_hash") == kernel_source_hash() and e.get("workload") == [workload, B] + list(shape):
+                return float(e["traffic_bytes_guide_recipe"])
     except Exception:
         pass
     return None

@@ -9,7 +9,9 @@ dst = os.path.join(ROOT, "profiles", "round2", "final")
 os.makedirs(dst, exist_ok=True)
 for name, pat in (("kernel_stats.csv", "trace/runc/*kernel_stats.csv"), ("kernel_trace.csv", "trace/runc/*kernel_trace.csv"),
                   ("kernel_stats_sparse.csv", "trace_sparse/runc/*kernel_stats.csv"), ("pmc_fetch_size.csv", "fetch/runc/*counter_collection.csv"),
-                  ("pmc_write_size.csv", "write/runc/*counter_collection.csv"), ("pmc_sq.csv", "sq/runc/*counter_collection.csv")):
+                  ("pmc_write_size.csv", "write/runc/*counter_collection.csv"), ("pmc_sq.csv", "sq/runc/*counter_collection.csv"),
+                  ("pmc_fetch_size_sparse.csv", "fetch_sparse/runc/*counter_collection.csv"), ("pmc_write_size_sparse.csv", "write_sparse/runc/*counter_collection.csv"),
+                  ("pmc_sq_sparse.csv", "sq_sparse/runc/*counter_collection.csv")):
     f = glob.glob(os.path.join(src, pat))[0]
     rows = list(csv.DictReader(open(f)))
     if "counter_collection" in f or "kernel_trace" in f:      # keep the product kernels only (the copies of the generator run are noise)
@@ -29,6 +31,15 @@ out = {"kernel": "k_lcqp_run<2>", "workload": ["dense", 1024, 256, 512, 64], "so
        "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-pipelined "
                "--no-resident` (tools/run_profiles.sh); traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md (HBM); source_hash = "
                "bench.kernel_source_hash() of the profiled sources: bench.py reports the figure only while it matches"}
+bs = json.load(open(os.path.join(dst, "bench_sparse.json")))
+Bs = bs["config"]["global_batch"]
+def sum_counter(fname, counter):      # k_sparse_setup + k_sparse_run of the one profiled step
+    return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(dst, fname))) if "k_sparse" in r["Kernel_Name"] and r["Counter_Name"] == counter)
+fs, ws = sum_counter("pmc_fetch_size_sparse.csv", "FETCH_SIZE"), sum_counter("pmc_write_size_sparse.csv", "WRITE_SIZE")
+sparse = {"kernel": "k_sparse_setup + k_sparse_run", "workload": ["sparse", Bs, 4096, 2048, 512], "source_hash": bench.kernel_source_hash(),
+          "FETCH_SIZE_KiB": fs, "WRITE_SIZE_KiB": ws, "traffic_bytes_guide_recipe": (2 * fs + ws) * 1024, "traffic_bytes_uncorrected": (fs + ws) * 1024,
+          "note": "same recipe, `python3 bench.py --workload sparse --steps 1 --warmup 0 --cpu-sample 0`"}
+out["entries"] = [dict(out), sparse]
 json.dump(out, open(os.path.join(ROOT, "profiles", "latest_traffic.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

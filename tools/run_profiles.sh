@@ -12,5 +12,8 @@ rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.p
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY -d $O/sq --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $D --no-backsolve > /dev/null 2>> $O/rocprof.err
 python3 $R/bench.py --workload sparse --steps 2 --warmup 1 > $O/bench_sparse.json 2> $O/bench_sparse.err
 rocprofv3 --kernel-trace --stats -d $O/trace_sparse --output-format csv -- python3 $R/bench.py --workload sparse --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>> $O/rocprof.err
+rocprofv3 --pmc FETCH_SIZE -d $O/fetch_sparse --output-format csv -- python3 $R/bench.py --workload sparse --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>> $O/rocprof.err
+rocprofv3 --pmc WRITE_SIZE -d $O/write_sparse --output-format csv -- python3 $R/bench.py --workload sparse --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>> $O/rocprof.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/sq_sparse --output-format csv -- python3 $R/bench.py --workload sparse --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>> $O/rocprof.err
 find $O -name "*.csv" | head -50 > $O/files.txt
 ls -la $O >> $O/files.txt
