@@ -11,7 +11,7 @@
 //     and an active-set polish on [Q + delta I, Ea'; Ea, -delta2 I] in iterative-refinement form, refactorised only when the
 //     working set changes.  oracle/lcqp_oracle_sparse.c is the same algorithm in scalar C.
 // The KKT matrices are factorised as BAND matrices in a reverse Cuthill-McKee ordering computed once per pattern on the host
-// (all instances of a batch share it): LDL' with a sliding G x G window in LDS (half bandwidth w <= G - 1 <= 63), triangular
+// (all instances of a batch share it): LDL' with a sliding G x G window in registers (G <= 16) or LDS (half bandwidth w <= G - 1 <= 63), triangular
 // solves that keep the G pending rows of an instance in its G lanes (axpy form both ways, no reductions in the chain; the finished
 // entry is broadcast inside the lane group by DPP).  A group of lanes behaves like a small workgroup of its own: every branch
 // condition is uniform inside a group, groups of one wavefront diverge through the execution mask, there are no workgroup barriers.
@@ -402,7 +402,7 @@ __device__ __forceinline__ void sp_assemble(SpCtx<G>& c, double dprim, Dd ddual,
 // ---- band LDL' with a sliding G x G window in LDS ---------------------------------------------------------------------------------
 // The elimination is a chain of N column steps with O(w^2) work each, run by the G lanes of the instance without barriers; the rows
 // that enter the window are fetched 16 columns ahead.  Window slot of K[r][c]: win[(r % G) * G + (c % G)].
-// in: Kb assembled band rows; out: the unit lower factor L in the two folded layouts the sweeps stream (band_sweep), Kd = 1/D:
+// in: Kb assembled band rows; out: the unit lower factor L in the folded layout the sweeps stream (band_sweep), Kd = 1/D:
 //     KF[((j / G) * G + r % G) * G + j % G] = L[r][j]          (forward: columns finish in ascending order)
 template <int G>
 __device__ __forceinline__ void sp_factor_lds(SpCtx<G>& c, GD KF, GD Kd)
