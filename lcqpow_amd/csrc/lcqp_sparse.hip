@@ -62,6 +62,7 @@ struct SpBatch {
     int hasLbL, hasLbR;
     lcqp_options_t opt;
     const int *Qp, *Qi, *Ep, *Ei, *ETp, *ETi, *ETmap, *iperm, *bandQ, *bandE;
+    const int *bsrc, *pnode, *qdiag, *Erow;   // band entry -> value it comes from (sp_factor_reg), node of a band position, Q_ii, row of an E entry
     EllMat ellQ, ellE, ellT; // rows of Q, rows of E, columns of E in ELL slabs
     double *Qx, *Ex;         // [B][nnzQ], [B][nnzE] (CSR order)
     double *Kb;              // [B][N*ld] assembled band rows (input of a factorisation): Kb[i*ld + k] = K[i][i-w+k]
@@ -459,17 +460,33 @@ __device__ __forceinline__ void sp_factor_lds(SpCtx<G>& c, GD KF, GD Kd)
 // no indexed register access, no LDS.  The pivot and the multipliers L[j+bb][j] travel inside the lane group by DPP; lane u, whose
 // row is finished at step u, takes over row j + G (fetched two blocks ahead, 8 G bytes per lane, the rows of a group contiguous).
 // Rows >= N are identity rows.  Same arithmetic, in the same order, as the LDS version and the oracle.
-template <int G>
-__device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd)
+template <int G, class Dd, class Use>
+__device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double dprim, Dd ddual, Use use)
 {
     constexpr int GM = G - 1;
     const int N = c.db->N, Np = c.db->Np, l = here(c.gl);
-    GD Kb = c.Kb();
+    const int nnzQ = c.db->nnzQ, nvar = c.db->n;
+    const int* __restrict__ bsrc = c.db->bsrc;
+    GD Qv = c.Qx(), Ev = c.Ex();
     const int NG = (N + GM) & ~GM;
-    auto load_row = [&](double* dst, int r) {              // band row r in band order (entry k: column r - (G-1) + k)
+    // band row r in band order (entry k: column r - (G-1) + k), assembled on the fly from the values of Q and E: variables carry
+    // Q + dprim I; constraint row rr carries its entries of E and -ddual(rr) on the diagonal when it is in the working set, -1 alone
+    // when it is not (the KKT matrix is never written to memory)
+    auto load_row = [&](double* dst, int r) {
         if (r < N) {
+            int code[G];
 #pragma unroll
-            for (int k = 0; k < G; k += 2) { const dv2 v = Kb.ld2(r * G + k); dst[k] = v.x; dst[k + 1] = v.y; }
+            for (int k = 0; k < GM; k++) code[k] = bsrc[r * G + k];
+            const int node = c.db->pnode[r];
+#pragma unroll
+            for (int k = 0; k < GM; k++) {
+                double v = 0.0;
+                if (code[k] >= nnzQ) { const int e = code[k] - nnzQ; if (use(c.db->Erow[e])) v = Ev[e]; }
+                else if (code[k] >= 0) v = Qv[code[k]];
+                dst[k] = v;
+            }
+            if (node < nvar) { const int qd = c.db->qdiag[node]; dst[GM] = (qd >= 0 ? (double)Qv[qd] : 0.0) + dprim; }
+            else { const int rr = node - nvar; dst[GM] = use(rr) ? -ddual(rr) : -1.0; }
         } else {
 #pragma unroll
             for (int k = 0; k < G; k++) dst[k] = (k == GM) ? 1.0 : 0.0;
@@ -517,15 +534,16 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd)
 #pragma unroll
         for (int k = 0; k < G; k++) nx[k] = nn[k];
     }
-    c.bytes += 8.0 * (3.0 * (double)N * (c.db->w + 1));
+    c.bytes += 12.0 * (c.db->nnzQ + c.db->nnzE) + 8.0 * (double)N * (c.db->w + 2);      // matrix entries read, factor and 1/D written
     c.cFact++;
     SPROF(c, SP_FACTOR);
 }
-template <int G>
-__device__ __forceinline__ void sp_factor(SpCtx<G>& c, GD KF, GD Kd)
+// the KKT matrix [Q + dprim I, E_use'; E_use, -diag(ddual)] factorised: assembled on the fly (G <= 16) or through the band array
+template <int G, class Dd, class Use>
+__device__ __forceinline__ void sp_factor(SpCtx<G>& c, GD KF, GD Kd, double dprim, Dd ddual, Use use)
 {
-    if constexpr (G <= 16) sp_factor_reg<G>(c, KF, Kd);
-    else sp_factor_lds<G>(c, KF, Kd);
+    if constexpr (G <= 16) sp_factor_reg<G>(c, KF, Kd, dprim, ddual, use);
+    else { sp_assemble<G>(c, dprim, ddual, use); sp_factor_lds<G>(c, KF, Kd); }
 }
 
 // ---- band sweeps: L y = b, z = y / D (forward) and L' x = z (backward), in place ----------------------------------------------------
@@ -726,8 +744,7 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
             for (int r = t; r < m; r += G) diff |= ((stf[r] != ST_INACT) != (st[r] != ST_INACT));
             if (g_any<G>(diff)) {
                 const double d2 = c.info->delta2;
-                sp_assemble<G>(c, c.info->delta, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; });
-                sp_factor<G>(c, c.KF(false), c.KD(false));
+                sp_factor<G>(c, c.KF(false), c.KD(false), c.info->delta, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; });
                 g_map<G, 8>(m, t, [&](int r) { return st[r]; }, [&](int r, int v) { stf[r] = v; });
                 if (t == 0) c.info->stfValid = 1;
                 g_sync();
@@ -879,8 +896,7 @@ __global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db)
         c.info->phiConst = phiConst; c.info->haveSolution = 0; c.info->stfValid = 0; c.info->bytes = 0.0;
     }
     g_sync();
-    sp_assemble<G>(c, db.opt.admmSigma * scale, [=](int r) { return 1.0 / rhov[r]; }, [](int) { return true; });
-    sp_factor<G>(c, c.KF(true), c.KD(true));
+    sp_factor<G>(c, c.KF(true), c.KD(true), db.opt.admmSigma * scale, [=](int r) { return 1.0 / rhov[r]; }, [](int) { return true; });
     if (t == 0) c.info->bytes = c.bytes;
 }
 
@@ -1125,6 +1141,11 @@ try {
     std::vector<int> bandQ(nnzQ, -1), bandE(nnzA);
     for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) { const int pi = iperm[i], pj = iperm[Qi[k]]; if (pj <= pi) bandQ[k] = pi * ld + wS - (pi - pj); }
     for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { const int pr = iperm[n + r], pc = iperm[Ei[k]]; const int hi = std::max(pr, pc), lo = std::min(pr, pc); bandE[k] = hi * ld + wS - (hi - lo); }
+    // where every off-diagonal band entry comes from (assembly inside the factorisation): -1 nothing, k < nnzQ the entry k of Q,
+    // nnzQ + k the entry k of E (CSR order); the node behind a band position; the entry of Q_ii; the row of an entry of E
+    std::vector<int> bsrc((size_t)N * ld, -1), pnode(perm.begin(), perm.end()), qdiag(n, -1), Erow(nnzA);
+    for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) { if (Qi[k] == i) qdiag[i] = k; else if (bandQ[k] >= 0) bsrc[bandQ[k]] = k; }
+    for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { bsrc[bandE[k]] = nnzQ + k; Erow[k] = r; }
     if (hipSetDevice(device) != hipSuccess) { g_sp_err = "hipSetDevice failed"; return nullptr; }
     lcqp_hip_sparse* h = new (std::nothrow) lcqp_hip_sparse();
     if (!h) return nullptr;
@@ -1141,7 +1162,9 @@ try {
     ok = ok && (d.Qp = sp_alloc<int>(h, n + 1, Qp)) && (d.Qi = sp_alloc<int>(h, nnzQ, Qi)) && (d.Ep = sp_alloc<int>(h, m + 1, Ep.data())) &&
          (d.Ei = sp_alloc<int>(h, nnzA, Ei.data())) && (d.ETp = sp_alloc<int>(h, n + 1, ETp.data())) && (d.ETi = sp_alloc<int>(h, nnzA, ETi.data())) &&
          (d.ETmap = sp_alloc<int>(h, nnzA, ETmap.data())) && (d.iperm = sp_alloc<int>(h, N, iperm.data())) &&
-         (d.bandQ = sp_alloc<int>(h, nnzQ, bandQ.data())) && (d.bandE = sp_alloc<int>(h, nnzA, bandE.data()));
+         (d.bandQ = sp_alloc<int>(h, nnzQ, bandQ.data())) && (d.bandE = sp_alloc<int>(h, nnzA, bandE.data())) &&
+         (d.bsrc = sp_alloc<int>(h, bsrc.size(), bsrc.data())) && (d.pnode = sp_alloc<int>(h, N, pnode.data())) &&
+         (d.qdiag = sp_alloc<int>(h, n, qdiag.data())) && (d.Erow = sp_alloc<int>(h, nnzA, Erow.data()));
     // ELL slabs of the three gathers (g_ell): rows of Q, rows of E, columns of E
     auto make_ell = [&](EllMat& e, int rows, const std::vector<int>& ptr, const std::vector<int>& idx, const int* map, const int* dptr, const int* didx, const int* dmap) {
         int mx = 0;
