@@ -458,7 +458,7 @@ __device__ __forceinline__ void sp_factor_lds(SpCtx<G>& c, GD KF, GD Kd)
 // Row r of the window lives in lane r % G, its entry of column c in register slot c % G, so that at step j (unrolled G times: u =
 // j % G is static) every lane finds the entry of column j in slot u and the entries it updates, columns j + bb, in slot (u + bb) % G:
 // no indexed register access, no LDS.  The pivot and the multipliers L[j+bb][j] travel inside the lane group by DPP; lane u, whose
-// row is finished at step u, takes over row j + G (fetched two blocks ahead, 8 G bytes per lane, the rows of a group contiguous).
+// row is finished at step u, takes over row j + G (gathered three blocks ahead from the values of Q and E).
 // Rows >= N are identity rows.  Same arithmetic, in the same order, as the LDS version and the oracle.
 template <int G, class Dd, class Use>
 __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double dprim, Dd ddual, Use use)
@@ -492,7 +492,7 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
             for (int k = 0; k < G; k++) dst[k] = (k == GM) ? 1.0 : 0.0;
         }
     };
-    double wr[G], nx[G], nn[G], kf[G];
+    double wr[G], nx[G], nn[G], n3[G], kf[G];       // current row; the rows of this lane one, two and three blocks ahead
     {
         double tmp[G];
         load_row(tmp, l);
@@ -505,9 +505,10 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
             for (int sl = 0; sl < G; sl++) if (((l + 1 + k) & GM) == sl) wr[sl] = tmp[k];
     }
     load_row(nx, G + l);
+    load_row(nn, 2 * G + l);
     double rinv = 1.0;
     for (int j0 = 0; j0 < NG; j0 += G) {
-        load_row(nn, j0 + 2 * G + l);
+        load_row(n3, j0 + 3 * G + l);
 #pragma unroll
         for (int u = 0; u < G; u++) {
             const int j = j0 + u;
@@ -532,7 +533,7 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
         for (int k = 0; k < G; k += 2) { dv2 v; v.x = kf[k]; v.y = kf[k + 1]; *reinterpret_cast<dv2*>(reinterpret_cast<char*>(KF.base) + (size_t)(KF.off + (unsigned)((j0 + l) * G + k) * 8u)) = v; }
         if (j0 + l < Np) Kd[j0 + l] = rinv;
 #pragma unroll
-        for (int k = 0; k < G; k++) nx[k] = nn[k];
+        for (int k = 0; k < G; k++) { nx[k] = nn[k]; nn[k] = n3[k]; }
     }
     c.bytes += 12.0 * (c.db->nnzQ + c.db->nnzE) + 8.0 * (double)N * (c.db->w + 2);      // matrix entries read, factor and 1/D written
     c.cFact++;
