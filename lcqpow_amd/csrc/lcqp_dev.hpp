@@ -24,7 +24,7 @@ struct InstInfo {
     int ndep, ns;                                                         // ndep: active rows flagged dependent (I_DEP); ns: slots of Ti in use (high-water mark, free slots inside count)
     int cNnz, pad3;                                                       // cNnz: non-zeros of C held in compressed rows (k_compress_C), -1: C is swept as a dense matrix
     double scale, sigma, spv, rhoAdmm, phiConst;
-    double hist[8];
+    double hist[64];     // the last nDynamicPenalty complementarity values (src/LCQProblem.cpp:1344-1375; the reference's default is 3)
     double work[4];   // exact work sums for the byte accounting: sum(nT), sum(nT*ns) over corrections; bytes of Ti and M moved by working-set updates; number of updates
 };
 

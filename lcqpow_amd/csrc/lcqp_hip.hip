@@ -238,7 +238,7 @@ catch (...) { }   // nothing throws across the C boundary
 extern "C" int lcqp_hip_batch_set_options(lcqp_hip_batch_t* h, const lcqp_options_t* opt)
 try {
     if (!h || !opt) return LCQP_INVALID_ARGUMENT;
-    if (opt->nDynamicPenalty > 8) { g_err = "nDynamicPenalty > 8 unsupported"; return LCQP_HIP_UNSUPPORTED; }
+    if (opt->nDynamicPenalty > 64) { g_err = "nDynamicPenalty > 64 unsupported"; return LCQP_HIP_UNSUPPORTED; }
     {
         // tracking vectors of OutputStatistics (src/OutputStatistics.cpp:131-164), first 1024 iterates; the buffers are sized
         // for the largest maxIterations seen with storeSteps on and grow when a later setOptions raises it

@@ -49,7 +49,7 @@ enum { MI_ST, MI_STT, MI_STF, MI_NEW, MI_NUM };
 struct SpInfo {
     int haveSolution, stfValid, hasY0, pad;
     double scale, sigma, delta, delta2, phiConst;
-    double hist[8];
+    double hist[64];
     double bytes;        // algorithmic bytes counted by the kernel
     double prof[8];      // -DLCQP_PROFILE: clock ticks per phase (SP_* below)
 };
@@ -1218,7 +1218,7 @@ extern "C" int lcqp_hip_sparse_get_ordering(const lcqp_hip_sparse_t* h, int* per
 extern "C" int lcqp_hip_sparse_set_options(lcqp_hip_sparse_t* h, const lcqp_options_t* opt)
 {
     if (!h || !opt) return LCQP_INVALID_ARGUMENT;
-    if (opt->nDynamicPenalty > 8) { g_sp_err = "nDynamicPenalty > 8 unsupported"; return LCQP_HIP_UNSUPPORTED; }
+    if (opt->nDynamicPenalty > 64) { g_sp_err = "nDynamicPenalty > 64 unsupported"; return LCQP_HIP_UNSUPPORTED; }
     h->db.opt = *opt;
     return 0;
 }

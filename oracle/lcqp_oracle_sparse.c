@@ -370,7 +370,7 @@ int orc_sparse_lcqp_solve(int nV, int nC, int nComp,
     if (x0) memcpy(xk, x0, sizeof(double) * n);
     memcpy(gtil, g, sizeof(double) * n);
     double rho = opt->initialPenaltyParameter, alphak = 1.0;
-    double hist[8]; int histLen = 0, rc = 0, qpIter = 0, flag = 0, totalIter = 0, algoStat = 0;
+    double hist[64]; int histLen = 0, rc = 0, qpIter = 0, flag = 0, totalIter = 0, algoStat = 0;
     uint64_t perturbCounter = 0;
 #define SP_CPROD(v, out) do { sp_Ex(q, (v), lx); for (int i_ = 0; i_ < n; i_++) (out)[i_] = 0.0;                                       \
         for (int i_ = 0; i_ < nComp; i_++) {                                                                                          \

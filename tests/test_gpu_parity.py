@@ -475,6 +475,7 @@ def test_lcqp_second_pass_for_failed_instances(hip, oracle):
     dict(solveZeroPenaltyFirst=0),                              # first QP already carries the penalty (src/LCQProblem.cpp:452-467)
     dict(nDynamicPenalty=0),                                    # no Leyffer test (:1275-1313)
     dict(nDynamicPenalty=1, etaDynamicPenalty=0.5),
+    dict(nDynamicPenalty=12, etaDynamicPenalty=0.95),            # a window longer than the 8 of round 1
     dict(initialPenaltyParameter=1.0, penaltyUpdateFactor=10.0),
     dict(maxIterations=7),                                      # MAX_ITERATIONS_REACHED (:536-539)
     dict(maxPenaltyParameter=0.05),                             # MAX_PENALTY_REACHED (:541-543)
