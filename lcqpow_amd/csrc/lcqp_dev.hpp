@@ -105,7 +105,7 @@ __device__ __forceinline__ Ctx<NCH> make_ctx(const DevBatch& db, int b, Lds lds)
 }
 
 // phase buckets of the diagnostic build (tools/gpu_phase_profile.py)
-enum { P_LCQP = 0, P_RESID = 1, P_GRAM = 2, P_CHOL = 3, P_CORR_L1 = 4, P_CORR_ROWS = 5, P_CORR_S = 6, P_ADMM = 7, P_MISC = 8 };
+enum { P_LCQP = 0, P_RESID = 1, P_GRAM = 2, P_CHOL = 3, P_CORR_L1 = 4, P_CORR_ROWS = 5, P_CORR_S = 6, P_ADMM = 7, P_MISC = 8, P_DEL = 9, P_UPD_PRE = 10 };
 #ifdef LCQP_PROFILE
 #define PROF(c, k) do { unsigned long long t_ = clock64(); (c).prof[k] += t_ - (c).tlast; (c).tlast = t_; } while (0)
 #else
@@ -438,20 +438,43 @@ __device__ __forceinline__ int ti_bulk(Ctx<NCH>& c, int na, double tau, int& nT,
     double *F = c.S2, *Ti = c.S, *DS = c.DS;
     nT = na; ns = na;
     if (na == 0) return 0;
-    for (int e = t; e < nn * nn; e += WG) {
-        const int i = e / nn, j = e - i * nn;
-        if (j > i) continue;
-        double v = (i == j) ? 1.0 : 0.0;
-        if (i < na) v = c.MM[(size_t)idx[i] * mMld + idx[j]];
-        F[(size_t)i * ld + j] = v;
+    // element loops with eight gathers in flight per thread (a load - store - load chain pays a memory round trip per element)
+    {
+        const int tot = nn * nn;
+        int i = t / nn, j = t - i * nn;
+        for (int e0 = t; e0 < tot; e0 += 8 * WG) {
+            double v[8]; int ii[8], jj[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                ii[u] = i; jj[u] = j;
+                const bool in = (e0 + u * WG < tot) && (j <= i);
+                v[u] = (i == j) ? 1.0 : 0.0;
+                if (in && i < na) v[u] = c.MM[(size_t)idx[i] * mMld + idx[j]];
+                if (!in) ii[u] = -1;
+                j += WG; while (j >= nn) { j -= nn; i++; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (ii[u] >= 0) F[(size_t)ii[u] * ld + jj[u]] = v[u];
+        }
     }
     __syncthreads();
     wg_chol(F, ld, nb, na, tau, DS, c.Sv(S_D0), nullptr, c.lds, 4096);
     // Ti: zero, diagonal blocks D_J (dense lower copies in DS)
-    for (int e = t; e < nn * nn; e += WG) {
-        const int i = e / nn, j = e - i * nn;
-        const int I = i >> 6, J = j >> 6;
-        Ti[(size_t)i * ld + j] = (I == J) ? DS[(size_t)I * 4096 + (i & 63) * 64 + (j & 63)] : 0.0;
+    {
+        const int tot = nn * nn;
+        int i = t / nn, j = t - i * nn;
+        for (int e0 = t; e0 < tot; e0 += 8 * WG) {
+            double v[8]; int ii[8], jj[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                ii[u] = (e0 + u * WG < tot) ? i : -1; jj[u] = j;
+                v[u] = 0.0;
+                if (ii[u] >= 0 && (i >> 6) == (j >> 6)) v[u] = DS[(size_t)(i >> 6) * 4096 + (i & 63) * 64 + (j & 63)];
+                j += WG; while (j >= nn) { j -= nn; i++; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (ii[u] >= 0) Ti[(size_t)ii[u] * ld + jj[u]] = v[u];
+        }
     }
     __syncthreads();
     auto ident = [](int r) { return (long)r; };
@@ -717,6 +740,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             if (trial >= 2 && nT - ndel + nadd > c.n && ndel + nadd > max(c.n / 2, 32)) return 0;
             // in one piece when the factor is empty, when most of it would change, or when promotions dictate the order
             // (oracle: the same rule; there "in one piece" is a reset followed by appends in list order)
+            PROF(c, P_UPD_PRE);
             const bool bulk = (ROBUST && prioCtr > 0) || (nT == 0 && nadd > 0) || (ndel > 0 && ndel >= max(nT / 2, 8)) || nadd >= 16;
             int naAll = 0;
             if (bulk) {
@@ -743,7 +767,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                         ti_delete<NCH>(c, sl, nT, ns);
                         touched = 1;
                     }
-                PROF(c, P_GRAM);
+                PROF(c, P_DEL);
                 for (int stamp = (ROBUST && bulk) ? prioCtr : 0; stamp >= 0; stamp--) {
                     // stamp > 0: the rows of one promotion; stamp == 0: every active row that is not in the factor yet
                     const int cnt = wg_compact(mE, [&](int r) { return st[r] != ST_INACT && rslot[r] < 0 && (stamp == 0 || prio[r] == stamp); }, list, c.lds);

@@ -28,8 +28,8 @@ print("timing (setup ms, solve ms):", bt.last_timing(), "solved", sum(s["returnV
 prof = np.zeros((B, 16), dtype=np.uint64)
 la.lib().lcqp_hip_batch_read_profile.argtypes = [C.c_void_p, C.c_void_p]
 la.lib().lcqp_hip_batch_read_profile(bt.h, prof.ctypes.data_as(C.c_void_p))
-names = ["lcqp-level sweeps", "trial residual (Q+E sweep)", "gram S=TT'", "chol(S)", "corr: L1 trsv", "corr: rows of Et", "corr: S trsv", "admm", "misc/logic"]
-tot = prof[:, :9].sum(axis=1).astype(float)
+names = ["lcqp-level sweeps", "trial residual (Q+E sweep)", "factor: one-piece rebuild", "factor: appends", "corr: L1 trsv", "corr: rows of Et", "corr: pass over T", "admm", "misc/logic", "factor: rotations (deletes)", "factor: working-set bookkeeping"]
+tot = prof[:, :11].sum(axis=1).astype(float)
 print("mean cycles per instance: %.3e  (max %.3e, min %.3e)" % (tot.mean(), tot.max(), tot.min()))
 qs = np.percentile(tot, [10, 50, 90, 99])
 print("percentiles 10/50/90/99: %.3e %.3e %.3e %.3e;  mean/max = %.3f (share of the launch an average workgroup slot is busy)" % (*qs, tot.mean() / tot.max()))
