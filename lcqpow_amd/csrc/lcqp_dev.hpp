@@ -663,20 +663,21 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
         int chg = 0;
         PROF(c, P_MISC);
         // leaving rows (wrong-signed multipliers) drop out before the residual is formed
-        for (int r = t; r < mE; r += WG) {
-            double yv = yt[r];
-            if (trial > 0) {
-                const int s = st[r];
-                if ((s == ST_LOWER && yv > ytol) || (s == ST_UPPER && yv < -ytol)) { st[r] = ST_INACT; yv = 0.0; yt[r] = 0.0; chg = 1; }
-                else if (ROBUST && s == ST_INACT && yv != 0.0) { yv = 0.0; yt[r] = 0.0; }   // left as "dependent, inside" in the last trial
-            }
-            coef[r] = yv;
-        }
+        wg_map<4>(mE, [&](int r) { return MapID{st[r], yt[r]}; },
+                  [&](int r, MapID v) {
+                      double yv = v.a;
+                      if (trial > 0) {
+                          const int s = v.s;
+                          if ((s == ST_LOWER && yv > ytol) || (s == ST_UPPER && yv < -ytol)) { st[r] = ST_INACT; yv = 0.0; yt[r] = 0.0; chg = 1; }
+                          else if (ROBUST && s == ST_INACT && yv != 0.0) { yv = 0.0; yt[r] = 0.0; }   // left as "dependent, inside" in the last trial
+                      }
+                      coef[r] = yv;
+                  });
         __syncthreads();
         if (trial == 0 && reuse) {
             const double *r1s = c.V(V_R1S), *gs0 = c.V(V_GS), *exs = c.M(M_EXS);
             for (int i = t; i < np; i += WG) r1[i] = r1s[i] + (gs0[i] - g[i]);
-            for (int r = t; r < mE; r += WG) ex[r] = exs[r];
+            wg_map<4>(mE, [&](int r) { return exs[r]; }, [&](int r, double v) { ex[r] = v; });
             __syncthreads();
         } else {
             // residual evaluation: one sweep over Q, one over E
@@ -686,21 +687,22 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
         }
         const double res_stat = wg_maxabs(r1, np, c.lds);
         double res_eq = 0.0, bmax = 0.0;
-        for (int r = t; r < mE; r += WG) {
-            const int s = st[r];
-            const double e = ex[r];
-            if (s == ST_INACT) {
-                if (trial > 0) {
-                    const double ftol = o.feasTol * (1.0 + fabs(e));
-                    if (e < l[r] - ftol) { st[r] = ST_LOWER; chg = 1; }
-                    else if (e > u[r] + ftol) { st[r] = ST_UPPER; chg = 1; }
-                }
-            } else {
-                const double bb = (s == ST_UPPER) ? u[r] : l[r];
-                res_eq = fmax(res_eq, fabs(bb - e));
-                bmax = fmax(bmax, fabs(bb));
-            }
-        }
+        wg_map<4>(mE, [&](int r) { return MapID3{st[r], ex[r], l[r], u[r]}; },
+                  [&](int r, MapID3 v) {
+                      const int s = v.s;
+                      const double e = v.a;
+                      if (s == ST_INACT) {
+                          if (trial > 0) {
+                              const double ftol = o.feasTol * (1.0 + fabs(e));
+                              if (e < v.b - ftol) { st[r] = ST_LOWER; chg = 1; }
+                              else if (e > v.c + ftol) { st[r] = ST_UPPER; chg = 1; }
+                          }
+                      } else {
+                          const double bb = (s == ST_UPPER) ? v.c : v.b;
+                          res_eq = fmax(res_eq, fabs(bb - e));
+                          bmax = fmax(bmax, fabs(bb));
+                      }
+                  });
         int changed;
         if (ROBUST) {
             if (trial > 0 && uniform_i(c.info->ndep) > 0) chg |= polish_dependent_rows(st, dep, prio, ex, l, u, mE, o.feasTol, prioCtr + 1);
@@ -718,7 +720,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             // A'y_A + y_box = -E'y = g + Qx + r1 at the verified point (all three are direct sums of this trial)
             double* qxn = c.V(V_QXN);
             for (int i = t; i < np; i += WG) { r1s[i] = r1[i]; gs0[i] = g[i]; aty[i] = g[i] + qx[i] + r1[i]; qxn[i] = qx[i]; }
-            for (int r = t; r < mE; r += WG) exs[r] = ex[r];
+            wg_map<4>(mE, [&](int r) { return ex[r]; }, [&](int r, double v) { exs[r] = v; });
             __syncthreads();
             return 1;
         }
@@ -732,7 +734,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             int touched = 0, ndepNow = 0;
             const int ndel = wg_compact(ns, [&](int sl) { const int r = idx[sl]; return r >= 0 && st[r] == ST_INACT; }, list, c.lds);
             int cntAdd = 0;
-            for (int r = t; r < mE; r += WG) cntAdd += (st[r] != ST_INACT && rslot[r] < 0);
+            wg_map<4>(mE, [&](int r) { return MapID{st[r], (double)rslot[r]}; }, [&](int, MapID v) { cntAdd += (v.s != ST_INACT && v.a < 0.0); });
             const int nadd = block_sum_i(cntAdd, c.lds);
             // more active rows than variables while the set still changes by more than max(n/2, 32) rows per trial: the primal-dual update has
             // overshot (a cold start far from the solution, where every violated row enters at once) and more trials only thrash with
@@ -852,7 +854,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
     const double *l = c.M(M_L), *u = c.M(M_U), *rhov = c.M(M_RHOV);
     int *st = c.I(I_ST), *stt = c.I(I_STT);
     int bad = 0;
-    for (int r = t; r < mE; r += WG) bad |= (l[r] > u[r]);
+    wg_map<4>(mE, [&](int r) { return MapD4{l[r], u[r], 0.0, 0.0}; }, [&](int, MapD4 v) { bad |= (v.a > v.b); });
     if (block_or(bad, c.lds)) return 2;
     if (ROBUST && uniform_i(c.info->prioCtr) != 0) {     // promotions of dependent rows last for one solve
         int* prio = c.I(I_PRIO);
@@ -872,7 +874,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         __syncthreads();
     }
     wg_copy(xa, xq, np);
-    for (int r = t; r < mE; r += WG) ya[r] = yq[r];
+    wg_map<4>(mE, [&](int r) { return yq[r]; }, [&](int r, double v) { ya[r] = v; });
     __syncthreads();
     int n_admm = initial ? o.admmFirst : o.admmHot;
     const int use_stored = (!initial && c.info->haveSolution && n_admm == 0);
@@ -888,20 +890,20 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
             admm_ready = 1;
         }
         if (n_admm > 0) qp_admm<NCH>(c, g, n_admm);
-        for (int r = t; r < mE; r += WG) {
-            int s;
-            if (round == 0 && use_stored) {
-                s = st[r];
-                if (l[r] == u[r]) s = ST_EQ;
-            } else {
-                const double lo = l[r], hi = u[r], z = za[r], y = ya[r];
-                s = ST_INACT;
-                if (isfinite(lo) && (z - lo < -y)) s = ST_LOWER;
-                if (isfinite(hi) && (hi - z < y)) s = ST_UPPER;
-                if (lo == hi) s = ST_EQ;
-            }
-            stt[r] = s;
-            yt[r] = (s != ST_INACT) ? ya[r] : 0.0;
+        if (round == 0 && use_stored) {
+            wg_map<4>(mE, [&](int r) { return MapID3{st[r], l[r], u[r], ya[r]}; },
+                      [&](int r, MapID3 v) { const int s = (v.a == v.b) ? (int)ST_EQ : v.s; stt[r] = s; yt[r] = (s != ST_INACT) ? v.c : 0.0; });
+        } else {
+            wg_map<4>(mE, [&](int r) { return MapD4{l[r], u[r], za[r], ya[r]}; },
+                      [&](int r, MapD4 v) {
+                          const double lo = v.a, hi = v.b, z = v.c, y = v.d;
+                          int s = ST_INACT;
+                          if (isfinite(lo) && (z - lo < -y)) s = ST_LOWER;
+                          if (isfinite(hi) && (hi - z < y)) s = ST_UPPER;
+                          if (lo == hi) s = ST_EQ;
+                          stt[r] = s;
+                          yt[r] = (s != ST_INACT) ? y : 0.0;
+                      });
         }
         for (int i = t; i < np; i += WG) xt[i] = xa[i];
         __syncthreads();
@@ -918,7 +920,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
     *iterations = (c.cTrials - trials0) + (c.cAdmm - admm0);
     if (!solved) return certificate ? certificate : 1;
     for (int i = t; i < np; i += WG) xq[i] = xt[i];
-    for (int r = t; r < mE; r += WG) { yq[r] = yt[r]; st[r] = stt[r]; }
+    wg_map<4>(mE, [&](int r) { return MapID{stt[r], yt[r]}; }, [&](int r, MapID v) { yq[r] = v.a; st[r] = v.s; });
     if (t == 0) c.info->haveSolution = 1;
     __syncthreads();
     return 0;
@@ -931,7 +933,7 @@ __device__ __forceinline__ void qp_export(Ctx<NCH>& c, double* xdst /*np or n*/,
     const int t = tid_here(), n = c.n, nC = c.mA;
     const double *xq = c.V(V_XQ), *yq = c.M(M_YQ);
     for (int i = t; i < xlen; i += WG) xdst[i] = xq[i];
-    for (int i = t; i < n + nC; i += WG) yref[i] = (i < n) ? 0.0 : -yq[i - n];
+    wg_map<4>(n + nC, [&](int i) { return (i < n) ? 0.0 : -yq[i - n]; }, [&](int i, double v) { yref[i] = v; });
     __syncthreads();
     for (int k = t; k < c.info->nfin; k += WG) yref[c.boxidx[k]] = -yq[nC + k];
     __syncthreads();

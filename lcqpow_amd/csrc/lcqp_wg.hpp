@@ -72,6 +72,25 @@ __device__ __forceinline__ double uniform_d(double v)
 }
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Element-wise loop over n entries by the workgroup: all the loads of a tile of U*WG entries (load(i) returns them by value) are
+// issued before the first store of the tile (store(i, v)).  Written as load - store - load ... the compiler has to keep the order
+// (the arrays may alias) and a loop over 640 rows pays three memory round trips instead of one.
+template <int U, class L, class S>
+__device__ __forceinline__ void wg_map(int n, L load, S store)
+{
+    const int t = tid_here();
+    for (int i0 = t; i0 < n; i0 += U * WG) {
+        decltype(load(0)) v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = i0 + u * WG; v[u] = load(i < n ? i : 0); }
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int i = i0 + u * WG; if (i < n) store(i, v[u]); }
+    }
+}
+struct MapID { int s; double a; };
+struct MapID3 { int s; double a, b, c; };
+struct MapD4 { double a, b, c, d; };
+
 // workgroup reductions; result is uniform across the workgroup (and held in SGPRs). Ends with a barrier.
 __device__ __forceinline__ double block_sum(double v, Lds lds)
 {
