@@ -1180,7 +1180,7 @@ try {
     ok = ok && make_ell(d.ellQ, n, std::vector<int>(Qp, Qp + n + 1), std::vector<int>(Qi, Qi + nnzQ), nullptr, d.Qp, d.Qi, nullptr) &&
          make_ell(d.ellE, m, Ep, Ei, nullptr, d.Ep, d.Ei, nullptr) && make_ell(d.ellT, n, ETp, ETi, ETmap.data(), d.ETp, d.ETi, d.ETmap);
     ok = ok && (d.Qx = sp_alloc<double>(h, B * nnzQ)) && (d.Ex = sp_alloc<double>(h, B * nnzA)) &&
-         (d.Kb = sp_alloc<double>(h, B * N * ld)) &&
+         (d.Kb = sp_alloc<double>(h, G > 16 ? B * N * ld : 0)) &&      // the band array is only written by the LDS-window factorisation
          (d.KaF = sp_alloc<double>(h, B * Np * G)) && (d.KaD = sp_alloc<double>(h, B * Np)) &&
          (d.KpF = sp_alloc<double>(h, B * Np * G)) && (d.KpD = sp_alloc<double>(h, B * Np)) &&
          (d.nv = sp_alloc<double>(h, B * NV_NUM * n)) && (d.mv = sp_alloc<double>(h, B * MV_NUM * m)) && (d.Nv = sp_alloc<double>(h, B * 2 * Np)) &&

@@ -109,6 +109,17 @@ def test_sparse_default_options_and_admm_first(hip, oracle):
         sb.close()
 
 
+def test_sparse_profile_entry_point_needs_a_profile_build(hip):
+    """lcqp_hip_sparse_read_profile reports LCQP_HIP_UNSUPPORTED (901) on the product build: the phase stamps exist only in
+    -DLCQP_PROFILE builds (tools/gpu_sparse_profile.py)"""
+    import ctypes as C
+    sb, inst, x, y, st = _run(hip, 64, 32, 8, 2)
+    out = np.zeros(8)
+    hip.lib().lcqp_hip_sparse_read_profile.argtypes = [C.c_void_p, C.c_void_p]
+    assert hip.lib().lcqp_hip_sparse_read_profile(sb.h, out.ctypes.data_as(C.c_void_p)) == 901
+    sb.close()
+
+
 def test_sparse_pattern_outside_the_band_engine_is_refused(hip):
     """the arrow-shaped KKT matrix of examples/OptimizeOnCircle.cpp (one dense constraint row) is not banded: the sparse engine
     says so, it does not run past its window (the host layer runs this problem on the dense kernels behind the OSQP_SPARSE
