@@ -109,6 +109,38 @@ def test_sparse_default_options_and_admm_first(hip, oracle):
         sb.close()
 
 
+@pytest.mark.parametrize("case", ["shifted complementarity bounds", "x0 and y0 given"])
+def test_sparse_bounds_and_initial_guess(hip, oracle, case):
+    """lbL, lbR > 0 (phi_const and g_phi of src/LCQProblem.cpp:969-996), finite ubL; and a warm start (x0, y0 with the sign of
+    src/SubsolverOSQP.cpp:196-199): the sparse loadLCQP overload's optional arguments (src/LCQProblem.cpp:390-441), HIP vs oracle"""
+    n, nC, nK, B = 512, 256, 64, 5
+    Qp, Ap = P.sparse_pattern(n, nC, nK)
+    inst = [P.sparse_instance(i, n, nC, nK) for i in range(B)]
+    kw = []
+    for b in range(B):
+        rng = np.random.default_rng(b)
+        if case.startswith("shifted"):
+            kw.append(dict(lbL=np.full(nK, 0.01), lbR=np.full(nK, 0.02), ubL=np.full(nK, 5.0), ubR=np.full(nK, np.inf)))
+        else:
+            kw.append(dict(x0=rng.uniform(-0.5, 0.5, n), y0=rng.uniform(-0.1, 0.1, nC + 2 * nK)))
+    sb = hip.SparseBatchLCQP(B, n, nC, nK, Qp, Ap, opt=hip.default_options(perturbStep=0, printLevel=0))
+    stacked = {k: np.stack([q[k] for q in kw]) for k in kw[0]}
+    assert sb.load(0, B, np.stack([d["Q"].data for d in inst]), np.stack([d["g"] for d in inst]), np.stack([d["E"].data for d in inst]),
+                   lbA=np.stack([d["lbA"] for d in inst]), ubA=np.stack([d["ubA"] for d in inst]), **stacked) == 0
+    sb.run()
+    x, y, st = sb.solution()
+    for b in range(B):
+        d = inst[b]
+        ro = oracle.sparse_lcqp_solve(n, nC, nK, d["Q"].tocsr(), d["g"], d["E"].tocsr(), lbA=d["lbA"], ubA=d["ubA"],
+                                      opt=oracle.default_options(perturbStep=0), **kw[b])
+        assert st[b]["returnValue"] == ro["ret"] == 0, (case, b, st[b], ro["stats"])
+        assert np.abs(x[b] - ro["x"]).max() < 1e-8 and np.abs(y[b] - ro["y"]).max() < 1e-6
+        if case.startswith("shifted"):
+            Lx, Rx = x[b][8 * np.arange(nK)], x[b][8 * np.arange(nK) + 4]
+            assert ((Lx - 0.01) * (Rx - 0.02)).sum() < 2.2e-13 and Lx.min() > 0.01 - 1e-9 and Rx.min() > 0.02 - 1e-9
+    sb.close()
+
+
 def test_sparse_profile_entry_point_needs_a_profile_build(hip):
     """lcqp_hip_sparse_read_profile reports LCQP_HIP_UNSUPPORTED (901) on the product build: the phase stamps exist only in
     -DLCQP_PROFILE builds (tools/gpu_sparse_profile.py)"""
