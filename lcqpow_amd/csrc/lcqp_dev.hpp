@@ -22,7 +22,7 @@ enum { S_R2, S_DY, S_D0, S_SV, S_W, S_NUM };   // slot-space vectors (length cap
 struct InstInfo {
     int mE, nfin, hasY0, setupFail, haveSolution, isSetup, nT, prioCtr;   // nT: rows of the inverse factor Ti (= rows of the working set it holds); prioCtr: promotion stamps in use (I_PRIO)
     int ndep, ns;                                                         // ndep: active rows flagged dependent (I_DEP); ns: slots of Ti in use (high-water mark, free slots inside count)
-    int cNnz, pad3;                                                       // cNnz: non-zeros of C held in compressed rows (k_compress_C), -1: C is swept as a dense matrix
+    int cNnz, kReady;                                                     // cNnz: non-zeros of C held in compressed rows (k_compress_C), -1: C is swept as a dense matrix; kReady: L_K exists (qp_build_K)
     double scale, sigma, spv, rhoAdmm, phiConst;
     double hist[64];     // the last nDynamicPenalty complementarity values (src/LCQProblem.cpp:1344-1375; the reference's default is 3)
     double work[4];   // exact work sums for the byte accounting: sum(nT), sum(nT*ns) over corrections; bytes of Ti and M moved by working-set updates; number of updates
@@ -213,6 +213,47 @@ __device__ __forceinline__ int qp_certificate(Ctx<NCH>& c, const double* g)
 }
 
 // ---------------------------------------------------------------------------------------------
+// K = Q + sigma I + E' diag(rho) E and its Cholesky factor L_K, by this workgroup alone.  ADMM is the fallback of the subsolver
+// (about one instance in a hundred of the synthetic workload ever runs it), so the factor is built when the first ADMM
+// iteration of an instance needs it, not for every instance at setup; rho adaptation rebuilds it the same way.  The tiles are
+// the ones k_build_K computed when this was a setup kernel.  Returns 1 (uniform) when a pivot is not positive.
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+__device__ __forceinline__ int qp_build_K(Ctx<NCH>& c)
+{
+    constexpr int np = 128 * NCH;
+    const double* rhov = c.M(M_RHOV);
+    const int mE = c.mE;
+    const double sigma = c.info->sigma;
+    for (int I = 0; I < c.nblk; I++)
+        for (int J = 0; J <= I; J++) {
+            double acc[4][4];
+            wg_tile_tn(acc, c.E, np, 64 * I, c.E, np, 64 * J, mE, [=](int r) { return rhov[r]; }, c.lds);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int gi = 64 * I + tile_li(i, j), gj = 64 * J + tile_lj(i, j);
+                    const double v = acc[i][j] + c.Q[(size_t)gi * np + gj] + (gi == gj ? sigma : 0.0);
+                    c.FK[(size_t)gi * np + gj] = v;
+                    // mirror only off-diagonal tiles: inside a diagonal tile (i,j) and (j,i) are both computed, and
+                    // (rho*e_i)*e_j != (rho*e_j)*e_i in the last bit
+                    if (I != J) c.FK[(size_t)gj * np + gi] = v;
+                }
+        }
+    __syncthreads();
+    int* fail = c.lds.ired + 15;
+    if (tid_here() == 0) *fail = 0;
+    __syncthreads();
+    wg_chol(c.FK, np, c.nblk, c.n, 0.0, c.dscr, nullptr, fail, c.lds, 0);
+    __syncthreads();
+    const int failed = uniform_i(*fail);
+    __syncthreads();
+    if (tid_here() == 0) c.info->kReady = 1;
+    return failed;
+}
+
+// ---------------------------------------------------------------------------------------------
 // OSQP's rho adaptation for the fallback rounds (oracle: qp_adapt_rho): after a failed round, scale all rho_i by
 //   sqrt( (|E xa - za| / max(|E xa|, |za|)) / (|Q xa + g + E'ya| / max(|Q xa|, |E'ya|, |g|)) )   (infinity norms, clipped to
 // [1e-3, 1e3]) when that factor is above 5 or below 1/5, and refactorise K = Q + sigma I + E' diag(rho) E in place (the
@@ -244,24 +285,7 @@ __device__ __forceinline__ int qp_adapt_rho(Ctx<NCH>& c, const double* g)
     for (int r = t; r < mE; r += WG) rhov[r] *= fac;
     if (t == 0) c.info->rhoAdmm *= fac;
     __syncthreads();
-    const double sigma = c.info->sigma;
-    for (int I = 0; I < c.nblk; I++)
-        for (int J = 0; J <= I; J++) {
-            double acc[4][4];
-            wg_tile_tn(acc, c.E, np, 64 * I, c.E, np, 64 * J, mE, [=](int r) { return rhov[r]; }, c.lds);
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int gi = 64 * I + tile_li(i, j), gj = 64 * J + tile_lj(i, j);
-                    const double v = acc[i][j] + c.Q[(size_t)gi * np + gj] + (gi == gj ? sigma : 0.0);
-                    c.FK[(size_t)gi * np + gj] = v;
-                    if (I != J) c.FK[(size_t)gj * np + gi] = v;     // see k_build_K
-                }
-        }
-    __syncthreads();
-    wg_chol(c.FK, np, c.nblk, c.n, 0.0, c.dscr, nullptr, nullptr, c.lds, 0);
-    __syncthreads();
+    qp_build_K<NCH>(c);
     c.cFact++;
     return 1;
 }
@@ -889,7 +913,10 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
             __syncthreads();
             admm_ready = 1;
         }
-        if (n_admm > 0) qp_admm<NCH>(c, g, n_admm);
+        if (n_admm > 0) {
+            if (!uniform_i(c.info->kReady) && qp_build_K<NCH>(c)) return 3;     // first ADMM iteration of this instance: L_K is built now
+            qp_admm<NCH>(c, g, n_admm);
+        }
         if (round == 0 && use_stored) {
             wg_map<4>(mE, [&](int r) { return MapID3{st[r], l[r], u[r], ya[r]}; },
                       [&](int r, MapID3 v) { const int s = (v.a == v.b) ? (int)ST_EQ : v.s; stt[r] = s; yt[r] = (s != ST_INACT) ? v.c : 0.0; });

@@ -445,7 +445,6 @@ static int launch_setup(lcqp_hip_batch* h)
     const int ntile = d.nblk * (d.nblk + 1) / 2;
     dispatch_db(h, ID_k_prepare, d.B);
     if (d.nComp > 0) { dispatch_db(h, ID_k_build_C, d.B * ntile); dispatch_db(h, ID_k_compress_C, d.B); }
-    dispatch_db(h, ID_k_build_K, d.B * ntile);
     dispatch_db(h, ID_k_factor, d.B);
     dispatch_db(h, ID_k_trsm, d.B * ((d.mEcap + 63) / 64));
     { const int nb = d.mMld / 64; dispatch_db(h, ID_k_build_M, d.B * (nb * (nb + 1) / 2)); }

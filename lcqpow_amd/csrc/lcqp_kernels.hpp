@@ -170,38 +170,7 @@ __global__ __launch_bounds__(WG) void k_compress_C(DevBatch db)
     }
 }
 
-// ---- k_build_K: FK = Q + sigma I + E' diag(rho) E  (lower tiles, mirrored) -------------------------
-template <int NCH>
-__global__ __launch_bounds__(WG) void k_build_K(DevBatch db)
-{
-    LCQP_LDS_N(NCH)
-    constexpr int np = 128 * NCH;
-    const int ntile = db.nblk * (db.nblk + 1) / 2;
-    const int b = blockIdx.x / ntile, tIdx = blockIdx.x % ntile;
-    int I, J;
-    tri_tile(tIdx, I, J);
-    const double* E = db.E + (size_t)b * db.mEcap * np;
-    const double* Q = db.Q + (size_t)b * np * np;
-    double* FK = db.FK + (size_t)b * np * np;
-    const double* rhov = db.mv + (size_t)b * M_NUM * db.mEcap + (size_t)M_RHOV * db.mEcap;
-    const InstInfo* info = db.info + b;
-    double acc[4][4];
-    wg_tile_tn(acc, E, np, 64 * I, E, np, 64 * J, info->mE, [=](int r) { return rhov[r]; }, lds);
-    const double sigma = info->sigma;
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int gi = 64 * I + tile_li(i, j), gj = 64 * J + tile_lj(i, j);
-            const double v = acc[i][j] + Q[(size_t)gi * np + gj] + (gi == gj ? sigma : 0.0);
-            FK[(size_t)gi * np + gj] = v;
-            // mirror only off-diagonal tiles: inside a diagonal tile (i,j) and (j,i) are both computed, and
-            // (rho*e_i)*e_j != (rho*e_j)*e_i in the last bit -- mirroring there would be a write race
-            if (I != J) FK[(size_t)gj * np + gi] = v;
-        }
-}
-
-// ---- k_factor: the two constant factorisations (L1 of Q + sp I, LK of K) ---------------------------
+// ---- k_factor: the constant factorisation L1 of Q + sp I (L_K of the ADMM fallback is built on demand, qp_build_K) ----
 template <int NCH>
 __global__ __launch_bounds__(WG) void k_factor(DevBatch db)
 {
@@ -215,9 +184,12 @@ __global__ __launch_bounds__(WG) void k_factor(DevBatch db)
     double spv = 0.0;
     for (int pass = 0; pass < 2; pass++) {
         spv = (pass == 0 ? db.opt.proxSmall : db.opt.proxBig) * scale;
-        for (int e = t; e < np * np; e += WG) {
-            const int i = e / np, j = e - i * np;
-            c.F1[e] = c.Q[e] + (i == j ? spv : 0.0);
+        for (int e0 = t; e0 < np * np; e0 += 8 * WG) {      // eight loads in flight per thread, then the stores
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int e = e0 + u * WG; const int i = e / np, j = e - i * np; v[u] = c.Q[e] + (i == j ? spv : 0.0); }
+#pragma unroll
+            for (int u = 0; u < 8; u++) c.F1[e0 + u * WG] = v[u];
         }
         if (t == 0) sfail = 0;
         __syncthreads();
@@ -233,13 +205,10 @@ __global__ __launch_bounds__(WG) void k_factor(DevBatch db)
         if (!failed && (pass == 1 || minpiv >= db.opt.pivotThreshold * scale)) break;
         if (pass == 1) break;
     }
-    if (t == 0) sfail = 0;
-    __syncthreads();
-    wg_chol(c.FK, np, c.nblk, c.n, 0.0, c.dscr, nullptr, &sfail, lds, 0);
-    __syncthreads();
     if (t == 0) {
         c.info->spv = spv;
-        if (failed || sfail) c.info->setupFail = 3;
+        c.info->kReady = 0;          // L_K (ADMM fallback) is built by the first instance that needs it: qp_build_K
+        if (failed) c.info->setupFail = 3;
     }
 }
 
@@ -497,7 +466,6 @@ static void launch_impl(int kid, int grid, hipStream_t s, const LaunchArgs& a)
         case ID_k_prepare:    hipLaunchKernelGGL((k_prepare<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_build_C:    hipLaunchKernelGGL((k_build_C<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_compress_C: hipLaunchKernelGGL((k_compress_C<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
-        case ID_k_build_K:    hipLaunchKernelGGL((k_build_K<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_factor:     hipLaunchKernelGGL((k_factor<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_trsm:       hipLaunchKernelGGL((k_trsm<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_build_M:    hipLaunchKernelGGL((k_build_M<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
