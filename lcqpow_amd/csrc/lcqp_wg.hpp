@@ -520,14 +520,19 @@ __device__ __forceinline__ void wg_tile_nt(double (&acc)[4][4], const double* __
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+    // software-pipelined: the operands of panel k0 + 16 are fetched into registers before the products of panel k0 start
+    double2 a0 = {0.0, 0.0}, a1 = {0.0, 0.0}, b0 = {0.0, 0.0}, b1 = {0.0, 0.0};
+    if (ap && K > 0) { a0 = *reinterpret_cast<const double2*>(ap); a1 = *reinterpret_cast<const double2*>(ap + 2); }
+    if (bp && K > 0) { b0 = *reinterpret_cast<const double2*>(bp); b1 = *reinterpret_cast<const double2*>(bp + 2); }
     for (int k0 = 0; k0 < K; k0 += 16) {
-        double2 a0 = {0.0, 0.0}, a1 = {0.0, 0.0}, b0 = {0.0, 0.0}, b1 = {0.0, 0.0};
-        if (ap) { a0 = *reinterpret_cast<const double2*>(ap + k0); a1 = *reinterpret_cast<const double2*>(ap + k0 + 2); }
-        if (bp) { b0 = *reinterpret_cast<const double2*>(bp + k0); b1 = *reinterpret_cast<const double2*>(bp + k0 + 2); }
         __syncthreads();   // previous panel fully consumed
         As[(kq + 0) * PL + lr] = a0.x; As[(kq + 1) * PL + lr] = a0.y; As[(kq + 2) * PL + lr] = a1.x; As[(kq + 3) * PL + lr] = a1.y;
         Bs[(kq + 0) * PL + lr] = b0.x; Bs[(kq + 1) * PL + lr] = b0.y; Bs[(kq + 2) * PL + lr] = b1.x; Bs[(kq + 3) * PL + lr] = b1.y;
         __syncthreads();
+        if (k0 + 16 < K) {
+            if (ap) { a0 = *reinterpret_cast<const double2*>(ap + k0 + 16); a1 = *reinterpret_cast<const double2*>(ap + k0 + 18); }
+            if (bp) { b0 = *reinterpret_cast<const double2*>(bp + k0 + 16); b1 = *reinterpret_cast<const double2*>(bp + k0 + 18); }
+        }
         if (active) tile_panel(acc, As, Bs);
     }
     __syncthreads();
@@ -738,21 +743,28 @@ __device__ __forceinline__ void wg_tile_tn(double (&acc)[4][4], const double* __
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
-    for (int k0 = 0; k0 < nrows; k0 += 16) {
-        const int r = k0 + kk;
-        double2 a0 = {0.0, 0.0}, a1 = {0.0, 0.0}, b0 = {0.0, 0.0}, b1 = {0.0, 0.0};
+    // software-pipelined: the operands of panel k0 + 16 are fetched into registers before the products of panel k0 start
+    double2 a0, a1, b0, b1;
+    double wv = 0.0;
+    auto fetch = [&](int r) {
+        a0 = a1 = b0 = b1 = double2{0.0, 0.0};
+        wv = 0.0;
         if (r < nrows) {
-            const double wv = wgt(r);
+            wv = wgt(r);
             const double* ap = A + (size_t)r * lda + ca + c4;
             const double* bp = Bm + (size_t)r * ldb + cb + c4;
             a0 = *reinterpret_cast<const double2*>(ap); a1 = *reinterpret_cast<const double2*>(ap + 2);
             b0 = *reinterpret_cast<const double2*>(bp); b1 = *reinterpret_cast<const double2*>(bp + 2);
-            a0.x *= wv; a0.y *= wv; a1.x *= wv; a1.y *= wv;
         }
+    };
+    fetch(kk);
+    for (int k0 = 0; k0 < nrows; k0 += 16) {
+        a0.x *= wv; a0.y *= wv; a1.x *= wv; a1.y *= wv;
         __syncthreads();
         *reinterpret_cast<double2*>(As + kk * PL + c4) = a0; *reinterpret_cast<double2*>(As + kk * PL + c4 + 2) = a1;
         *reinterpret_cast<double2*>(Bs + kk * PL + c4) = b0; *reinterpret_cast<double2*>(Bs + kk * PL + c4 + 2) = b1;
         __syncthreads();
+        if (k0 + 16 < nrows) fetch(k0 + 16 + kk);
         tile_panel(acc, As, Bs);
     }
     __syncthreads();
