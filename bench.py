@@ -203,7 +203,8 @@ def main():
         ws = bt.work_sums()
         n_corr = max(1, sum(s["corrections"] for s in st)); n_fact = max(1, sum(s["factorizations"] for s in st))
         cfg_extra = {"mean_backsolve_pairs": mean("corrections"), "mean_factor_updates": mean("factorizations"),
-                     "mean_active_rows_per_backsolve": float(ws[0] / n_corr), "mean_factor_update_kbytes": float(ws[2] / n_fact / 1e3)}
+                     "mean_active_rows_per_backsolve": float(ws[0] / n_corr), "mean_factor_update_kbytes": float(ws[2] / n_fact / 1e3),
+                     "mean_E_rows_read_per_sweep": float(ws[4] / max(1.0, sum(s_["reserved"] for s_ in st)))}
         wl = (f"synthetic dense batch={B}/GPU n={n} nC={nC} nComp={nComp} (BASELINE configs[2]; SplitMix64 seed0=0x4C43515000000001, "
               f"perturbStep=0, printLevel=NONE)")
         metric = ("LCQPs/sec (batched dense n=256,nC=512,nComp=64)" if shape == (256, 512, 64)

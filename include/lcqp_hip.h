@@ -157,9 +157,10 @@ int  lcqp_hip_batch_read_profile(lcqp_hip_batch_t* b, unsigned long long* out);
 void* lcqp_hip_batch_stream(lcqp_hip_batch_t* b);
 /* algorithmic HBM bytes of the last run, from the work counters the kernels keep */
 double lcqp_hip_batch_algorithmic_bytes(lcqp_hip_batch_t* b);
-/* the work sums that enter it, summed over the batch: out[0] = sum of active rows na over all corrections,
- * out[1] = sum of na^2 over corrections, out[2], out[3] = the same over factorisations (counted by the kernel) */
-int    lcqp_hip_batch_work_sums(lcqp_hip_batch_t* b, double out[4]);
+/* the work sums that enter it, summed over the batch (counted by the kernel): out[0] = sum of the active rows over all corrections,
+ * out[1] = sum of (active rows x slots of the inverse factor) over corrections, out[2] = bytes moved by the working-set updates,
+ * out[3] = number of working-set updates, out[4] = rows of E read by the residual sweeps (row screening) */
+int    lcqp_hip_batch_work_sums(lcqp_hip_batch_t* b, double out[5]);
 
 /* ------------------------------------------------------------------------------------------------
  * Building blocks exposed for parity tests and micro-benchmarks (each is one kernel launch over a

@@ -255,8 +255,9 @@ class BatchLCQP:
         return lib().lcqp_hip_batch_algorithmic_bytes(self.h)
 
     def work_sums(self):
-        """batch totals of (sum na, sum na^2) over corrections and over factorisations, counted by the kernel"""
-        out = np.zeros(4)
+        """batch totals counted by the kernel: sum of active rows and of rows x slots over the corrections, bytes and number of the
+        working-set updates, rows of E read by the residual sweeps"""
+        out = np.zeros(5)
         _check(lib().lcqp_hip_batch_work_sums(self.h, _p(out)), "work_sums")
         return out
 

@@ -13,19 +13,19 @@ namespace lcqp {
 
 // per-instance vectors of length np (padded nV)
 enum { V_G, V_GPHI, V_GTIL, V_XK, V_PK, V_XNEW, V_GK, V_QX, V_CX, V_QP, V_CP, V_STATK, V_TMP,
-       V_XQ, V_XA, V_XT, V_R1, V_C, V_DU, V_W, V_RHS, V_LB, V_UB, V_X0, V_R1S, V_GS, V_ATY, V_QXN, V_NUM };   // V_QXN: Q x at the last verified QP solution
+       V_XQ, V_XA, V_XT, V_R1, V_C, V_DU, V_W, V_RHS, V_LB, V_UB, V_X0, V_R1S, V_GS, V_ATY, V_QXN, V_XS, V_NUM };   // V_QXN: Q x at the last verified QP solution; V_XS: x of the last residual sweep
 // per-instance vectors of length mEcap (rows of E = [A; L; R; box rows])
-enum { M_L, M_U, M_RHOV, M_YQ, M_YA, M_ZA, M_YT, M_EX, M_COEF, M_EXS, M_DY, M_NUM };   // M_DY: change of ya in the last ADMM iteration
+enum { M_L, M_U, M_RHOV, M_YQ, M_YA, M_ZA, M_YT, M_EX, M_COEF, M_EXS, M_DY, M_RN, M_MG, M_NUM };   // M_DY: change of ya in the last ADMM iteration; M_RN: |E_r|; M_MG: safe margins of the inactive rows (row screening)
 enum { I_ST, I_STT, I_DEP, I_PRIO, I_SLOT, I_LIST, I_NUM };   // I_DEP: row is active but linearly dependent on the rows of the factor; I_PRIO: promotion stamp (0: none); I_SLOT: slot of the row in the inverse factor (-1: none); I_LIST: scratch list of rows / slots
 enum { S_R2, S_DY, S_D0, S_SV, S_W, S_NUM };   // slot-space vectors (length capS): S_SV / S_W: column of S and inv(S) times it when a row is appended
 
 struct InstInfo {
     int mE, nfin, hasY0, setupFail, haveSolution, isSetup, nT, prioCtr;   // nT: rows of the inverse factor Ti (= rows of the working set it holds); prioCtr: promotion stamps in use (I_PRIO)
     int ndep, ns;                                                         // ndep: active rows flagged dependent (I_DEP); ns: slots of Ti in use (high-water mark, free slots inside count)
-    int cNnz, kReady;                                                     // cNnz: non-zeros of C held in compressed rows (k_compress_C), -1: C is swept as a dense matrix; kReady: L_K exists (qp_build_K)
+    int cNnz, kReady, rnReady, pad4;                                                   // cNnz: non-zeros of C held in compressed rows (k_compress_C), -1: C is swept as a dense matrix; kReady: L_K exists (qp_build_K); rnReady: M_RN holds the row norms of E
     double scale, sigma, spv, rhoAdmm, phiConst;
     double hist[64];     // the last nDynamicPenalty complementarity values (src/LCQProblem.cpp:1344-1375; the reference's default is 3)
-    double work[4];   // exact work sums for the byte accounting: sum(nT), sum(nT*ns) over corrections; bytes of Ti and M moved by working-set updates; number of updates
+    double work[6];   // exact work sums for the byte accounting: sum(nT), sum(nT*ns) over corrections; bytes of Ti and M moved by working-set updates; number of updates; rows of E read by the residual sweeps
 };
 
 struct DevBatch {
@@ -704,9 +704,41 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             wg_map<4>(mE, [&](int r) { return exs[r]; }, [&](int r, double v) { ex[r] = v; });
             __syncthreads();
         } else {
-            // residual evaluation: one sweep over Q, one over E
+            // residual evaluation: one sweep over Q, one over the rows of E that can matter.  Row screening: an inactive row r whose
+            // value lay m_r inside its (tolerance-widened) bounds when it was last evaluated cannot be violated while
+            // |E_r| * (sum of |x - x_last sweep| since) < m_r (Cauchy-Schwarz), so it is not read -- its stale E_r x is only ever used
+            // for that violation test.  Active rows are always read.  The decisions, hence the iterates, are those of a full sweep.
+            double *rn = c.M(M_RN), *mg = c.M(M_MG), *xs = c.V(V_XS);
+            int* list = c.I(I_LIST);
+            if (!uniform_i(c.info->rnReady)) {
+                wg_row_norms<NCH>(c.E, mE, rn);
+                for (int r = t; r < mE; r += WG) mg[r] = -1.0;
+                if (t == 0) c.info->rnReady = 1;
+                __syncthreads();
+            }
+            double d2 = 0.0;
+            for (int i = t; i < c.n; i += WG) { const double xv = x[i], dd = xv - xs[i]; d2 += dd * dd; xs[i] = xv; }     // the n variables, not the padding
+            const double dl = sqrt(block_sum(d2, c.lds)) * (1.0 + 1e-6);
+            wg_map<4>(mE, [&](int r) { return MapID3{st[r], mg[r], rn[r], 0.0}; },
+                      [&](int r, MapID3 v) { mg[r] = (v.s != ST_INACT) ? -1.0 : v.a - v.b * dl; });
+            __syncthreads();
+#ifdef LCQP_SCREEN_ALL      // test hook: every row is read (the list machinery without the screening)
+            const int nread = wg_compact(mE, [&](int) { return true; }, list, c.lds);
+#else
+            const int nread = wg_compact(mE, [&](int r) { return !(mg[r] > 1e-10); }, list, c.lds);
+#endif
             wg_symv<NCH>(c.Q, nullptr, c.n, x, nullptr, qx, nullptr, nullptr, nullptr, c.lds);
-            wg_rows<NCH>(c.E, nullptr, mE, x, ex, coef, c.lds, [&](int i, double s) { r1[i] = -g[i] - qx[i] - s; });
+            wg_rows<NCH, true>(c.E, list, nread, x, ex, coef, c.lds, [&](int i, double s) { r1[i] = -g[i] - qx[i] - s; });
+            // fresh margins of the inactive rows just evaluated
+            for (int a = t; a < nread; a += WG) {
+                const int r = list[a];
+                if (st[r] == ST_INACT) {
+                    const double e = ex[r], ftol = o.feasTol * (1.0 + fabs(e));
+                    mg[r] = fmin(e - (l[r] - ftol), (u[r] + ftol) - e);
+                }
+            }
+            if (t == 0) c.info->work[4] += (double)nread;
+            __syncthreads();
             c.cSweeps++;
         }
         const double res_stat = wg_maxabs(r1, np, c.lds);
@@ -992,7 +1024,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     uint64_t perturbCounter = 0;
     double* hist = c.info->hist;
     if (t == 0) {
-        c.info->work[0] = c.info->work[1] = c.info->work[2] = c.info->work[3] = 0.0;
+        c.info->work[0] = c.info->work[1] = c.info->work[2] = c.info->work[3] = c.info->work[4] = 0.0;
         if (db.traceCap > 0) db.traceLen[c.b] = 0;     // a run that records nothing leaves an empty trace, not the last run's
     }
 

@@ -559,7 +559,7 @@ try {
     for (int b = 0; b < d.B; b++) {
         // the active rows of each correction and the bytes of each working-set update are summed by the kernel (InstInfo::work), not estimated
         const double naC = info[b].work[0], tiC = info[b].work[1], updBytes = info[b].work[2];
-        total += st[b].reserved * 8.0 * (n * n + m * n);   // trials that swept Q and E (hot-start trials reuse the last residual)
+        total += st[b].reserved * 8.0 * n * n + 8.0 * n * info[b].work[4];   // trials that swept Q and the rows of E the screening let through (hot-start trials reuse the last residual)
         total += st[b].corrections * bs + 2.0 * 8.0 * naC * n + 8.0 * (tiC + 2.0 * naC);
         total += updBytes;
         total += st[b].admmIter * (bs + 2.0 * 8.0 * m * n);
@@ -570,7 +570,7 @@ try {
 }
 catch (...) { return 0.0; }   // nothing throws across the C boundary
 
-extern "C" int lcqp_hip_batch_work_sums(lcqp_hip_batch_t* h, double out[4])
+extern "C" int lcqp_hip_batch_work_sums(lcqp_hip_batch_t* h, double out[5])
 try {
     if (!h || !out) return LCQP_INVALID_ARGUMENT;
     DevBatch& d = h->db;
@@ -578,8 +578,8 @@ try {
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<InstInfo> info(d.B);
     HIPCHK(hipMemcpy(info.data(), d.info, sizeof(InstInfo) * (size_t)d.B, hipMemcpyDeviceToHost));
-    out[0] = out[1] = out[2] = out[3] = 0.0;
-    for (int b = 0; b < d.B; b++) for (int k = 0; k < 4; k++) out[k] += info[b].work[k];
+    for (int k = 0; k < 5; k++) out[k] = 0.0;
+    for (int b = 0; b < d.B; b++) for (int k = 0; k < 5; k++) out[k] += info[b].work[k];
     return 0;
 }
 catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary

@@ -208,6 +208,7 @@ __global__ __launch_bounds__(WG) void k_factor(DevBatch db)
     if (t == 0) {
         c.info->spv = spv;
         c.info->kReady = 0;          // L_K (ADMM fallback) is built by the first instance that needs it: qp_build_K
+        c.info->rnReady = 0;         // row norms of E for the row screening of the residual sweeps: first sweep
         if (failed) c.info->setupFail = 3;
     }
 }

@@ -90,6 +90,7 @@ __device__ __forceinline__ void wg_map(int n, L load, S store)
 struct MapID { int s; double a; };
 struct MapID3 { int s; double a, b, c; };
 struct MapD4 { double a, b, c, d; };
+struct MapID4 { int s; double a, b, c, d; };
 
 // workgroup reductions; result is uniform across the workgroup (and held in SGPRs). Ends with a barrier.
 __device__ __forceinline__ double block_sum(double v, Lds lds)
@@ -286,6 +287,33 @@ __device__ __forceinline__ void wg_symv(const double* __restrict__ M0, const dou
     else wg_symv_t<NCH, false, false>(M0, nullptr, n, v0, nullptr, o00, nullptr, nullptr, nullptr, lds);
 }
 
+// Euclidean norms of the m rows of an m x np row-major matrix (one wave per row, four rows in flight).
+template <int NCH>
+__device__ __forceinline__ void wg_row_norms(const double* __restrict__ Mx, int m, double* out)
+{
+    constexpr int np = 128 * NCH;
+    const int l = lane_id(), w = wave_id();
+    for (int r0 = w; r0 < m; r0 += 4 * NWAVE) {
+        double2 mm[4][NCH];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int r = r0 + NWAVE * d;
+#pragma unroll
+            for (int k = 0; k < NCH; k++) mm[d][k] = (r < m) ? (reinterpret_cast<const double2*>(Mx + (size_t)r * np) + l)[64 * k] : double2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            double s2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < NCH; k++) s2 += mm[d][k].x * mm[d][k].x + mm[d][k].y * mm[d][k].y;
+            s2 = wave_sum(s2);
+            const int r = r0 + NWAVE * d;
+            if (l == 0 && r < m) out[r] = sqrt(s2);
+        }
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row sweep over an m x np row-major matrix (optionally through a row-index list):
 //   dots[a]  = row_a . x                       (if x != nullptr)
@@ -295,7 +323,8 @@ __device__ __forceinline__ void wg_symv(const double* __restrict__ M0, const dou
 // Rows are dealt to waves in chunks of 16; lane j<16 of a wave carries the scalars of row j.
 // LDS: arena[0..4np) combine, arena[4np..5np) x.
 // ---------------------------------------------------------------------------------------------
-template <int NCH, class Post>
+// BYROW: dots[] and coef[] are indexed by the row number (idx[a]) instead of the list position a.
+template <int NCH, bool BYROW = false, class Post>
 __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int* __restrict__ idx, int m,
                         const double* __restrict__ x, double* dots,
                         const double* __restrict__ coef, Lds lds, Post post)
@@ -322,7 +351,7 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
         const int mya = a0 + l;
         const bool mine = (l < 16) && (mya < m);
         int myrow = mine ? (idx ? idx[mya] : mya) : -1;
-        double mycoef = (mine && coef) ? coef[mya] : 0.0;
+        double mycoef = (mine && coef && (!BYROW || myrow >= 0)) ? coef[BYROW ? myrow : mya] : 0.0;
         double mydot = 0.0;
         const int cnt = min(16, m - a0);
         for (int j0 = 0; j0 < cnt; j0 += D) {
@@ -358,7 +387,7 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
                 }
             }
         }
-        if (mine && dots) dots[mya] = mydot;
+        if (mine && dots && (!BYROW || myrow >= 0)) dots[BYROW ? myrow : mya] = mydot;
     }
     if (coef) wg_combine<NCH>(acc, lds, post);
     else __syncthreads();

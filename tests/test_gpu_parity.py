@@ -324,13 +324,15 @@ def test_lcqp_full_batch_properties(hip, oracle):
     m = nC + 2 * nComp
     bs = 8.0 * n * (n + 2)
     tot = lambda k: float(sum(s[k] for s in st2))
-    # ws = (sum of active rows nT, sum of nT * slots, bytes moved by working-set updates, number of updates)
-    expect = (tot("reserved") * 8.0 * (n * n + m * n) + tot("corrections") * bs + 16.0 * ws[0] * n + 8.0 * (ws[1] + 2.0 * ws[0])
+    # ws = (sum of active rows nT, sum of nT * slots, bytes moved by working-set updates, number of updates, rows of E read by the sweeps)
+    expect = (tot("reserved") * 8.0 * n * n + 8.0 * n * ws[4] + tot("corrections") * bs + 16.0 * ws[0] * n + 8.0 * (ws[1] + 2.0 * ws[0])
               + ws[2] + tot("admmIter") * (bs + 16.0 * m * n) + B * 16.0 * n * n + (tot("iterTotal") + B) * 12.0 * (2 * nComp))
     # (LCQP level: one sweep over Q and C per homotopy; C pk per iterate from the 2 nComp non-zeros of C = L'R + R'L for one-hot L, R)
     assert abs(bt.algorithmic_bytes() - expect) <= 1e-9 * expect
     assert 64 < ws[0] / tot("corrections") < n and ws[1] >= ws[0] ** 2 / tot("corrections")      # mean active rows; slots >= rows
     assert ws[3] == tot("factorizations") and ws[2] > 0
+    # row screening: active rows are always read, inactive ones only when their safe margin is used up
+    assert ws[0] / tot("corrections") < ws[4] / tot("reserved") < 0.75 * m
     bt.close()
 
 
@@ -497,7 +499,9 @@ def test_lcqp_option_sweep(hip, oracle, kw):
         rh = P.hip_solve(hip, d, hip.default_options(**base))
         assert rh["ret"] == ro["ret"], (kw, rh["ret"], ro["ret"])
         so, sh = ro["stats"], rh["stats"]
-        assert abs(so["iterTotal"] - sh["iterTotal"]) <= 4 and abs(so["iterOuter"] - sh["iterOuter"]) <= 1, (kw, so, sh)
+        # one inner cycle more or less; a long Leyffer window compares more near-zero complementarity values
+        slack = 4 * max(1, base.get("nDynamicPenalty", 3) // 3)
+        assert abs(so["iterTotal"] - sh["iterTotal"]) <= slack and abs(so["iterOuter"] - sh["iterOuter"]) <= 1, (kw, so, sh)
         if ro["ret"] == 0:
             assert np.abs(ro["x"] - rh["x"]).max() < 1e-7, kw
             assert so["status"] == sh["status"]
