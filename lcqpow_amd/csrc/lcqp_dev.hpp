@@ -704,6 +704,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             wg_map<4>(mE, [&](int r) { return exs[r]; }, [&](int r, double v) { ex[r] = v; });
             __syncthreads();
         } else {
+            if constexpr (NCH <= 4) {
             // residual evaluation: one sweep over Q, one over the rows of E that can matter.  Row screening: an inactive row r whose
             // value lay m_r inside its (tolerance-widened) bounds when it was last evaluated cannot be violated while
             // |E_r| * (sum of |x - x_last sweep| since) < m_r (Cauchy-Schwarz), so it is not read -- its stale E_r x is only ever used
@@ -716,9 +717,11 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                 if (t == 0) c.info->rnReady = 1;
                 __syncthreads();
             }
-            double d2 = 0.0;
-            for (int i = t; i < c.n; i += WG) { const double xv = x[i], dd = xv - xs[i]; d2 += dd * dd; xs[i] = xv; }     // the n variables, not the padding
-            const double dl = sqrt(block_sum(d2, c.lds)) * (1.0 + 1e-6);
+            double d2 = 0.0, x2 = 0.0;
+            for (int i = t; i < c.n; i += WG) { const double xv = x[i], dd = xv - xs[i]; d2 += dd * dd; x2 += xv * xv; xs[i] = xv; }     // the n variables, not the padding
+            // |E_r (x - x_last)| <= |E_r| |x - x_last|; the factor covers the tolerance that moves with E_r x (feasTol (1 + |E_r x|)),
+            // the second term the rounding of a computed E_r x (~ eps |E_r| |x|)
+            const double dl = sqrt(block_sum(d2, c.lds)) * (1.0 + 1e-6 + o.feasTol) + 1e-13 * sqrt(block_sum(x2, c.lds));
             wg_map<4>(mE, [&](int r) { return MapID3{st[r], mg[r], rn[r], 0.0}; },
                       [&](int r, MapID3 v) { mg[r] = (v.s != ST_INACT) ? -1.0 : v.a - v.b * dl; });
             __syncthreads();
@@ -739,6 +742,12 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             }
             if (t == 0) c.info->work[4] += (double)nread;
             __syncthreads();
+            } else {
+                // np = 1024 (single large problems): the plain sweep over all rows
+                wg_symv<NCH>(c.Q, nullptr, c.n, x, nullptr, qx, nullptr, nullptr, nullptr, c.lds);
+                wg_rows<NCH>(c.E, nullptr, mE, x, ex, coef, c.lds, [&](int i, double s) { r1[i] = -g[i] - qx[i] - s; });
+                if (t == 0) c.info->work[4] += (double)mE;
+            }
             c.cSweeps++;
         }
         const double res_stat = wg_maxabs(r1, np, c.lds);
