@@ -704,7 +704,11 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             wg_map<4>(mE, [&](int r) { return exs[r]; }, [&](int r, double v) { ex[r] = v; });
             __syncthreads();
         } else {
+#ifdef LCQP_SCREEN_NCH8
+            if constexpr (true) {
+#else
             if constexpr (NCH <= 4) {
+#endif
             // residual evaluation: one sweep over Q, one over the rows of E that can matter.  Row screening: an inactive row r whose
             // value lay m_r inside its (tolerance-widened) bounds when it was last evaluated cannot be violated while
             // |E_r| * (sum of |x - x_last sweep| since) < m_r (Cauchy-Schwarz), so it is not read -- its stale E_r x is only ever used
@@ -743,7 +747,9 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             if (t == 0) c.info->work[4] += (double)nread;
             __syncthreads();
             } else {
-                // np = 1024 (single large problems): the plain sweep over all rows
+                // np = 1024 (single large problems): the plain sweep over all rows.  (-DLCQP_SCREEN_NCH8 enables the screening here too;
+                // measured broken: the row-indexed list sweep wg_rows<8, true> returns wrong residuals at the 256 VGPR + AGPR budget
+                // of this instantiation -- open)
                 wg_symv<NCH>(c.Q, nullptr, c.n, x, nullptr, qx, nullptr, nullptr, nullptr, c.lds);
                 wg_rows<NCH>(c.E, nullptr, mE, x, ex, coef, c.lds, [&](int i, double s) { r1[i] = -g[i] - qx[i] - s; });
                 if (t == 0) c.info->work[4] += (double)mE;
