@@ -831,6 +831,9 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                 ndepNow = ti_bulk<NCH>(c, na2, o.depTau, nT, ns);
                 touched = 1;
                 PROF(c, P_GRAM);
+#ifdef LCQP_PROFILE
+                c.prof[11] += 1; c.prof[12] += (unsigned long long)na2;      // one-piece rebuilds and their rows
+#endif
             } else {
                 // row by row: the usual small change -- or more candidate rows than the factor has room for (most of them
                 // dependent, e.g. duplicated constraints): each is tested against the factor and only independent rows take a slot
@@ -841,6 +844,9 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                         touched = 1;
                     }
                 PROF(c, P_DEL);
+#ifdef LCQP_PROFILE
+                if (!bulk) c.prof[13] += (unsigned long long)ndel;
+#endif
                 for (int stamp = (ROBUST && bulk) ? prioCtr : 0; stamp >= 0; stamp--) {
                     // stamp > 0: the rows of one promotion; stamp == 0: every active row that is not in the factor yet
                     const int cnt = wg_compact(mE, [&](int r) { return st[r] != ST_INACT && rslot[r] < 0 && (stamp == 0 || prio[r] == stamp); }, list, c.lds);
@@ -851,6 +857,9 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                         if (ROBUST && t == 0) dep[r] = (rc == 0);
                         ndepNow += (rc == 0);
                         touched = 1;
+#ifdef LCQP_PROFILE
+                        c.prof[14] += 1;
+#endif
                     }
                 }
             }

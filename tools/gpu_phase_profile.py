@@ -37,6 +37,7 @@ it = np.array([s["iterTotal"] for s in st], dtype=float)
 print("correlation of cycles with LCQP iterates: %.3f; iterates min/mean/max %d/%.1f/%d" % (np.corrcoef(tot, it)[0, 1], it.min(), it.mean(), it.max()))
 for k, nme in enumerate(names):
     print(f"  {nme:28s} {100 * prof[:, k].astype(float).sum() / tot.sum():6.2f} %")
+print("  per LCQP: one-piece rebuilds %.2f (mean rows %.0f), rotations %.1f, appends %.1f" % (prof[:, 11].mean(), prof[:, 12].sum() / max(1, prof[:, 11].sum()), prof[:, 13].mean(), prof[:, 14].mean()))
 order = np.argsort(-tot)[:6]
 for b in order:
     s = st[b]
