@@ -702,6 +702,9 @@ try {
             if (std::isfinite(q->lb[i]) || std::isfinite(q->ub[i])) { l[nC + k] = q->lb[i]; u[nC + k] = q->ub[i]; k++; }
         if (hipMemcpyAsync(d.mv + (size_t)M_L * d.mEcap, l.data(), sizeof(double) * d.mEcap, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipMemcpyAsync(d.mv + (size_t)M_U * d.mEcap, u.data(), sizeof(double) * d.mEcap, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            // new bound values: the safe margins of the row screening (M_MG, relative to the old bounds) are void -- NaN margins make
+            // the next residual sweep read every row
+            hipMemsetAsync(d.mv + (size_t)M_MG * d.mEcap, 0xFF, sizeof(double) * d.mEcap, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) { *exit_flag = -1; return LCQP_SUBPROBLEM_SOLVER_ERROR; }
     }
     // linear term of this call

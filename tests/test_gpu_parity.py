@@ -101,6 +101,35 @@ def test_subsolver_matches_oracle_and_kkt(hip, oracle, n, m, seed):
     qh.close()
 
 
+def test_subsolver_hot_start_with_new_bound_values(hip, oracle):
+    """SubsolverBase::solve takes the bounds with every call (src/Subsolver.cpp:94-110): hot starts whose bound VALUES change (same
+    finite / equality pattern) -- rows that were far inside their bounds become violated, so the safe margins of the row screening
+    must not survive the call"""
+    n, m = 96, 160
+    r2 = np.random.default_rng(11)
+    M = r2.standard_normal((n, n)); Q = M.T @ M / n + np.eye(n)
+    A = r2.standard_normal((m, n)) / np.sqrt(n); xs = r2.standard_normal(n)
+    lbA = A @ xs - r2.uniform(2.0, 4.0, m); ubA = A @ xs + r2.uniform(2.0, 4.0, m)      # wide: almost every row inactive and safe
+    g = r2.standard_normal(n)
+    qo = oracle.QP(Q, A); qh = hip.SubsolverHIP(n, m, Q, A)
+    ro = qo.solve(True, g, lbA, ubA, np.zeros(n), None); rh = qh.solve(True, g, lbA, ubA, np.zeros(n), None)
+    assert (ro[0], ro[2]) == (rh[0], rh[2]) == (0, 0)
+    for k in range(4):
+        # tighten a different third of the rows around the current solution so that they cut it off
+        xh, _ = qh.getSolution()
+        ax = A @ xh
+        lb2, ub2 = lbA.copy(), ubA.copy()
+        sel = np.arange(k, m, 3)
+        ub2[sel] = ax[sel] - 0.05 * (1 + k)
+        lb2[sel] = np.minimum(lb2[sel], ub2[sel] - 1.0)
+        ro = qo.solve(False, g, lb2, ub2, None, None); rh = qh.solve(False, g, lb2, ub2, None, None)
+        assert (ro[0], ro[2]) == (rh[0], rh[2]) == (0, 0), (k, ro, rh)
+        (xo, yo), (xh, yh) = qo.solution(), qh.getSolution()
+        assert np.abs(xo - xh).max() < X_TOL and np.abs(yo - yh).max() < Y_TOL
+        assert (A @ xh <= ub2 + 1e-8).all() and (A @ xh >= lb2 - 1e-8).all()
+    qh.close()
+
+
 def test_subsolver_certificates(hip, oracle):
     """exit flags 4 (infeasible) and 5 (unbounded) from the ADMM iterates, same as the oracle"""
     inf, unb = P.certificate_qps()
