@@ -1158,6 +1158,16 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
                 Cx[i] = Cx[i] + alphak * Cp[i];
             }
             __syncthreads();
+#ifdef LCQP_DIAG_DIRECT      // diagnostic: Q xk and C xk as direct products every iterate (what the oracle did before round 3)
+            wg_symv<NCH>(c.Q, c.C, n, xk, nullptr, Qx, Cx, nullptr, nullptr, c.lds);
+#endif
+#ifdef LCQP_DIAG_ATY         // diagnostic: A'yk_A + yk_box as a direct product over all rows of E
+            {
+                double* aty = c.V(V_ATY);
+                const double* yq = c.M(M_YQ);
+                wg_rows<NCH>(c.E, nullptr, c.mE, nullptr, nullptr, yq, c.lds, [&](int i, double s) { aty[i] = -s; });
+            }
+#endif
             // updateStationarity :1246-1272: statk = Qk xk + g_tilde - A' yk_A - yk_box
             {
                 const double* aty = c.V(V_ATY);

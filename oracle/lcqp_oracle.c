@@ -708,6 +708,39 @@ static void ti_delete(orc_qp_t* q, int p)
     while (q->ns > 0 && q->slot_row[q->ns - 1] < 0) q->ns--;      /* free slots at the end are given back */
 }
 
+
+/* Dot product in the summation order of the device's row sweeps (wg_rows, lcqp_wg.hpp): 64 lanes, lane l sums the columns
+ * 128k + 2l, 128k + 2l + 1 of every 128-column chunk k, then a butterfly over the lanes (offsets 32, 16, ... 1).
+ * Why the oracle's QP solver sums E x this way (round 3): at the end of every inner loop of the homotopy the step p = xnew - xk
+ * is ~1e-8 and getOptimalStepLength (src/LCQProblem.cpp:1217-1237) divides lk = p'(Qk xk + g~) ~ -1e-16 by qk = p'Qk p ~ 1e-16.
+ * lk contains (E_a p)'y, which is zero in exact arithmetic and in floating point is y' times the rounding noise of the
+ * feasibility residual b - E_a x that the last correction removed, plus the rounding of x itself (~4e-17, unavoidable with x
+ * stored in doubles -- any subsolver has it, qpOASES included).  So whether alpha comes out as 1 or as 0.8 there is a coin flip,
+ * and one flip moves a penalty update by one cycle of nDynamicPenalty + 1 iterates.  With a left-to-right sum the noise of E x is
+ * about four times that of the device's tree sum: the oracle's lk then lands far outside (-qk, 0) and alpha = 1 almost always,
+ * the device's lands inside it a quarter of the time -- a 4:1 bias in the iterate counts (1990 instances +4, 484 -4 of 8192)
+ * although both end in the same point to 2e-14.  With the same summation order the noise has the same size on both sides and the
+ * histogram is symmetric (tools/cmp_iters.py).  orc_qp_set_sum_order(0) restores the left-to-right sum
+ * (tests/test_oracle_solver.py uses it to show that the oracle differs from ITSELF in the same way when only this order changes). */
+static int g_sum_order = 1;
+void orc_qp_set_sum_order(int device_order) { g_sum_order = device_order; }
+static double dot_lanes(const double* a, const double* x, int n)
+{
+    double v[64];
+    for (int l = 0; l < 64; l++) {
+        double s = 0;
+        for (int k0 = 0; k0 < n; k0 += 128) {
+            const int c = k0 + 2 * l;
+            if (c < n) s += a[c] * x[c];
+            if (c + 1 < n) s += a[c + 1] * x[c + 1];
+        }
+        v[l] = s;
+    }
+    for (int o = 32; o > 0; o >>= 1)
+        for (int l = 0; l < o; l++) v[l] += v[l + o];
+    return v[0];
+}
+
 /* Primal-dual active-set polish in correction (iterative refinement) form.
  * Start: x, yfull (OSQP sign, zero on inactive rows), active set st.  Each trial evaluates the true KKT
  * residuals (one pass over Q and E), tests optimality, else updates the active set (all violated rows
@@ -746,9 +779,8 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
         }
         for (int r = 0; r < mE; r++) {
             const double* e = q->E + (size_t)r * n;
-            double s = 0;
-            for (int k = 0; k < n; k++) s += e[k] * x[k];
-            Ex[r] = s;
+            if (g_sum_order) Ex[r] = dot_lanes(e, x, n);
+            else { double s = 0; for (int k = 0; k < n; k++) s += e[k] * x[k]; Ex[r] = s; }
             double yr = yfull[r];
             if (yr != 0.0)
                 for (int k = 0; k < n; k++) r1[k] -= e[k] * yr;

@@ -127,6 +127,8 @@ int orc_lcqp_solve(int nV, int nC, int nComp,
  * apply the dependent-row rules of orc_qp_*: k_qp_solve under the reference's host loop over SubsolverHIP, and the second pass
  * for failed batch instances, k_lcqp_rerun */
 void orc_lcqp_set_robust(int on);
+/* 1 (default): the QP solver sums E x in the device's order (64 lanes + butterfly); 0: left to right.  See dot_lanes in lcqp_oracle.c. */
+void orc_qp_set_sum_order(int device_order);
 
 /* ---- synthetic instances (include/lcqp_synth.h) and a threaded batch driver for the CPU baseline ---- */
 void orc_synth_generate(uint64_t seed0, uint64_t instance, int n, int nC, int nComp,

@@ -129,6 +129,11 @@ def lcqp_set_robust(on):
     lib().orc_lcqp_set_robust(int(on))
 
 
+def qp_set_sum_order(device_order):
+    """summation order of E x in the oracle's QP solver: 1 = the device's (default), 0 = left to right (oracle/lcqp_oracle.c, dot_lanes)"""
+    lib().orc_qp_set_sum_order(int(device_order))
+
+
 def synth_generate(instance, n=256, nC=512, nComp=64, seed0=SEED0):
     Q = np.empty((n, n)); g = np.empty(n); L = np.empty((nComp, n)); R = np.empty((nComp, n))
     A = np.empty((nC, n)); lbA = np.empty(nC); ubA = np.empty(nC)

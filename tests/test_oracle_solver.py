@@ -155,3 +155,27 @@ def test_synthetic_golden(oracle):
         assert np.abs(r["x"] - GOLD[key + "_x"]).max() < 1e-9
         x = r["x"]
         assert abs((d["L"] @ x) @ (d["R"] @ x)) < 1e-12
+
+
+def test_iterate_path_is_a_coin_flip_at_the_rounding_floor(oracle):
+    """Why GPU and oracle cannot be held to the same iterate COUNT on every instance: at the end of each inner
+    loop getOptimalStepLength (src/LCQProblem.cpp:1217-1237) divides two numbers of size 1e-16 that carry rounding noise of the
+    same size, and one flipped decision moves a penalty update by one cycle of nDynamicPenalty + 1 = 4 iterates.  The oracle
+    differs from ITSELF in exactly this way when nothing but the summation order of E x in its QP solver changes: same solutions,
+    iterate counts apart by multiples of 4 on a sizeable share of the instances."""
+    import os
+    n_inst = 96
+    opt = oracle.default_options(perturbStep=0, printLevel=0)
+    threads = min(8, len(os.sched_getaffinity(0)))
+    try:
+        oracle.qp_set_sum_order(0)
+        _, x0, _, s0 = oracle.synth_batch_solve(0, n_inst, 256, 512, 64, opt=opt, threads=threads)
+        oracle.qp_set_sum_order(1)
+        _, x1, _, s1 = oracle.synth_batch_solve(0, n_inst, 256, 512, 64, opt=opt, threads=threads)
+    finally:
+        oracle.qp_set_sum_order(1)
+    assert all(s["returnValue"] == 0 for s in s0) and all(s["returnValue"] == 0 for s in s1)
+    assert np.abs(x0 - x1).max() < 1e-12                                  # the same points ...
+    d = np.array([a["iterTotal"] - b["iterTotal"] for a, b in zip(s0, s1)])
+    assert np.all(d % 4 == 0)                                               # ... reached over whole cycles more or less
+    assert 0.05 < np.mean(d != 0) < 0.6, np.mean(d != 0)                    # on a sizeable share (measured: 0.27 of 1024)

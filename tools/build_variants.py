@@ -1,0 +1,16 @@
+import sys, os
+sys.path.insert(0, "/root/repo")
+import __graft_entry__ as g
+from concurrent.futures import ThreadPoolExecutor
+vars_ = {}
+for a in sys.argv[1:]:
+    name, _, defs = a.partition(":")
+    vars_[name] = [d for d in defs.split(",") if d]
+def one(kv):
+    name, defs = kv
+    out = os.path.join("/root/repo/ab_tmp", name + ".so")
+    g.build_hip(force=True, out=out, defines=defs, only_nch=2)
+    return out
+with ThreadPoolExecutor(2) as ex:
+    for o in ex.map(one, vars_.items()):
+        print("built", o)
