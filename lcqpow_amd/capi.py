@@ -255,9 +255,9 @@ class BatchLCQP:
         return lib().lcqp_hip_batch_algorithmic_bytes(self.h)
 
     def work_sums(self):
-        """batch totals counted by the kernel: sum of active rows and of rows x slots over the corrections, bytes and number of the
-        working-set updates, rows of E read by the residual sweeps"""
-        out = np.zeros(5)
+        """batch totals counted by the kernel: rows of Et read by the corrections, rows x slots over the corrections, bytes and number of
+        the working-set updates, rows of E read by the residual sweeps, triangular solves with L1 (include/lcqp_hip.h)"""
+        out = np.zeros(6)
         _check(lib().lcqp_hip_batch_work_sums(self.h, _p(out)), "work_sums")
         return out
 

@@ -13,10 +13,10 @@ namespace lcqp {
 
 // per-instance vectors of length np (padded nV)
 enum { V_G, V_GPHI, V_GTIL, V_XK, V_PK, V_XNEW, V_GK, V_QX, V_CX, V_QP, V_CP, V_STATK, V_TMP,
-       V_XQ, V_XA, V_XT, V_R1, V_C, V_DU, V_W, V_RHS, V_LB, V_UB, V_X0, V_R1S, V_GS, V_ATY, V_QXN, V_XS, V_NUM };   // V_QXN: Q x at the last verified QP solution; V_XS: x of the last residual sweep
+       V_XQ, V_XA, V_XT, V_R1, V_C, V_DU, V_W, V_RHS, V_LB, V_UB, V_X0, V_R1S, V_GS, V_ATY, V_QXN, V_XS, V_XREF, V_NUM };   // V_QXN: Q x at the last verified QP solution; V_XS: x of the last residual sweep; V_XREF: anchor of the proximal term (the point the solve started from)
 // per-instance vectors of length mEcap (rows of E = [A; L; R; box rows])
-enum { M_L, M_U, M_RHOV, M_YQ, M_YA, M_ZA, M_YT, M_EX, M_COEF, M_EXS, M_DY, M_RN, M_MG, M_NUM };   // M_DY: change of ya in the last ADMM iteration; M_RN: |E_r|; M_MG: safe margins of the inactive rows (row screening)
-enum { I_ST, I_STT, I_DEP, I_PRIO, I_SLOT, I_LIST, I_NUM };   // I_DEP: row is active but linearly dependent on the rows of the factor; I_PRIO: promotion stamp (0: none); I_SLOT: slot of the row in the inverse factor (-1: none); I_LIST: scratch list of rows / slots
+enum { M_L, M_U, M_RHOV, M_YQ, M_YA, M_ZA, M_YT, M_EX, M_COEF, M_EXS, M_DY, M_RN, M_MG, M_YLV, M_NUM };   // M_DY: change of ya in the last ADMM iteration; M_RN: |E_r|; M_MG: safe margins of the inactive rows (row screening); M_YLV: multipliers of the rows that left the working set in the current trial (zero otherwise)
+enum { I_ST, I_STT, I_DEP, I_PRIO, I_SLOT, I_LIST, I_LIST2, I_NUM };   // I_DEP: row is active but linearly dependent on the rows of the factor; I_PRIO: promotion stamp (0: none); I_SLOT: slot of the row in the inverse factor (-1: none); I_LIST, I_LIST2: scratch lists of rows / slots
 enum { S_R2, S_DY, S_D0, S_SV, S_W, S_NUM };   // slot-space vectors (length capS): S_SV / S_W: column of S and inv(S) times it when a row is appended
 
 struct InstInfo {
@@ -25,7 +25,7 @@ struct InstInfo {
     int cNnz, kReady, rnReady, pad4;                                                   // cNnz: non-zeros of C held in compressed rows (k_compress_C), -1: C is swept as a dense matrix; kReady: L_K exists (qp_build_K); rnReady: M_RN holds the row norms of E
     double scale, sigma, spv, rhoAdmm, phiConst;
     double hist[64];     // the last nDynamicPenalty complementarity values (src/LCQProblem.cpp:1344-1375; the reference's default is 3)
-    double work[6];   // exact work sums for the byte accounting: sum(nT), sum(nT*ns) over corrections; bytes of Ti and M moved by working-set updates; number of updates; rows of E read by the residual sweeps
+    double work[6];   // exact work sums for the byte accounting: [0] rows of Et read by the corrections, [1] sum(nT*ns) over corrections (pass over Ti), [2] bytes of Ti and M moved by working-set updates and predicted corrections, [3] number of updates, [4] rows of E read by the residual sweeps (both stages), [5] triangular solves with L1
 };
 
 struct DevBatch {
@@ -660,6 +660,26 @@ __device__ __forceinline__ void ti_delete(Ctx<NCH>& c, int p, int& nT, int& ns)
 // Primal-dual active-set polish in correction form (oracle: qp_polish).
 // In/out: x = V_XT, multipliers M_YT (OSQP sign, zero on inactive rows), active set I_STT.
 // Returns 1 (uniform) on a verified KKT point.
+//
+// Round 3: a trial does not evaluate the whole KKT residual before it knows whether it needs it.  After a correction the state is
+// known up to rounding: the stationarity residual is sigma_p dx (taken as 0) and the rows in the factor sit on their bounds.  A trial:
+//   (a) rows whose multiplier has the wrong sign leave (multipliers remembered in M_YLV);
+//   (b) STAGE 1: E_r x of the inactive rows the screening cannot rule out (and of active rows flagged dependent); violated rows enter;
+//   (c) nothing changed: STAGE 2, the true residual -- one sweep over Q and one over the active rows of E; only these true residuals
+//       accept a point (accuracy is what it was), else a full correction with them follows;
+//   (d) the set changed: the factor follows, then a PREDICTED correction: r1 = sum over the rows that left of y_r E_r, so
+//       c = L1^-1 r1 = sum y_r Et_r (no forward solve), Et_W c = sum y_r M[r][W] (entries of M = Et Et', no pass over Et_W), r2 = 0 on
+//       the rows that were in the factor and b - E_r x on those that entered; dx = L1^-T (c - Et_W' dy): one pass over Et_W, one
+//       backward solve.  Intermediate trials read neither Q nor the active rows of E.
+// What is solved is the PROXIMAL QP  min 1/2 x'Qx + g'x + sigma_p/2 |x - xref|^2,  xref = the point the solve started from (V_XREF) and
+// sigma_p the weight the constant factor L1 = chol(Q + sigma_p I) carries anyway: the corrections are exact Newton steps of the problem
+// whose residual is tested (the predicted residual after a correction is exactly zero), and the QP has ONE solution also when Q has
+// flat directions (the minimiser nearest xref up to O(sigma_p)), whatever path -- working sets, ADMM rounds -- leads there.  It is
+// returned when it also satisfies the QP as given to the tolerance (always so for sigma_p = 1e-12 max|Q_ii|); otherwise xref moves to
+// it and the iteration continues: the proximal-point method, every step of which has a unique solution.
+// Row screening (round 2): an inactive row that lay m_r inside its (tolerance-widened) bounds when it was last evaluated cannot be
+// violated while |E_r| * (sum of |x - x_last sweep| since) < m_r (Cauchy-Schwarz), so it is not read.  The decisions are those of a
+// sweep over all rows.  Margins are void after anything but this routine wrote x-dependent state (cold entry: every row is read).
 // reuse != 0 (hot start from the last verified solution): the first trial needs no sweep, because
 // r1 = r1_last + (g_last - g) and E x = ex_last hold exactly for an unchanged (x, y).
 // ---------------------------------------------------------------------------------------------
@@ -667,13 +687,20 @@ template <int NCH, bool ROBUST>
 __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse)
 {
     constexpr int np = 128 * NCH;
+#ifdef LCQP_SCREEN_NCH8
+    constexpr bool LISTS = true;
+#else
+    constexpr bool LISTS = NCH <= 4;      // np = 1024: the list sweep wg_rows<8, true> is not trusted: plain sweeps over all rows
+#endif
     const lcqp_options_t& o = c.db->opt;
     const int t = tid_here(), mE = c.mE, capS = c.capS;
-    double *x = c.V(V_XT), *r1 = c.V(V_R1), *cv = c.V(V_C), *du = c.V(V_DU), *qx = c.V(V_TMP);
-    double *yt = c.M(M_YT), *ex = c.M(M_EX), *coef = c.M(M_COEF);
+    double *x = c.V(V_XT), *r1 = c.V(V_R1), *cv = c.V(V_C), *du = c.V(V_DU), *qx = c.V(V_TMP), *xs = c.V(V_XS);
+    double* xref = c.V(V_XREF);
+    const double spv = uniform_d(c.info->spv);
+    double *yt = c.M(M_YT), *ex = c.M(M_EX), *ylv = c.M(M_YLV), *rn = c.M(M_RN), *mg = c.M(M_MG);
     const double *l = c.M(M_L), *u = c.M(M_U);
     int* st = c.I(I_STT);
-    int *dep = c.I(I_DEP), *prio = c.I(I_PRIO);
+    int *dep = c.I(I_DEP), *prio = c.I(I_PRIO), *list = c.I(I_LIST), *rslot = c.I(I_SLOT);
     double *r2 = c.Sv(S_R2), *dy = c.Sv(S_DY);
     int* idx = c.idx;
     const double gs = 1.0 + wg_maxabs(g, c.n, c.lds);
@@ -682,126 +709,160 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
     int prioCtr = ROBUST ? uniform_i(c.info->prioCtr) : 0;
     const int capNa = min(min(min(max(2 * c.n, 64), mE), capS), max_active(NCH));   // room for the degenerate vertices of small problems
 
+    // |x - x_last sweep| for the margins; x becomes the x of the last sweep.  Returns the shrink of the margins per unit row norm.
+    auto sweep_distance = [&]() -> double {
+        double d2 = 0.0, x2 = 0.0;
+        for (int i = t; i < c.n; i += WG) { const double xv = x[i], dd = xv - xs[i]; d2 += dd * dd; x2 += xv * xv; xs[i] = xv; }     // the n variables, not the padding
+        // |E_r (x - x_last)| <= |E_r| |x - x_last|; the factor covers the tolerance that moves with E_r x (feasTol (1 + |E_r x|)),
+        // the second term the rounding of a computed E_r x (~ eps |E_r| |x|)
+        return sqrt(block_sum(d2, c.lds)) * (1.0 + 1e-6 + o.feasTol) + 1e-13 * sqrt(block_sum(x2, c.lds));
+    };
+
+    // a polish that gives up leaves no multipliers of leaving rows behind (M_YLV is zero between trials)
+    auto give_up = [&]() -> int {
+        for (int r = t; r < mE; r += WG) ylv[r] = 0.0;
+        __syncthreads();
+        return 0;
+    };
+
     for (int trial = 0; trial < o.maxTrials; trial++) {
         c.cTrials++;
-        int chg = 0;
+        int changed = 0, nlv = 0, have_true = 0, need_true = 0;
+        const bool cold = (trial == 0 && !reuse);
         PROF(c, P_MISC);
-        // leaving rows (wrong-signed multipliers) drop out before the residual is formed
-        wg_map<4>(mE, [&](int r) { return MapID{st[r], yt[r]}; },
-                  [&](int r, MapID v) {
-                      double yv = v.a;
-                      if (trial > 0) {
-                          const int s = v.s;
-                          if ((s == ST_LOWER && yv > ytol) || (s == ST_UPPER && yv < -ytol)) { st[r] = ST_INACT; yv = 0.0; yt[r] = 0.0; chg = 1; }
-                          else if (ROBUST && s == ST_INACT && yv != 0.0) { yv = 0.0; yt[r] = 0.0; }   // left as "dependent, inside" in the last trial
-                      }
-                      coef[r] = yv;
-                  });
-        __syncthreads();
-        if (trial == 0 && reuse) {
-            const double *r1s = c.V(V_R1S), *gs0 = c.V(V_GS), *exs = c.M(M_EXS);
-            for (int i = t; i < np; i += WG) r1[i] = r1s[i] + (gs0[i] - g[i]);
-            wg_map<4>(mE, [&](int r) { return exs[r]; }, [&](int r, double v) { ex[r] = v; });
-            __syncthreads();
-        } else {
-#ifdef LCQP_SCREEN_NCH8
-            if constexpr (true) {
-#else
-            if constexpr (NCH <= 4) {
-#endif
-            // residual evaluation: one sweep over Q, one over the rows of E that can matter.  Row screening: an inactive row r whose
-            // value lay m_r inside its (tolerance-widened) bounds when it was last evaluated cannot be violated while
-            // |E_r| * (sum of |x - x_last sweep| since) < m_r (Cauchy-Schwarz), so it is not read -- its stale E_r x is only ever used
-            // for that violation test.  Active rows are always read.  The decisions, hence the iterates, are those of a full sweep.
-            double *rn = c.M(M_RN), *mg = c.M(M_MG), *xs = c.V(V_XS);
-            int* list = c.I(I_LIST);
-            if (!uniform_i(c.info->rnReady)) {
-                wg_row_norms<NCH>(c.E, mE, rn);
-                for (int r = t; r < mE; r += WG) mg[r] = -1.0;
-                if (t == 0) c.info->rnReady = 1;
+        if (trial == 0) {
+            if (reuse) {
+                const double *r1s = c.V(V_R1S), *gs0 = c.V(V_GS), *exs = c.M(M_EXS);
+                for (int i = t; i < np; i += WG) r1[i] = (r1s[i] + (gs0[i] - g[i])) - spv * (x[i] - xref[i]);
+                wg_map<4>(mE, [&](int r) { return exs[r]; }, [&](int r, double v) { ex[r] = v; });
                 __syncthreads();
+                have_true = 1;      // the first trial only corrects: the working set it was handed stays
+            } else {
+                // cold entry: the whole residual, every row of E, fresh margins.  (Whatever ran before -- ADMM, rho adaptation, a solve
+                // with other bounds -- may have left M_EX and the margins in any state.)
+                if (!uniform_i(c.info->rnReady)) {
+                    wg_row_norms<NCH>(c.E, mE, rn);
+                    if (t == 0) c.info->rnReady = 1;
+                }
+                wg_map<4>(mE, [&](int r) { return MapID{st[r], yt[r]}; },
+                          [&](int r, MapID v) { if (ROBUST && v.s == ST_INACT && v.a != 0.0) yt[r] = 0.0; ylv[r] = 0.0; });
+                (void)sweep_distance();
+                need_true = 1;
             }
-            double d2 = 0.0, x2 = 0.0;
-            for (int i = t; i < c.n; i += WG) { const double xv = x[i], dd = xv - xs[i]; d2 += dd * dd; x2 += xv * xv; xs[i] = xv; }     // the n variables, not the padding
-            // |E_r (x - x_last)| <= |E_r| |x - x_last|; the factor covers the tolerance that moves with E_r x (feasTol (1 + |E_r x|)),
-            // the second term the rounding of a computed E_r x (~ eps |E_r| |x|)
-            const double dl = sqrt(block_sum(d2, c.lds)) * (1.0 + 1e-6 + o.feasTol) + 1e-13 * sqrt(block_sum(x2, c.lds));
-            wg_map<4>(mE, [&](int r) { return MapID3{st[r], mg[r], rn[r], 0.0}; },
-                      [&](int r, MapID3 v) { mg[r] = (v.s != ST_INACT) ? -1.0 : v.a - v.b * dl; });
-            __syncthreads();
-#ifdef LCQP_SCREEN_ALL      // test hook: every row is read (the list machinery without the screening)
-            const int nread = wg_compact(mE, [&](int) { return true; }, list, c.lds);
+        } else {
+            // (a) leaving rows; margins of the inactive rows shrink by |E_r| * |x - x_last sweep|
+            const double dl = LISTS ? sweep_distance() : 0.0;
+            int cntLv = 0;
+            wg_map<4>(mE, [&](int r) { return MapID3{st[r], yt[r], mg[r], rn[r]}; },
+                      [&](int r, MapID3 v) {
+                          int s = v.s;
+                          if ((s == ST_LOWER && v.a > ytol) || (s == ST_UPPER && v.a < -ytol)) { ylv[r] = v.a; yt[r] = 0.0; st[r] = ST_INACT; s = ST_INACT; cntLv++; }
+                          if (LISTS) mg[r] = (s != ST_INACT) ? -1.0 : v.b - v.c * dl;
+                      });
+            nlv = block_sum_i(cntLv, c.lds);
+            changed = nlv > 0;
+            // (b) stage 1: E_r x of the inactive rows the margins cannot rule out, and of the active rows flagged dependent
+            const bool depRows = ROBUST && uniform_i(c.info->ndep) > 0;
+            int nread;
+            if (LISTS) {
+#ifdef LCQP_SCREEN_ALL      // test hook: every inactive row is read (the list machinery without the screening)
+                nread = wg_compact(mE, [&](int r) { return st[r] == ST_INACT || (depRows && dep[r]); }, list, c.lds);
 #else
-            const int nread = wg_compact(mE, [&](int r) { return !(mg[r] > 1e-10); }, list, c.lds);
+                nread = wg_compact(mE, [&](int r) { return (st[r] == ST_INACT) ? !(mg[r] > 1e-10) : (depRows && dep[r] != 0); }, list, c.lds);
 #endif
-            wg_symv<NCH>(c.Q, nullptr, c.n, x, nullptr, qx, nullptr, nullptr, nullptr, c.lds);
-            wg_rows<NCH, true>(c.E, list, nread, x, ex, coef, c.lds, [&](int i, double s) { r1[i] = -g[i] - qx[i] - s; });
-            // fresh margins of the inactive rows just evaluated
+                wg_rows<NCH, true>(c.E, list, nread, x, ex, nullptr, c.lds, [](int, double) {});
+            } else {
+                nread = mE;
+                wg_rows<NCH>(c.E, nullptr, mE, x, ex, nullptr, c.lds, [](int, double) {});
+            }
+            // violated rows enter; fresh margins for the others; the two rules for rows flagged dependent
+            int chg = 0, cntLv2 = 0;
             for (int a = t; a < nread; a += WG) {
-                const int r = list[a];
-                if (st[r] == ST_INACT) {
-                    const double e = ex[r], ftol = o.feasTol * (1.0 + fabs(e));
-                    mg[r] = fmin(e - (l[r] - ftol), (u[r] + ftol) - e);
+                const int r = LISTS ? list[a] : a;
+                const int s = st[r];
+                const double e = ex[r], ftol = o.feasTol * (1.0 + fabs(e));
+                if (s == ST_INACT) {
+                    if (e < l[r] - ftol) { st[r] = ST_LOWER; chg |= 1; }
+                    else if (e > u[r] + ftol) { st[r] = ST_UPPER; chg |= 1; }
+                    else if (LISTS) mg[r] = fmin(e - (l[r] - ftol), (u[r] + ftol) - e);
+                } else if (depRows && dep[r]) {
+                    bool viol, inside = false;
+                    if (s == ST_LOWER) { viol = e < l[r] - ftol; inside = e > l[r] + ftol; }
+                    else if (s == ST_UPPER) { viol = e > u[r] + ftol; inside = e < u[r] - ftol; }
+                    else viol = fabs(e - l[r]) > ftol;
+                    if (inside) { const double yv = yt[r]; ylv[r] = yv; yt[r] = 0.0; st[r] = ST_INACT; cntLv2 += (yv != 0.0); chg |= 1; }
+                    else if (viol) { prio[r] = prioCtr + 1; chg |= 2; }
                 }
             }
             if (t == 0) c.info->work[4] += (double)nread;
-            __syncthreads();
-            } else {
-                // np = 1024 (single large problems): the plain sweep over all rows.  (-DLCQP_SCREEN_NCH8 enables the screening here too;
-                // measured broken: the row-indexed list sweep wg_rows<8, true> returns wrong residuals at the 256 VGPR + AGPR budget
-                // of this instantiation -- open)
-                wg_symv<NCH>(c.Q, nullptr, c.n, x, nullptr, qx, nullptr, nullptr, nullptr, c.lds);
-                wg_rows<NCH>(c.E, nullptr, mE, x, ex, coef, c.lds, [&](int i, double s) { r1[i] = -g[i] - qx[i] - s; });
-                if (t == 0) c.info->work[4] += (double)mE;
-            }
-            c.cSweeps++;
-        }
-        const double res_stat = wg_maxabs(r1, np, c.lds);
-        double res_eq = 0.0, bmax = 0.0;
-        wg_map<4>(mE, [&](int r) { return MapID3{st[r], ex[r], l[r], u[r]}; },
-                  [&](int r, MapID3 v) {
-                      const int s = v.s;
-                      const double e = v.a;
-                      if (s == ST_INACT) {
-                          if (trial > 0) {
-                              const double ftol = o.feasTol * (1.0 + fabs(e));
-                              if (e < v.b - ftol) { st[r] = ST_LOWER; chg = 1; }
-                              else if (e > v.c + ftol) { st[r] = ST_UPPER; chg = 1; }
-                          }
-                      } else {
-                          const double bb = (s == ST_UPPER) ? v.c : v.b;
-                          res_eq = fmax(res_eq, fabs(bb - e));
-                          bmax = fmax(bmax, fabs(bb));
-                      }
-                  });
-        int changed;
-        if (ROBUST) {
-            if (trial > 0 && uniform_i(c.info->ndep) > 0) chg |= polish_dependent_rows(st, dep, prio, ex, l, u, mE, o.feasTol, prioCtr + 1);
+            if (depRows) nlv += block_sum_i(cntLv2, c.lds);
             const int chgBits = block_or_bits(chg, c.lds);
-            if (chgBits & 2) { prioCtr++; if (t == 0) c.info->prioCtr = prioCtr; }
-            changed = chgBits != 0;
-        } else {
-            changed = block_or(chg, c.lds);
+            if (ROBUST && (chgBits & 2)) { prioCtr++; if (t == 0) c.info->prioCtr = prioCtr; }
+            changed |= (chgBits != 0);
+            need_true = !changed;
         }
-        res_eq = block_max(res_eq, c.lds);
-        bmax = block_max(bmax, c.lds);
         PROF(c, P_RESID);
-        if (trial > 0 && !changed && res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) {
-            double *r1s = c.V(V_R1S), *gs0 = c.V(V_GS), *exs = c.M(M_EXS), *aty = c.V(V_ATY);
-            // A'y_A + y_box = -E'y = g + Qx + r1 at the verified point (all three are direct sums of this trial)
-            double* qxn = c.V(V_QXN);
-            for (int i = t; i < np; i += WG) { r1s[i] = r1[i]; gs0[i] = g[i]; aty[i] = g[i] + qx[i] + r1[i]; qxn[i] = qx[i]; }
-            wg_map<4>(mE, [&](int r) { return ex[r]; }, [&](int r, double v) { exs[r] = v; });
-            __syncthreads();
-            return 1;
+        if (need_true) {
+            // (c) stage 2: the true residual -- Q and the active rows of E (cold entry: every row)
+            int nact = mE;
+            int* lact = c.I(I_LIST2);
+            wg_symv<NCH>(c.Q, nullptr, c.n, x, nullptr, qx, nullptr, nullptr, nullptr, c.lds);
+            if (LISTS) {
+                nact = wg_compact(mE, [&](int r) { return cold || st[r] != ST_INACT; }, lact, c.lds);
+                // du: the residual of the QP as given (the next hot start and A'y need it without the proximal term); r1: with it
+                wg_rows<NCH, true>(c.E, lact, nact, x, ex, yt, c.lds, [&](int i, double s) { const double ro = -g[i] - qx[i] - s; du[i] = ro; r1[i] = ro - spv * (x[i] - xref[i]); });
+            } else {
+                wg_rows<NCH>(c.E, nullptr, mE, x, ex, yt, c.lds, [&](int i, double s) { const double ro = -g[i] - qx[i] - s; du[i] = ro; r1[i] = ro - spv * (x[i] - xref[i]); });
+            }
+            if (t == 0) c.info->work[4] += (double)nact;
+            c.cSweeps++;
+            if (cold) {
+                if (LISTS) {
+                    wg_map<4>(mE, [&](int r) { return MapID3{st[r], ex[r], l[r], u[r]}; },
+                              [&](int r, MapID3 v) {
+                                  const double e = v.a, ftol = o.feasTol * (1.0 + fabs(e));
+                                  mg[r] = (v.s != ST_INACT) ? -1.0 : fmin(e - (v.b - ftol), (v.c + ftol) - e);
+                              });
+                    __syncthreads();
+                }
+            } else {
+                const double res_stat = wg_maxabs(r1, np, c.lds);
+                double res_eq = 0.0, bmax = 0.0;
+                for (int a = t; a < nact; a += WG) {
+                    const int r = LISTS ? lact[a] : a;
+                    const int s = st[r];
+                    if (s == ST_INACT) continue;
+                    const double bb = (s == ST_UPPER) ? u[r] : l[r];
+                    res_eq = fmax(res_eq, fabs(bb - ex[r]));
+                    bmax = fmax(bmax, fabs(bb));
+                }
+                res_eq = block_max(res_eq, c.lds);
+                bmax = block_max(bmax, c.lds);
+                // the proximal QP is solved: is it the QP as given (sigma_p |x - xref| below the tolerance too)?  Else (PSD Hessians far from
+                // xref) the next step of the proximal-point iteration is anchored here
+                if (res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax) && !(wg_maxabs(du, np, c.lds) <= o.resTol * gs)) {
+                    for (int i = t; i < np; i += WG) { xref[i] = x[i]; r1[i] = du[i]; }
+                    __syncthreads();
+                } else
+                if (res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) {
+                    double *r1s = c.V(V_R1S), *gs0 = c.V(V_GS), *exs = c.M(M_EXS), *aty = c.V(V_ATY);
+                    // A'y_A + y_box = -E'y = g + Qx + r1 at the verified point (all three are direct sums of this trial)
+                    double* qxn = c.V(V_QXN);
+                    for (int i = t; i < np; i += WG) { const double ro = du[i]; r1s[i] = ro; gs0[i] = g[i]; aty[i] = g[i] + qx[i] + ro; qxn[i] = qx[i]; }
+                    wg_map<4>(mE, [&](int r) { return ex[r]; }, [&](int r, double v) { exs[r] = v; });
+                    __syncthreads();
+                    PROF(c, P_RESID);
+                    return 1;
+                }
+            }
+            have_true = 1;
+            PROF(c, P_RESID);
         }
         if (changed) fact_valid = 0;
         if (!fact_valid) {
             // bring the inverse factor to the working set st[]: rows that left are rotated out, rows that entered (and rows flagged
             // dependent earlier, which may have become independent) are appended in ascending row order (oracle: the same)
             int nT = uniform_i(c.info->nT), ns = uniform_i(c.info->ns);
-            int* rslot = c.I(I_SLOT);
-            int* list = c.I(I_LIST);
             int touched = 0, ndepNow = 0;
             const int ndel = wg_compact(ns, [&](int sl) { const int r = idx[sl]; return r >= 0 && st[r] == ST_INACT; }, list, c.lds);
             int cntAdd = 0;
@@ -810,7 +871,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             // more active rows than variables while the set still changes by more than max(n/2, 32) rows per trial: the primal-dual update has
             // overshot (a cold start far from the solution, where every violated row enters at once) and more trials only thrash with
             // factors at full rank -- give up and let ADMM produce a working set (oracle: the same rule)
-            if (trial >= 2 && nT - ndel + nadd > c.n && ndel + nadd > max(c.n / 2, 32)) return 0;
+            if (trial >= 2 && nT - ndel + nadd > c.n && ndel + nadd > max(c.n / 2, 32)) return give_up();
             // in one piece when the factor is empty, when most of it would change, or when promotions dictate the order
             // (oracle: the same rule; there "in one piece" is a reset followed by appends in list order)
             PROF(c, P_UPD_PRE);
@@ -853,7 +914,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                     for (int k = 0; k < cnt; k++) {
                         const int r = uniform_i(list[k]);
                         const int rc = ti_append<NCH>(c, r, o.depTau, capNa, nT, ns);
-                        if (rc < 0) { if (t == 0) { c.info->nT = nT; c.info->ns = ns; } __syncthreads(); return 0; }
+                        if (rc < 0) { if (t == 0) { c.info->nT = nT; c.info->ns = ns; } __syncthreads(); return give_up(); }
                         if (ROBUST && t == 0) dep[r] = (rc == 0);
                         ndepNow += (rc == 0);
                         touched = 1;
@@ -877,39 +938,72 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             __syncthreads();
             fact_valid = 1;
         }
-        // correction:  c = L1^-1 r1 ;  S dy = T c - r2 ;  dx = L1^-T (c - T' dy)      (T: the rows of Et in the slots of the factor)
         const int nsp = 64 * ((nsl + 63) >> 6);
-        for (int a = t; a < nsp; a += WG) {
-            double v = 0.0;
-            const int r = (a < nsl) ? idx[a] : -1;
-            if (r >= 0) { const double bb = (st[r] == ST_UPPER) ? u[r] : l[r]; v = bb - ex[r]; }
-            r2[a] = v;
-        }
-        wg_copy(cv, r1, np);
-        PROF(c, P_MISC);
-        wg_trsv(c.F1, np, c.nblk, cv, true, c.lds);
-        PROF(c, P_CORR_L1);
-        if (na > 0) {
-            wg_rows<NCH>(c.Et, idx, nsl, cv, dy, nullptr, c.lds, [](int, double) {});
-            for (int a = t; a < nsp; a += WG) dy[a] = (a < nsl && idx[a] >= 0) ? dy[a] - r2[a] : 0.0;
+        if (have_true) {
+            // full correction:  c = L1^-1 r1 ;  S dy = T c - r2 ;  dx = L1^-T (c - T' dy)      (T: the rows of Et in the slots of the factor)
+            for (int a = t; a < nsp; a += WG) {
+                double v = 0.0;
+                const int r = (a < nsl) ? idx[a] : -1;
+                if (r >= 0) { const double bb = (st[r] == ST_UPPER) ? u[r] : l[r]; v = bb - ex[r]; }
+                r2[a] = v;
+            }
+            wg_copy(cv, r1, np);
+            PROF(c, P_MISC);
+            wg_trsv(c.F1, np, c.nblk, cv, true, c.lds);
+            PROF(c, P_CORR_L1);
+            if (na > 0) {
+                wg_rows<NCH>(c.Et, idx, nsl, cv, dy, nullptr, c.lds, [](int, double) {});
+                for (int a = t; a < nsp; a += WG) dy[a] = (a < nsl && idx[a] >= 0) ? dy[a] - r2[a] : 0.0;
+                __syncthreads();
+                PROF(c, P_CORR_ROWS);
+            }
+            if (t == 0) { c.info->work[0] += 2.0 * na; c.info->work[5] += 2.0; }
+        } else {
+            // predicted correction: c = sum over the rows that left of y_r Et_r; t = sum y_r M[r][W] - r2
+            int nl = 0;
+            if (nlv > 0) {
+                nl = wg_compact(mE, [&](int r) { return ylv[r] != 0.0; }, list, c.lds);
+                wg_rows<NCH, true>(c.Et, list, nl, nullptr, nullptr, ylv, c.lds, [&](int i, double s) { cv[i] = s; });
+            }
+            const int mMld = c.db->mMld;
+            for (int a = t; a < nsp; a += WG) {
+                double v = 0.0;
+                const int r = (a < nsl) ? idx[a] : -1;
+                if (r >= 0) {
+                    const double bb = (st[r] == ST_UPPER) ? u[r] : l[r];
+                    for (int k = 0; k < nl; k++) { const int rl = list[k]; v += ylv[rl] * c.MM[(size_t)rl * mMld + r]; }
+                    v -= bb - ex[r];
+                }
+                dy[a] = v;
+            }
             __syncthreads();
+            for (int k = t; k < nl; k += WG) ylv[list[k]] = 0.0;
+            if (t == 0) { c.info->work[0] += (double)(na + nl); c.info->work[5] += 1.0; c.info->work[2] += 8.0 * (double)nl * nsl; }
+            nlv = nl;        // 0: c = 0
             PROF(c, P_CORR_ROWS);
+        }
+        if (na > 0) {
             ti_apply<NCH>(c, dy, dy, na, nsl);
             PROF(c, P_CORR_S);
-            wg_rows<NCH>(c.Et, idx, nsl, nullptr, nullptr, dy, c.lds, [&](int i, double s) { du[i] = cv[i] - s; });
+            const bool withC = have_true || nlv > 0;      // c = 0 when nothing left: cv is not read
+            wg_rows<NCH>(c.Et, idx, nsl, nullptr, nullptr, dy, c.lds, [&](int i, double s) { du[i] = (withC ? cv[i] : 0.0) - s; });
             PROF(c, P_CORR_ROWS);
         } else {
-            wg_copy(du, cv, np);
+            if (have_true || nlv > 0) wg_copy(du, cv, np);
+            else wg_fill(du, 0.0, np);
         }
         wg_trsv(c.F1, np, c.nblk, du, false, c.lds);
         PROF(c, P_CORR_L1);
         for (int i = t; i < np; i += WG) x[i] += du[i];
-        for (int a = t; a < nsl; a += WG) if (idx[a] >= 0) yt[idx[a]] += dy[a];
-        if (t == 0) { c.info->work[0] += (double)na; c.info->work[1] += (double)na * nsl; }
+        for (int a = t; a < nsl; a += WG) {
+            const int r = idx[a];
+            if (r >= 0) { yt[r] += dy[a]; ex[r] = (st[r] == ST_UPPER) ? u[r] : l[r]; }      // the rows of the factor now sit on their bounds (up to rounding)
+        }
+        if (t == 0) c.info->work[1] += (double)na * nsl;
         __syncthreads();
         c.cCorr++;
     }
-    return 0;
+    return give_up();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -953,7 +1047,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         }
         __syncthreads();
     }
-    wg_copy(xa, xq, np);
+    for (int i = t; i < np; i += WG) { const double v = xq[i]; xa[i] = v; c.V(V_XREF)[i] = v; }      // V_XREF: anchor of the proximal term (qp_polish)
     wg_map<4>(mE, [&](int r) { return yq[r]; }, [&](int r, double v) { ya[r] = v; });
     __syncthreads();
     int n_admm = initial ? o.admmFirst : o.admmHot;
@@ -1048,7 +1142,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     uint64_t perturbCounter = 0;
     double* hist = c.info->hist;
     if (t == 0) {
-        c.info->work[0] = c.info->work[1] = c.info->work[2] = c.info->work[3] = c.info->work[4] = 0.0;
+        c.info->work[0] = c.info->work[1] = c.info->work[2] = c.info->work[3] = c.info->work[4] = c.info->work[5] = 0.0;
         if (db.traceCap > 0) db.traceLen[c.b] = 0;     // a run that records nothing leaves an empty trace, not the last run's
     }
 
@@ -1217,7 +1311,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
             if (statInf < o.stationarityTolerance) {
                 if (getPhi() < o.complementarityTolerance) {
                     // transformDuals :1381-1409 (rows of L, R are rows nC.., nC+nComp.. of E)
-                    double* lx = c.M(M_EX);
+                    double* lx = c.M(M_COEF);      // scratch (M_EX belongs to the subsolver's hot start)
                     wg_rows<NCH>(c.E, nullptr, mA, xk, lx, nullptr, c.lds, [](int, double) {});
                     // determineStationarityType :1412-1453 on the untransformed duals, weak set :1456-1482
                     int sflag = 1, mflag = 1, wflag = 0;

@@ -558,9 +558,9 @@ try {
     double total = 0.0;
     for (int b = 0; b < d.B; b++) {
         // the active rows of each correction and the bytes of each working-set update are summed by the kernel (InstInfo::work), not estimated
-        const double naC = info[b].work[0], tiC = info[b].work[1], updBytes = info[b].work[2];
-        total += st[b].reserved * 8.0 * n * n + 8.0 * n * info[b].work[4];   // trials that swept Q and the rows of E the screening let through (hot-start trials reuse the last residual)
-        total += st[b].corrections * bs + 2.0 * 8.0 * naC * n + 8.0 * (tiC + 2.0 * naC);
+        const double rowsEt = info[b].work[0], tiC = info[b].work[1], updBytes = info[b].work[2], nTrsv = info[b].work[5];
+        total += st[b].reserved * 8.0 * n * n + 8.0 * n * info[b].work[4];   // true-residual sweeps over Q; rows of E read by both stages of the trials (hot-start trials reuse the last residual)
+        total += nTrsv * 0.5 * bs + 8.0 * rowsEt * n + 8.0 * (tiC + rowsEt);   // corrections: triangular solves with L1 (two per full, one per predicted correction), rows of Et, pass over Ti
         total += updBytes;
         total += st[b].admmIter * (bs + 2.0 * 8.0 * m * n);
         total += 2.0 * 8.0 * n * n;                                                   // Q x0, C x0: the one sweep over Q and C
@@ -570,7 +570,7 @@ try {
 }
 catch (...) { return 0.0; }   // nothing throws across the C boundary
 
-extern "C" int lcqp_hip_batch_work_sums(lcqp_hip_batch_t* h, double out[5])
+extern "C" int lcqp_hip_batch_work_sums(lcqp_hip_batch_t* h, double out[6])
 try {
     if (!h || !out) return LCQP_INVALID_ARGUMENT;
     DevBatch& d = h->db;
@@ -578,8 +578,8 @@ try {
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<InstInfo> info(d.B);
     HIPCHK(hipMemcpy(info.data(), d.info, sizeof(InstInfo) * (size_t)d.B, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 5; k++) out[k] = 0.0;
-    for (int b = 0; b < d.B; b++) for (int k = 0; k < 5; k++) out[k] += info[b].work[k];
+    for (int k = 0; k < 6; k++) out[k] = 0.0;
+    for (int b = 0; b < d.B; b++) for (int k = 0; k < 6; k++) out[k] += info[b].work[k];
     return 0;
 }
 catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary

@@ -239,7 +239,7 @@ struct orc_qp {
     /* ADMM state */
     double *xa, *ya, *za;
     /* scratch */
-    double *w_n1, *w_n2, *w_n3, *w_m1, *w_a1, *w_a2, *w_a3, *w_a4;
+    double *w_n1, *w_n2, *w_n3, *w_m1, *w_m2, *w_a1, *w_a2, *w_a3, *w_a4;
     /* The working-set system S dy = t, S = Et_W Et_W', is solved with an inverse factor that is UPDATED when rows enter or
      * leave the working set W (what qpOASES does with its factors on a hot start, src/SubsolverQPOASES.cpp:158):
      *   Ti (nT rows x ns slots) with Ti'Ti = inv(S_W);  slot_row[s] = row of E held by slot s (-1: free), row_slot = its inverse,
@@ -249,7 +249,8 @@ struct orc_qp {
     int *slot_row, *row_slot, *crow;
     int nT, ns;
     double upd_bytes;   /* bytes of Ti read or written by updates (device byte accounting) */
-    double *r1_last, *ex_last, *g_last; /* residual, E x and linear term of the last verified solution */
+    double *r1_last, *ex_last, *g_last; /* residual (of the QP as given, without the proximal term), E x and linear term of the last verified solution */
+    double *xref;       /* anchor of the proximal term: the point the solve started from (x0, or the previous solution on a hot start) */
     int *newst;
     double *dy_last, *dx_last; /* change of (ya, xa) in the last ADMM iteration: OSQP's infeasibility certificates */
     /* dependent-row rules of the single-QP path (SubsolverHIP / k_qp_solve); the batched homotopy kernel runs without them */
@@ -262,6 +263,8 @@ struct orc_qp {
     double *xsol, *ysol;
     /* counters */
     int c_admm, c_trials, c_fact, c_corr, c_sweeps;
+    int c_pred, c_trsv;            /* predicted corrections; triangular solves with L1 */
+    double rows_swept, rows_corr;  /* rows of E read by the residual sweeps; rows of Et read by the corrections */
 };
 
 orc_qp_t* orc_qp_create(int nV, int nC, const double* Q, const double* A, const orc_options_t* opt)
@@ -283,14 +286,14 @@ static void qp_free_setup(orc_qp_t* q)
 {
     free(q->boxidx); free(q->E); free(q->Et); free(q->l); free(q->u); free(q->rhov);
     free(q->L1); free(q->LK); free(q->x); free(q->y); free(q->st); free(q->xa); free(q->ya); free(q->za);
-    free(q->w_n1); free(q->w_n2); free(q->w_n3); free(q->w_m1); free(q->w_a1); free(q->w_a2); free(q->w_a3); free(q->w_a4);
+    free(q->xref); free(q->w_n1); free(q->w_n2); free(q->w_n3); free(q->w_m1); free(q->w_m2); free(q->w_a1); free(q->w_a2); free(q->w_a3); free(q->w_a4);
     free(q->Ti); free(q->slot_row); free(q->row_slot); free(q->crow);
     q->Ti = NULL; q->slot_row = q->row_slot = q->crow = NULL;
     free(q->dy_last); free(q->dx_last); q->dy_last = q->dx_last = NULL;
     free(q->newst); free(q->dep); free(q->prio); q->dep = q->prio = NULL; free(q->r1_last); free(q->ex_last); free(q->g_last);
     q->r1_last = q->ex_last = q->g_last = NULL;
     q->boxidx = NULL; q->E = q->Et = q->l = q->u = q->rhov = q->L1 = q->LK = q->x = q->y = NULL;
-    q->st = NULL; q->xa = q->ya = q->za = q->w_n1 = q->w_n2 = q->w_n3 = q->w_m1 = q->w_a1 = q->w_a2 = q->w_a3 = q->w_a4 = NULL;
+    q->st = NULL; q->xa = q->ya = q->za = q->w_n1 = q->w_n2 = q->w_n3 = q->w_m1 = q->w_m2 = q->w_a1 = q->w_a2 = q->w_a3 = q->w_a4 = NULL;
     q->newst = NULL;
     q->is_setup = 0;
 }
@@ -389,7 +392,7 @@ static int qp_setup(orc_qp_t* q, const double* lbA, const double* ubA, const dou
 
     q->x = dalloc(n); q->y = dalloc(mE); q->st = (int*)calloc(mE ? mE : 1, sizeof(int));
     q->xa = dalloc(n); q->ya = dalloc(mE); q->za = dalloc(mE);
-    q->w_n1 = dalloc(n); q->w_n2 = dalloc(n); q->w_n3 = dalloc(n); q->w_m1 = dalloc(mE);
+    q->w_n1 = dalloc(n); q->w_n2 = dalloc(n); q->w_n3 = dalloc(n); q->w_m1 = dalloc(mE); q->w_m2 = dalloc(mE);
     q->cap_na = (2 * n > 64) ? 2 * n : 64;   /* room for the degenerate vertices of small problems (many rows, few variables) */
     if (q->cap_na > mE) q->cap_na = mE;
     { const int lim = n > 512 ? 1216 : 896;   /* the device keeps the active-row solves in LDS (max_active(NCH)); binds for nV > 448 only */
@@ -406,7 +409,7 @@ static int qp_setup(orc_qp_t* q, const double* lbA, const double* ubA, const dou
     q->row_slot = (int*)calloc(mE ? mE : 1, sizeof(int));
     for (int r = 0; r < mE; r++) q->row_slot[r] = -1;
     q->nT = q->ns = 0;
-    q->r1_last = dalloc(n); q->ex_last = dalloc(mE); q->g_last = dalloc(n);
+    q->r1_last = dalloc(n); q->ex_last = dalloc(mE); q->g_last = dalloc(n); q->xref = dalloc(n);
     q->have_solution = 0;
     q->is_setup = 1;
     return 0;
@@ -742,14 +745,31 @@ static double dot_lanes(const double* a, const double* x, int n)
 }
 
 /* Primal-dual active-set polish in correction (iterative refinement) form.
- * Start: x, yfull (OSQP sign, zero on inactive rows), active set st.  Each trial evaluates the true KKT
- * residuals (one pass over Q and E), tests optimality, else updates the active set (all violated rows
- * enter, all wrong-signed multipliers leave) and solves one correction with the constant factor L1 and
- * the Cholesky factor of S = Et_act Et_act'.   Returns 1 on a verified KKT point. */
-/* q->robust (the single-QP path; the batched device loop runs without it): rows the safeguarded factorisation flags as
- * linearly dependent get two extra rules -- strictly inside the bound: the row leaves; violated: the row is promoted to
- * the front of the ordered active list, so that another row becomes the dependent one. */
-/* reuse != 0 (hot start from the last verified solution): the first trial needs no sweep --
+ * Start: x, yfull (OSQP sign, zero on inactive rows), active set st.  Returns 1 on a verified KKT point.
+ *
+ * Round 3: a trial no longer evaluates the whole KKT residual before it knows whether it needs it.  After a correction the state
+ * is known up to rounding: the stationarity residual is sigma_p * dx (~1e-12 relative, taken as 0), and the rows in the factor sit
+ * on their bounds.  So a trial is
+ *   (a)  rows whose multiplier has the wrong sign leave (their multipliers are remembered in ylv);
+ *   (b)  STAGE 1: E x of the inactive rows only (and of active rows flagged dependent) -- on the device only the rows the
+ *        screening cannot rule out; violated rows enter;
+ *   (c)  nothing changed: STAGE 2, the true residual -- one pass over Q and the active rows of E; the point is accepted on
+ *        these true residuals only (so accuracy is what it was), else a full correction with them follows;
+ *   (d)  the set changed: the factor follows, then a PREDICTED correction: r1 = sum over the rows that left of y_r e_r, hence
+ *        c = L1^-1 r1 = sum y_r Et_r (no forward solve), Et_W c from entries of M = Et Et' on the device, r2 = 0 on the rows that
+ *        were in the factor and b - E x on the rows that entered; dx = L1^-T (c - Et_W' dy): one pass over Et_W, one backward solve.
+ * Intermediate trials read neither Q nor the active rows of E.
+ * What is solved is the PROXIMAL QP  min 1/2 x'Qx + g'x + sigma_p/2 |x - xref|^2  with xref = the point the solve started from and
+ * sigma_p the weight the constant factor L1 = chol(Q + sigma_p I) carries anyway (1e-12 max|Q_ii|; 1e-8 max|Q_ii| when Q is only PSD):
+ * the corrections are then exact Newton steps of the problem whose residual is tested (the predicted residual after a correction is
+ * exactly zero), and the QP has ONE solution also when Q has flat directions -- the minimiser nearest xref up to O(sigma_p) --,
+ * whatever path (working sets, ADMM rounds) leads there.  A solution of the proximal QP is returned when it also satisfies the QP as
+ * given to the tolerance (sigma_p |x - xref| <= resTol (1 + |g|): always so for sigma_p = 1e-12 max|Q_ii|); otherwise xref moves to
+ * it and the iteration continues -- the proximal-point method, every step of which has a unique solution.
+ * q->robust: rows the safeguarded factor update flags as linearly dependent get two extra rules -- strictly inside the bound:
+ * the row leaves; violated: the row is promoted to the front of the ordered active list, so that another row becomes the
+ * dependent one.
+ * reuse != 0 (hot start from the last verified solution): the first trial needs no sweep --
  * r1 = r1_last + (g_last - g) and E x = ex_last hold exactly for an unchanged (x, y). */
 static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int* st, int reuse)
 {
@@ -758,92 +778,123 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
     double gmax = 0;
     for (int i = 0; i < n; i++) { double a = fabs(g[i]); if (a > gmax) gmax = a; }
     const double gs = 1.0 + gmax;
-    double *r1 = q->w_n1, *c = q->w_n2, *du = q->w_n3, *Ex = q->w_m1;
+    const double ytol = o->feasTol * gs;
+    double *r1 = q->w_n1, *c = q->w_n2, *du = q->w_n3, *Ex = q->w_m1, *ylv = q->w_m2;
     double* dy = q->w_a4;
-    int na = 0, fact_valid = 0;
+    int fact_valid = 0;
+    const double spv = q->spv;
+    for (int r = 0; r < mE; r++) ylv[r] = 0.0;
 
     for (int trial = 0; trial < o->maxTrials; trial++) {
         q->c_trials++;
-        if (trial == 0 && reuse) {
-            for (int i = 0; i < n; i++) r1[i] = q->r1_last[i] + (q->g_last[i] - g[i]);
-            memcpy(Ex, q->ex_last, sizeof(double) * mE);
-        } else {
-        q->c_sweeps++;
-        if (robust) for (int r = 0; r < mE; r++) if (st[r] == ST_INACT) yfull[r] = 0.0;   /* rows that left as "dependent, inside" */
-        /* residual evaluation */
-        for (int i = 0; i < n; i++) {
-            const double* qr = q->Q + (size_t)i * n;
-            double s = 0;
-            for (int k = 0; k < n; k++) s += qr[k] * x[k];
-            r1[i] = -g[i] - s;
-        }
-        for (int r = 0; r < mE; r++) {
-            const double* e = q->E + (size_t)r * n;
-            if (g_sum_order) Ex[r] = dot_lanes(e, x, n);
-            else { double s = 0; for (int k = 0; k < n; k++) s += e[k] * x[k]; Ex[r] = s; }
-            double yr = yfull[r];
-            if (yr != 0.0)
-                for (int k = 0; k < n; k++) r1[k] -= e[k] * yr;
-        }
-        }
-        double res_stat = 0, res_eq = 0, bmax = 0;
-        for (int i = 0; i < n; i++) { double a = fabs(r1[i]); if (a > res_stat) res_stat = a; }
-        int changed = 0, promoted = 0;
-        for (int r = 0; r < mE; r++) {
-            int s = st[r], ns = s;
-            if (s == ST_INACT) {
-                double ftol = o->feasTol * (1.0 + fabs(Ex[r]));
-                if (Ex[r] < q->l[r] - ftol) ns = ST_LOWER;
-                else if (Ex[r] > q->u[r] + ftol) ns = ST_UPPER;
+        int changed = 0, promoted = 0, nlv = 0, have_true = 0;
+        if (trial == 0) {
+            if (reuse) {
+                for (int i = 0; i < n; i++) r1[i] = (q->r1_last[i] + (q->g_last[i] - g[i])) - spv * (x[i] - q->xref[i]);
+                memcpy(Ex, q->ex_last, sizeof(double) * mE);
             } else {
-                double b = (s == ST_UPPER) ? q->u[r] : q->l[r];
-                double a = fabs(b - Ex[r]);
-                if (a > res_eq) res_eq = a;
-                if (fabs(b) > bmax) bmax = fabs(b);
-                double ytol = o->feasTol * gs;
-                if (s == ST_LOWER && yfull[r] > ytol) ns = ST_INACT;
-                if (s == ST_UPPER && yfull[r] < -ytol) ns = ST_INACT;
-                if (robust && ns == s && trial > 0 && q->dep[r]) {
-                    /* the last factorisation flagged this row as dependent on the rows before it, so the correction
-                     * left its multiplier alone and did not enforce its equation.  Strictly inside its bound: the row
-                     * is not active.  Violated: it must be active, so it moves to the front of the list and a
-                     * different row becomes the dependent one. */
-                    const double ftol = o->feasTol * (1.0 + fabs(Ex[r]));
+                /* cold: the whole residual, every row of E */
+                q->c_sweeps++; q->rows_swept += mE;
+                if (robust) for (int r = 0; r < mE; r++) if (st[r] == ST_INACT) yfull[r] = 0.0;
+                for (int i = 0; i < n; i++) {
+                    const double* qr = q->Q + (size_t)i * n;
+                    double s = 0;
+                    for (int k = 0; k < n; k++) s += qr[k] * x[k];
+                    r1[i] = -g[i] - s;
+                }
+                for (int r = 0; r < mE; r++) {
+                    const double* e = q->E + (size_t)r * n;
+                    if (g_sum_order) Ex[r] = dot_lanes(e, x, n);
+                    else { double s = 0; for (int k = 0; k < n; k++) s += e[k] * x[k]; Ex[r] = s; }
+                    double yr = yfull[r];
+                    if (yr != 0.0)
+                        for (int k = 0; k < n; k++) r1[k] -= e[k] * yr;
+                }
+                for (int i = 0; i < n; i++) r1[i] -= spv * (x[i] - q->xref[i]);
+            }
+            have_true = 1;      /* the first trial only corrects: the working set it was handed stays */
+        } else {
+            /* (a) leaving rows */
+            for (int r = 0; r < mE; r++) {
+                const int s = st[r];
+                if ((s == ST_LOWER && yfull[r] > ytol) || (s == ST_UPPER && yfull[r] < -ytol)) {
+                    ylv[r] = yfull[r]; yfull[r] = 0.0; st[r] = ST_INACT; nlv++; changed = 1;
+                }
+            }
+            /* (b) stage 1: E x of the inactive rows and of the active rows flagged dependent */
+            for (int r = 0; r < mE; r++) {
+                if (!(st[r] == ST_INACT || (robust && q->dep[r]))) continue;
+                const double* e = q->E + (size_t)r * n;
+                if (g_sum_order) Ex[r] = dot_lanes(e, x, n);
+                else { double s = 0; for (int k = 0; k < n; k++) s += e[k] * x[k]; Ex[r] = s; }
+                q->rows_swept++;
+            }
+            for (int r = 0; r < mE; r++) {
+                const int s = st[r];
+                const double ftol = o->feasTol * (1.0 + fabs(Ex[r]));
+                if (s == ST_INACT) {
+                    if (Ex[r] < q->l[r] - ftol) { st[r] = ST_LOWER; changed = 1; }
+                    else if (Ex[r] > q->u[r] + ftol) { st[r] = ST_UPPER; changed = 1; }
+                } else if (robust && q->dep[r]) {
+                    /* the last factor update flagged this row as dependent on the rows before it, so the correction left its
+                     * multiplier alone and did not enforce its equation.  Strictly inside its bound: the row is not active.
+                     * Violated: it must be active, so it moves to the front of the list and a different row becomes the
+                     * dependent one. */
                     int viol, inside = 0;
                     if (s == ST_LOWER) { viol = Ex[r] < q->l[r] - ftol; inside = Ex[r] > q->l[r] + ftol; }
                     else if (s == ST_UPPER) { viol = Ex[r] > q->u[r] + ftol; inside = Ex[r] < q->u[r] - ftol; }
                     else viol = fabs(Ex[r] - q->l[r]) > ftol;
-                    if (inside) { ns = ST_INACT; q->dep[r] = 2; }
+                    if (inside) { ylv[r] = yfull[r]; yfull[r] = 0.0; st[r] = ST_INACT; nlv += (ylv[r] != 0.0); changed = 1; }
                     else if (viol) { q->prio[r] = q->prio_ctr + 1; promoted = 1; }
                 }
             }
-            q->newst[r] = ns;
-            if (ns != s) changed = 1;
-        }
-        if (promoted) { q->prio_ctr++; changed = 1; }
-        if (trial > 0 && !changed && res_stat <= o->resTol * gs && res_eq <= o->resTol * (1.0 + bmax)) {
-            memcpy(q->r1_last, r1, sizeof(double) * n);
-            memcpy(q->ex_last, Ex, sizeof(double) * mE);
-            memcpy(q->g_last, g, sizeof(double) * n);
-            return 1;
-        }
-        if (changed && trial > 0) {
-            for (int r = 0; r < mE; r++) {
-                int ns = q->newst[r];
-                if (ns == ST_INACT && st[r] != ST_INACT && !(robust && q->dep[r] == 2)) {
-                    /* leaving row: remove its multiplier from the stationarity residual (a row that leaves as
-                     * "dependent, inside" keeps it until the next sweep, as the device code does) */
-                    double yr = yfull[r];
-                    if (yr != 0.0) {
-                        const double* e = q->E + (size_t)r * n;
-                        for (int k = 0; k < n; k++) r1[k] += e[k] * yr;
-                    }
-                    yfull[r] = 0.0;
+            if (promoted) { q->prio_ctr++; changed = 1; }
+            if (!changed) {
+                /* (c) stage 2: the true residual -- Q and the active rows of E */
+                q->c_sweeps++;
+                for (int i = 0; i < n; i++) {
+                    const double* qr = q->Q + (size_t)i * n;
+                    double s = 0;
+                    for (int k = 0; k < n; k++) s += qr[k] * x[k];
+                    r1[i] = -g[i] - s;
                 }
-                st[r] = ns;
+                double res_stat = 0, res_eq = 0, bmax = 0;
+                for (int r = 0; r < mE; r++) {
+                    if (st[r] == ST_INACT) continue;
+                    const double* e = q->E + (size_t)r * n;
+                    if (g_sum_order) Ex[r] = dot_lanes(e, x, n);
+                    else { double s = 0; for (int k = 0; k < n; k++) s += e[k] * x[k]; Ex[r] = s; }
+                    q->rows_swept++;
+                    const double yr = yfull[r];
+                    if (yr != 0.0)
+                        for (int k = 0; k < n; k++) r1[k] -= e[k] * yr;
+                    const double b = (st[r] == ST_UPPER) ? q->u[r] : q->l[r];
+                    if (fabs(b - Ex[r]) > res_eq) res_eq = fabs(b - Ex[r]);
+                    if (fabs(b) > bmax) bmax = fabs(b);
+                }
+                for (int i = 0; i < n; i++) {
+                    du[i] = r1[i];                         /* residual of the QP as given: the next hot start needs it without the proximal term */
+                    r1[i] -= spv * (x[i] - q->xref[i]);
+                    double a = fabs(r1[i]); if (a > res_stat) res_stat = a;
+                }
+                if (res_stat <= o->resTol * gs && res_eq <= o->resTol * (1.0 + bmax)) {
+                    /* the proximal QP is solved.  Is it the QP as given, i.e. is sigma_p |x - xref| below the tolerance too? */
+                    double res_orig = 0;
+                    for (int i = 0; i < n; i++) { double a = fabs(du[i]); if (a > res_orig) res_orig = a; }
+                    if (res_orig <= o->resTol * gs) {
+                        memcpy(q->r1_last, du, sizeof(double) * n);
+                        memcpy(q->ex_last, Ex, sizeof(double) * mE);
+                        memcpy(q->g_last, g, sizeof(double) * n);
+                        return 1;
+                    }
+                    /* no (PSD Hessians, sigma_p = 1e-8 max|Q_ii|, far from xref): next step of the proximal-point iteration, anchored here */
+                    memcpy(q->xref, x, sizeof(double) * n);
+                    memcpy(r1, du, sizeof(double) * n);
+                }
+                have_true = 1;
             }
-            fact_valid = 0;
         }
+        if (changed) fact_valid = 0;
         if (!fact_valid) {
             /* bring the inverse factor to the working set st[]: rows that left are rotated out, rows that entered (and rows
              * flagged dependent earlier, which may have become independent) are appended in ascending row order */
@@ -853,67 +904,104 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
             /* more active rows than variables while the set still changes by more than max(n/2, 32) rows per trial: the primal-dual update has
              * overshot (a cold start far from the solution, where every violated row enters at once) and more trials only thrash
              * with factors at full rank -- give up and let ADMM produce a working set */
-            if (trial >= 2 && q->nT - ndel + nadd > n && ndel + nadd > (n / 2 > 32 ? n / 2 : 32)) return 0;
+            if (trial >= 2 && q->nT - ndel + nadd > n && ndel + nadd > (n / 2 > 32 ? n / 2 : 32)) {
+                for (int r = 0; r < mE; r++) ylv[r] = 0.0;
+                return 0;
+            }
             /* from scratch when the factor is empty, when most of it would change, or when promotions dictate the order (the
              * device builds the factor in one piece then: blocked Cholesky and blocked triangular inverse, ti_bulk) */
             const int bulk = (robust && q->prio_ctr > 0) || (q->nT == 0 && nadd > 0) || (ndel > 0 && ndel >= (q->nT / 2 > 8 ? q->nT / 2 : 8))
                              || nadd >= 16;
+            int full = 0;
             if (bulk) {
                 ti_reset(q); touched = 1;
                 /* promotions: latest first (ascending row index within one), so that a row OTHER than the promoted one is
                  * found dependent; then the rest in ascending order (the loop below) */
-                for (int stamp = robust ? q->prio_ctr : 0; stamp >= 1; stamp--)
-                    for (int r = 0; r < mE; r++)
+                for (int stamp = robust ? q->prio_ctr : 0; stamp >= 1 && !full; stamp--)
+                    for (int r = 0; r < mE && !full; r++)
                         if (st[r] != ST_INACT && q->prio[r] == stamp) {
                             const int rc = ti_append(q, r, o->depTau);
-                            if (rc < 0) return 0;
+                            if (rc < 0) { full = 1; break; }
                             q->dep[r] = (rc == 0);
                         }
             } else {
                 for (int sl = 0; sl < q->ns; sl++)
                     if (q->slot_row[sl] >= 0 && st[q->slot_row[sl]] == ST_INACT) { ti_delete(q, sl); touched = 1; }
             }
-            for (int r = 0; r < mE; r++) {
-                if (st[r] == ST_INACT) { q->dep[r] = (robust && q->dep[r] == 2) ? 2 : 0; continue; }
+            for (int r = 0; r < mE && !full; r++) {
+                if (st[r] == ST_INACT) { q->dep[r] = 0; continue; }
                 if (q->row_slot[r] >= 0) continue;
                 const int rc = ti_append(q, r, o->depTau);
-                if (rc < 0) return 0;
+                if (rc < 0) { full = 1; break; }
                 q->dep[r] = (rc == 0);
                 touched = 1;
             }
-            na = q->nT;
+            if (full) { for (int r = 0; r < mE; r++) ylv[r] = 0.0; return 0; }
             if (touched) q->c_fact++;
             fact_valid = 1;
         }
-        /* correction:  c = L1^-1 r1 ;  S dy = T c - r2 ;  dx = L1^-T (c - T' dy)   (T = rows of Et in the slots of the factor) */
         const int nsl = q->ns;
         double* tv = q->w_a2;
-        memcpy(c, r1, sizeof(double) * n);
-        trsv_lower(q->L1, n, c);
-        for (int sl = 0; sl < nsl; sl++) {
-            const int r = q->slot_row[sl];
-            if (r < 0) { tv[sl] = 0.0; continue; }
-            const double bb = (st[r] == ST_UPPER) ? q->u[r] : q->l[r];
-            const double* ta = q->Et + (size_t)r * n;
-            double sdot = 0;
-            for (int k = 0; k < n; k++) sdot += ta[k] * c[k];
-            tv[sl] = sdot - (bb - Ex[r]);
+        if (have_true) {
+            /* full correction:  c = L1^-1 r1 ;  S dy = T c - r2 ;  dx = L1^-T (c - T' dy)   (T = rows of Et in the slots of the factor) */
+            memcpy(c, r1, sizeof(double) * n);
+            trsv_lower(q->L1, n, c);
+            q->c_trsv++;
+            for (int sl = 0; sl < nsl; sl++) {
+                const int r = q->slot_row[sl];
+                if (r < 0) { tv[sl] = 0.0; continue; }
+                const double bb = (st[r] == ST_UPPER) ? q->u[r] : q->l[r];
+                const double* ta = q->Et + (size_t)r * n;
+                double sdot = 0;
+                for (int k = 0; k < n; k++) sdot += ta[k] * c[k];
+                tv[sl] = sdot - (bb - Ex[r]);
+                q->rows_corr++;
+            }
+        } else {
+            /* predicted correction: c = sum over the rows that left of y_r Et_r (= L1^-1 of their share of the residual) */
+            for (int i = 0; i < n; i++) c[i] = 0.0;
+            if (nlv > 0)
+                for (int r = 0; r < mE; r++) {
+                    const double yr = ylv[r];
+                    if (yr == 0.0) continue;
+                    const double* tr = q->Et + (size_t)r * n;
+                    for (int k = 0; k < n; k++) c[k] += yr * tr[k];
+                    q->rows_corr++;
+                }
+            for (int sl = 0; sl < nsl; sl++) {
+                const int r = q->slot_row[sl];
+                if (r < 0) { tv[sl] = 0.0; continue; }
+                const double bb = (st[r] == ST_UPPER) ? q->u[r] : q->l[r];
+                double sdot = 0;
+                if (nlv > 0) { const double* ta = q->Et + (size_t)r * n; for (int k = 0; k < n; k++) sdot += ta[k] * c[k]; }   /* device: sum_r y_r M[r][row] */
+                tv[sl] = sdot - (bb - Ex[r]);
+            }
+            q->c_pred++;
         }
+        for (int r = 0; r < mE; r++) ylv[r] = 0.0;
         ti_apply(q, tv, dy);
         memcpy(du, c, sizeof(double) * n);
         for (int sl = 0; sl < nsl; sl++) {
             const int r = q->slot_row[sl];
-            if (r < 0 || dy[sl] == 0.0) continue;
+            if (r < 0) continue;
+            q->rows_corr++;
+            if (dy[sl] == 0.0) continue;
             const double* ta = q->Et + (size_t)r * n;
             const double v = dy[sl];
             for (int k = 0; k < n; k++) du[k] -= ta[k] * v;
         }
         trsv_lower_t(q->L1, n, du);
+        q->c_trsv++;
         for (int i = 0; i < n; i++) x[i] += du[i];
-        for (int sl = 0; sl < nsl; sl++) if (q->slot_row[sl] >= 0) yfull[q->slot_row[sl]] += dy[sl];
-        (void)na;
+        for (int sl = 0; sl < nsl; sl++) {
+            const int r = q->slot_row[sl];
+            if (r < 0) continue;
+            yfull[r] += dy[sl];
+            Ex[r] = (st[r] == ST_UPPER) ? q->u[r] : q->l[r];      /* the rows of the factor now sit on their bounds (up to rounding) */
+        }
         q->c_corr++;
     }
+    for (int r = 0; r < mE; r++) ylv[r] = 0.0;
     return 0;
 }
 
@@ -951,6 +1039,7 @@ int orc_qp_solve(orc_qp_t* q, int initialSolve, int* iterations, int* exit_flag,
         }
     }
     memcpy(q->xa, q->x, sizeof(double) * n);
+    memcpy(q->xref, q->x, sizeof(double) * n);      /* anchor of the proximal term (qp_polish) */
     memcpy(q->ya, q->y, sizeof(double) * mE);
     int n_admm = initialSolve ? o->admmFirst : o->admmHot;
     int use_stored_set = (!initialSolve && q->have_solution && n_admm == 0);
