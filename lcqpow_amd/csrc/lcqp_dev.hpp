@@ -684,7 +684,7 @@ __device__ __forceinline__ void ti_delete(Ctx<NCH>& c, int p, int& nT, int& ns)
 // r1 = r1_last + (g_last - g) and E x = ex_last hold exactly for an unchanged (x, y).
 // ---------------------------------------------------------------------------------------------
 template <int NCH, bool ROBUST>
-__device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse)
+__device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse, double gs)
 {
     constexpr int np = 128 * NCH;
 #ifdef LCQP_SCREEN_NCH8
@@ -703,8 +703,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
     int *dep = c.I(I_DEP), *prio = c.I(I_PRIO), *list = c.I(I_LIST), *rslot = c.I(I_SLOT);
     double *r2 = c.Sv(S_R2), *dy = c.Sv(S_DY);
     int* idx = c.idx;
-    const double gs = 1.0 + wg_maxabs(g, c.n, c.lds);
-    const double ytol = o.feasTol * gs;
+    const double ytol = o.feasTol * gs;      // gs = 1 + |g|_inf
     int na = 0, nsl = 0, fact_valid = 0;
     int prioCtr = ROBUST ? uniform_i(c.info->prioCtr) : 0;
     const int capNa = min(min(min(max(2 * c.n, 64), mE), capS), max_active(NCH));   // room for the degenerate vertices of small problems
@@ -1015,7 +1014,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
 // ---------------------------------------------------------------------------------------------
 // ADAPT: rho adaptation between fallback rounds (qp_adapt_rho); on in every kernel (the switch stays for A/B builds).
 template <int NCH, bool ROBUST, bool ADAPT>
-__device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* g, const double* y0ref, int* iterations)
+__device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* g, const double* y0ref, int* iterations, double gmaxHint = -1.0, int checkBounds = 1)
 {
     constexpr int np = 128 * NCH;
     const lcqp_options_t& o = c.db->opt;
@@ -1027,9 +1026,13 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
     double *yq = c.M(M_YQ), *ya = c.M(M_YA), *za = c.M(M_ZA), *yt = c.M(M_YT), *ex = c.M(M_EX);
     const double *l = c.M(M_L), *u = c.M(M_U), *rhov = c.M(M_RHOV);
     int *st = c.I(I_ST), *stt = c.I(I_STT);
-    int bad = 0;
-    wg_map<4>(mE, [&](int r) { return MapD4{l[r], u[r], 0.0, 0.0}; }, [&](int, MapD4 v) { bad |= (v.a > v.b); });
-    if (block_or(bad, c.lds)) return 2;
+    if (checkBounds) {      // (a homotopy checks once: its bounds do not change between the QPs)
+        int bad = 0;
+        wg_map<4>(mE, [&](int r) { return MapD4{l[r], u[r], 0.0, 0.0}; }, [&](int, MapD4 v) { bad |= (v.a > v.b); });
+        if (block_or(bad, c.lds)) return 2;
+    }
+    // the tolerances scale with 1 + |g|_inf: handed over by a caller that has just formed g, else one pass
+    const double gsc = 1.0 + (gmaxHint >= 0.0 ? gmaxHint : wg_maxabs(g, c.n, c.lds));
     if (ROBUST && uniform_i(c.info->prioCtr) != 0) {     // promotions of dependent rows last for one solve
         int* prio = c.I(I_PRIO);
         for (int r = t; r < mE; r += WG) prio[r] = 0;
@@ -1084,7 +1087,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         }
         for (int i = t; i < np; i += WG) xt[i] = xa[i];
         __syncthreads();
-        if (qp_polish<NCH, ROBUST>(c, g, round == 0 && use_stored)) { solved = 1; break; }
+        if (qp_polish<NCH, ROBUST>(c, g, round == 0 && use_stored, gsc)) { solved = 1; break; }
         if (ADAPT && round >= 1 && n_admm > 0) qp_adapt_rho<NCH>(c, g);
         if (round >= 2) {    // at least 20 ADMM iterations behind us: is the QP infeasible or unbounded?
             certificate = qp_certificate<NCH>(c, g);
@@ -1150,30 +1153,21 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     for (int i = t; i < np; i += WG) { xk[i] = c.V(V_X0)[i]; gtil[i] = g[i]; }
     __syncthreads();
 
-    auto getPhi = [&]() -> double {   // :1172-1185 with Cx = C*xk current
-        double s = 0.0;
-        for (int i = t; i < n; i += WG) s += (hasPhi ? gphi[i] * xk[i] : 0.0) + 0.5 * xk[i] * Cx[i];
-        return phiConst + block_sum(s, c.lds);
-    };
-    auto updatePenalty = [&]() {      // :1199-1214 (Qk = Q + rho C is never materialised: Qk v = Qv + rho Cv)
+    auto updatePenalty = [&]() {      // :1199-1214 (Qk = Q + rho C is never materialised: Qk v = Qv + rho Cv; g_tilde follows in the fused pass)
         if (o.nDynamicPenalty > 0) histLen = 0;
         rho *= o.penaltyUpdateFactor;
         st.rhoOpt = rho;
-        if (hasPhi) { for (int i = t; i < np; i += WG) gtil[i] = g[i] + rho * gphi[i]; __syncthreads(); }
     };
-    auto solveQP = [&](int initial) -> int {   // :1115-1148
+    double gmax = -1.0;      // max |gk| over the n variables, handed to the subsolver (it scales its tolerances with 1 + |g|_inf); < 0: not known
+    auto solveQP = [&](int initial) -> int {   // :1115-1148 (getSolution, yk_A and pk = xnew - xk follow in the fused pass / at the exit)
         const double* y0 = (initial && c.info->hasY0) ? db.y0 + (size_t)c.b * db.nd : nullptr;
         PROF(c, P_LCQP);
-        const int ef = qp_solve<NCH, ROBUST, true>(c, initial, gk, y0, &qpIter);
+        const int ef = qp_solve<NCH, ROBUST, true>(c, initial, gk, y0, &qpIter, gmax, /*checkBounds=*/initial);
         PROF(c, P_MISC);
         st.subproblemIter += qpIter;
         st.qpSolverExitFlag = ef;
         st.qpSolves++;
-        if (ef != 0) return LCQP_SUBPROBLEM_SOLVER_ERROR;
-        qp_export<NCH>(c, xnew, np, yk);
-        for (int i = t; i < np; i += WG) pk[i] = xnew[i] - xk[i];
-        __syncthreads();
-        return 0;
+        return ef != 0 ? LCQP_SUBPROBLEM_SOLVER_ERROR : 0;
     };
 
     // first QP (:452-467)
@@ -1184,114 +1178,132 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
         for (int i = t; i < np; i += WG) gk[i] = rho * Cx[i] + gtil[i];
         __syncthreads();
     }
-    // One call site for the QP subsolver and one for the Q/C sweep (the kernel carries a single copy of each): the pass
-    // below starts with the QP whose linear term gk is current -- the first QP of :452-467, then the hot starts of :545 --
-    // and continues with the top of the reference's loop.
-    // One sweep over Q and C per iterate: Q*[pk, xk] and C*[pk, xk] (the sweep getOptimalStepLength needs,
-    // :1217-1237).  Q*(xk + alpha pk) in updateStep follows by linearity from these two direct products (no
-    // recurrence over iterates), and A'yk_A + yk_box is taken from the verified KKT residual of the subproblem
-    // (V_ATY), so updateStationarity needs no sweep of its own.
+    // One call site for the QP subsolver (the kernel carries a single copy of it): the pass below starts with the QP whose linear
+    // term gk is current -- the first QP of :452-467, then the hot starts of :545 -- and continues with the top of the reference's
+    // loop.  Everything between two QPs is ONE fused pass (round 3): thread t holds the entries t, t + 256, ... of every vector in
+    // registers from the loads to the stores; pk goes through LDS for the product with the compressed rows of C; the scalars meet
+    // in three workgroup reductions (step length; stationarity and complementarity; |gk| for the subsolver).  Q xk and C xk are kept up
+    // to date by linearity (Q x_new is the direct product of the subsolver's last verification, V_QXN), A'yk_A + yk_box is taken from
+    // the verified KKT residual (V_ATY): no sweep over a matrix at this level after the first.
     {
+        constexpr int EPT = (np + WG - 1) / WG;      // entries per thread
         int initial = 1;
         wg_symv<NCH>(c.Q, c.C, n, xk, nullptr, Qx, Cx, nullptr, nullptr, c.lds);      // Q x0, C x0: the one sweep over Q and C of the homotopy
+        const double *xq = c.V(V_XQ), *qxn = c.V(V_QXN), *aty = c.V(V_ATY);
+        double* sP = c.lds.arena;                     // pk for the gather through the rows of C
         for (;;) {
             rc = solveQP(initial);
             if (rc != 0) break;
-            if (initial) {
-                st.rhoOpt = rho;   // :473
-            } else if (o.perturbStep) {
-                // perturbStep :1353-1362 (seeded SplitMix64 instead of time-seeded rand())
-                for (int i = t; i < n; i += WG) {
+            if (initial) st.rhoOpt = rho;   // :473
+            const int cnz = uniform_i(c.info->cNnz);
+            const int* cp = db.Cp + (size_t)c.b * (np + 1);
+            const int* ci = db.Ci + (size_t)c.b * db.capC;
+            const double* ccv = db.Cv + (size_t)c.b * db.capC;
+            double vx[EPT], vp[EPT], vQx[EPT], vQp[EPT], vCx[EPT], vCp[EPT], vgt[EPT], vaty[EPT], vg[EPT], vgp[EPT];
+            int c0[EPT], c1[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const int i = t + e * WG;
+                const bool in = i < np;
+                vx[e] = in ? xk[i] : 0.0;
+                const double xn = in ? xq[i] : 0.0;           // getSolution :1138
+                vQx[e] = in ? Qx[i] : 0.0; vQp[e] = (in ? qxn[i] : 0.0) - vQx[e];      // Q pk = Q x_new - Q xk
+                vCx[e] = in ? Cx[i] : 0.0; vgt[e] = in ? gtil[i] : 0.0; vaty[e] = in ? aty[i] : 0.0;
+                vg[e] = (hasPhi && in) ? g[i] : 0.0; vgp[e] = (hasPhi && in) ? gphi[i] : 0.0;
+                c0[e] = (cnz >= 0 && i < n) ? cp[i] : 0; c1[e] = (cnz >= 0 && i < n) ? cp[i + 1] : 0;
+                vp[e] = xn - vx[e];                             // pk = xnew - xk :1145
+                if (!initial && o.perturbStep && i < n) {
+                    // perturbStep :1353-1362 (seeded SplitMix64 instead of time-seeded rand()); pk is the unperturbed difference
                     uint64_t z = o.perturbSeed + (perturbCounter + (uint64_t)i + 1ULL) * 0x9E3779B97F4A7C15ULL;
                     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
                     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
                     z = z ^ (z >> 31);
-                    xk[i] += ((int)(z % 3ULL) - 1) * 2.221e-16;
+                    vx[e] += ((int)(z % 3ULL) - 1) * 2.221e-16;
                 }
-                perturbCounter += (uint64_t)n;
-                __syncthreads();
+                if (in) sP[i] = vp[e];
             }
-            // Q pk and C pk (the products getOptimalStepLength needs, :1217-1237).  Q x_new is the direct product the subsolver formed when
-            // it verified its solution (V_QXN), so Q pk = Q x_new - Q xk needs no sweep; C is applied from its compressed rows when it is
-            // sparse (one-hot L, R: 2 nComp non-zeros), else swept.  Q xk and C xk follow from the step (updateStep below).
-            {
-                const double* qxn = c.V(V_QXN);
-                for (int i = t; i < np; i += WG) Qp[i] = qxn[i] - Qx[i];
-                const int cnz = uniform_i(c.info->cNnz);
-                if (cnz >= 0) {
-                    const int* cp = db.Cp + (size_t)c.b * (np + 1);
-                    const int* ci = db.Ci + (size_t)c.b * db.capC;
-                    const double* cv = db.Cv + (size_t)c.b * db.capC;
-                    for (int i = t; i < np; i += WG) {
-                        double sdot = 0.0;
-                        if (i < n) for (int k = cp[i]; k < cp[i + 1]; k++) sdot += cv[k] * pk[ci[k]];
-                        Cp[i] = sdot;
-                    }
-                    __syncthreads();
-                } else {
-                    __syncthreads();
-                    wg_symv<NCH>(c.C, nullptr, n, pk, nullptr, Cp, nullptr, nullptr, nullptr, c.lds);
+            if (!initial && o.perturbStep) perturbCounter += (uint64_t)n;
+            __syncthreads();
+            // C pk (:1217-1237 need Qk pk): from the compressed rows of C when it is sparse (one-hot L, R: 2 nComp non-zeros), else a sweep
+            if (cnz >= 0) {
+#pragma unroll
+                for (int e = 0; e < EPT; e++) {
+                    double sdot = 0.0;
+                    for (int k = c0[e]; k < c1[e]; k++) sdot += ccv[k] * sP[ci[k]];
+                    vCp[e] = sdot;
                 }
+                __syncthreads();
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPT; e++) { const int i = t + e * WG; if (i < np) pk[i] = vp[e]; }
+                __syncthreads();
+                wg_symv<NCH>(c.C, nullptr, n, pk, nullptr, Cp, nullptr, nullptr, nullptr, c.lds);
+#pragma unroll
+                for (int e = 0; e < EPT; e++) { const int i = t + e * WG; vCp[e] = (i < np) ? Cp[i] : 0.0; }
             }
             if (!initial) {
                 // getOptimalStepLength :1217-1237: qk = pk'Qk pk, lk = pk'(Qk xk + g_tilde)
                 double sq = 0.0, sl = 0.0;
-                for (int i = t; i < n; i += WG) {
-                    sq += pk[i] * (Qp[i] + rho * Cp[i]);
-                    sl += pk[i] * ((Qx[i] + rho * Cx[i]) + gtil[i]);
-                }
-                const double qk = block_sum(sq, c.lds), lk = block_sum(sl, c.lds);
+#pragma unroll
+                for (int e = 0; e < EPT; e++)
+                    if (t + e * WG < n) {
+                        sq += vp[e] * (vQp[e] + rho * vCp[e]);
+                        sl += vp[e] * ((vQx[e] + rho * vCx[e]) + vgt[e]);
+                    }
+                double qk, lk;
+                block_sum2(sq, sl, qk, lk, c.lds);
                 alphak = 1.0;
                 if (qk > 0 && lk < 0) alphak = fmin(-lk / qk, 1.0);
             }
             initial = 0;
-            // updateStep :1240-1243
-            for (int i = t; i < np; i += WG) {
-                xk[i] = xk[i] + alphak * pk[i];
-                Qx[i] = Qx[i] + alphak * Qp[i];
-                Cx[i] = Cx[i] + alphak * Cp[i];
+            // updateStep :1240-1243, updateStationarity :1246-1272 (statk = Qk xk + g_tilde - A' yk_A - yk_box), getPhi :1172-1185
+            double smax = 0.0, sphi = 0.0, pmax = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                vx[e] += alphak * vp[e];
+                vQx[e] += alphak * vQp[e];
+                vCx[e] += alphak * vCp[e];
+                if (t + e * WG < n) {
+                    smax = fmax(smax, fabs((vQx[e] + rho * vCx[e]) + vgt[e] - vaty[e]));
+                    sphi += vgp[e] * vx[e] + 0.5 * vx[e] * vCx[e];
+                    pmax = fmax(pmax, fabs(vp[e]));
+                }
             }
-            __syncthreads();
-#ifdef LCQP_DIAG_DIRECT      // diagnostic: Q xk and C xk as direct products every iterate (what the oracle did before round 3)
-            wg_symv<NCH>(c.Q, c.C, n, xk, nullptr, Qx, Cx, nullptr, nullptr, c.lds);
-#endif
-#ifdef LCQP_DIAG_ATY         // diagnostic: A'yk_A + yk_box as a direct product over all rows of E
-            {
-                double* aty = c.V(V_ATY);
-                const double* yq = c.M(M_YQ);
-                wg_rows<NCH>(c.E, nullptr, c.mE, nullptr, nullptr, yq, c.lds, [&](int i, double s) { aty[i] = -s; });
-            }
-#endif
-            // updateStationarity :1246-1272: statk = Qk xk + g_tilde - A' yk_A - yk_box
-            {
-                const double* aty = c.V(V_ATY);
-                for (int i = t; i < np; i += WG) statk[i] = (i < n) ? (Qx[i] + rho * Cx[i]) + gtil[i] - aty[i] : 0.0;
-                __syncthreads();
-            }
-            const double statInf = wg_maxabs(statk, n, c.lds);
+            double statInf, phiNow;
+            block_max_sum(smax, sphi, statInf, phiNow, c.lds);
+            phiNow += phiConst;
             if (db.traceCap > 0 && totalIter < db.traceCap) {   // storeSteps :488-490
-                const double phiNow = getPhi();
                 // getObj :1161-1169, getMerit :1188-1196 and the step size of updateTrackingVectors (src/OutputStatistics.cpp:131-164)
                 double so = 0.0, sm = 0.0;
-                for (int i = t; i < n; i += WG) { so += g[i] * xk[i] + 0.5 * xk[i] * Qx[i]; sm += 0.5 * rho * xk[i] * Cx[i]; }
-                const double objNow = block_sum(so, c.lds), meritNow = objNow + block_sum(sm, c.lds);
-                const double stepNow = wg_maxabs(pk, n, c.lds);
+#pragma unroll
+                for (int e = 0; e < EPT; e++) {
+                    const int i = t + e * WG;
+                    if (i < n) { so += g[i] * vx[e] + 0.5 * vx[e] * vQx[e]; sm += 0.5 * rho * vx[e] * vCx[e]; }
+                }
+                double objNow, mer;
+                block_sum2(so, sm, objNow, mer, c.lds);
+                const double meritNow = objNow + mer;
+                const double stepNow = block_max(pmax, c.lds);
                 double* ts = db.traceS + ((size_t)c.b * db.traceCap + totalIter) * 8;
                 double* tx = db.traceX + ((size_t)c.b * db.traceCap + totalIter) * n;
                 if (t == 0) {
                     ts[0] = statInf; ts[1] = phiNow; ts[2] = rho; ts[3] = alphak;
                     ts[4] = objNow; ts[5] = meritNow; ts[6] = stepNow; ts[7] = (double)qpIter;
+#ifdef LCQP_PROFILE_STAMPS      // diagnostic: when did this iterate end (shader clock), instead of the QP iteration count
+                    ts[7] = (double)clock64();
+#endif
                     db.traceLen[c.b] = totalIter + 1;
                 }
-                for (int i = t; i < n; i += WG) tx[i] = xk[i];
+#pragma unroll
+                for (int e = 0; e < EPT; e++) { const int i = t + e * WG; if (i < n) tx[i] = vx[e]; }
             }
             totalIter++; st.iterTotal++;
-            // leyfferCheckPositive :1275-1313
+            // leyfferCheckPositive :1275-1313 (getPhi is the value of this iterate wherever the reference calls it)
             bool leyffer = false;
             {
                 const int nd = o.nDynamicPenalty;
                 if (nd > 0) {
-                    const double cur = getPhi();
+                    const double cur = phiNow;
                     if (histLen < nd) { if (t == 0) hist[histLen] = cur; histLen++; __syncthreads(); }
                     else if (cur < o.complementarityTolerance) {
                         __syncthreads();
@@ -1306,45 +1318,61 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
                     }
                 }
             }
-            if (leyffer) { updatePenalty(); st.iterOuter++; }
+            bool penaltyUpdated = false;
+            if (leyffer) { updatePenalty(); st.iterOuter++; penaltyUpdated = true; }
             // stationarity / complementarity checks :511-534
+            bool converged = false;
             if (statInf < o.stationarityTolerance) {
-                if (getPhi() < o.complementarityTolerance) {
-                    // transformDuals :1381-1409 (rows of L, R are rows nC.., nC+nComp.. of E)
-                    double* lx = c.M(M_COEF);      // scratch (M_EX belongs to the subsolver's hot start)
-                    wg_rows<NCH>(c.E, nullptr, mA, xk, lx, nullptr, c.lds, [](int, double) {});
-                    // determineStationarityType :1412-1453 on the untransformed duals, weak set :1456-1482
-                    int sflag = 1, mflag = 1, wflag = 0;
-                    const double ctol = o.complementarityTolerance;
-                    for (int i = 0; i < nComp; i++) {   // uniform scalar loop, order matters for the W exit
-                        const double Lx = lx[nC + i], Rx = lx[nC + nComp + i];
-                        if (!(Lx <= ctol && Rx <= ctol)) continue;
-                        const double a = yk[n + nC + i], bq = yk[n + nC + nComp + i];
-                        const double dualProd = a * bq, dualMin = fmin(a, bq);
-                        if (dualMin < 0) sflag = 0;
-                        if (fabs(dualProd) >= ctol && dualMin <= 0) {
-                            if (dualProd <= ctol) { wflag = 1; break; }
-                            mflag = 0;
-                        }
-                    }
-                    algoStat = wflag ? 1 : (sflag ? 4 : (mflag ? 3 : 2));
-                    __syncthreads();
-                    for (int i = t; i < nComp; i += WG) {
-                        const double Lx = lx[nC + i], Rx = lx[nC + nComp + i];
-                        yk[n + nC + i] -= rho * Rx;
-                        yk[n + nC + nComp + i] -= rho * Lx;
-                    }
-                    __syncthreads();
-                    rc = 0;
-                    break;
-                } else {
-                    updatePenalty(); st.iterOuter++;
+                if (phiNow < o.complementarityTolerance) converged = true;
+                else { updatePenalty(); st.iterOuter++; penaltyUpdated = true; }
+            }
+            // xk, Q xk, C xk; g_tilde = g + rho g_phi (updatePenalty :1199-1214); updateLinearization :1105-1112: gk = rho C xk + g_tilde
+            double gm = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const int i = t + e * WG;
+                if (i < np) {
+                    xk[i] = vx[e]; Qx[i] = vQx[e]; Cx[i] = vCx[e];
+                    // (g_tilde = g until the first penalty update: initializeSolver :966-967 leaves rho * g_phi out, updatePenalty puts it in)
+                    const double gt = (hasPhi && penaltyUpdated) ? vg[e] + rho * vgp[e] : vgt[e];
+                    if (hasPhi && penaltyUpdated) gtil[i] = gt;
+                    const double gkv = rho * vCx[e] + gt;
+                    gk[i] = gkv;
+                    if (i < n) gm = fmax(gm, fabs(gkv));
                 }
             }
+            gmax = block_max(gm, c.lds);
+            if (converged) { rc = 0; algoStat = -1; break; }
             if (totalIter > o.maxIterations) { rc = LCQP_MAX_ITERATIONS_REACHED; break; }
             if (rho > o.maxPenaltyParameter) { rc = LCQP_MAX_PENALTY_REACHED; break; }
-            // updateLinearization :1105-1112: gk = rho C xk + g_tilde
-            for (int i = t; i < np; i += WG) gk[i] = rho * Cx[i] + gtil[i];
+        }
+        // getSolution (:1138-1142): the duals of the last QP that was solved, whatever the exit
+        if (uniform_i(c.info->haveSolution)) qp_export<NCH>(c, xnew, np, yk);
+        if (algoStat == -1) {
+            // transformDuals :1381-1409 (rows of L, R are rows nC.., nC+nComp.. of E)
+            double* lx = c.M(M_COEF);      // scratch (M_EX belongs to the subsolver's hot start)
+            wg_rows<NCH>(c.E, nullptr, mA, xk, lx, nullptr, c.lds, [](int, double) {});
+            // determineStationarityType :1412-1453 on the untransformed duals, weak set :1456-1482
+            int sflag = 1, mflag = 1, wflag = 0;
+            const double ctol = o.complementarityTolerance;
+            for (int i = 0; i < nComp; i++) {   // uniform scalar loop, order matters for the W exit
+                const double Lx = lx[nC + i], Rx = lx[nC + nComp + i];
+                if (!(Lx <= ctol && Rx <= ctol)) continue;
+                const double a = yk[n + nC + i], bq = yk[n + nC + nComp + i];
+                const double dualProd = a * bq, dualMin = fmin(a, bq);
+                if (dualMin < 0) sflag = 0;
+                if (fabs(dualProd) >= ctol && dualMin <= 0) {
+                    if (dualProd <= ctol) { wflag = 1; break; }
+                    mflag = 0;
+                }
+            }
+            algoStat = wflag ? 1 : (sflag ? 4 : (mflag ? 3 : 2));
+            __syncthreads();
+            for (int i = t; i < nComp; i += WG) {
+                const double Lx = lx[nC + i], Rx = lx[nC + nComp + i];
+                yk[n + nC + i] -= rho * Rx;
+                yk[n + nC + nComp + i] -= rho * Lx;
+            }
             __syncthreads();
         }
     }

@@ -35,6 +35,18 @@ struct Lds {
     int* ired;      // 16 ints
 };
 
+// Matrix streams (rows of Q, E, Et, the factor L1): every byte is used once per pass and the matrices of a batch (12 GB) never fit a
+// cache, so these loads are non-temporal and leave L2 / the Infinity Cache to what IS re-read: the vectors and the inverse factor T
+// (139 KB per instance).  Same-box A/B 40.1 -> 38.3 ms (profiles/round3); -DLCQP_NO_NT_STREAMS restores plain loads.
+#ifndef LCQP_NO_NT_STREAMS
+typedef double d2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld_stream(const double2* p) { const d2v_t v = __builtin_nontemporal_load(reinterpret_cast<const d2v_t*>(p)); return double2{v.x, v.y}; }
+__device__ __forceinline__ double ld_stream(const double* p) { return __builtin_nontemporal_load(p); }
+#else
+__device__ __forceinline__ double2 ld_stream(const double2* p) { return *p; }
+__device__ __forceinline__ double ld_stream(const double* p) { return *p; }
+#endif
+
 // Everything a thread computes from its thread number and uniform values is invariant in every loop of a kernel, and the compiler
 // hoists it all to the top of the kernel (hundreds of addresses and masks, spilled to scratch at once).  An empty volatile asm cannot
 // be hoisted: what is derived from the laundered thread number stays inside the routine that uses it.
@@ -110,6 +122,27 @@ __device__ __forceinline__ double block_max(double v, Lds lds)
     double r = fmax(fmax(lds.red[0], lds.red[1]), fmax(lds.red[2], lds.red[3]));
     __syncthreads();
     return uniform_d(r);
+}
+// two reductions for the price of one barrier pair: (sum, sum) and (max, sum)
+__device__ __forceinline__ void block_sum2(double a, double b, double& ra, double& rb, Lds lds)
+{
+    a = wave_sum(a); b = wave_sum(b);
+    if (lane_id() == 0) { lds.red[wave_id()] = a; lds.red[4 + wave_id()] = b; }
+    __syncthreads();
+    const double sa = lds.red[0] + lds.red[1] + lds.red[2] + lds.red[3];
+    const double sb = lds.red[4] + lds.red[5] + lds.red[6] + lds.red[7];
+    __syncthreads();
+    ra = uniform_d(sa); rb = uniform_d(sb);
+}
+__device__ __forceinline__ void block_max_sum(double a, double b, double& ra, double& rb, Lds lds)
+{
+    a = wave_max(a); b = wave_sum(b);
+    if (lane_id() == 0) { lds.red[wave_id()] = a; lds.red[4 + wave_id()] = b; }
+    __syncthreads();
+    const double sa = fmax(fmax(lds.red[0], lds.red[1]), fmax(lds.red[2], lds.red[3]));
+    const double sb = lds.red[4] + lds.red[5] + lds.red[6] + lds.red[7];
+    __syncthreads();
+    ra = uniform_d(sa); rb = uniform_d(sb);
 }
 __device__ __forceinline__ int block_or(int v, Lds lds)
 {
@@ -248,11 +281,11 @@ __device__ __forceinline__ void wg_symv_t(const double* __restrict__ M0, const d
         for (int d = 0; d < D; d++) {
             const double2* row0 = reinterpret_cast<const double2*>(M0 + (size_t)(r0 + NWAVE * d) * np) + l;
 #pragma unroll
-            for (int k = 0; k < NCH; k++) m0[d][k] = row0[64 * k];
+            for (int k = 0; k < NCH; k++) m0[d][k] = ld_stream(row0 + 64 * k);
             if (TWO_M) {
                 const double2* row1 = reinterpret_cast<const double2*>(M1 + (size_t)(r0 + NWAVE * d) * np) + l;
 #pragma unroll
-                for (int k = 0; k < NCH; k++) m1[d][k] = row1[64 * k];
+                for (int k = 0; k < NCH; k++) m1[d][k] = ld_stream(row1 + 64 * k);
             }
         }
 #pragma unroll
@@ -366,7 +399,7 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
                 if (rows[d] >= 0) {
                     const double2* rp = reinterpret_cast<const double2*>(Mx + (size_t)rows[d] * np) + l;
 #pragma unroll
-                    for (int k = 0; k < NCH; k++) mm[d][k] = rp[64 * k];
+                    for (int k = 0; k < NCH; k++) mm[d][k] = ld_stream(rp + 64 * k);
                 } else {
 #pragma unroll
                     for (int k = 0; k < NCH; k++) mm[d][k] = double2{0.0, 0.0};
@@ -421,7 +454,7 @@ __device__ __forceinline__ void wg_trsv(const double* __restrict__ F, int ld, in
                 f[cc] = Fd[(size_t)c * ld + l];
 #else
                 f[cc] = 0.0;
-                if (forward ? (c <= l) : (c >= l)) f[cc] = Fd[(size_t)c * ld + l];
+                if (forward ? (c <= l) : (c >= l)) f[cc] = ld_stream(Fd + (size_t)c * ld + l);
 #endif
             }
             double acc = 0.0;
@@ -442,7 +475,7 @@ __device__ __forceinline__ void wg_trsv(const double* __restrict__ F, int ld, in
                 const double* Fp = F + (size_t)(64 * I + 16 * w) * ld + 64 * cb + l;
                 double f[16];
 #pragma unroll
-                for (int cc = 0; cc < 16; cc++) f[cc] = Fp[(size_t)cc * ld];
+                for (int cc = 0; cc < 16; cc++) f[cc] = ld_stream(Fp + (size_t)cc * ld);
                 double acc = 0.0;
 #pragma unroll
                 for (int cc = 0; cc < 16; cc++) acc += f[cc] * b[64 * I + 16 * w + cc];
