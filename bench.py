@@ -5,7 +5,7 @@ Default workload (BASELINE configs[2]): a "step" is one complete solve of one sy
 n = 256, nC = 512, nComp = 64, generated directly in HBM before the timed region (include/lcqp_synth.h).  Every step re-runs
 everything runSolver does: constant-matrix setup (C, the two factorisations, Et, M = Et Et') and the homotopy kernel from x0 = 0.
 --workload sparse (BASELINE configs[4]): B sparse LCQPs with n = 4096, nC = 2048, nComp = 512 of one banded pattern
-(tests/problems.py), uploaded before the timed region; a step = KKT factorisation + homotopy for every instance.
+(lcqpow_amd/synth_sparse.py), uploaded before the timed region; a step = KKT factorisation + homotopy for every instance.
 
 N > 1: independent instances are sharded over the GPUs (GPU r solves instance ids [r*B, (r+1)*B)); there is no data-path
 collective and no RCCL anywhere.  Two ways to get N GPUs:
@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--no-backsolve", action="store_true", help="skip the standalone back-solve kernel measurement")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-batches-in-flight measurement")
     ap.add_argument("--no-resident", action="store_true", help="skip the 8192-resident-instances measurement")
+    ap.add_argument("--no-sparse", action="store_true", help="skip the sparse_config5 object (BASELINE configs[4]) of the default line")
+    ap.add_argument("--sparse-batch", type=int, default=16384, help="instances of the sparse_config5 object")
     args = ap.parse_args()
     sparse = args.workload == "sparse"
     B = args.batch or (16384 if sparse else 1024)
@@ -138,20 +140,25 @@ def main():
 
     opt = la.default_options(perturbStep=0, printLevel=0)     # defaults except these two
 
-    if sparse:
-        import problems as P
-        Qpat, Apat = P.sparse_pattern(n, nC, nComp)
-
-        def make_batch(dev):
-            gidx = devices.index(dev) if not launched else rank
-            first, _ = shard_range(gidx, world, B)
-            inst = [P.sparse_instance(first + i, n, nC, nComp) for i in range(B)]
-            sb = la.SparseBatchLCQP(B, n, nC, nComp, Qpat, Apat, device=dev, opt=opt)
-            rc = sb.load(0, B, np.stack([d["Q"].data for d in inst]), np.stack([d["g"] for d in inst]), np.stack([d["E"].data for d in inst]),
+    def make_sparse_batch(dev, first, Bs, ns, nCs, nKs):
+        """Bs instances [first, first + Bs) of the sparse synthetic workload (lcqpow_amd/synth_sparse.py) loaded on device dev"""
+        from lcqpow_amd import synth_sparse as S
+        Qpat, Apat, qo, eo = S.sparse_pattern_arrays(ns, nCs, nKs)
+        sb = la.SparseBatchLCQP(Bs, ns, nCs, nKs, Qpat, Apat, device=dev, opt=opt)
+        chunk = 1024                                       # host staging: 1024 instances are 0.4 GB of values
+        for c0 in range(0, Bs, chunk):
+            inst = [S.sparse_values(first + i, ns, nCs, nKs, orders=(qo, eo)) for i in range(c0, min(Bs, c0 + chunk))]
+            rc = sb.load(c0, len(inst), np.stack([d["Qx"] for d in inst]), np.stack([d["g"] for d in inst]), np.stack([d["Ex"] for d in inst]),
                          lbA=np.stack([d["lbA"] for d in inst]), ubA=np.stack([d["ubA"] for d in inst]))
             if rc != 0:
                 raise SystemExit(f"sparse load failed: {rc}")
-            return sb
+        return sb
+
+    if sparse:
+        def make_batch(dev):
+            gidx = devices.index(dev) if not launched else rank
+            first, _ = shard_range(gidx, world, B)
+            return make_sparse_batch(dev, first, B, n, nC, nComp)
     else:
         def make_batch(dev):
             gidx = devices.index(dev) if not launched else rank
@@ -194,7 +201,7 @@ def main():
         kname = "k_sparse_setup + k_sparse_run"
         cfg_extra = {"kkt_half_bandwidth": bt.bandwidth(), "nnz_Q": bt.nnzQ, "nnz_E": bt.nnzA,
                      "mean_kkt_factorizations": mean("factorizations"), "mean_band_solves": mean("corrections") + mean("admmIter")}
-        wl = (f"synthetic sparse batch={B}/GPU n={n} nC={nC} nComp={nComp} (BASELINE configs[4]; banded pattern of tests/problems.py, "
+        wl = (f"synthetic sparse batch={B}/GPU n={n} nC={nC} nComp={nComp} (BASELINE configs[4]; banded pattern of lcqpow_amd/synth_sparse.py, "
               f"numpy PCG64 seed0=0x4C43515000000005 ^ instance id, perturbStep=0, printLevel=NONE)")
         metric = f"LCQPs/sec (batched sparse n={n},nC={nC},nComp={nComp}, OSQP-style ADMM KKT + polish)"
     else:
@@ -258,6 +265,27 @@ def main():
                                 "roofline_frac": btR.algorithmic_bytes() / (kR * 1e-3) / 1e9 / HBM_PEAK_GBS}
         btR.close()
 
+    if main_proc and world == 1 and not sparse and not args.no_sparse and shape == (256, 512, 64) and B == 1024:
+        # BASELINE configs[4] in the default line: the sparse arm (OSQP-style ADMM KKT + polish on the banded KKT matrix) on the batch that
+        # fills the GPU once (8 instances per wavefront, 2 wavefronts per SIMD: 16 384 resident), one warm-up and one timed step;
+        # `python bench.py --workload sparse` runs the same workload as the headline with steps / warmup / cpu_baseline
+        Bs, ns, nCs, nKs = args.sparse_batch, 4096, 2048, 512
+        sb = make_sparse_batch(devices[0], 0, Bs, ns, nCs, nKs)
+        sb.run(); sb.synchronize()
+        ts = time.perf_counter(); sb.run(); sb.synchronize(); dts = time.perf_counter() - ts
+        _, _, sts = sb.solution()
+        s_ms, k_ms = sb.last_timing()
+        sbytes = sb.algorithmic_bytes()
+        ach = sbytes / ((s_ms + k_ms) * 1e-3) / 1e9
+        out["sparse_config5"] = {"metric": f"LCQPs/sec (batched sparse n={ns},nC={nCs},nComp={nKs}, OSQP-style ADMM KKT + polish)", "value": Bs / dts, "unit": "LCQPs/s",
+                                 "batch": Bs, "steps": 1, "ms_per_step": 1e3 * dts, "solved": sum(1 for s_ in sts if s_["returnValue"] == 0),
+                                 "kkt_half_bandwidth": sb.bandwidth(), "lanes_per_instance": sb.lanes(),
+                                 "mean_lcqp_iterates": float(np.mean([s_["iterTotal"] for s_ in sts])),
+                                 "roofline": {"bound": "hbm", "kernel": "k_sparse_setup + k_sparse_run", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("sparse", Bs, (ns, nCs, nKs)), "algorithmic_bytes_per_launch": sbytes},
+                                 "data": "synthetic (lcqpow_amd/synth_sparse.py: banded pattern, numpy PCG64 seed0=0x4C43515000000005 ^ instance id)"}
+        sb.close()
+
     if main_proc and not sparse and not args.no_backsolve:
         # the factor-once / back-solve-many kernel pair on its own (bytes_bs(N) = 8 N (N+2)), cache-cold: 4096
         # factors of order n = 2 GiB at n = 256, far beyond the 256 MiB Infinity Cache, one right-hand side each; the in-situ
@@ -284,10 +312,13 @@ def main():
         oopt = O.default_options(perturbStep=0, printLevel=0)
         if sparse:
             import threading
-            import problems as P
+            import scipy.sparse as sp
+            from lcqpow_amd import synth_sparse as S
             cnt = min(B, max(args.cpu_sample, threads))
-            inst = [P.sparse_instance(i, n, nC, nComp) for i in range(cnt)]
-            csr = [(d["Q"].tocsr(), d["E"].tocsr()) for d in inst]
+            Qpat, Apat, qo, eo = S.sparse_pattern_arrays(n, nC, nComp)
+            inst = [S.sparse_values(i, n, nC, nComp, orders=(qo, eo)) for i in range(cnt)]
+            csr = [(sp.csc_matrix((d["Qx"], Qpat.indices, Qpat.indptr), shape=Qpat.shape).tocsr(),
+                    sp.csc_matrix((d["Ex"], Apat.indices, Apat.indptr), shape=Apat.shape).tocsr()) for d in inst]
             perm, w = O.kkt_ordering(n, csr[0][0].indptr, csr[0][0].indices, csr[0][1].indptr, csr[0][1].indices)
             res = [None] * cnt
 

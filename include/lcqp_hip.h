@@ -222,6 +222,9 @@ int  lcqp_hip_sparse_synchronize(lcqp_hip_sparse_t* s);
 int  lcqp_hip_sparse_last_timing(lcqp_hip_sparse_t* s, float* setup_ms, float* solve_ms);
 int  lcqp_hip_sparse_get_solution(lcqp_hip_sparse_t* s, double* x, double* y, lcqp_stats_t* stats);   /* y: [B][nC + 2 nComp] */
 double lcqp_hip_sparse_algorithmic_bytes(lcqp_hip_sparse_t* s);
+/* per-iterate trace of one instance of the last run (options.storeSteps), same layout as lcqp_hip_batch_get_trace
+ * (src/LCQProblem.cpp:1365-1378, 1528-1576: the host LCQProblem rebuilds the tracking vectors and the iteration table from it) */
+int  lcqp_hip_sparse_get_trace(lcqp_hip_sparse_t* s, int instance, int cap, double* scalars, double* x, int* len);
 /* mean clock ticks per instance in 8 phases of the last run; LCQP_HIP_UNSUPPORTED unless the library was built with -DLCQP_PROFILE */
 int  lcqp_hip_sparse_read_profile(lcqp_hip_sparse_t* s, double* out);
 

@@ -59,6 +59,9 @@ void lcqp_host_problem_set_device(lcqp_host_problem_t* p, int device);          
 /* HIP_DENSE runs the whole homotopy on the device (batch of one); hostLoop != 0 keeps the reference's host loop (src/LCQProblem.cpp:444-560)
  * over the SubsolverHIP plugin for it as well -- the reference's three solver values always use the host loop */
 void lcqp_host_problem_set_host_loop(lcqp_host_problem_t* p, int hostLoop);
+/* which engine the last runSolver used: 0 none yet, 1 host loop over the subsolver plugin, 2 whole homotopy on the device (dense kernels),
+ * 3 the sparse engine (OSQP_SPARSE arm with a banded KKT pattern) */
+int lcqp_host_problem_last_engine(const lcqp_host_problem_t* p);
 void lcqp_host_problem_set_options(lcqp_host_problem_t* p, const lcqp_host_options_t* o);   /* include/LCQProblem.hpp:242 */
 
 /* dense loadLCQP, src/LCQProblem.cpp:87-144 */

@@ -367,6 +367,7 @@ class SparseBatchLCQP:
         L.lcqp_hip_sparse_synchronize.argtypes = [C.c_void_p]
         L.lcqp_hip_sparse_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.lcqp_hip_sparse_get_solution.argtypes = [C.c_void_p, c_double_p, c_double_p, C.c_void_p]
+        L.lcqp_hip_sparse_get_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, C.POINTER(C.c_int)]
         L.lcqp_hip_sparse_algorithmic_bytes.restype = C.c_double
         L.lcqp_hip_sparse_algorithmic_bytes.argtypes = [C.c_void_p]
         self.B, self.nV, self.nC, self.nComp, self.m = batch, nV, nC, nComp, nC + 2 * nComp
@@ -422,6 +423,12 @@ class SparseBatchLCQP:
         st = (Stats * self.B)()
         self._chk(lib().lcqp_hip_sparse_get_solution(self.h, _p(x), _p(y), st), "get_solution")
         return x, y, [s.asdict() for s in st]
+
+    def trace(self, instance, cap=1024):
+        """per-iterate (|statk|inf, phi, rho, alphak, obj, merit, |pk|inf, QP iterations) and xk of one instance (needs options.storeSteps)"""
+        sc = np.zeros((cap, 8)); xs = np.zeros((cap, self.nV)); n = C.c_int(0)
+        self._chk(lib().lcqp_hip_sparse_get_trace(self.h, instance, cap, _p(sc), _p(xs), C.byref(n)), "get_trace")
+        return sc[:n.value].copy(), xs[:n.value].copy()
 
     def algorithmic_bytes(self):
         return lib().lcqp_hip_sparse_algorithmic_bytes(self.h)

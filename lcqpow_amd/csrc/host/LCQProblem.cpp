@@ -306,6 +306,7 @@ void LCQProblem::finishFromTrace(const std::vector<double>& sc, const std::vecto
         }
         inner++;
     }
+    if (pl != NONE) std::fflush(stdout);
 }
 
 ReturnValue LCQProblem::runOnDevice()
@@ -351,30 +352,45 @@ ReturnValue LCQProblem::runOnDevice()
     return ret;
 }
 
-// OSQP_SPARSE arm with CSC data: the sparse engine (lcqp_hip_sparse_*, band LDL' of the KKT matrix) when the pattern is banded and
-// no per-iterate output is asked for (the sparse kernel keeps no trace); otherwise the caller falls back to the host loop over the
-// dense kernels.
+// OSQP_SPARSE arm with CSC data: the sparse engine (lcqp_hip_sparse_*, band LDL' of the KKT matrix) when the pattern is banded; the
+// tracking vectors and the iteration table are rebuilt from the device trace as on the dense path.  Returns false when the engine does
+// not take the problem (pattern not banded, an option it does not support): the caller then runs the host loop over the dense kernels.
 bool LCQProblem::runSparseOnDevice(ReturnValue& ret)
 {
-    if (!sparseSolver || options.getStoreSteps() || options.getPrintLevel() != NONE) return false;
+    if (!sparseSolver) return false;
     lcqp_hip_sparse_t* sb = lcqp_hip_sparse_create(1, nV, nC, nComp, Q_sparse->p, Q_sparse->i, A_sparse->p, A_sparse->i, device);
     if (!sb) return false;                        // not a banded pattern (lcqp_hip_sparse_last_error says so)
     const int m = nC + 2 * nComp;
-    int rc = lcqp_hip_sparse_set_options(sb, &options.getHIPOptions());
-    if (!rc) rc = lcqp_hip_sparse_load(sb, 0, 1, Q_sparse->x, g.data(), A_sparse->x, lbA.data(), ubA.data(), haveLbL ? lbL.data() : 0, &ubA[nC],
-                                       haveLbR ? lbR.data() : 0, &ubA[nC + nComp], xk.data(), haveYk ? yk.data() : 0);
+    lcqp_options_t o = options.getHIPOptions();
+    const bool wantTrace = o.storeSteps != 0 || o.printLevel != 0;
+    o.storeSteps = wantTrace ? 1 : 0;
+    int rc = lcqp_hip_sparse_set_options(sb, &o);
+    if (rc) { lcqp_hip_sparse_destroy(sb); return false; }      // e.g. nDynamicPenalty > 64: the host loop takes it
+    rc = lcqp_hip_sparse_load(sb, 0, 1, Q_sparse->x, g.data(), A_sparse->x, lbA.data(), ubA.data(), haveLbL ? lbL.data() : 0, &ubA[nC],
+                              haveLbR ? lbR.data() : 0, &ubA[nC + nComp], xk.data(), haveYk ? yk.data() : 0);
+    if (rc > 0 && rc < LCQP_HIP_ERROR) { lcqp_hip_sparse_destroy(sb); ret = (ReturnValue)rc; lastEngine = ENGINE_SPARSE_DEVICE; return true; }      // the reference's own code for bad problem data
     if (!rc) rc = lcqp_hip_sparse_run(sb);
     lcqp_stats_t st;
     std::memset(&st, 0, sizeof(st));
     yk.assign(m, 0.0);
     if (!rc) rc = lcqp_hip_sparse_get_solution(sb, xk.data(), yk.data(), &st);
+    if (!rc) {
+        stats.updateIterTotal(st.iterTotal); stats.updateIterOuter(st.iterOuter); stats.updateSubproblemIter(st.subproblemIter);
+        stats.updateRhoOpt(st.rhoOpt); stats.updateQPSolverExitFlag(st.qpSolverExitFlag);
+        algoStat = (AlgorithmStatus)st.status;
+        stats.updateSolutionStatus(algoStat);
+        if (wantTrace) {
+            const int cap = std::min(st.iterTotal + 1, 4096);
+            std::vector<double> sc((size_t)cap * 8), xs((size_t)cap * nV);
+            int len = 0;
+            if (!lcqp_hip_sparse_get_trace(sb, 0, cap, sc.data(), xs.data(), &len)) finishFromTrace(sc, xs, len);
+        }
+        ret = (ReturnValue)st.returnValue;
+    } else {
+        ret = SUBPROBLEM_SOLVER_ERROR;
+    }
     lcqp_hip_sparse_destroy(sb);
-    if (rc) { ret = SUBPROBLEM_SOLVER_ERROR; return true; }
-    stats.updateIterTotal(st.iterTotal); stats.updateIterOuter(st.iterOuter); stats.updateSubproblemIter(st.subproblemIter);
-    stats.updateRhoOpt(st.rhoOpt); stats.updateQPSolverExitFlag(st.qpSolverExitFlag);
-    algoStat = (AlgorithmStatus)st.status;
-    stats.updateSolutionStatus(algoStat);
-    ret = (ReturnValue)st.returnValue;
+    lastEngine = ENGINE_SPARSE_DEVICE;
     return true;
 }
 
@@ -382,10 +398,19 @@ ReturnValue LCQProblem::runSolver()
 {
     const QPSolver arm = options.getQPSolver();
     const bool deviceLoop = (arm == HIP_DENSE && !hostLoop);
-    ReturnValue ret = initializeSolver(!deviceLoop);
+    lastEngine = ENGINE_NONE;
+    // the sparse engine is tried before anything dense is built for the OSQP_SPARSE arm (no dense copies of a 4096-variable problem, no
+    // dense plugin object that would go unused)
+    const bool trySparse = (arm == OSQP_SPARSE && !hostLoop && sparseSolver);
+    ReturnValue ret = initializeSolver(!(deviceLoop || trySparse));
     if (ret != SUCCESSFUL_RETURN) return ret;
-    if (deviceLoop) return runOnDevice();
-    if (arm == OSQP_SPARSE && !hostLoop && runSparseOnDevice(ret)) return ret;
+    if (deviceLoop) { lastEngine = ENGINE_DENSE_DEVICE; return runOnDevice(); }
+    if (trySparse) {
+        if (runSparseOnDevice(ret)) return ret;
+        ret = initializeSolver(true);      // not a pattern for the sparse engine: the host loop over the dense kernels
+        if (ret != SUCCESSFUL_RETURN) return ret;
+    }
+    lastEngine = ENGINE_HOST_LOOP;
     if (options.getSolveZeroPenaltyFirst()) gk = g;
     else updateLinearization();
     ret = solveQPSubproblem(true);

@@ -55,6 +55,10 @@ class LCQProblem {
     // HIP_DENSE runs the whole homotopy on the device (a batch of one through lcqp_hip_batch_*); the reference's three solver values keep
     // the reference's host loop over the subsolver plugin.  hostLoop = true forces the host loop for HIP_DENSE too.
     void setHostLoop(bool hostLoop_) { hostLoop = hostLoop_; }
+    // which engine the last runSolver used: 0 none yet, 1 the reference's host loop over the subsolver plugin, 2 the whole homotopy on the
+    // device (dense kernels, k_lcqp_run), 3 the sparse engine (k_sparse_run)
+    enum Engine { ENGINE_NONE = 0, ENGINE_HOST_LOOP = 1, ENGINE_DENSE_DEVICE = 2, ENGINE_SPARSE_DEVICE = 3 };
+    int getLastEngine() const { return lastEngine; }
 
   private:
     ReturnValue initializeSolver(bool needSubsolver = true);
@@ -88,6 +92,7 @@ class LCQProblem {
 
     int nV, nC, nComp, nDuals, boxDualOffset, device;
     bool loaded, haveYk, haveLbL, haveLbR, haveBox, sparseSolver, hostLoop;
+    int lastEngine = ENGINE_NONE;
     std::vector<double> y0Full, ysub;   // y0 as loaded (reference layout nV + nC + 2 nComp); subsolver dual vector (box duals first)
     csc *Q_sparse, *A_sparse, *L_sparse, *R_sparse, *C_sparse;
     std::vector<double> Q, g, L, R, A, lbA, ubA, lb, ub, lbL, lbR, C, Qk;

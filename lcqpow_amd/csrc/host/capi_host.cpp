@@ -107,6 +107,7 @@ void lcqp_host_problem_destroy(lcqp_host_problem_t* p) { delete p; }
 
 void lcqp_host_problem_set_device(lcqp_host_problem_t* p, int device) { if (p) p->lcqp.setDevice(device); }
 void lcqp_host_problem_set_host_loop(lcqp_host_problem_t* p, int hostLoop) { if (p) p->lcqp.setHostLoop(hostLoop != 0); }
+int lcqp_host_problem_last_engine(const lcqp_host_problem_t* p) { return p ? p->lcqp.getLastEngine() : 0; }
 
 void lcqp_host_problem_set_options(lcqp_host_problem_t* p, const lcqp_host_options_t* o)
 {

@@ -473,7 +473,7 @@ __device__ __forceinline__ int ti_bulk(Ctx<NCH>& c, int na, double tau, int& nT,
                 ii[u] = i; jj[u] = j;
                 const bool in = (e0 + u * WG < tot) && (j <= i);
                 v[u] = (i == j) ? 1.0 : 0.0;
-                if (in && i < na) v[u] = c.MM[(size_t)idx[i] * mMld + idx[j]];
+                if (in && i < na) { const int ri = idx[i], rj = idx[j]; v[u] = c.MM[(size_t)max(ri, rj) * mMld + min(ri, rj)]; }      // M holds its lower triangle
                 if (!in) ii[u] = -1;
                 j += WG; while (j >= nn) { j -= nn; i++; }
             }
@@ -552,16 +552,16 @@ __device__ __forceinline__ int ti_append(Ctx<NCH>& c, int r, double tau, int cap
     double *sv = c.Sv(S_SV), *wv = c.Sv(S_W);
     int *idx = c.idx, *rslot = c.I(I_SLOT);
     double* Ti = c.S;
-    const double* Mr = c.MM + (size_t)r * c.db->mMld;
+    const int mMld = c.db->mMld;
     const int nsp = 64 * ((ns + 63) >> 6);
     int freeSlot = 1 << 30;
     for (int sl = t; sl < nsp; sl += WG) {
         const int rr = (sl < ns) ? idx[sl] : -2;
-        sv[sl] = (rr >= 0) ? Mr[rr] : 0.0;
+        sv[sl] = (rr >= 0) ? c.MM[(size_t)max(r, rr) * mMld + min(r, rr)] : 0.0;      // M holds its lower triangle
         if (rr == -1) freeSlot = min(freeSlot, sl);
     }
     __syncthreads();
-    double d2 = Mr[r];
+    double d2 = c.MM[(size_t)r * mMld + r];
     const double srr = uniform_d(d2);
     if (nT > 0) {
         ti_apply<NCH>(c, sv, wv, nT, ns);
@@ -970,7 +970,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                 const int r = (a < nsl) ? idx[a] : -1;
                 if (r >= 0) {
                     const double bb = (st[r] == ST_UPPER) ? u[r] : l[r];
-                    for (int k = 0; k < nl; k++) { const int rl = list[k]; v += ylv[rl] * c.MM[(size_t)rl * mMld + r]; }
+                    for (int k = 0; k < nl; k++) { const int rl = list[k]; v += ylv[rl] * c.MM[(size_t)max(rl, r) * mMld + min(rl, r)]; }
                     v -= bb - ex[r];
                 }
                 dy[a] = v;

@@ -447,7 +447,7 @@ static int launch_setup(lcqp_hip_batch* h)
     if (d.nComp > 0) { dispatch_db(h, ID_k_build_C, d.B * ntile); dispatch_db(h, ID_k_compress_C, d.B); }
     dispatch_db(h, ID_k_factor, d.B);
     dispatch_db(h, ID_k_trsm, d.B * ((d.mEcap + 63) / 64));
-    { const int nb = d.mMld / 64; dispatch_db(h, ID_k_build_M, d.B * (nb * (nb + 1) / 2)); }
+    { const int nb = (d.mMld + 127) / 128; dispatch_db(h, ID_k_build_M, d.B * (nb * (nb + 1) / 2)); }      // 128 x 128 tiles of the lower triangle
     HIPCHK(hipGetLastError());
     h->setupDone = true;
     return 0;

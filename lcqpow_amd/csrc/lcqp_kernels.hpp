@@ -260,32 +260,78 @@ __global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
     }
 }
 
-// ---- k_build_M: M = Et Et' (lower 64x64 tiles, mirrored): every entry of every working-set matrix S_W = Et_W Et_W' ------------
-// (fp64 MFMA tiles; replaces the Gram products the subsolver used to repeat at every working-set change)
+// ---- k_build_M: M = Et Et', every entry of every working-set matrix S_W = Et_W Et_W' (lower triangle; readers take M[max][min]) ----
+// fp64 MFMA, 128 x 128 output tiles (round 3; round 2: 64 x 64 tiles through wg_tile_nt, 35 TFLOP/s): the four waves own the four
+// 64 x 64 quadrants as 4 x 4 blocks of v_mfma_f64_16x16x4_f64, so that one 16-deep panel pair in LDS (k-major, pitch 144 doubles:
+// conflict-free operand reads) feeds 64 MFMAs per wave between two barriers, and every operand read from LDS is used four times.
+// The panels of step k + 16 are fetched into registers while the products of step k run.  Diagonal tiles use one panel for both operands.
 template <int NCH>
 __global__ __launch_bounds__(WG) void k_build_M(DevBatch db)
 {
-    LCQP_LDS_N(NCH)
     constexpr int np = 128 * NCH;
-    const int nb = db.mMld / 64, ntile = nb * (nb + 1) / 2;
+    constexpr int P = 144;
+    __shared__ double As[16 * P], Bs[16 * P];
+    const int nb = (db.mMld + 127) / 128, ntile = nb * (nb + 1) / 2;
     const int b = blockIdx.x / ntile, tIdx = blockIdx.x % ntile;
     int I, J;
     tri_tile(tIdx, I, J);
-    const InstInfo* info = db.info + b;
-    const int mE = info->mE;
-    if (64 * J >= mE) return;       // I >= J: both row blocks beyond the rows in use
+    const int mE = db.info[b].mE, ld = db.mMld;
+    if (128 * J >= mE) return;       // I >= J: both row blocks beyond the rows in use
     const double* Et = db.Et + (size_t)b * db.mEcap * np;
-    double* M = db.MM + (size_t)b * db.mMld * db.mMld;
-    double acc[4][4];
-    wg_tile_nt(acc, Et, np, [=](int r) { return (long)(64 * I + r < mE ? 64 * I + r : -1); },
-               Et, np, [=](int r) { return (long)(64 * J + r < mE ? 64 * J + r : -1); }, np, lds);
+    double* M = db.MM + (size_t)b * ld * ld;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, wy = w >> 1, wx = w & 1;
+    const int lr = t >> 1, kh = (t & 1) * 8;      // loader: row lr of the tile, eight consecutive k
+    const bool diag = (I == J);
+    const double* ap = (128 * I + lr < mE) ? Et + (size_t)(128 * I + lr) * np + kh : nullptr;
+    const double* bp = (!diag && 128 * J + lr < mE) ? Et + (size_t)(128 * J + lr) * np + kh : nullptr;
+    d4_t acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int gi = 64 * I + tile_li(i, j), gj = 64 * J + tile_lj(i, j);
-            M[(size_t)gi * db.mMld + gj] = acc[i][j];
-            if (I != J) M[(size_t)gj * db.mMld + gi] = acc[i][j];      // inside a diagonal tile both (i,j) and (j,i) are computed
+        for (int j = 0; j < 4; j++) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+    double2 ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            ra[q] = ap ? *reinterpret_cast<const double2*>(ap + k0 + 2 * q) : double2{0.0, 0.0};
+            rb[q] = bp ? *reinterpret_cast<const double2*>(bp + k0 + 2 * q) : double2{0.0, 0.0};
+        }
+    };
+    fetch(0);
+    const double* Bsrc = diag ? As : Bs;
+    for (int k0 = 0; k0 < np; k0 += 16) {
+        __syncthreads();      // the panels of the last step are consumed
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            As[(kh + 2 * q) * P + lr] = ra[q].x; As[(kh + 2 * q + 1) * P + lr] = ra[q].y;
+            if (!diag) { Bs[(kh + 2 * q) * P + lr] = rb[q].x; Bs[(kh + 2 * q + 1) * P + lr] = rb[q].y; }
+        }
+        __syncthreads();
+        if (k0 + 16 < np) fetch(k0 + 16);
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) {
+            const int ko = (4 * k4 + (lane >> 4)) * P + (lane & 15);
+            double av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { av[i] = As[ko + 64 * wy + 16 * i]; bv[i] = Bsrc[ko + 64 * wx + 16 * i]; }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // block (i, j), accumulator register q: row 16 i + (lane >> 4) + 4 q, column 16 j + (lane & 15)   (C/D layout of the f64 MFMA)
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int gi = 128 * I + 64 * wy + 16 * i + (lane >> 4) + 4 * q;
+            if (gi >= ld) continue;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int gj = 128 * J + 64 * wx + 16 * j + (lane & 15);
+                if (gj < ld) M[(size_t)gi * ld + gj] = acc[i][j][q];
+            }
         }
 }
 

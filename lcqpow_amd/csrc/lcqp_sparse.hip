@@ -74,6 +74,11 @@ struct SpBatch {
     SpInfo* info;
     lcqp_stats_t* stats;
     double *xout, *yout;     // [B][n], [B][m]
+    // per-iterate tracking (options.storeSteps, src/LCQProblem.cpp:1365-1378), as on the dense path: [B][traceCap][8] = (|statk|inf, phi, rho,
+    // alphak, obj, merit, |pk|inf, QP iterations), [B][traceCap][n] = xk, traceLen[B]; traceCap == 0: not allocated
+    double *traceS, *traceX;
+    int* traceLen;
+    int traceCap;
 };
 
 // ---- addressing: uniform base pointer + 32-bit lane offset -------------------------------------------------------------------------
@@ -921,6 +926,7 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_run(SpBatch d
     int rc = 0, qpIter = 0, histLen = 0, algoStat = 0, totalIter = 0;
     double alphak = 1.0, rho = o.initialPenaltyParameter;
     uint64_t perturbCounter = 0;
+    if (db.traceCap > 0 && t == 0) db.traceLen[c.b] = 0;     // a run that records nothing leaves an empty trace
     { GD x0 = c.V(NV_X0);
       g_map<G, 8>(n, t, [&](int i) { return D2{x0[i], g[i]}; }, [&](int i, D2 v) { xk[i] = v.a; gtil[i] = v.b; }); }
     g_sync();
@@ -979,6 +985,19 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_run(SpBatch d
         // updateStationarity without a box term: statk = Qk xk + g_tilde - E'yk
         const double statMax = sp_ETy<G>(c, yk, tmp, [&](int i) { return D3{Qx[i], Cx[i], gtil[i]}; }, [&](D3 v) { return (v.a + rho * v.b) + v.c; });
         const double statInf = statMax;
+        if (db.traceCap > 0 && totalIter < db.traceCap) {   // storeSteps :488-490, printIteration :1528-1576 (the host rebuilds both from this)
+            const double phiNow = getPhi();
+            double so = 0.0, sm = 0.0, pm = 0.0;
+            for (int i = t; i < n; i += G) { const double xv = xk[i]; so += g[i] * xv + 0.5 * xv * Qx[i]; sm += 0.5 * rho * xv * Cx[i]; pm = fmax(pm, fabs(pk[i])); }
+            const double objNow = g_sum<G>(so), meritNow = objNow + g_sum<G>(sm), stepNow = g_max<G>(pm);
+            double* ts = db.traceS + ((size_t)c.b * db.traceCap + totalIter) * 8;
+            double* tx = db.traceX + ((size_t)c.b * db.traceCap + totalIter) * n;
+            if (t == 0) {
+                ts[0] = statInf; ts[1] = phiNow; ts[2] = rho; ts[3] = alphak; ts[4] = objNow; ts[5] = meritNow; ts[6] = stepNow; ts[7] = (double)qpIter;
+                db.traceLen[c.b] = totalIter + 1;
+            }
+            for (int i = t; i < n; i += G) tx[i] = xk[i];
+        }
         totalIter++; st.iterTotal++;
         bool leyffer = false;
         const int nd = o.nDynamicPenalty;
@@ -1220,6 +1239,35 @@ extern "C" int lcqp_hip_sparse_set_options(lcqp_hip_sparse_t* h, const lcqp_opti
     if (!h || !opt) return LCQP_INVALID_ARGUMENT;
     if (opt->nDynamicPenalty > 64) { g_sp_err = "nDynamicPenalty > 64 unsupported"; return LCQP_HIP_UNSUPPORTED; }
     h->db.opt = *opt;
+    // per-iterate tracking buffers, sized once for the largest trace this handle is asked for
+    const int want = opt->storeSteps ? std::min(std::max(opt->maxIterations + 1, 1), 4096) : 0;
+    if (want > h->db.traceCap) {
+        if (hipSetDevice(h->device) != hipSuccess) { g_sp_err = "hipSetDevice failed"; return LCQP_HIP_ERROR; }
+        SpBatch& d = h->db;
+        double *ts = sp_alloc<double>(h, (size_t)d.B * want * 8), *tx = sp_alloc<double>(h, (size_t)d.B * want * d.n);
+        int* tl = sp_alloc<int>(h, (size_t)d.B);
+        if (!ts || !tx || !tl) { g_sp_err = "out of device memory for the iterate trace"; return LCQP_HIP_ERROR; }
+        d.traceS = ts; d.traceX = tx; d.traceLen = tl; d.traceCap = want;
+    }
+    return 0;
+}
+
+/* per-iterate trace of one instance of the last run (needs options.storeSteps), as lcqp_hip_batch_get_trace */
+extern "C" int lcqp_hip_sparse_get_trace(lcqp_hip_sparse_t* h, int instance, int cap, double* scalars, double* x, int* len)
+{
+    if (!h || !len) return LCQP_INVALID_ARGUMENT;
+    SpBatch& d = h->db;
+    *len = 0;
+    if (instance < 0 || instance >= d.B) return LCQP_INVALID_ARGUMENT;
+    if (d.traceCap == 0) return 0;
+    SPCHK(hipSetDevice(h->device));
+    SPCHK(hipStreamSynchronize(h->stream));
+    int n = 0;
+    SPCHK(hipMemcpy(&n, d.traceLen + instance, sizeof(int), hipMemcpyDeviceToHost));
+    n = std::min(n, std::min(cap, d.traceCap));
+    if (n > 0 && scalars) SPCHK(hipMemcpy(scalars, d.traceS + (size_t)instance * d.traceCap * 8, sizeof(double) * 8 * n, hipMemcpyDeviceToHost));
+    if (n > 0 && x) SPCHK(hipMemcpy(x, d.traceX + (size_t)instance * d.traceCap * d.n, sizeof(double) * (size_t)d.n * n, hipMemcpyDeviceToHost));
+    *len = n;
     return 0;
 }
 

@@ -138,6 +138,7 @@ def _host():
         L.lcqp_host_problem_destroy.argtypes = [vp]
         L.lcqp_host_problem_set_device.argtypes = [vp, C.c_int]
         L.lcqp_host_problem_set_host_loop.argtypes = [vp, C.c_int]
+        L.lcqp_host_problem_last_engine.argtypes = [vp]
         L.lcqp_host_problem_set_options.argtypes = [vp, vp]
         L.lcqp_host_problem_load_dense.argtypes = [vp] + [_dp] * 15
         cp = C.POINTER(_CscArg)
@@ -318,6 +319,11 @@ class LCQProblem:
         """QPSolver.HIP_DENSE runs the whole homotopy on the device; True keeps the reference's host loop over the SubsolverHIP plugin
         for it too (no reference analogue; the reference's three solver values always use the host loop)"""
         _host().lcqp_host_problem_set_host_loop(self._h, int(bool(host_loop)))
+
+    def getLastEngine(self):
+        """which engine the last runSolver used: 0 none yet, 1 host loop over the subsolver plugin, 2 whole homotopy on the device (dense
+        kernels), 3 the sparse engine (no reference analogue)"""
+        return int(_host().lcqp_host_problem_last_engine(self._h))
 
     def loadLCQP(self, Q=None, g=None, L=None, R=None, lbL=None, ubL=None, lbR=None, ubR=None, A=None, lbA=None, ubA=None,
                  lb=None, ub=None, x0=None, y0=None, *, order="F",

@@ -160,49 +160,26 @@ def branch_qp_solution(O, d, x, tol=1e-7):
 
 
 # ---- sparse synthetic workload (BASELINE config 5): banded, OCP-like, one pattern for the whole batch ------------------------------
-SPARSE_SEED0 = 0x4C43515000000005
+from lcqpow_amd.synth_sparse import SPARSE_SEED0  # noqa: E402
 
 
 def sparse_pattern(n=4096, nC=2048, nComp=512, span=6):
-    """Pattern of the sparse synthetic LCQPs: Q tridiagonal; row r of A touches the `span` (6) variables around 2 r (n = 2 nC);
-    complementarity pairs L_i = e_{8 i}, R_i = e_{8 i + 4} (n = 8 nComp).  Returns scipy CSC matrices of ones (Q, stacked [A; L; R])."""
+    """Pattern of the sparse synthetic LCQPs (lcqpow_amd/synth_sparse.py, the one definition of the workload) as scipy CSC matrices
+    of ones: (Q, stacked [A; L; R])."""
     import scipy.sparse as sp
-    assert n >= 2 * nC and n >= 8 * nComp and n >= max(8, span)
-    qi = np.concatenate([np.arange(n), np.arange(n - 1), np.arange(1, n)])
-    qj = np.concatenate([np.arange(n), np.arange(1, n), np.arange(n - 1)])
-    Q = sp.csc_matrix((np.ones(qi.size), (qi, qj)), shape=(n, n))
-    c0 = np.clip(2 * np.arange(nC) - 2, 0, n - span)
-    ai = np.repeat(np.arange(nC), span); aj = (c0[:, None] + np.arange(span)[None, :]).ravel()
-    li = nC + np.arange(nComp); lj = 8 * np.arange(nComp)
-    ri = nC + nComp + np.arange(nComp); rj = 8 * np.arange(nComp) + 4
-    A = sp.csc_matrix((np.ones(ai.size + 2 * nComp), (np.concatenate([ai, li, ri]), np.concatenate([aj, lj, rj]))), shape=(nC + 2 * nComp, n))
-    Q.sort_indices(); A.sort_indices()
-    return Q, A
+    from lcqpow_amd import synth_sparse as S
+    Qp, Ep, _, _ = S.sparse_pattern_arrays(n, nC, nComp, span)
+    mk = lambda pt: sp.csc_matrix((np.ones(pt.nnz), pt.indices, pt.indptr), shape=pt.shape)
+    return mk(Qp), mk(Ep)
 
 
 def sparse_instance(inst, n=4096, nC=2048, nComp=512, seed0=SPARSE_SEED0, span=6):
-    """Values of instance `inst` (numpy PCG64 seeded with seed0 ^ inst): Q = B'B + I with B upper bidiagonal (SPD, tridiagonal),
-    g in U(-1,1), A values U(-1,1)/sqrt(6), bounds strictly feasible around a point x* that satisfies the complementarities.
-    Returns dict(Q, E (scipy CSR/CSC with values), g, lbA, ubA, nV, nC, nComp)."""
+    """Instance `inst` of the sparse synthetic workload (lcqpow_amd/synth_sparse.py) with scipy matrices:
+    dict(Q, E (CSC with values), g, lbA, ubA, nV, nC, nComp)."""
     import scipy.sparse as sp
-    rng = np.random.Generator(np.random.PCG64(seed0 ^ inst))
-    a = rng.uniform(0.5, 1.5, n); bq = rng.uniform(-0.5, 0.5, n - 1)
-    dq = a * a + 1.0; dq[1:] += bq * bq
-    off = a[:-1] * bq
-    Q = sp.diags([off, dq, off], [-1, 0, 1], format="csc")
-    g = rng.uniform(-1, 1, n)
-    xs = rng.uniform(-1, 1, n)
-    coin = rng.integers(0, 2, nComp)
-    xs[8 * np.arange(nComp)] = np.where(coin == 0, 0.0, rng.uniform(0, 1, nComp))
-    xs[8 * np.arange(nComp) + 4] = np.where(coin == 0, rng.uniform(0, 1, nComp), 0.0)
-    c0 = np.clip(2 * np.arange(nC) - 2, 0, n - span)
-    av = rng.uniform(-1, 1, (nC, span)) / np.sqrt(float(span))
-    ai = np.repeat(np.arange(nC), span); aj = (c0[:, None] + np.arange(span)[None, :]).ravel()
-    A = sp.csr_matrix((av.ravel(), (ai, aj)), shape=(nC, n))
-    ax = A @ xs
-    lbA = ax - rng.uniform(0.1, 1.0, nC); ubA = ax + rng.uniform(0.1, 1.0, nC)
-    L = sp.csr_matrix((np.ones(nComp), (np.arange(nComp), 8 * np.arange(nComp))), shape=(nComp, n))
-    R = sp.csr_matrix((np.ones(nComp), (np.arange(nComp), 8 * np.arange(nComp) + 4)), shape=(nComp, n))
-    E = sp.vstack([A, L, R], format="csc")
-    Q.sort_indices(); E.sort_indices()
-    return dict(Q=Q, E=E, g=g, lbA=lbA, ubA=ubA, nV=n, nC=nC, nComp=nComp)
+    from lcqpow_amd import synth_sparse as S
+    Qp, Ep, qo, eo = S.sparse_pattern_arrays(n, nC, nComp, span)
+    v = S.sparse_values(inst, n, nC, nComp, seed0=seed0, span=span, orders=(qo, eo))
+    Q = sp.csc_matrix((v["Qx"], Qp.indices, Qp.indptr), shape=Qp.shape)
+    E = sp.csc_matrix((v["Ex"], Ep.indices, Ep.indptr), shape=Ep.shape)
+    return dict(Q=Q, E=E, g=v["g"], lbA=v["lbA"], ubA=v["ubA"], nV=n, nC=nC, nComp=nComp)

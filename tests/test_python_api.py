@@ -368,3 +368,39 @@ def test_python_option_sweep_host_loop(hip, oracle, kw):
                 assert np.abs(x - ro["x"]).max() < 1e-7 and int(stats.getSolutionStatus()) == so["status"]
     finally:
         oracle.lcqp_set_robust(1)
+
+
+@pytest.mark.gpu
+def test_python_osqp_sparse_runs_on_the_sparse_engine(hip, oracle, capfd):
+    """A banded n = 512 problem through LCQProblem with the reference's OSQP_SPARSE arm and the reference's DEFAULT print level
+    (INNER_LOOP_ITERATES, src/Options.cpp:312) plus storeSteps: the sparse engine runs (not the densified host loop), matches the
+    sparse oracle, the iteration table of src/LCQProblem.cpp:1528-1576 is printed from the device trace and the tracking vectors
+    of src/OutputStatistics.cpp:131-164 are filled from it."""
+    lcqpow = _lcqpow()
+    n, nC, nK = 512, 256, 64
+    Qp, Ap = P.sparse_pattern(n, nC, nK)
+    d = P.sparse_instance(3, n, nC, nK)
+    ro = oracle.sparse_lcqp_solve(n, nC, nK, d["Q"].tocsr(), d["g"], d["E"].tocsr(), lbA=d["lbA"], ubA=d["ubA"], opt=oracle.default_options(perturbStep=0))
+    E = d["E"].tocsc(); Q = d["Q"].tocsc()
+    A, L, R = E[:nC].tocsc(), E[nC:nC + nK].tocsc(), E[nC + nK:].tocsc()
+    w = lambda M: lcqpow.cscWrapper(M.shape[0], M.shape[1], M.nnz, np.asarray(M.data, dtype=float), M.indices, M.indptr)
+    lcqp = lcqpow.LCQProblem(nV=n, nC=nC, nComp=nK)
+    options = lcqpow.Options()
+    options.setPerturbStep(False)
+    options.setQPSolver(lcqpow.QPSolver.OSQP_SPARSE)
+    options.setStoreSteps(True)                       # print level stays the reference's default
+    lcqp.setOptions(options)
+    assert lcqp.loadLCQP(Q=w(Q), g=d["g"], L=w(L), R=w(R), A=w(A), lbA=d["lbA"], ubA=d["ubA"]) == 0
+    assert lcqp.getLastEngine() == 0
+    assert lcqp.runSolver() == ro["ret"] == 0
+    assert lcqp.getLastEngine() == 3                  # the sparse engine, not the densified host loop
+    assert np.abs(lcqp.getPrimalSolution() - ro["x"]).max() < 1e-9
+    assert np.abs(lcqp.getDualSolution() - ro["y"]).max() < 1e-7
+    stats = lcqpow.OutputStatistics()
+    lcqp.getOutputStatistics(stats)
+    assert abs(stats.getIterTotal() - ro["stats"]["iterTotal"]) <= 4 and stats.getSolutionStatus() == ro["stats"]["status"]
+    out = capfd.readouterr().out
+    assert " outer |  inner |   station  |   complem  |     rho    |   norm p   |    alpha   | sub it" in out
+    assert len([ln for ln in out.splitlines() if ln.strip() and ln.lstrip()[0].isdigit()]) == stats.getIterTotal()
+    xs = stats.getxSteps()
+    assert len(xs) == stats.getIterTotal() and np.abs(np.asarray(xs[-1]) - lcqp.getPrimalSolution()).max() < 1e-12

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$1
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-D="--cpu-sample 0 --no-pipelined --no-resident --no-backsolve"
+D="--cpu-sample 0 --no-pipelined --no-resident --no-backsolve --no-sparse"
 rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 $D > $O/bench_under_rocprof.json 2>> $O/rocprof.err
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $D > /dev/null 2>> $O/rocprof.err
 rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $D > /dev/null 2>> $O/rocprof.err
