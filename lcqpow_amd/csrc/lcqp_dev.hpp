@@ -683,7 +683,7 @@ __device__ __forceinline__ void ti_delete(Ctx<NCH>& c, int p, int& nT, int& ns)
 // reuse != 0 (hot start from the last verified solution): the first trial needs no sweep, because
 // r1 = r1_last + (g_last - g) and E x = ex_last hold exactly for an unchanged (x, y).
 // ---------------------------------------------------------------------------------------------
-template <int NCH, bool ROBUST>
+template <int NCH, bool ROBUST, bool LR>
 __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse, double gs)
 {
     constexpr int np = 128 * NCH;
@@ -697,9 +697,13 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
     double *x = c.V(V_XT), *r1 = c.V(V_R1), *cv = c.V(V_C), *du = c.V(V_DU), *qx = c.V(V_TMP), *xs = c.V(V_XS);
     double* xref = c.V(V_XREF);
     const double spv = uniform_d(c.info->spv);
-    double *yt = c.M(M_YT), *ex = c.M(M_EX), *ylv = c.M(M_YLV), *rn = c.M(M_RN), *mg = c.M(M_MG);
+    // LR: multipliers, E x, margins and status of the rows live in LDS for the whole launch (lcqp_wg.hpp, LDS_ROWS_*)
+    double* yt = LR ? c.lds.arena + LDS_ROWS_OFF : c.M(M_YT);
+    double* ex = LR ? c.lds.arena + LDS_ROWS_OFF + LDS_ROWS_MAX : c.M(M_EX);
+    double* mg = LR ? c.lds.arena + LDS_ROWS_OFF + 2 * LDS_ROWS_MAX : c.M(M_MG);
+    int* st = LR ? reinterpret_cast<int*>(c.lds.arena + LDS_ROWS_OFF + 3 * LDS_ROWS_MAX) : c.I(I_STT);
+    double *ylv = c.M(M_YLV), *rn = c.M(M_RN);
     const double *l = c.M(M_L), *u = c.M(M_U);
-    int* st = c.I(I_STT);
     int *dep = c.I(I_DEP), *prio = c.I(I_PRIO), *list = c.I(I_LIST), *rslot = c.I(I_SLOT);
     double *r2 = c.Sv(S_R2), *dy = c.Sv(S_DY);
     int* idx = c.idx;
@@ -888,7 +892,18 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                     for (int stamp = prioCtr; stamp >= 1; stamp--)
                         na2 += wg_compact(mE, [&](int r) { return st[r] != ST_INACT && prio[r] == stamp; }, idx + na2, c.lds);
                 na2 += wg_compact(mE, [&](int r) { return st[r] != ST_INACT && (!ROBUST || prioCtr == 0 || prio[r] == 0); }, idx + na2, c.lds);
+                if (LR) {      // the Cholesky tile of the one-piece rebuild takes the whole arena: the row state waits in its global arrays
+                    double *gyt = c.M(M_YT), *gex = c.M(M_EX), *gmg = c.M(M_MG); int* gst = c.I(I_STT);
+                    for (int r = t; r < mE; r += WG) { gyt[r] = yt[r]; gex[r] = ex[r]; gmg[r] = mg[r]; gst[r] = st[r]; }
+                    __syncthreads();
+                }
                 ndepNow = ti_bulk<NCH>(c, na2, o.depTau, nT, ns);
+                if (LR) {
+                    const double *gyt = c.M(M_YT), *gex = c.M(M_EX), *gmg = c.M(M_MG); const int* gst = c.I(I_STT);
+                    __syncthreads();
+                    for (int r = t; r < mE; r += WG) { yt[r] = gyt[r]; ex[r] = gex[r]; mg[r] = gmg[r]; st[r] = gst[r]; }
+                    __syncthreads();
+                }
                 touched = 1;
                 PROF(c, P_GRAM);
 #ifdef LCQP_PROFILE
@@ -1013,7 +1028,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
 // Returns 0, or the exit flag (1 max rounds, 2 infeasible bounds, 3 setup failure).
 // ---------------------------------------------------------------------------------------------
 // ADAPT: rho adaptation between fallback rounds (qp_adapt_rho); on in every kernel (the switch stays for A/B builds).
-template <int NCH, bool ROBUST, bool ADAPT>
+template <int NCH, bool ROBUST, bool ADAPT, bool LR = false>
 __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* g, const double* y0ref, int* iterations, double gmaxHint = -1.0, int checkBounds = 1)
 {
     constexpr int np = 128 * NCH;
@@ -1023,9 +1038,11 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
     *iterations = 0;
     if (c.info->setupFail) return 3;
     double *xq = c.V(V_XQ), *xa = c.V(V_XA), *xt = c.V(V_XT);
-    double *yq = c.M(M_YQ), *ya = c.M(M_YA), *za = c.M(M_ZA), *yt = c.M(M_YT), *ex = c.M(M_EX);
+    double *yq = c.M(M_YQ), *ya = c.M(M_YA), *za = c.M(M_ZA), *ex = c.M(M_EX);      // (M_EX here: scratch of the ADMM start)
+    double* yt = LR ? c.lds.arena + LDS_ROWS_OFF : c.M(M_YT);                               // working multipliers / working set of the polish
+    int* stt = LR ? reinterpret_cast<int*>(c.lds.arena + LDS_ROWS_OFF + 3 * LDS_ROWS_MAX) : c.I(I_STT);
     const double *l = c.M(M_L), *u = c.M(M_U), *rhov = c.M(M_RHOV);
-    int *st = c.I(I_ST), *stt = c.I(I_STT);
+    int* st = c.I(I_ST);
     if (checkBounds) {      // (a homotopy checks once: its bounds do not change between the QPs)
         int bad = 0;
         wg_map<4>(mE, [&](int r) { return MapD4{l[r], u[r], 0.0, 0.0}; }, [&](int, MapD4 v) { bad |= (v.a > v.b); });
@@ -1087,7 +1104,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         }
         for (int i = t; i < np; i += WG) xt[i] = xa[i];
         __syncthreads();
-        if (qp_polish<NCH, ROBUST>(c, g, round == 0 && use_stored, gsc)) { solved = 1; break; }
+        if (qp_polish<NCH, ROBUST, LR>(c, g, round == 0 && use_stored, gsc)) { solved = 1; break; }
         if (ADAPT && round >= 1 && n_admm > 0) qp_adapt_rho<NCH>(c, g);
         if (round >= 2) {    // at least 20 ADMM iterations behind us: is the QP infeasible or unbounded?
             certificate = qp_certificate<NCH>(c, g);
@@ -1124,7 +1141,7 @@ __device__ __forceinline__ void qp_export(Ctx<NCH>& c, double* xdst /*np or n*/,
 // ---------------------------------------------------------------------------------------------
 // ROBUST selects the QP subsolver variant (qp_solve<NCH, ROBUST>): false in k_lcqp_run, true in k_lcqp_rerun, which repeats
 // the instances that ended with SUBPROBLEM_SOLVER_ERROR.
-template <int NCH, bool ROBUST>
+template <int NCH, bool ROBUST, bool LR = false>
 __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
 {
     constexpr int np = 128 * NCH;
@@ -1162,7 +1179,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     auto solveQP = [&](int initial) -> int {   // :1115-1148 (getSolution, yk_A and pk = xnew - xk follow in the fused pass / at the exit)
         const double* y0 = (initial && c.info->hasY0) ? db.y0 + (size_t)c.b * db.nd : nullptr;
         PROF(c, P_LCQP);
-        const int ef = qp_solve<NCH, ROBUST, true>(c, initial, gk, y0, &qpIter, gmax, /*checkBounds=*/initial);
+        const int ef = qp_solve<NCH, ROBUST, true, LR>(c, initial, gk, y0, &qpIter, gmax, /*checkBounds=*/initial);
         PROF(c, P_MISC);
         st.subproblemIter += qpIter;
         st.qpSolverExitFlag = ef;

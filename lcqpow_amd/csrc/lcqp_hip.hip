@@ -91,7 +91,7 @@ extern "C" void lcqp_hip_options_default(lcqp_options_t* o)
     o->admmRho = 0.1; o->admmSigma = 1e-6; o->admmAlpha = 1.6; o->rhoEqMult = 1e3;
     o->proxSmall = 1e-12; o->proxBig = 1e-8; o->pivotThreshold = 1e-7; o->depTau = 1e-12;
     o->feasTol = 1e-9; o->resTol = 1e-12;
-    o->admmFirst = 0; o->admmHot = 0; o->maxTrials = 12; o->maxRounds = 40;
+    o->admmFirst = 0; o->admmHot = 0; o->maxTrials = 16; o->maxRounds = 40;      // maxTrials: 12 until round 3 -- cold starts of the synthetic workload need up to 14 trials, and a polish that runs out of trials costs an ADMM round (the factor L_K, ten iterations, a second cold polish): those instances were the tail of the launch
 }
 
 struct lcqp_hip_batch {

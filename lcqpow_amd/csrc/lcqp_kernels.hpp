@@ -339,13 +339,14 @@ __global__ __launch_bounds__(WG) void k_build_M(DevBatch db)
 #ifndef LCQP_MINWAVES
 #define LCQP_MINWAVES 4      // waves per SIMD the register allocation is held to (4 workgroups per CU)
 #endif
-template <int NCH>
+// LR: the row state of the subsolver lives in LDS (np <= 256 and at most LDS_ROWS_MAX rows of E; lcqp_wg.hpp)
+template <int NCH, bool LR>
 __global__ __launch_bounds__(WG, LCQP_MINWAVES) void k_lcqp_run(DevBatch db)
 {
     LCQP_LDS_N(NCH)
     Ctx<NCH> c = make_ctx<NCH>(db, blockIdx.x, lds);
-    lcqp_run<NCH, true>(c);      // with the dependent-row rules: since the factor is updated instead of rebuilt they cost nothing here
-                                 // (A/B 73.0 vs 72.0 ms, profiles/round2), so the batched loop and the per-QP path are ONE algorithm
+    lcqp_run<NCH, true, LR>(c);      // with the dependent-row rules: since the factor is updated instead of rebuilt they cost nothing here
+                                     // (A/B 73.0 vs 72.0 ms, profiles/round2), so the batched loop and the per-QP path are ONE algorithm
 }
 
 // ---- repeat the instances whose QP subsolver gave up (same algorithm as k_lcqp_run since round 2, from a clean subsolver state;
@@ -516,7 +517,13 @@ static void launch_impl(int kid, int grid, hipStream_t s, const LaunchArgs& a)
         case ID_k_factor:     hipLaunchKernelGGL((k_factor<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_trsm:       hipLaunchKernelGGL((k_trsm<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_build_M:    hipLaunchKernelGGL((k_build_M<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
-        case ID_k_lcqp_run:   hipLaunchKernelGGL((k_lcqp_run<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
+        case ID_k_lcqp_run:
+#ifndef LCQP_NO_LDS_ROWS      // experiment switch: the row state in global memory for every size
+            if constexpr (NCH <= 2) {
+                if (a.db.mEcap <= LDS_ROWS_MAX) { hipLaunchKernelGGL((k_lcqp_run<NCH, true>), dim3(grid), dim3(WG), 0, s, a.db); break; }
+            }
+#endif
+            hipLaunchKernelGGL((k_lcqp_run<NCH, false>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_lcqp_rerun: hipLaunchKernelGGL((k_lcqp_rerun<NCH>), dim3(grid), dim3(WG), 0, s, a.db, a.list); break;
         case ID_k_qp_solve:   hipLaunchKernelGGL((k_qp_solve<NCH>), dim3(grid), dim3(WG), 0, s, a.db, a.initial); break;
         case ID_k_synth_fill: hipLaunchKernelGGL((k_synth_fill<NCH>), dim3(grid), dim3(WG), 0, s, a.db, a.seed0, a.first); break;

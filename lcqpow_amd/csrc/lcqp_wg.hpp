@@ -29,6 +29,16 @@ constexpr int LCQP_MAX_ACTIVE = max_active(4);
 
 enum { ST_INACT = 0, ST_LOWER = 1, ST_UPPER = 2, ST_EQ = 3 };
 
+// Row state of the subsolver kept in LDS by the homotopy kernel (round 3; np <= 256 and at most LDS_ROWS_MAX rows of E): multipliers,
+// E x, screening margins and status of every row live in arena[LDS_ROWS_OFF ..) for the whole launch -- the passes over them between
+// the sweeps are LDS passes instead of round trips through L2 (with 1024 instances per GPU the 170 KB of vectors per instance do not
+// stay in the 4 MiB L2 of an XCD).  Below LDS_ROWS_OFF the arena stays routine-private scratch (6 np doubles for the sweeps, 3 capS for
+// the rotations, 2048 for the widest pass over the inverse factor); the one user of the whole arena, the 64 x 64 tile of wg_chol, runs
+// between a save and a restore of the row state (qp_polish).
+constexpr int LDS_ROWS_MAX = 640;
+constexpr int LDS_ROWS_OFF = 2048;
+static_assert(LDS_ROWS_OFF + 3 * LDS_ROWS_MAX + LDS_ROWS_MAX / 2 <= 4512, "row state must fit the arena");
+
 struct Lds {
     double* arena;  // arena_doubles(NCH) doubles
     double* red;    // 16 doubles

@@ -43,7 +43,7 @@ void orc_options_default(orc_options_t* o)
     o->resTol = 1e-12;
     o->admmFirst = 0;
     o->admmHot = 0;
-    o->maxTrials = 12;
+    o->maxTrials = 16;   /* 12 until round 3: cold starts of the synthetic workload need up to 14 trials (lcqp_hip_options_default) */
     o->maxRounds = 40;
 }
 

@@ -168,11 +168,11 @@ def test_subsolver_warm_start_duals(hip, oracle):
 
 
 # ---- LCQProblem::loadLCQP / runSolver on the device ----------------------------------------------------
-def _cmp(ro, rh, xtol=X_TOL, ytol=Y_TOL, iters=True):
+def _cmp(ro, rh, xtol=X_TOL, ytol=Y_TOL, iters=True, status=True):
     assert rh["ret"] == ro["ret"]
     so, sh = ro["stats"], rh["stats"]
     if iters:
-        for k in ("iterTotal", "iterOuter", "status", "rhoOpt"):
+        for k in ("iterTotal", "iterOuter", "rhoOpt") + (("status",) if status else ()):
             assert so[k] == sh[k], (k, so, sh)
     if ro["ret"] == 0:
         assert np.abs(ro["x"] - rh["x"]).max() < xtol
@@ -189,7 +189,10 @@ def test_lcqp_reference_problems(hip, oracle, name):
         # box bounds duplicate complementarity rows in this fixture (lb = 0 on variables that L selects), so
         # the multipliers of the duplicated rows are not unique: compare x and the dual-dependent quantity
         # that is unique, the LCQP stationarity residual  Qx + g - A'y_A - L'y_L - R'y_R - y_box
-        _cmp(ro, rh, xtol=1e-7, ytol=np.inf)
+        # (the stationarity TYPE, src/LCQProblem.cpp:1412-1453, is read off the signs of the multipliers of L and R; on biactive pairs whose
+        # rows are duplicated by a box bound it depends on how the unique SUM is split between the duplicates -- S or W for the same point)
+        _cmp(ro, rh, xtol=1e-7, ytol=np.inf, status=False)
+        assert rh["stats"]["status"] in (1, 4) and ro["stats"]["status"] in (1, 4)
         n, nC, nComp = d["nV"], d["nC"], d["nComp"]
         for r in (ro, rh):
             yy = r["y"]
@@ -207,7 +210,8 @@ def test_lcqp_reference_problems(hip, oracle, name):
     else:
         _cmp(ro, rh, xtol=1e-7 if name != "warm_up_binary" else X_TOL, ytol=1e-5)
     s = GOLD[name + "_stats"]
-    assert [rh["ret"], rh["stats"]["iterTotal"], rh["stats"]["iterOuter"], rh["stats"]["status"]] == list(s[:4].astype(int))
+    nst = 3 if name == "example_data" else 4
+    assert [rh["ret"], rh["stats"]["iterTotal"], rh["stats"]["iterOuter"], rh["stats"]["status"]][:nst] == list(s[:nst].astype(int))
     assert np.abs(rh["x"] - GOLD[name + "_x"]).max() < 1e-7
     if name == "circle":     # examples/OptimizeOnCircle.cpp:144
         assert np.abs(rh["x"][:2] - [0.1811, -0.9835]).max() < 1e-4

@@ -8,6 +8,7 @@
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 GOLD = os.path.join(ROOT, "tests", "golden")
 os.makedirs(GOLD, exist_ok=True)
