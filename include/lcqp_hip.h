@@ -174,6 +174,10 @@ int lcqp_hip_util_symv(int batch, int n, double alpha, const double* A, const do
 int lcqp_hip_util_gemv_t(int batch, int m, int n, const double* A, const double* b, double* c);
 /* Utilities::MatrixMultiplication with p = 1, src/Utilities.cpp:38-47: c = A * b */
 int lcqp_hip_util_gemv(int batch, int m, int n, const double* A, const double* b, double* c);
+/* the row sweep of the subsolver's trials on its own (wg_rows through a row list, scalars indexed by row): for the nlist rows r = list[b][k]
+ * of every instance, dots[b][r] = A_r . x (other entries of dots stay) and outT[b] = sum_k coef[b][r] A_r; x, coef, dots, outT may be NULL */
+int lcqp_hip_util_rows_list(int batch, int m, int n, const double* A, const int* list, int nlist, const double* x, const double* coef,
+                            double* dots, double* outT);
 /* Utilities::MatrixSymmetrizationProduct, src/Utilities.cpp:104-116: C = A'B + B'A (A, B are m x n) */
 int lcqp_hip_util_symm_product(int batch, int m, int n, const double* A, const double* B, double* C);
 /* ---- CSC utilities on the device (host pointers, synchronous) ----

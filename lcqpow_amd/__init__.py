@@ -9,4 +9,4 @@ package is only ctypes plumbing: :mod:`lcqpow_amd.capi` binds ``include/lcqp_hip
 using them without the built libraries raises.
 """
 from .capi import (Options, Stats, BatchLCQP, SubsolverHIP, default_options, lib, library_path,  # noqa: F401
-                   util_symv, util_gemv, util_gemv_t, util_symm_product, chol_solve, device_count, CSCMatrix, SparseBatchLCQP)
+                   util_symv, util_gemv, util_gemv_t, util_symm_product, util_rows_list, chol_solve, device_count, CSCMatrix, SparseBatchLCQP)

@@ -91,6 +91,7 @@ def lib():
         L.lcqp_hip_util_gemv.argtypes = [C.c_int, C.c_int, C.c_int] + [c_double_p] * 3
         L.lcqp_hip_util_gemv_t.argtypes = [C.c_int, C.c_int, C.c_int] + [c_double_p] * 3
         L.lcqp_hip_util_symm_product.argtypes = [C.c_int, C.c_int, C.c_int] + [c_double_p] * 3
+        L.lcqp_hip_util_rows_list.argtypes = [C.c_int, C.c_int, C.c_int, c_double_p, C.POINTER(C.c_int), C.c_int] + [c_double_p] * 4
         L.lcqp_hip_csc_create.restype = C.c_void_p
         L.lcqp_hip_csc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), c_double_p, C.c_int]
         L.lcqp_hip_csc_destroy.argtypes = [C.c_void_p]
@@ -298,6 +299,18 @@ def util_gemv_t(A, b):
     c = np.zeros((batch, n))
     _check(lib().lcqp_hip_util_gemv_t(batch, m, n, _p(A), _p(b), _p(c)), "util_gemv_t")
     return c
+
+
+def util_rows_list(A, lists, x=None, coef=None, dots0=None):
+    """wg_rows through a row list (lcqp_hip_util_rows_list): A [batch][m][n], lists [batch][nlist] -> (dots [batch][m], outT [batch][n])"""
+    A = _arr(A); x = _arr(x); coef = _arr(coef)
+    batch, m, n = A.shape
+    lists = np.ascontiguousarray(lists, dtype=np.int32)
+    dots = np.zeros((batch, m)) if dots0 is None else np.ascontiguousarray(dots0, dtype=np.float64).copy()
+    out = np.zeros((batch, n))
+    _check(lib().lcqp_hip_util_rows_list(batch, m, n, _p(A), lists.ctypes.data_as(C.POINTER(C.c_int)), lists.shape[1], _p(x), _p(coef),
+                                         _p(dots) if x is not None else None, _p(out) if coef is not None else None), "util_rows_list")
+    return dots, out
 
 
 def util_symm_product(A, B):

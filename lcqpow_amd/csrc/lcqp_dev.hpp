@@ -106,10 +106,18 @@ __device__ __forceinline__ Ctx<NCH> make_ctx(const DevBatch& db, int b, Lds lds)
 
 // phase buckets of the diagnostic build (tools/gpu_phase_profile.py)
 enum { P_LCQP = 0, P_RESID = 1, P_GRAM = 2, P_CHOL = 3, P_CORR_L1 = 4, P_CORR_ROWS = 5, P_CORR_S = 6, P_ADMM = 7, P_MISC = 8, P_DEL = 9, P_UPD_PRE = 10 };
-#ifdef LCQP_PROFILE
+#if defined(LCQP_PROFILE) && !defined(LCQP_PROFILE_BULK)
 #define PROF(c, k) do { unsigned long long t_ = clock64(); (c).prof[k] += t_ - (c).tlast; (c).tlast = t_; } while (0)
 #else
 #define PROF(c, k) do { } while (0)
+#endif
+// -DLCQP_PROFILE -DLCQP_PROFILE_BULK: the buckets are the stages of the one-piece factor rebuild instead (ti_bulk)
+#if defined(LCQP_PROFILE) && defined(LCQP_PROFILE_BULK)
+#define PROFB0(c) do { (c).tlast = clock64(); } while (0)
+#define PROFB(c, k) do { unsigned long long t_ = clock64(); (c).prof[k] += t_ - (c).tlast; (c).tlast = t_; } while (0)
+#else
+#define PROFB0(c) do { } while (0)
+#define PROFB(c, k) do { } while (0)
 #endif
 
 __device__ __forceinline__ double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -462,6 +470,7 @@ __device__ __forceinline__ int ti_bulk(Ctx<NCH>& c, int na, double tau, int& nT,
     double *F = c.S2, *Ti = c.S, *DS = c.DS;
     nT = na; ns = na;
     if (na == 0) return 0;
+    PROFB0(c);
     // element loops with eight gathers in flight per thread (a load - store - load chain pays a memory round trip per element)
     {
         const int tot = nn * nn;
@@ -482,7 +491,9 @@ __device__ __forceinline__ int ti_bulk(Ctx<NCH>& c, int na, double tau, int& nT,
         }
     }
     __syncthreads();
+    PROFB(c, 0);
     wg_chol(F, ld, nb, na, tau, DS, c.Sv(S_D0), nullptr, c.lds, 4096);
+    PROFB(c, 1);
     // Ti: zero, diagonal blocks D_J (dense lower copies in DS)
     {
         const int tot = nn * nn;
@@ -501,6 +512,7 @@ __device__ __forceinline__ int ti_bulk(Ctx<NCH>& c, int na, double tau, int& nT,
         }
     }
     __syncthreads();
+    PROFB(c, 2);
     auto ident = [](int r) { return (long)r; };
     for (int J = 0; J + 1 < nb; J++)
         for (int I = J + 1; I < nb; I++) {
@@ -520,6 +532,7 @@ __device__ __forceinline__ int ti_bulk(Ctx<NCH>& c, int na, double tau, int& nT,
                 for (int j = 0; j < 4; j++) Ti[(size_t)(64 * I + tile_li(i, j)) * ld + 64 * J + tile_lj(i, j)] = -acc2[i][j];
             __syncthreads();
         }
+    PROFB(c, 3);
     // slots; rows whose pivot was flagged (stored inverse diagonal 1/1e150) are dependent on the rows before them
     int nflag = 0;
     for (int a = t; a < na; a += WG) {
@@ -538,6 +551,7 @@ __device__ __forceinline__ int ti_bulk(Ctx<NCH>& c, int na, double tau, int& nT,
         __syncthreads();
     }
     if (t == 0) c.info->work[2] += 8.0 * 3.0 * (double)na * na;      // S gathered, factor written, inverse written (lower halves: about na^2 / 2 each, read and written)
+    PROFB(c, 4);
     return nflag;
 }
 
@@ -687,10 +701,13 @@ template <int NCH, bool ROBUST, bool LR>
 __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse, double gs)
 {
     constexpr int np = 128 * NCH;
-#ifdef LCQP_SCREEN_NCH8
-    constexpr bool LISTS = true;
+    // every size sweeps through row lists (round 2 kept the plain sweep at np = 1024 because the list sweep returned wrong residuals in that
+    // instantiation of the old kernel; in the round-3 kernel it is correct on every np = 1024 shape and on its own:
+    // tests/test_gpu_parity.py::test_row_list_sweep); -DLCQP_PLAIN_SWEEPS keeps the plain sweeps as a cross-check
+#ifdef LCQP_PLAIN_SWEEPS
+    constexpr bool LISTS = false;
 #else
-    constexpr bool LISTS = NCH <= 4;      // np = 1024: the list sweep wg_rows<8, true> is not trusted: plain sweeps over all rows
+    constexpr bool LISTS = true;
 #endif
     const lcqp_options_t& o = c.db->opt;
     const int t = tid_here(), mE = c.mE, capS = c.capS;
@@ -878,7 +895,9 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             // in one piece when the factor is empty, when most of it would change, or when promotions dictate the order
             // (oracle: the same rule; there "in one piece" is a reset followed by appends in list order)
             PROF(c, P_UPD_PRE);
-            const bool bulk = (ROBUST && prioCtr > 0) || (nT == 0 && nadd > 0) || (ndel > 0 && ndel >= max(nT / 2, 8)) || nadd >= 16;
+            // ... or when the row-by-row updates would cost more than the rebuild (measured: a rotation ~ 3, an append ~ 7, a rebuild ~ 96 units of
+            // 7 us under load; same-box A/B 35.1 -> 34.5 ms)
+            const bool bulk = (ROBUST && prioCtr > 0) || (nT == 0 && nadd > 0) || (ndel > 0 && ndel >= max(nT / 2, 8)) || nadd >= 16 || (3 * ndel + 7 * nadd >= 96);
             int naAll = 0;
             if (bulk) {
                 int cntAct = 0;

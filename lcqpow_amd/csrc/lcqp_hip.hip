@@ -821,6 +821,32 @@ static int util_rows(int batch, int m, int n, const double* A, const double* x, 
     return 0;
 }
 
+extern "C" int lcqp_hip_util_rows_list(int batch, int m, int n, const double* A, const int* list, int nlist, const double* x, const double* coef,
+                                       double* dots, double* outT)
+try {
+    if (n <= 0 || n > 1024 || batch <= 0 || m <= 0 || nlist < 0 || nlist > m || !list) return LCQP_HIP_UNSUPPORTED;
+    const int nch = (n + 127) / 128 > 4 ? 8 : (n + 127) / 128, np = 128 * nch;
+    TmpBuf tb;
+    double* dA = tb.get((size_t)batch * m * np);
+    double* dx = x ? tb.get((size_t)batch * np) : nullptr;
+    double* dd = dots ? tb.get((size_t)batch * m) : nullptr;
+    double* dcf = coef ? tb.get((size_t)batch * m) : nullptr;
+    double* dout = outT ? tb.get((size_t)batch * np) : nullptr;
+    int* dl = reinterpret_cast<int*>(tb.get(((size_t)batch * std::max(nlist, 1) + 1) / 2 + 1));
+    if (!dA || !dl) return set_err("hipMalloc", hipErrorOutOfMemory);
+    int rc = upload_padded(dA, A, batch, m, n, np, m); if (rc) return rc;
+    if (x) { rc = upload_padded(dx, x, batch, 1, n, np, 1); if (rc) return rc; }
+    if (coef) HIPCHK(hipMemcpy(dcf, coef, sizeof(double) * (size_t)batch * m, hipMemcpyHostToDevice));
+    if (dots) HIPCHK(hipMemcpy(dd, dots, sizeof(double) * (size_t)batch * m, hipMemcpyHostToDevice));      // rows outside the list keep the caller's values
+    if (nlist > 0) HIPCHK(hipMemcpy(dl, list, sizeof(int) * (size_t)batch * nlist, hipMemcpyHostToDevice));
+    { LaunchArgs la; la.m = m; la.n = nlist; la.A = dA; la.list = dl; la.x = dx; la.dots = dd; la.coef = dcf; la.outT = dout; lcqp_dispatch(nch, ID_k_util_rows_list, batch, 0, la); }
+    HIPCHK(hipDeviceSynchronize());
+    if (dots) HIPCHK(hipMemcpy(dots, dd, sizeof(double) * (size_t)batch * m, hipMemcpyDeviceToHost));
+    if (outT) return download_padded(outT, dout, batch, 1, n, np, 1);
+    return 0;
+}
+catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
+
 extern "C" int lcqp_hip_util_gemv(int batch, int m, int n, const double* A, const double* b, double* c)
 try {
     return util_rows(batch, m, n, A, b, c, nullptr, nullptr);

@@ -506,6 +506,18 @@ __global__ __launch_bounds__(WG) void k_util_rows(int m, const double* A, const 
                  coef ? coef + (size_t)b * m : nullptr, lds, [&](int i, double s) { if (o) o[i] = s; });
 }
 
+// the row sweep through a row list with row-indexed scalars (wg_rows<NCH, true>: stage 1 / stage 2 of the subsolver's trials), on its own
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_util_rows_list(int m, int nlist, const double* A, const int* list, const double* x, double* dots, const double* coef, double* outT)
+{
+    LCQP_LDS_N(NCH)
+    constexpr int np = 128 * NCH;
+    const int b = blockIdx.x;
+    double* o = outT ? outT + (size_t)b * np : nullptr;
+    wg_rows<NCH, true>(A + (size_t)b * m * np, list + (size_t)b * nlist, nlist, x ? x + (size_t)b * np : nullptr, dots ? dots + (size_t)b * m : nullptr,
+                       coef ? coef + (size_t)b * m : nullptr, lds, [&](int i, double s) { if (o) o[i] = s; });
+}
+
 // ---- launcher of this translation unit's instantiation (declared in lcqp_launch.hpp) -----------------------------------------
 template <int NCH>
 static void launch_impl(int kid, int grid, hipStream_t s, const LaunchArgs& a)
@@ -530,6 +542,7 @@ static void launch_impl(int kid, int grid, hipStream_t s, const LaunchArgs& a)
         case ID_k_synth_Q:    hipLaunchKernelGGL((k_synth_Q<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_util_symv:  hipLaunchKernelGGL((k_util_symv<NCH>), dim3(grid), dim3(WG), 0, s, a.n, a.alpha, a.A, a.b, a.c, a.d); break;
         case ID_k_util_rows:  hipLaunchKernelGGL((k_util_rows<NCH>), dim3(grid), dim3(WG), 0, s, a.m, a.A, a.x, a.dots, a.coef, a.outT); break;
+        case ID_k_util_rows_list: hipLaunchKernelGGL((k_util_rows_list<NCH>), dim3(grid), dim3(WG), 0, s, a.m, a.n, a.A, a.list, a.x, a.dots, a.coef, a.outT); break;
         default: break;
     }
 }

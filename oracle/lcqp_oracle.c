@@ -911,7 +911,7 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
             /* from scratch when the factor is empty, when most of it would change, or when promotions dictate the order (the
              * device builds the factor in one piece then: blocked Cholesky and blocked triangular inverse, ti_bulk) */
             const int bulk = (robust && q->prio_ctr > 0) || (q->nT == 0 && nadd > 0) || (ndel > 0 && ndel >= (q->nT / 2 > 8 ? q->nT / 2 : 8))
-                             || nadd >= 16;
+                             || nadd >= 16 || (3 * ndel + 7 * nadd >= 96);      /* the last: the device's cost model of updates against a rebuild */
             int full = 0;
             if (bulk) {
                 ti_reset(q); touched = 1;

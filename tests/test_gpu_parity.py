@@ -167,6 +167,27 @@ def test_subsolver_warm_start_duals(hip, oracle):
     q1.close(); q2.close()
 
 
+@pytest.mark.parametrize("n", [100, 256, 300, 512, 700, 1024])
+def test_row_list_sweep(hip, n):
+    """wg_rows through a row list with row-indexed scalars (stage 1 / stage 2 of the subsolver's trials) on its own, every padded size
+    np = 128 ... 1024: row products for the listed rows only (the others keep their values), the weighted row sum over the list.
+    (Round 2 saw this routine return wrong residuals inside the np = 1024 instantiation of the homotopy kernel.)"""
+    rng = np.random.default_rng(n)
+    batch, m = 3, 157
+    A = rng.standard_normal((batch, m, n)); x = rng.standard_normal((batch, n)); coef = rng.standard_normal((batch, m))
+    for nlist in (1, 16, 17, 60, 157):
+        lists = np.stack([np.sort(rng.choice(m, nlist, replace=False)) for _ in range(batch)]).astype(np.int32)
+        d0 = rng.standard_normal((batch, m))
+        dots, out = hip.util_rows_list(A, lists, x=x, coef=coef, dots0=d0)
+        for b in range(batch):
+            ref = d0[b].copy(); ref[lists[b]] = A[b, lists[b]] @ x[b]
+            assert np.abs(dots[b] - ref).max() < 1e-12 * n
+            assert np.abs(out[b] - coef[b, lists[b]] @ A[b, lists[b]]).max() < 1e-12 * n
+        dots2, _ = hip.util_rows_list(A, lists, x=x, dots0=d0)            # products only
+        _, out2 = hip.util_rows_list(A, lists, coef=coef)                 # row sum only
+        assert np.array_equal(dots2, dots) and np.array_equal(out2, out)
+
+
 # ---- LCQProblem::loadLCQP / runSolver on the device ----------------------------------------------------
 def _cmp(ro, rh, xtol=X_TOL, ytol=Y_TOL, iters=True, status=True):
     assert rh["ret"] == ro["ret"]

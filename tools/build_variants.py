@@ -1,3 +1,5 @@
+"""Build library variants for A/B runs into ab_tmp/: python tools/build_variants.py name:-DFLAG,-DFLAG2 ...   (LCQP_VARIANT_NCH=8 in the
+environment builds the kernels of another padded size than np = 256)"""
 import sys, os
 sys.path.insert(0, "/root/repo")
 import __graft_entry__ as g
@@ -9,7 +11,7 @@ for a in sys.argv[1:]:
 def one(kv):
     name, defs = kv
     out = os.path.join("/root/repo/ab_tmp", name + ".so")
-    g.build_hip(force=True, out=out, defines=defs, only_nch=2)
+    g.build_hip(force=True, out=out, defines=defs, only_nch=int(os.environ.get("LCQP_VARIANT_NCH", "2")))
     return out
 with ThreadPoolExecutor(2) as ex:
     for o in ex.map(one, vars_.items()):
