@@ -387,6 +387,8 @@ class SparseBatchLCQP:
         self._pat = [np.ascontiguousarray(a, dtype=np.int32) for a in (Qpat.indptr, Qpat.indices, Apat.indptr, Apat.indices)]
         if self._pat[0].size != nV + 1 or self._pat[2].size != nV + 1:
             raise ValueError("pattern column pointers must have nV + 1 entries (CSC)")
+        if self._pat[1].size != int(self._pat[0][-1]) or self._pat[3].size != int(self._pat[2][-1]):
+            raise ValueError("pattern index arrays must have indptr[-1] entries")        # the C side reads exactly that many
         self.nnzQ, self.nnzA = int(self._pat[0][-1]), int(self._pat[2][-1])
         self.h = L.lcqp_hip_sparse_create(batch, nV, nC, nComp, *[a.ctypes.data_as(ip) for a in self._pat], device)
         if not self.h:

@@ -257,7 +257,7 @@ __device__ __forceinline__ int qp_build_K(Ctx<NCH>& c)
     __syncthreads();
     const int failed = uniform_i(*fail);
     __syncthreads();
-    if (tid_here() == 0) c.info->kReady = 1;
+    if (tid_here() == 0) c.info->kReady = failed ? 0 : 1;      // a factor with a non-positive pivot is never reused by a later hot start
     return failed;
 }
 
@@ -265,7 +265,8 @@ __device__ __forceinline__ int qp_build_K(Ctx<NCH>& c)
 // OSQP's rho adaptation for the fallback rounds (oracle: qp_adapt_rho): after a failed round, scale all rho_i by
 //   sqrt( (|E xa - za| / max(|E xa|, |za|)) / (|Q xa + g + E'ya| / max(|Q xa|, |E'ya|, |g|)) )   (infinity norms, clipped to
 // [1e-3, 1e3]) when that factor is above 5 or below 1/5, and refactorise K = Q + sigma I + E' diag(rho) E in place (the
-// work k_build_K and k_factor do at setup, here by this workgroup alone).  Returns 1 (uniform) when rho changed.
+// work k_build_K and k_factor do at setup, here by this workgroup alone).  Returns 1 (uniform) when rho changed, 0 when it stays,
+// -1 when neither the new nor the old rho gives a positive definite K.
 // ---------------------------------------------------------------------------------------------
 template <int NCH>
 __device__ __forceinline__ int qp_adapt_rho(Ctx<NCH>& c, const double* g)
@@ -293,9 +294,19 @@ __device__ __forceinline__ int qp_adapt_rho(Ctx<NCH>& c, const double* g)
     for (int r = t; r < mE; r += WG) rhov[r] *= fac;
     if (t == 0) c.info->rhoAdmm *= fac;
     __syncthreads();
-    qp_build_K<NCH>(c);
-    c.cFact++;
-    return 1;
+    // one call site for the factorisation: a second pass with the old rho when a pivot is not positive at the new one
+    int failed = 1, restored = 0;
+    for (int attempt = 0; attempt < 2 && failed; attempt++) {
+        c.cFact++;
+        failed = qp_build_K<NCH>(c);
+        if (failed && attempt == 0) {
+            for (int r = t; r < mE; r += WG) rhov[r] /= fac;
+            if (t == 0) c.info->rhoAdmm /= fac;
+            __syncthreads();
+            restored = 1;
+        }
+    }
+    return failed ? -1 : (restored ? 0 : 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -502,7 +513,7 @@ __device__ __forceinline__ int ti_bulk(Ctx<NCH>& c, int na, double tau, int& nT,
             double v[8]; int ii[8], jj[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                ii[u] = (e0 + u * WG < tot) ? i : -1; jj[u] = j;
+                ii[u] = (e0 + u * WG < tot && (j >> 6) >= (i >> 6)) ? i : -1; jj[u] = j;      // the blocks below the diagonal are written by the products that follow
                 v[u] = 0.0;
                 if (ii[u] >= 0 && (i >> 6) == (j >> 6)) v[u] = DS[(size_t)(i >> 6) * 4096 + (i & 63) * 64 + (j & 63)];
                 j += WG; while (j >= nn) { j -= nn; i++; }
@@ -985,7 +996,12 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             wg_trsv(c.F1, np, c.nblk, cv, true, c.lds);
             PROF(c, P_CORR_L1);
             if (na > 0) {
+                // (plain loads: the same rows are read again a few microseconds later; same-box A/B 35.1 -> 33.8 ms)
+#ifdef LCQP_NO_ET_KEEP
                 wg_rows<NCH>(c.Et, idx, nsl, cv, dy, nullptr, c.lds, [](int, double) {});
+#else
+                wg_rows<NCH, false, true>(c.Et, idx, nsl, cv, dy, nullptr, c.lds, [](int, double) {});
+#endif
                 for (int a = t; a < nsp; a += WG) dy[a] = (a < nsl && idx[a] >= 0) ? dy[a] - r2[a] : 0.0;
                 __syncthreads();
                 PROF(c, P_CORR_ROWS);
@@ -1124,7 +1140,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         for (int i = t; i < np; i += WG) xt[i] = xa[i];
         __syncthreads();
         if (qp_polish<NCH, ROBUST, LR>(c, g, round == 0 && use_stored, gsc)) { solved = 1; break; }
-        if (ADAPT && round >= 1 && n_admm > 0) qp_adapt_rho<NCH>(c, g);
+        if (ADAPT && round >= 1 && n_admm > 0 && qp_adapt_rho<NCH>(c, g) < 0) return 3;      // no usable ADMM factor left
         if (round >= 2) {    // at least 20 ADMM iterations behind us: is the QP infeasible or unbounded?
             certificate = qp_certificate<NCH>(c, g);
             if (certificate) break;

@@ -1131,7 +1131,28 @@ static void rcm_order(int N, const std::vector<std::vector<int>>& adj, std::vect
 extern "C" lcqp_hip_sparse_t* lcqp_hip_sparse_create(int batch, int nV, int nC, int nComp, const int* Qp, const int* Qi, const int* Ap, const int* Ai, int device)
 try {
     if (batch <= 0 || nV <= 0 || nC < 0 || nComp <= 0 || !Qp || !Qi || !Ap || !Ai) { g_sp_err = "invalid arguments"; return nullptr; }
-    const int n = nV, m = nC + 2 * nComp, N = n + m, nnzQ = Qp[n], nnzA = Ap[n];
+    const int n = nV, m = nC + 2 * nComp, N = n + m;
+    // the pattern is taken at its word below, so it is checked first: column pointers start at 0 and never decrease; row indices inside a
+    // column strictly increase (sorted, no duplicates: a duplicate would share one band slot and lose a value); Q structurally symmetric
+    // (both triangles given, as the reference hands Q to OSQP's P -- only entries with a mirror image reach the band)
+    for (int pass = 0; pass < 2; pass++) {
+        const int* P = pass ? Ap : Qp; const int* I = pass ? Ai : Qi; const int rows = pass ? m : n;
+        if (P[0] != 0) { g_sp_err = "column pointers must start at 0"; return nullptr; }
+        for (int c = 0; c < n; c++) {
+            if (P[c + 1] < P[c]) { g_sp_err = "column pointers must not decrease"; return nullptr; }
+            for (int k = P[c]; k < P[c + 1]; k++) {
+                if (I[k] < 0 || I[k] >= rows) { g_sp_err = pass ? "row index out of bounds" : "Q index out of bounds"; return nullptr; }
+                if (k > P[c] && I[k] <= I[k - 1]) { g_sp_err = "row indices of a column must be sorted and free of duplicates"; return nullptr; }
+            }
+        }
+    }
+    for (int c = 0; c < n; c++)
+        for (int k = Qp[c]; k < Qp[c + 1]; k++) {
+            const int r = Qi[k];
+            if (r == c) continue;
+            if (!std::binary_search(Qi + Qp[r], Qi + Qp[r + 1], c)) { g_sp_err = "Q must be structurally symmetric (both triangles given)"; return nullptr; }
+        }
+    const int nnzQ = Qp[n], nnzA = Ap[n];
     // CSC of the stacked matrix -> CSR (pattern and the value permutation)
     std::vector<int> Ep(m + 1, 0), Ei(nnzA), csr2csc(nnzA), ETp(Ap, Ap + n + 1), ETi(Ai, Ai + nnzA), ETmap(nnzA);
     for (int k = 0; k < nnzA; k++) { if (Ai[k] < 0 || Ai[k] >= m) { g_sp_err = "row index out of bounds"; return nullptr; } Ep[Ai[k] + 1]++; }
@@ -1169,6 +1190,7 @@ try {
     if (hipSetDevice(device) != hipSuccess) { g_sp_err = "hipSetDevice failed"; return nullptr; }
     lcqp_hip_sparse* h = new (std::nothrow) lcqp_hip_sparse();
     if (!h) return nullptr;
+    struct Guard { lcqp_hip_sparse* h; ~Guard() { if (h) lcqp_hip_sparse_destroy(h); } } guard{h};      // an exception below must not leak the handle
     h->device = device; h->nnzA = nnzA; h->loaded = false; h->ran = false; h->csr2csc = csr2csc; h->perm = perm;
     h->stream = nullptr; h->ev0 = h->ev1 = h->ev2 = nullptr;
     SpBatch& d = h->db;
@@ -1206,7 +1228,8 @@ try {
          (d.lbL = sp_alloc<double>(h, B * nComp)) && (d.lbR = sp_alloc<double>(h, B * nComp)) && (d.mi = sp_alloc<int>(h, B * MI_NUM * m)) &&
          (d.info = sp_alloc<SpInfo>(h, B)) && (d.stats = sp_alloc<lcqp_stats_t>(h, B)) && (d.xout = sp_alloc<double>(h, B * n)) &&
          (d.yout = sp_alloc<double>(h, B * m));
-    if (!ok) { g_sp_err = "device allocation failed"; lcqp_hip_sparse_destroy(h); return nullptr; }
+    if (!ok) { g_sp_err = "device allocation failed"; return nullptr; }      // (the guard destroys the handle)
+    guard.h = nullptr;
     return h;
 }
 catch (...) { g_sp_err = "out of host memory"; return nullptr; }

@@ -367,7 +367,9 @@ __device__ __forceinline__ void wg_row_norms(const double* __restrict__ Mx, int 
 // LDS: arena[0..4np) combine, arena[4np..5np) x.
 // ---------------------------------------------------------------------------------------------
 // BYROW: dots[] and coef[] are indexed by the row number (idx[a]) instead of the list position a.
-template <int NCH, bool BYROW = false, class Post>
+// KEEP: plain loads (the rows may stay in the caches) for a pass whose rows are read again within microseconds: the first of the two
+// passes over the working-set rows of Et in a full correction.
+template <int NCH, bool BYROW = false, bool KEEP = false, class Post>
 __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int* __restrict__ idx, int m,
                         const double* __restrict__ x, double* dots,
                         const double* __restrict__ coef, Lds lds, Post post)
@@ -409,7 +411,7 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
                 if (rows[d] >= 0) {
                     const double2* rp = reinterpret_cast<const double2*>(Mx + (size_t)rows[d] * np) + l;
 #pragma unroll
-                    for (int k = 0; k < NCH; k++) mm[d][k] = ld_stream(rp + 64 * k);
+                    for (int k = 0; k < NCH; k++) mm[d][k] = KEEP ? rp[64 * k] : ld_stream(rp + 64 * k);
                 } else {
 #pragma unroll
                     for (int k = 0; k < NCH; k++) mm[d][k] = double2{0.0, 0.0};

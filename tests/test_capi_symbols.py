@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -86,3 +88,28 @@ def test_missing_extension_fails_loudly(monkeypatch):
         capi.lib()
     with pytest.raises(RuntimeError):
         capi.BatchLCQP(1, 2, 0, 1)
+
+
+def test_sparse_pattern_validation_needs_no_gpu():
+    """lcqp_hip_sparse_create checks the CSC pattern before it touches a device: decreasing column pointers, unsorted or duplicated row
+    indices, an upper-triangular Q (OSQP's own convention for P -- this surface, like the reference's, takes the full matrix) and a short
+    index array are refused with a message (src/SubsolverOSQP.cpp:136-152 hands such arrays to OSQP unchecked)"""
+    import numpy as np
+    import lcqpow_amd as la
+
+    class Pat:
+        def __init__(self, indptr, indices):
+            self.indptr, self.indices = np.array(indptr, dtype=np.int32), np.array(indices, dtype=np.int32)
+    n, nC, nK = 4, 0, 1
+    Aok = Pat([0, 1, 2, 2, 2], [0, 1])                                  # L = e_0', R = e_1'
+    Qok = Pat([0, 2, 4, 5, 6], [0, 1, 0, 1, 2, 3])
+    cases = [(Pat([0, 2, 1, 5, 6], [0, 1, 0, 1, 2, 3]), Aok, "decrease"),
+             (Pat([0, 2, 4, 5, 6], [1, 0, 0, 1, 2, 3]), Aok, "sorted"),
+             (Pat([0, 2, 4, 5, 6], [0, 0, 0, 1, 2, 3]), Aok, "duplicates"),
+             (Pat([0, 1, 3, 4, 5], [0, 0, 1, 2, 3]), Aok, "symmetric"),          # upper triangle only
+             (Qok, Pat([0, 1, 2, 2, 2], [0, 7]), "out of bounds")]
+    for Qp, Ap, word in cases:
+        with pytest.raises(RuntimeError, match=word):
+            la.SparseBatchLCQP(1, n, nC, nK, Qp, Ap)
+    with pytest.raises(ValueError, match="indptr"):
+        la.SparseBatchLCQP(1, n, nC, nK, Pat([0, 2, 4, 5, 6], [0, 1, 0, 1, 2]), Aok)

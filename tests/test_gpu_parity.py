@@ -250,7 +250,18 @@ def test_lcqp_iterate_level_match(hip, oracle, name):
     ro = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0), trace=400)
     rh = P.hip_solve(hip, d, hip.default_options(perturbStep=0, storeSteps=1), trace=True)
     so, sh = ro["trace_scalars"], rh["trace_scalars"]
-    assert len(so) == len(sh) == ro["stats"]["iterTotal"] == rh["stats"]["iterTotal"]
+    assert len(so) == ro["stats"]["iterTotal"] and len(sh) == rh["stats"]["iterTotal"]
+    if name == "synthetic":
+        # The step-length test at the end of an inner loop is a coin flip at the rounding floor (oracle/lcqp_oracle.c, dot_lanes;
+        # tests/test_oracle_solver.py::test_iterate_path_is_a_coin_flip_at_the_rounding_floor): the two sides walk the same path iterate
+        # for iterate until one flip sends a penalty update one cycle of four iterates earlier or later; they meet again in the solution.
+        k = min(len(so), len(sh))
+        diff = np.nonzero(so[:k, 2] != sh[:k, 2])[0]
+        k = int(diff[0]) if diff.size else k
+        assert k >= 8 and (len(so) - len(sh)) % 4 == 0 and np.abs(ro["x"] - rh["x"]).max() < 1e-9
+        ro = dict(ro, trace_x=ro["trace_x"][:k - 1]); rh = dict(rh, trace_x=rh["trace_x"][:k - 1])
+        so, sh = so[:k - 1], sh[:k - 1]
+    assert len(so) == len(sh)
     assert np.array_equal(so[:, 2], sh[:, 2])                                   # rho per iterate
     # Every iterate is a QP solution verified to resTol * (1 + |gk|_inf) = 1e-12 * (1 + rho |C xk| + ...) on both sides, so with
     # rho up to 1e3 on these problems two correct solvers may differ by 1e-9 in an intermediate xk (the final x is compared at
@@ -389,6 +400,26 @@ def test_lcqp_full_batch_properties(hip, oracle):
     # one true-residual sweep per QP (plus the cold one); intermediate trials read only unscreened inactive rows
     assert tot("reserved") <= tot("qpSolves") * 1.25 + B
     assert ws[4] / tot("trials") < 0.6 * m
+    bt.close()
+
+
+@pytest.mark.parametrize("kw", [dict(admmFirst=20), dict(admmFirst=10, admmHot=5), dict(maxTrials=3)])
+def test_lcqp_polish_after_admm(hip, oracle, kw):
+    """the polish entered from ADMM iterates (admmFirst / admmHot > 0, or a trial budget so small that the fallback rounds run): ADMM
+    writes its own E x and moves x without the polish knowing, so the polish must not trust margins or row values from before (cold
+    entry: every row is read, margins rebuilt) -- same trials, same working sets, same solutions as the oracle, which screens nothing"""
+    B, n, nC, nComp = 6, 64, 96, 16
+    bt = hip.BatchLCQP(B, n, nC, nComp, opt=hip.default_options(perturbStep=0, **kw))
+    bt.generate_synthetic(0)
+    bt.run()
+    x, y, st = bt.solution()
+    for b in range(B):
+        d = bt.read_problem(b)
+        ro = oracle.lcqp_solve(d["Q"], d["g"], d["L"], d["R"], A=d["A"], lbA=d["lbA"], ubA=d["ubA"], opt=oracle.default_options(perturbStep=0, **kw))
+        assert st[b]["returnValue"] == ro["ret"] == 0
+        assert np.abs(ro["x"] - x[b]).max() < X_TOL and np.abs(ro["y"] - y[b]).max() < Y_TOL
+        assert st[b]["admmIter"] == ro["stats"]["admmIter"] > 0
+        assert abs(st[b]["trials"] - ro["stats"]["trials"]) <= 0.05 * ro["stats"]["trials"] + 4
     bt.close()
 
 
