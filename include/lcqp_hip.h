@@ -214,6 +214,7 @@ void lcqp_hip_sparse_destroy(lcqp_hip_sparse_t* s);
 const char* lcqp_hip_sparse_last_error(void);
 int  lcqp_hip_sparse_bandwidth(const lcqp_hip_sparse_t* s);              /* half bandwidth of the KKT band */
 int  lcqp_hip_sparse_lanes(const lcqp_hip_sparse_t* s);                  /* lanes of a wavefront per instance: 8, 16, 32 or 64 */
+int  lcqp_hip_sparse_border(const lcqp_hip_sparse_t* s);                 /* border nodes of the bordered band: the last positions of the ordering (0: plain band) */
 int  lcqp_hip_sparse_get_ordering(const lcqp_hip_sparse_t* s, int* perm); /* perm[nV + nC + 2 nComp]: position -> node */
 int  lcqp_hip_sparse_set_options(lcqp_hip_sparse_t* s, const lcqp_options_t* opt);
 /* loadLCQP, sparse overload (src/LCQProblem.cpp:390-441), values only: Qx [count][nnzQ], Ax [count][nnzA] in the CSC order of

@@ -34,6 +34,7 @@ using namespace lcqp;
 namespace {
 
 constexpr int SP_WMAX = 63;
+constexpr int SP_KBMAX = 16;   // border nodes of the bordered band (rows / variables too dense for a band)
 constexpr int WGS = 64;      // one wavefront per workgroup; 64 / G instances in it
 #ifndef SP_WAVES_PER_SIMD
 #define SP_WAVES_PER_SIMD 2  // register budget of k_sparse_run: 512 / SP_WAVES_PER_SIMD per lane
@@ -69,6 +70,15 @@ struct SpBatch {
     double *KaF, *KaD;       // ADMM KKT factor in the folded layout of band_sweep [B][Np*G], 1/D [B][Np]
     double *KpF, *KpD;       // polish KKT factor
     double *nv, *mv, *Nv;    // [B][NV_NUM][n], [B][MV_NUM][m], [B][2][Np]
+    // Bordered band (round 3): the last kb positions of the ordering are border nodes -- rows or variables too dense for any band (the
+    // coupling constraint and the two shared variables of examples/OptimizeOnCircle.cpp).  K = [Bd U'; U C]: the band engine factorises
+    // Bd with the border positions as isolated unit pivots; the border is carried by W = U inv(Bd) (kb band solves per factorisation) and
+    // the Schur complement S = C - W U' (kb x kb, dense LDL').  U: per border node the entries it shares with band nodes (Upos: band
+    // position, Usrc: entry of Q (k < nnzQ) or of E (nnzQ + k, CSR order), Ugate: the row of E whose membership in the working set gates
+    // the entry, -1 none); C: the entries among border nodes, lower triangle (Cb2: the other border node).
+    int kb, nU, nCb;
+    const int *bnode, *Uptr, *Upos, *Usrc, *Ugate, *Cptr, *Cb2, *Csrc, *Cgate;
+    double *bW, *bUv, *bS;   // [B][2][kb][Np] W rows, [B][2][nU] gated values of U, [B][2][kb][kb] factor of S   (index 0: polish, 1: ADMM)
     double *lbL, *lbR;       // [B][nComp]
     int* mi;                 // [B][MI_NUM][m]
     SpInfo* info;
@@ -132,6 +142,9 @@ struct SpCtx {
     __device__ __forceinline__ GD Kb() const { return arr(db->Kb, (size_t)db->N * db->ld); }
     __device__ __forceinline__ GD KF(bool admm) const { return arr(admm ? db->KaF : db->KpF, (size_t)db->Np * G); }
     __device__ __forceinline__ GD KD(bool admm) const { return arr(admm ? db->KaD : db->KpD, db->Np); }
+    __device__ __forceinline__ GD BW(bool admm) const { return arr(db->bW, (size_t)2 * db->kb * db->Np, (unsigned)(admm ? db->kb * db->Np : 0)); }
+    __device__ __forceinline__ GD BUv(bool admm) const { return arr(db->bUv, (size_t)2 * db->nU, (unsigned)(admm ? db->nU : 0)); }
+    __device__ __forceinline__ GD BS(bool admm) const { return arr(db->bS, (size_t)2 * db->kb * db->kb, (unsigned)(admm ? db->kb * db->kb : 0)); }
 };
 
 #ifdef LCQP_PROFILE
@@ -395,11 +408,13 @@ __device__ __forceinline__ void sp_assemble(SpCtx<G>& c, double dprim, Dd ddual,
     for (int k = t; k < db.nnzQ; k += G) { const int o = db.bandQ[k]; if (o >= 0) Kb[o] = c.Qx()[k]; }
     for (int r = t; r < m; r += G) {
         const bool on = use(r);
-        if (on) for (int k = db.Ep[r]; k < db.Ep[r + 1]; k++) Kb[db.bandE[k]] = c.Ex()[k];
+        if (on) for (int k = db.Ep[r]; k < db.Ep[r + 1]; k++) { const int o = db.bandE[k]; if (o >= 0) Kb[o] = c.Ex()[k]; }      // (-1: an entry of the border)
         Kb[(size_t)db.iperm[n + r] * ld + w] = on ? -ddual(r) : -1.0;
     }
     g_sync();
     for (int i = t; i < n; i += G) Kb[(size_t)db.iperm[i] * ld + w] += dprim;
+    g_sync();
+    for (int b = t; b < db.kb; b += G) Kb[(size_t)(db.N - db.kb + b) * ld + w] = 1.0;      // border positions: isolated unit pivots of the band
     g_sync();
     c.bytes += 8.0 * ((double)db.N * ld + db.nnzQ + db.nnzE) + 4.0 * (db.nnzQ + db.nnzE);
     SPROF(c, SP_ASSEMBLE);
@@ -490,7 +505,8 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
                 else if (code[k] >= 0) v = Qv[code[k]];
                 dst[k] = v;
             }
-            if (node < nvar) { const int qd = c.db->qdiag[node]; dst[GM] = (qd >= 0 ? (double)Qv[qd] : 0.0) + dprim; }
+            if (r >= N - c.db->kb) dst[GM] = 1.0;                       // a border position: an isolated unit pivot of the band
+            else if (node < nvar) { const int qd = c.db->qdiag[node]; dst[GM] = (qd >= 0 ? (double)Qv[qd] : 0.0) + dprim; }
             else { const int rr = node - nvar; dst[GM] = use(rr) ? -ddual(rr) : -1.0; }
         } else {
 #pragma unroll
@@ -544,9 +560,9 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
     c.cFact++;
     SPROF(c, SP_FACTOR);
 }
-// the KKT matrix [Q + dprim I, E_use'; E_use, -diag(ddual)] factorised: assembled on the fly (G <= 16) or through the band array
+// the band part of the KKT matrix [Q + dprim I, E_use'; E_use, -diag(ddual)] factorised: assembled on the fly (G <= 16) or through the band array
 template <int G, class Dd, class Use>
-__device__ __forceinline__ void sp_factor(SpCtx<G>& c, GD KF, GD Kd, double dprim, Dd ddual, Use use)
+__device__ __forceinline__ void sp_factor_band(SpCtx<G>& c, GD KF, GD Kd, double dprim, Dd ddual, Use use)
 {
     if constexpr (G <= 16) sp_factor_reg<G>(c, KF, Kd, dprim, ddual, use);
     else { sp_assemble<G>(c, dprim, ddual, use); sp_factor_lds<G>(c, KF, Kd); }
@@ -623,7 +639,7 @@ __device__ __forceinline__ void band_sweep(GD K, GD Kd, GD b, int Np, int gl)
 }
 
 template <int G>
-__device__ __forceinline__ void sp_solve(SpCtx<G>& c, bool admm, GD b)
+__device__ __forceinline__ void sp_solve_band(SpCtx<G>& c, bool admm, GD b)
 {
     const int Np = c.db->Np;
     SPROF(c, SP_VECTORS);
@@ -634,6 +650,116 @@ __device__ __forceinline__ void sp_solve(SpCtx<G>& c, bool admm, GD b)
     g_sync();
     SPROF(c, SP_BACKWARD);
     c.bytes += 8.0 * (2.0 * (double)c.db->N * c.db->w + 4.0 * c.db->N);
+}
+
+// ---- the border (oracle: kkt_factor / kkt_solve) ---------------------------------------------------------------------------------
+// After the band factorisation: the gated values of U (sp_border_prepare), W = U inv(Bd) -- one band solve per border node, run by the
+// caller through ITS call site of the band solve (sp_border_column scatters column j; the kernel carries one copy of the sweeps per
+// context) --, then S = C - W U' and its LDL' (sp_border_schur).
+template <int G, class Use>
+__device__ __forceinline__ void sp_border_prepare(SpCtx<G>& c, bool admm, Use use)
+{
+    const SpBatch& db = *c.db;
+    const int t = here(c.gl), kb = db.kb, Np = db.Np, nnzQ = db.nnzQ, nU = db.nU;
+    GD W = c.BW(admm), Uv = c.BUv(admm), Qv = c.Qx(), Ev = c.Ex();
+    for (int e = t; e < nU; e += G) {
+        const int src = db.Usrc[e], gate = db.Ugate[e];
+        Uv[e] = (gate >= 0 && !use(gate)) ? 0.0 : (src >= nnzQ ? (double)Ev[src - nnzQ] : (double)Qv[src]);
+    }
+    for (int p = t; p < kb * Np; p += G) W[p] = 0.0;
+    g_sync();
+}
+template <int G>
+__device__ __forceinline__ GD sp_border_column(SpCtx<G>& c, bool admm, int b)
+{
+    const SpBatch& db = *c.db;
+    const int t = here(c.gl);
+    GD wb = c.BW(admm) + b * db.Np, Uv = c.BUv(admm);
+    for (int e = db.Uptr[b] + t; e < db.Uptr[b + 1]; e += G) wb[db.Upos[e]] = Uv[e];
+    g_sync();
+    return wb;
+}
+template <int G, class Dd, class Use>
+__device__ __forceinline__ void sp_border_schur(SpCtx<G>& c, bool admm, double dprim, Dd ddual, Use use)
+{
+    const SpBatch& db = *c.db;
+    const int t = here(c.gl), kb = db.kb, Np = db.Np, nnzQ = db.nnzQ, nvar = db.n;
+    GD W = c.BW(admm), Uv = c.BUv(admm), S = c.BS(admm), Qv = c.Qx(), Ev = c.Ex();
+    // C: the border block itself (lane 0; a handful of entries), then S = C - W U'
+    if (t == 0) {
+        for (int e = 0; e < kb * kb; e++) S[e] = 0.0;
+        for (int a = 0; a < kb; a++) {
+            const int node = db.bnode[a];
+            double dg;
+            if (node < nvar) { const int qd = db.qdiag[node]; dg = (qd >= 0 ? (double)Qv[qd] : 0.0) + dprim; }
+            else { const int rr = node - nvar; dg = use(rr) ? -ddual(rr) : -1.0; }
+            S[a * kb + a] = dg;
+            for (int e = db.Cptr[a]; e < db.Cptr[a + 1]; e++) {
+                const int b2 = db.Cb2[e], src = db.Csrc[e], gate = db.Cgate[e];
+                const double v = (gate >= 0 && !use(gate)) ? 0.0 : (src >= nnzQ ? (double)Ev[src - nnzQ] : (double)Qv[src]);
+                S[a * kb + b2] += v; S[b2 * kb + a] += v;
+            }
+        }
+    }
+    g_sync();
+    for (int a = 0; a < kb; a++)
+        for (int b2 = 0; b2 < kb; b2++) {
+            GD wb = W + b2 * Np;
+            double sacc = 0.0;
+            for (int e = db.Uptr[a] + t; e < db.Uptr[a + 1]; e += G) sacc += Uv[e] * wb[db.Upos[e]];
+            sacc = g_sum<G>(sacc);
+            if (t == 0) S[a * kb + b2] -= sacc;
+        }
+    g_sync();
+    if (t == 0) {      // S = L D L' in place: L below the diagonal, D on it (quasi-definite: no pivoting)
+        for (int j = 0; j < kb; j++) {
+            double d = S[j * kb + j];
+            for (int k = 0; k < j; k++) { const double ljk = S[j * kb + k]; d -= ljk * ljk * S[k * kb + k]; }
+            S[j * kb + j] = d;
+            for (int i = j + 1; i < kb; i++) {
+                double v = S[i * kb + j];
+                for (int k = 0; k < j; k++) v -= S[i * kb + k] * S[j * kb + k] * S[k * kb + k];
+                S[i * kb + j] = v / d;
+            }
+        }
+    }
+    g_sync();
+    c.bytes += 8.0 * (2.0 * (double)db.nU + (double)kb * Np);
+}
+// After the band solve of b (the border positions pass through it untouched): the border unknowns from S, then the band part corrected
+template <int G>
+__device__ __forceinline__ void sp_border_solve(SpCtx<G>& c, bool admm, GD b)
+{
+    const SpBatch& db = *c.db;
+    const int t = here(c.gl), kb = db.kb, Np = db.Np, Nb = db.N - db.kb;
+    GD W = c.BW(admm), Uv = c.BUv(admm), S = c.BS(admm);
+    for (int a = 0; a < kb; a++) {
+        double sacc = 0.0;
+        for (int e = db.Uptr[a] + t; e < db.Uptr[a + 1]; e += G) sacc += Uv[e] * b[db.Upos[e]];
+        sacc = g_sum<G>(sacc);
+        if (t == 0) b[Nb + a] -= sacc;
+    }
+    g_sync();
+    if (t == 0) {
+        for (int i = 0; i < kb; i++) { double v = b[Nb + i]; for (int k = 0; k < i; k++) v -= S[i * kb + k] * b[Nb + k]; b[Nb + i] = v; }
+        for (int i = 0; i < kb; i++) b[Nb + i] = b[Nb + i] / S[i * kb + i];
+        for (int i = kb - 1; i >= 0; i--) { double v = b[Nb + i]; for (int k = i + 1; k < kb; k++) v -= S[k * kb + i] * b[Nb + k]; b[Nb + i] = v; }
+    }
+    g_sync();
+    for (int p = t; p < Nb; p += G) {
+        double acc = 0.0;
+        for (int a = 0; a < kb; a++) acc += W[a * Np + p] * b[Nb + a];
+        b[p] -= acc;
+    }
+    g_sync();
+    c.bytes += 8.0 * ((double)kb * Nb + 2.0 * Nb + db.nU);
+}
+// K x = b in place: the band solve, then the border
+template <int G>
+__device__ __forceinline__ void sp_solve(SpCtx<G>& c, bool admm, GD b)
+{
+    sp_solve_band<G>(c, admm, b);
+    if (c.db->kb > 0) sp_border_solve<G>(c, admm, b);
 }
 
 // ---- ADMM iterations (OSQP, KKT form; oracle: sqp_admm) ----------------------------------------------------------------------
@@ -684,7 +810,7 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
     const int* iperm = db.iperm;
     const double gs = 1.0 + sp_maxabs<G>(c, g, n);
     const double ytol = o.feasTol * gs;
-    int fact_valid = 0;
+    int fact_valid = 0, borderTodo = 0;
     for (int trial = 0; trial < o.maxTrials; trial++) {
         c.cTrials++;
         double res_stat;
@@ -750,7 +876,8 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
             for (int r = t; r < m; r += G) diff |= ((stf[r] != ST_INACT) != (st[r] != ST_INACT));
             if (g_any<G>(diff)) {
                 const double d2 = c.info->delta2;
-                sp_factor<G>(c, c.KF(false), c.KD(false), c.info->delta, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; });
+                sp_factor_band<G>(c, c.KF(false), c.KD(false), c.info->delta, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; });
+                if (db.kb > 0) { sp_border_prepare<G>(c, false, [=](int r) { return st[r] != ST_INACT; }); borderTodo = db.kb; }
                 g_map<G, 8>(m, t, [&](int r) { return st[r]; }, [&](int r, int v) { stf[r] = v; });
                 if (t == 0) c.info->stfValid = 1;
                 g_sync();
@@ -764,7 +891,15 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
                     [&](int, ID4 v) { b[v.p] = (v.s != ST_INACT) ? ((v.s == ST_UPPER) ? v.hi : v.lo) - v.e : 0.0; });
         g_sync();
         SPROF(c, SP_RHS);
-        sp_solve<G>(c, false, b);
+        // one call site of the band solve: first the columns of W = U inv(Bd) a fresh factorisation owes (none for a plain band), then b
+        for (int jb = 0; jb <= borderTodo; jb++) {
+            GD vec = b;
+            if (jb < borderTodo) vec = sp_border_column<G>(c, false, jb);
+            else if (borderTodo > 0) { const double d2 = c.info->delta2; sp_border_schur<G>(c, false, c.info->delta, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; }); }
+            sp_solve_band<G>(c, false, vec);
+        }
+        borderTodo = 0;
+        if (db.kb > 0) sp_border_solve<G>(c, false, b);
         g_map<G, 8>(n, t, [&](int i) { return D2{b[iperm[i]], x[i]}; }, [&](int i, D2 v) { x[i] = v.b + v.a; });
         g_map<G, 8>(m, t, [&](int r) { return ID2{st[r], b[iperm[n + r]], yt[r]}; }, [&](int r, ID2 v) { if (v.s != ST_INACT) yt[r] = v.y + v.v; });
         g_sync();
@@ -902,7 +1037,12 @@ __global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db)
         c.info->phiConst = phiConst; c.info->haveSolution = 0; c.info->stfValid = 0; c.info->bytes = 0.0;
     }
     g_sync();
-    sp_factor<G>(c, c.KF(true), c.KD(true), db.opt.admmSigma * scale, [=](int r) { return 1.0 / rhov[r]; }, [](int) { return true; });
+    sp_factor_band<G>(c, c.KF(true), c.KD(true), db.opt.admmSigma * scale, [=](int r) { return 1.0 / rhov[r]; }, [](int) { return true; });
+    if (db.kb > 0) {
+        sp_border_prepare<G>(c, true, [](int) { return true; });
+        for (int jb = 0; jb < db.kb; jb++) { GD vec = sp_border_column<G>(c, true, jb); sp_solve_band<G>(c, true, vec); }
+        sp_border_schur<G>(c, true, db.opt.admmSigma * scale, [=](int r) { return 1.0 / rhov[r]; }, [](int) { return true; });
+    }
     if (t == 0) c.info->bytes = c.bytes;
 }
 
@@ -1164,29 +1304,67 @@ try {
     for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) { const int j = Qi[k]; if (j < 0 || j >= n) { g_sp_err = "Q index out of bounds"; return nullptr; } if (j != i) adj[i].push_back(j); }
     for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { adj[n + r].push_back(Ei[k]); adj[Ei[k]].push_back(n + r); }
     for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
-    std::vector<int> perm, iperm(N);
-    rcm_order(N, adj, perm);
-    for (int p = 0; p < N; p++) iperm[perm[p]] = p;
+    // Ordering: reverse Cuthill-McKee; while the half bandwidth exceeds what a lane group covers, the node of highest degree moves to the
+    // border (at most SP_KBMAX nodes), the positions behind the band.  Arrow-shaped KKT matrices (a coupling row, a shared variable:
+    // examples/OptimizeOnCircle.cpp:44) become a narrow band plus a few border nodes.
+    std::vector<int> perm, iperm(N), border;
+    std::vector<char> isBorder(N, 0);
     int w = 0;
-    for (int v = 0; v < N; v++) for (int u : adj[v]) w = std::max(w, std::abs(iperm[v] - iperm[u]));
-    if (w > SP_WMAX) {
-        g_sp_err = "KKT band of this pattern has half bandwidth " + std::to_string(w) + " > " + std::to_string(SP_WMAX) +
-                   " after reverse Cuthill-McKee: not a banded problem (use the dense kernels)";
-        return nullptr;
+    for (;;) {
+        std::vector<std::vector<int>> sub(N);
+        for (int v = 0; v < N; v++) if (!isBorder[v]) for (int u : adj[v]) if (!isBorder[u]) sub[v].push_back(u);
+        std::vector<int> full;
+        rcm_order(N, sub, full);
+        perm.clear();
+        for (int v : full) if (!isBorder[v]) perm.push_back(v);
+        for (int v : border) perm.push_back(v);
+        for (int p = 0; p < N; p++) iperm[perm[p]] = p;
+        w = 0;
+        for (int v = 0; v < N; v++) if (!isBorder[v]) for (int u : sub[v]) w = std::max(w, std::abs(iperm[v] - iperm[u]));
+        if (w <= SP_WMAX) break;
+        if ((int)border.size() >= SP_KBMAX) {
+            g_sp_err = "KKT band of this pattern has half bandwidth " + std::to_string(w) + " > " + std::to_string(SP_WMAX) + " after reverse Cuthill-McKee with " +
+                       std::to_string(SP_KBMAX) + " border nodes: neither a banded nor a bordered problem (use the dense kernels)";
+            return nullptr;
+        }
+        int best = -1; size_t deg = 0;
+        for (int v = 0; v < N; v++) if (!isBorder[v] && sub[v].size() > deg) { deg = sub[v].size(); best = v; }
+        if (best < 0) { g_sp_err = "ordering failed"; return nullptr; }
+        isBorder[best] = 1; border.push_back(best);
     }
+    const int kb = (int)border.size(), Nband = N - kb;
     if (w < 1) w = 1;
     // lanes per instance: the smallest of 8, 16, 32, 64 above the half bandwidth (LCQP_SPARSE_LANES raises it: test hook)
     int G = w < 8 ? 8 : (w < 16 ? 16 : (w < 32 ? 32 : 64));
     if (const char* e = std::getenv("LCQP_SPARSE_LANES")) { const int v = std::atoi(e); if ((v == 16 || v == 32 || v == 64) && v > G) G = v; }
     const int ld = G, wS = G - 1;          // band rows are stored G wide: entry k of row i is K[i][i - (G-1) + k] (zero outside the true band)
-    std::vector<int> bandQ(nnzQ, -1), bandE(nnzA);
-    for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) { const int pi = iperm[i], pj = iperm[Qi[k]]; if (pj <= pi) bandQ[k] = pi * ld + wS - (pi - pj); }
-    for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { const int pr = iperm[n + r], pc = iperm[Ei[k]]; const int hi = std::max(pr, pc), lo = std::min(pr, pc); bandE[k] = hi * ld + wS - (hi - lo); }
+    std::vector<int> bandQ(nnzQ, -1), bandE(nnzA, -1);      // (-1: not in the band -- an upper-triangle entry of Q, or an entry of the border)
+    for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) { const int pi = iperm[i], pj = iperm[Qi[k]]; if (pj <= pi && pi < Nband) bandQ[k] = pi * ld + wS - (pi - pj); }
+    for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { const int pr = iperm[n + r], pc = iperm[Ei[k]]; const int hi = std::max(pr, pc), lo = std::min(pr, pc); if (hi < Nband) bandE[k] = hi * ld + wS - (hi - lo); }
     // where every off-diagonal band entry comes from (assembly inside the factorisation): -1 nothing, k < nnzQ the entry k of Q,
     // nnzQ + k the entry k of E (CSR order); the node behind a band position; the entry of Q_ii; the row of an entry of E
     std::vector<int> bsrc((size_t)N * ld, -1), pnode(perm.begin(), perm.end()), qdiag(n, -1), Erow(nnzA);
     for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) { if (Qi[k] == i) qdiag[i] = k; else if (bandQ[k] >= 0) bsrc[bandQ[k]] = k; }
-    for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { bsrc[bandE[k]] = nnzQ + k; Erow[k] = r; }
+    for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { if (bandE[k] >= 0) bsrc[bandE[k]] = nnzQ + k; Erow[k] = r; }
+    // the border: per border node its entries with band nodes (U) and with border nodes of lower index (C)
+    std::vector<int> Uptr(kb + 1, 0), Upos, Usrc, Ugate, Cptr(kb + 1, 0), Cb2, Csrc, Cgate;
+    for (int b = 0; b < kb; b++) {
+        const int v = border[b];
+        auto put = [&](int other, int src, int gate) {
+            const int po = iperm[other];
+            if (po < Nband) { Upos.push_back(po); Usrc.push_back(src); Ugate.push_back(gate); }
+            else if (po - Nband < b) { Cb2.push_back(po - Nband); Csrc.push_back(src); Cgate.push_back(gate); }
+        };
+        if (v < n) {
+            for (int k = Qp[v]; k < Qp[v + 1]; k++) if (Qi[k] != v) put(Qi[k], k, -1);                       // Q is symmetric: row v = column v
+            for (int kc = ETp[v]; kc < ETp[v + 1]; kc++) put(n + ETi[kc], nnzQ + ETmap[kc], ETi[kc]);       // column v of E
+        } else {
+            const int r = v - n;
+            for (int k = Ep[r]; k < Ep[r + 1]; k++) put(Ei[k], nnzQ + k, r);
+        }
+        Uptr[b + 1] = (int)Upos.size(); Cptr[b + 1] = (int)Cb2.size();
+    }
+    const int nU = (int)Upos.size(), nCb = (int)Cb2.size();
     if (hipSetDevice(device) != hipSuccess) { g_sp_err = "hipSetDevice failed"; return nullptr; }
     lcqp_hip_sparse* h = new (std::nothrow) lcqp_hip_sparse();
     if (!h) return nullptr;
@@ -1195,7 +1373,7 @@ try {
     h->stream = nullptr; h->ev0 = h->ev1 = h->ev2 = nullptr;
     SpBatch& d = h->db;
     memset(&d, 0, sizeof(d));
-    d.B = batch; d.n = n; d.m = m; d.nC = nC; d.nComp = nComp; d.N = N; d.Np = ((N + 63) / 64) * 64; d.w = w; d.ld = ld; d.nnzQ = nnzQ; d.nnzE = nnzA; d.G = G;
+    d.B = batch; d.n = n; d.m = m; d.nC = nC; d.nComp = nComp; d.N = N; d.Np = ((N + 63) / 64) * 64; d.w = w; d.ld = ld; d.nnzQ = nnzQ; d.nnzE = nnzA; d.G = G; d.kb = kb; d.nU = nU; d.nCb = nCb;
     const size_t Np = d.Np;
     lcqp_hip_options_default(&d.opt);
     bool ok = hipStreamCreate(&h->stream) == hipSuccess && hipEventCreate(&h->ev0) == hipSuccess && hipEventCreate(&h->ev1) == hipSuccess &&
@@ -1207,6 +1385,12 @@ try {
          (d.bandQ = sp_alloc<int>(h, nnzQ, bandQ.data())) && (d.bandE = sp_alloc<int>(h, nnzA, bandE.data())) &&
          (d.bsrc = sp_alloc<int>(h, bsrc.size(), bsrc.data())) && (d.pnode = sp_alloc<int>(h, N, pnode.data())) &&
          (d.qdiag = sp_alloc<int>(h, n, qdiag.data())) && (d.Erow = sp_alloc<int>(h, nnzA, Erow.data()));
+    if (kb > 0)
+        ok = ok && (d.bnode = sp_alloc<int>(h, kb, border.data())) && (d.Uptr = sp_alloc<int>(h, kb + 1, Uptr.data())) && (d.Upos = sp_alloc<int>(h, nU, Upos.data())) &&
+             (d.Usrc = sp_alloc<int>(h, nU, Usrc.data())) && (d.Ugate = sp_alloc<int>(h, nU, Ugate.data())) && (d.Cptr = sp_alloc<int>(h, kb + 1, Cptr.data())) &&
+             (d.Cb2 = sp_alloc<int>(h, nCb, Cb2.data())) && (d.Csrc = sp_alloc<int>(h, nCb, Csrc.data())) && (d.Cgate = sp_alloc<int>(h, nCb, Cgate.data())) &&
+             (d.bW = sp_alloc<double>(h, (size_t)batch * 2 * kb * d.Np)) && (d.bUv = sp_alloc<double>(h, (size_t)batch * 2 * nU)) &&
+             (d.bS = sp_alloc<double>(h, (size_t)batch * 2 * kb * kb));
     // ELL slabs of the three gathers (g_ell): rows of Q, rows of E, columns of E
     auto make_ell = [&](EllMat& e, int rows, const std::vector<int>& ptr, const std::vector<int>& idx, const int* map, const int* dptr, const int* didx, const int* dmap) {
         int mx = 0;
@@ -1250,6 +1434,7 @@ catch (...) { }
 
 extern "C" int lcqp_hip_sparse_bandwidth(const lcqp_hip_sparse_t* h) { return h ? h->db.w : -1; }
 extern "C" int lcqp_hip_sparse_lanes(const lcqp_hip_sparse_t* h) { return h ? h->db.G : -1; }
+extern "C" int lcqp_hip_sparse_border(const lcqp_hip_sparse_t* h) { return h ? h->db.kb : -1; }
 extern "C" int lcqp_hip_sparse_get_ordering(const lcqp_hip_sparse_t* h, int* perm)
 {
     if (!h || !perm) return LCQP_INVALID_ARGUMENT;

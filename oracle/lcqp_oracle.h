@@ -142,13 +142,14 @@ int orc_synth_batch_solve(uint64_t seed0, int first, int count, int n, int nC, i
 /* ---- sparse arm (lcqp_oracle_sparse.c): LCQProblem::runSolver with the OSQP_SPARSE conventions of src/LCQProblem.cpp:929-960
  * (no box constraints, nC + 2 nComp duals) over an OSQP-style subsolver (ADMM on the quasi-definite KKT matrix + active-set
  * polish).  Q: CSR of the full symmetric matrix; E = [A; L; R]: CSR, nC + 2 nComp rows; y0 / yOpt: nC + 2 nComp entries.
- * perm[nV + m]: ordering of the KKT matrix [Q E'; E .] (position -> node; node < nV: variable, else row node - nV) with half
- * bandwidth w -- the factorisations are band LDL'. */
+ * perm[nV + m]: ordering of the KKT matrix [Q E'; E .] (position -> node; node < nV: variable, else row node - nV); its first
+ * nV + m - kb positions form a band of half bandwidth w, the last kb are border nodes (rows / variables too dense for a band) -- the
+ * factorisations are bordered band LDL' (kb <= 64; kb = 0: plain band). */
 int orc_sparse_lcqp_solve(int nV, int nC, int nComp,
                           const int* Qp, const int* Qi, const double* Qx, const double* g,
                           const int* Ep, const int* Ei, const double* Ex,
                           const double* lbA, const double* ubA, const double* lbL, const double* ubL, const double* lbR, const double* ubR,
-                          const double* x0, const double* y0, const int* perm, int w,
+                          const double* x0, const double* y0, const int* perm, int w, int kb,
                           const orc_options_t* opt, double* xOpt, double* yOpt, orc_stats_t* stats);
 
 #ifdef __cplusplus

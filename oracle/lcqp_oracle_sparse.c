@@ -25,12 +25,18 @@
 enum { SP_INACT = 0, SP_LOWER = 1, SP_UPPER = 2, SP_EQ = 3 };
 
 typedef struct {
-    int N, w;
+    int N, w;      /* N: nodes inside the band (the border nodes come after them in the ordering) */
     double* B;     /* N x (w+1): B[i*(w+1) + k] = K[i][i-w+k]; after factorisation the unit lower factor, B[i][w] = D_i */
+    /* bordered band (round 3): K = [B U'; U C] with kb border nodes -- nodes whose rows are too dense for any band, e.g. the coupling
+     * constraint and the two shared variables of examples/OptimizeOnCircle.cpp.  B is factorised as a band, the border is carried by
+     * W = U inv(B) and the Schur complement S = C - U inv(B) U' (kb x kb, LDL' without pivoting: a Schur complement of a quasi-definite
+     * matrix is quasi-definite). */
+    int kb;
+    double *U, *W, *S;   /* kb x N (U, then W), kb x kb */
 } band_t;
 
 typedef struct {
-    int n, m, nC, nComp, N, w;
+    int n, m, nC, nComp, N, w, kb;      /* kb: border nodes, the last kb positions of perm */
     const int *Qp, *Qi; const double* Qx;      /* CSR of the symmetric Q */
     const int *Ep, *Ei; const double* Ex;      /* CSR of E = [A; L; R] */
     const int *perm; int* iperm;
@@ -101,35 +107,91 @@ static void band_solve(const band_t* f, double* b)
         for (int j = j0; j < i; j++) b[j] -= ri[w - (i - j)] * xi;
     }
 }
-/* K = [Q + dprim I, Ea'; Ea, -diag(ddual)] in the ordering perm; rows with use[r] == 0 are decoupled (diagonal -1) */
+/* K = [Q + dprim I, Ea'; Ea, -diag(ddual)] in the ordering perm; rows with use[r] == 0 are decoupled (diagonal -1).  Positions >= f->N
+ * are border nodes: their couplings go to U (with band nodes) and S (among themselves). */
+static void kkt_put(band_t* f, int pa, int pb, double v)
+{
+    const int Nb = f->N, w = f->w, ld = w + 1, kb = f->kb;
+    const int hi = pa > pb ? pa : pb, lo = pa > pb ? pb : pa;
+    if (hi < Nb) f->B[(size_t)hi * ld + w - (hi - lo)] += v;
+    else if (lo < Nb) f->U[(size_t)(hi - Nb) * Nb + lo] += v;
+    else { f->S[(size_t)(hi - Nb) * kb + (lo - Nb)] += v; if (hi != lo) f->S[(size_t)(lo - Nb) * kb + (hi - Nb)] += v; }
+}
 static void kkt_assemble(const sqp_t* q, band_t* f, double dprim, const double* ddual, const int* use)
 {
-    const int n = q->n, m = q->m, w = q->w, ld = w + 1;
+    const int n = q->n, m = q->m, w = q->w, ld = w + 1, kb = f->kb;
     memset(f->B, 0, sizeof(double) * (size_t)f->N * ld);
+    if (kb > 0) { memset(f->U, 0, sizeof(double) * (size_t)kb * f->N); memset(f->S, 0, sizeof(double) * (size_t)kb * kb); }
     for (int i = 0; i < n; i++) {
         const int pi = q->iperm[i];
         for (int k = q->Qp[i]; k < q->Qp[i + 1]; k++) {
             const int pj = q->iperm[q->Qi[k]];
-            if (pj <= pi) f->B[(size_t)pi * ld + w - (pi - pj)] += q->Qx[k];
+            if (pj <= pi) kkt_put(f, pi, pj, q->Qx[k]);
         }
-        f->B[(size_t)pi * ld + w] += dprim;
+        kkt_put(f, pi, pi, dprim);
     }
     for (int r = 0; r < m; r++) {
         const int pr = q->iperm[n + r];
-        if (use && !use[r]) { f->B[(size_t)pr * ld + w] = -1.0; continue; }
-        f->B[(size_t)pr * ld + w] = -ddual[r];
-        for (int k = q->Ep[r]; k < q->Ep[r + 1]; k++) {
-            const int pc = q->iperm[q->Ei[k]];
-            const int hi = pr > pc ? pr : pc, lo = pr > pc ? pc : pr;
-            f->B[(size_t)hi * ld + w - (hi - lo)] += q->Ex[k];
+        if (use && !use[r]) { kkt_put(f, pr, pr, -1.0); continue; }
+        kkt_put(f, pr, pr, -ddual[r]);
+        for (int k = q->Ep[r]; k < q->Ep[r + 1]; k++) kkt_put(f, pr, q->iperm[q->Ei[k]], q->Ex[k]);
+    }
+}
+/* the factorisation of the bordered matrix: band LDL' of B, W = U inv(B) row by row, S = C - W U', dense LDL' of S in place */
+static void kkt_factor(band_t* f)
+{
+    const int Nb = f->N, kb = f->kb;
+    band_factor(f);
+    for (int b = 0; b < kb; b++) {
+        double* wb = f->W + (size_t)b * Nb;
+        memcpy(wb, f->U + (size_t)b * Nb, sizeof(double) * Nb);
+        band_solve(f, wb);
+    }
+    for (int a = 0; a < kb; a++)
+        for (int b = 0; b < kb; b++) {
+            double s = 0;
+            const double *ua = f->U + (size_t)a * Nb, *wb = f->W + (size_t)b * Nb;
+            for (int p = 0; p < Nb; p++) if (ua[p] != 0.0) s += ua[p] * wb[p];
+            f->S[(size_t)a * kb + b] -= s;
         }
+    for (int j = 0; j < kb; j++) {       /* S = L D L': L below the diagonal, D on it */
+        double d = f->S[(size_t)j * kb + j];
+        for (int k = 0; k < j; k++) d -= f->S[(size_t)j * kb + k] * f->S[(size_t)j * kb + k] * f->S[(size_t)k * kb + k];
+        f->S[(size_t)j * kb + j] = d;
+        for (int i = j + 1; i < kb; i++) {
+            double v = f->S[(size_t)i * kb + j];
+            for (int k = 0; k < j; k++) v -= f->S[(size_t)i * kb + k] * f->S[(size_t)j * kb + k] * f->S[(size_t)k * kb + k];
+            f->S[(size_t)i * kb + j] = v / d;
+        }
+    }
+}
+/* K x = b in place (b in the ordering perm: band nodes first, then the border) */
+static void kkt_solve(const band_t* f, double* b)
+{
+    const int Nb = f->N, kb = f->kb;
+    band_solve(f, b);
+    if (kb == 0) return;
+    double t[64];
+    for (int a = 0; a < kb; a++) {
+        double s = b[Nb + a];
+        const double* ua = f->U + (size_t)a * Nb;
+        for (int p = 0; p < Nb; p++) if (ua[p] != 0.0) s -= ua[p] * b[p];
+        t[a] = s;
+    }
+    for (int i = 0; i < kb; i++) for (int k = 0; k < i; k++) t[i] -= f->S[(size_t)i * kb + k] * t[k];
+    for (int i = 0; i < kb; i++) t[i] /= f->S[(size_t)i * kb + i];
+    for (int i = kb - 1; i >= 0; i--) for (int k = i + 1; k < kb; k++) t[i] -= f->S[(size_t)k * kb + i] * t[k];
+    for (int a = 0; a < kb; a++) {
+        const double* wa = f->W + (size_t)a * Nb;
+        for (int p = 0; p < Nb; p++) b[p] -= wa[p] * t[a];
+        b[Nb + a] = t[a];
     }
 }
 
 /* ---- subsolver ---------------------------------------------------------------------------------------------------------- */
 static void sqp_free(sqp_t* q)
 {
-    free(q->iperm); free(q->l); free(q->u); free(q->rhov); free(q->Ka.B); free(q->Kp.B); free(q->stf); free(q->x); free(q->y);
+    free(q->iperm); free(q->l); free(q->u); free(q->rhov); free(q->Ka.B); free(q->Kp.B); free(q->Ka.U); free(q->Ka.W); free(q->Ka.S); free(q->Kp.U); free(q->Kp.W); free(q->Kp.S); free(q->stf); free(q->x); free(q->y);
     free(q->st); free(q->xa); free(q->ya); free(q->za); free(q->r1); free(q->ex); free(q->wN); free(q->r1_last); free(q->ex_last);
     free(q->g_last); free(q->newst);
 }
@@ -158,10 +220,13 @@ static int sqp_setup(sqp_t* q, const double* lbE, const double* ubE)
         else q->rhov[r] = rho;
         dd[r] = 1.0 / q->rhov[r];
     }
-    q->Ka.N = q->Kp.N = N; q->Ka.w = q->Kp.w = q->w;
-    q->Ka.B = dal((size_t)N * (q->w + 1)); q->Kp.B = dal((size_t)N * (q->w + 1));
+    const int kb = q->kb, Nb = N - kb;
+    q->Ka.N = q->Kp.N = Nb; q->Ka.w = q->Kp.w = q->w; q->Ka.kb = q->Kp.kb = kb;
+    q->Ka.B = dal((size_t)Nb * (q->w + 1)); q->Kp.B = dal((size_t)Nb * (q->w + 1));
+    q->Ka.U = dal((size_t)kb * Nb); q->Ka.W = dal((size_t)kb * Nb); q->Ka.S = dal((size_t)kb * kb);
+    q->Kp.U = dal((size_t)kb * Nb); q->Kp.W = dal((size_t)kb * Nb); q->Kp.S = dal((size_t)kb * kb);
     kkt_assemble(q, &q->Ka, q->sigma, dd, NULL);
-    band_factor(&q->Ka);
+    kkt_factor(&q->Ka);
     free(dd);
     q->stf = ial(m); q->stf_valid = 0;
     q->x = dal(n); q->y = dal(m); q->st = ial(m);
@@ -180,7 +245,7 @@ static void sqp_admm(sqp_t* q, const double* g, int n_it)
     for (int it = 0; it < n_it; it++) {
         for (int i = 0; i < n; i++) b[q->iperm[i]] = q->sigma * q->xa[i] - g[i];
         for (int r = 0; r < m; r++) b[q->iperm[n + r]] = q->za[r] - q->ya[r] / q->rhov[r];
-        band_solve(&q->Ka, b);
+        kkt_solve(&q->Ka, b);
         for (int r = 0; r < m; r++) {
             const double rv = q->rhov[r];
             const double zt = q->za[r] + (b[q->iperm[n + r]] - q->ya[r]) / rv;
@@ -262,7 +327,7 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
                 double* d2 = (double*)malloc(sizeof(double) * (m ? m : 1));
                 for (int r = 0; r < m; r++) { use[r] = (st[r] != SP_INACT); d2[r] = q->delta2; }
                 kkt_assemble(q, &q->Kp, q->delta, d2, use);
-                band_factor(&q->Kp);
+                kkt_factor(&q->Kp);
                 free(d2);
                 memcpy(q->stf, st, sizeof(int) * m); q->stf_valid = 1;
                 q->c_fact++;
@@ -276,7 +341,7 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
             if (st[r] != SP_INACT) v = ((st[r] == SP_UPPER) ? q->u[r] : q->l[r]) - Ex[r];
             b[q->iperm[n + r]] = v;
         }
-        band_solve(&q->Kp, b);
+        kkt_solve(&q->Kp, b);
         for (int i = 0; i < n; i++) x[i] += b[q->iperm[i]];
         for (int r = 0; r < m; r++) if (st[r] != SP_INACT) y[r] += b[q->iperm[n + r]];
         q->c_corr++;
@@ -338,14 +403,14 @@ int orc_sparse_lcqp_solve(int nV, int nC, int nComp,
                           const int* Qp, const int* Qi, const double* Qx, const double* g,
                           const int* Ep, const int* Ei, const double* Ex,
                           const double* lbA, const double* ubA, const double* lbL, const double* ubL, const double* lbR, const double* ubR,
-                          const double* x0, const double* y0, const int* perm, int w,
+                          const double* x0, const double* y0, const int* perm, int w, int kb,
                           const orc_options_t* opt, double* xOpt, double* yOpt, orc_stats_t* stats)
 {
     const int n = nV, m = nC + 2 * nComp;
     memset(stats, 0, sizeof(*stats));
     sqp_t Q_; memset(&Q_, 0, sizeof(Q_));
     sqp_t* q = &Q_;
-    q->n = n; q->m = m; q->nC = nC; q->nComp = nComp; q->w = w; q->perm = perm;
+    q->n = n; q->m = m; q->nC = nC; q->nComp = nComp; q->w = w; q->kb = kb; q->perm = perm;
     q->Qp = Qp; q->Qi = Qi; q->Qx = Qx; q->Ep = Ep; q->Ei = Ei; q->Ex = Ex; q->opt = *opt;
     /* stacked bounds: setConstraints / setComplementarityBounds (src/LCQProblem.cpp:585-608, 726-785) */
     double *lE = dal(m), *uE = dal(m);

@@ -313,25 +313,35 @@ def dns_to_csc(full):
     return L.orc_dns_to_csc(_p(full), full.shape[0], full.shape[1])
 
 
-def kkt_ordering(nV, Qp, Qi, Ep, Ei):
-    """Reverse Cuthill-McKee ordering of the KKT graph [Q E'; E .] (scipy, independent of the product's own analysis) and its half
-    bandwidth: perm[position] = node (node < nV: variable, else row node - nV)."""
+def kkt_ordering(nV, Qp, Qi, Ep, Ei, wmax=63, kbmax=16):
+    """Ordering of the KKT graph [Q E'; E .] with scipy (independent of the product's own analysis): reverse Cuthill-McKee; while the
+    half bandwidth exceeds wmax, the node of highest degree moves to the border (the last positions).  Returns (perm, w, kb):
+    perm[position] = node (node < nV: variable, else row node - nV), w = half bandwidth of the first N - kb positions."""
     import scipy.sparse as sp
     from scipy.sparse.csgraph import reverse_cuthill_mckee
     m = len(Ep) - 1
     N = nV + m
     Qs = sp.csr_matrix((np.ones(len(Qi)), np.asarray(Qi), np.asarray(Qp)), shape=(nV, nV))
     Es = sp.csr_matrix((np.ones(len(Ei)), np.asarray(Ei), np.asarray(Ep)), shape=(m, nV))
-    K = sp.bmat([[Qs, Es.T], [Es, None]], format="csr") + sp.identity(N, format="csr")
-    perm = np.asarray(reverse_cuthill_mckee(sp.csr_matrix(K), symmetric_mode=True), dtype=np.int32)
-    iperm = np.empty(N, dtype=np.int64); iperm[perm] = np.arange(N)
-    coo = K.tocoo()
-    w = int(np.abs(iperm[coo.row] - iperm[coo.col]).max()) if coo.nnz else 0
-    return perm, w
+    K = sp.csr_matrix(sp.bmat([[Qs, Es.T], [Es, None]], format="csr") + sp.identity(N, format="csr"))
+    border = []
+    while True:
+        keep = np.setdiff1d(np.arange(N), border)
+        Kk = K[keep][:, keep]
+        p = np.asarray(reverse_cuthill_mckee(sp.csr_matrix(Kk), symmetric_mode=True), dtype=np.int64)
+        ip = np.empty(len(keep), dtype=np.int64); ip[p] = np.arange(len(keep))
+        coo = Kk.tocoo()
+        w = int(np.abs(ip[coo.row] - ip[coo.col]).max()) if coo.nnz else 0
+        if w <= wmax or len(border) >= kbmax:
+            break
+        deg = np.asarray(Kk.getnnz(axis=1)).ravel()
+        border.append(int(keep[int(np.argmax(deg))]))
+    perm = np.concatenate([keep[p], np.array(border, dtype=np.int64)]).astype(np.int32)
+    return perm, w, len(border)
 
 
 def sparse_lcqp_solve(nV, nC, nComp, Qcsr, g, Ecsr, lbA=None, ubA=None, lbL=None, ubL=None, lbR=None, ubR=None, x0=None, y0=None,
-                      perm=None, w=None, opt=None):
+                      perm=None, w=None, kb=0, opt=None):
     """OSQP_SPARSE arm on the oracle (oracle/lcqp_oracle_sparse.c).  Qcsr / Ecsr: scipy CSR matrices (Q full symmetric,
     E = [A; L; R]).  Returns dict(ret, x, y (nC + 2 nComp), stats)."""
     L_ = lib()
@@ -341,7 +351,7 @@ def sparse_lcqp_solve(nV, nC, nComp, Qcsr, g, Ecsr, lbA=None, ubA=None, lbL=None
     Qp = np.ascontiguousarray(Qcsr.indptr, dtype=np.int32); Qi = np.ascontiguousarray(Qcsr.indices, dtype=np.int32); Qx = _arr(Qcsr.data)
     Ep = np.ascontiguousarray(Ecsr.indptr, dtype=np.int32); Ei = np.ascontiguousarray(Ecsr.indices, dtype=np.int32); Ex = _arr(Ecsr.data)
     if perm is None:
-        perm, w = kkt_ordering(nV, Qp, Qi, Ep, Ei)
+        perm, w, kb = kkt_ordering(nV, Qp, Qi, Ep, Ei)
     perm = np.ascontiguousarray(perm, dtype=np.int32)
     opt = opt or default_options()
     m = nC + 2 * nComp
@@ -350,5 +360,5 @@ def sparse_lcqp_solve(nV, nC, nComp, Qcsr, g, Ecsr, lbA=None, ubA=None, lbL=None
     L_.orc_sparse_lcqp_solve.restype = C.c_int
     ret = L_.orc_sparse_lcqp_solve(nV, nC, nComp, Qp.ctypes.data_as(ip), Qi.ctypes.data_as(ip), _p(Qx), _p(_arr(g)),
                                    Ep.ctypes.data_as(ip), Ei.ctypes.data_as(ip), _p(Ex), *[_p(v) for v in a],
-                                   perm.ctypes.data_as(ip), C.c_int(int(w)), C.byref(opt), _p(x), _p(y), C.byref(st))
-    return dict(ret=ret, x=x, y=y, stats=st.asdict(), perm=perm, w=int(w))
+                                   perm.ctypes.data_as(ip), C.c_int(int(w)), C.c_int(int(kb)), C.byref(opt), _p(x), _p(y), C.byref(st))
+    return dict(ret=ret, x=x, y=y, stats=st.asdict(), perm=perm, w=int(w), kb=int(kb))

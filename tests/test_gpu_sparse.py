@@ -152,12 +152,45 @@ def test_sparse_profile_entry_point_needs_a_profile_build(hip):
     sb.close()
 
 
-def test_sparse_pattern_outside_the_band_engine_is_refused(hip):
-    """the arrow-shaped KKT matrix of examples/OptimizeOnCircle.cpp (one dense constraint row) is not banded: the sparse engine
-    says so, it does not run past its window (the host layer runs this problem on the dense kernels behind the OSQP_SPARSE
-    surface: tests/test_python_api.py::test_python_reference_solver_arms)"""
+def test_sparse_bordered_band_circle(hip, oracle):
+    """examples/OptimizeOnCircle.cpp:44 (the reference's own OSQP_SPARSE example) has an arrow-shaped KKT matrix: the coupling row and the
+    two shared variables touch a hundred nodes each.  The engine orders it as a narrow band plus three border nodes (bordered band LDL':
+    band factor, W = U inv(B), Schur complement of the border) and matches the sparse oracle run with the same ordering, the dense oracle
+    and the optimum the reference prints (examples/OptimizeOnCircle.cpp:144)."""
     import scipy.sparse as sp
     d = P.circle(100)
+    n, nC, nK = d["nV"], d["nC"], d["nComp"]
     Q = sp.csc_matrix(d["Q"]); E = sp.csc_matrix(np.vstack([d["A"], d["L"], d["R"]]))
-    with pytest.raises(RuntimeError, match="bandwidth"):
-        hip.SparseBatchLCQP(1, d["nV"], d["nC"], d["nComp"], Q, E)
+    Q.sort_indices(); E.sort_indices()
+    B = 3
+    sb = hip.SparseBatchLCQP(B, n, nC, nK, Q, E, opt=hip.default_options(perturbStep=0, printLevel=0))
+    assert sb.border() == 3 and 1 <= sb.bandwidth() <= 63
+    perm = sb.ordering()
+    assert sorted(perm[-3:].tolist()) == [0, 1, n + nC - 1]                # x_0, x_1 and the row sum(theta) = 1
+    tile = lambda v: np.tile(np.asarray(v, dtype=float), (B, 1))
+    assert sb.load(0, B, tile(Q.data), tile(d["g"]), tile(E.data), lbA=tile(d["lbA"]), ubA=tile(d["ubA"]), x0=tile(d["x0"])) == 0
+    sb.run()
+    x, y, st = sb.solution()
+    ro = oracle.sparse_lcqp_solve(n, nC, nK, Q.tocsr(), d["g"], E.tocsr(), lbA=d["lbA"], ubA=d["ubA"], x0=d["x0"], perm=perm, w=sb.bandwidth(), kb=sb.border(),
+                                  opt=oracle.default_options(perturbStep=0))
+    rd = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0))
+    for b in range(B):
+        assert st[b]["returnValue"] == ro["ret"] == 0 and st[b]["status"] == ro["stats"]["status"]
+        assert np.abs(x[b] - ro["x"]).max() < 1e-9 and np.abs(y[b] - ro["y"]).max() < 1e-7
+        assert abs(st[b]["iterTotal"] - ro["stats"]["iterTotal"]) <= 4
+        assert np.abs(x[b] - rd["x"]).max() < 1e-7 and np.abs(x[b][:2] - [0.1811, -0.9835]).max() < 1e-4
+    sb.close()
+
+
+def test_sparse_pattern_that_is_neither_banded_nor_bordered_is_refused(hip):
+    """a pattern with more dense nodes than the border takes (here forty dense rows over two hundred variables): the engine says so, it
+    does not run past its window (the host layer runs such a problem on the dense kernels behind the OSQP_SPARSE surface)"""
+    import scipy.sparse as sp
+    n, nC, nK = 200, 40, 8
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((nC, n))
+    L = np.zeros((nK, n)); R = np.zeros((nK, n))
+    L[np.arange(nK), np.arange(nK)] = 1; R[np.arange(nK), nK + np.arange(nK)] = 1
+    Q = sp.csc_matrix(np.eye(n)); E = sp.csc_matrix(np.vstack([A, L, R]))
+    with pytest.raises(RuntimeError, match="neither a banded nor a bordered"):
+        hip.SparseBatchLCQP(1, n, nC, nK, Q, E)

@@ -311,6 +311,14 @@ def test_python_reference_solver_arms(hip, oracle):
     assert ret == RV.SUCCESSFUL_RETURN
     assert np.abs(lcqp.getPrimalSolution() - ro["x"]).max() < 1e-7
     assert np.abs(lcqp.getDualSolution() - ro["y"][c["nV"]:]).max() < 1e-5
+    # the example at its real size (interfaces/python/examples/OptimizeOnCircle.py:20, N = 100): an arrow-shaped KKT matrix -- the sparse
+    # engine takes it as a band with three border nodes (round 3); before, LCQProblem densified it and ran the host loop
+    c = P.circle(100)
+    ro = P.oracle_solve(oracle, c, oracle.default_options(perturbStep=0))
+    ret, lcqp = run(c, QS.OSQP_SPARSE, sparse=True)
+    assert ret == RV.SUCCESSFUL_RETURN and lcqp.getLastEngine() == 3
+    assert np.abs(lcqp.getPrimalSolution() - ro["x"]).max() < 1e-7
+    assert np.abs(lcqp.getPrimalSolution()[:2] - [0.1811, -0.9835]).max() < 1e-4          # examples/OptimizeOnCircle.cpp:144
 
 
 @pytest.mark.gpu
