@@ -194,3 +194,38 @@ def test_sparse_pattern_that_is_neither_banded_nor_bordered_is_refused(hip):
     Q = sp.csc_matrix(np.eye(n)); E = sp.csc_matrix(np.vstack([A, L, R]))
     with pytest.raises(RuntimeError, match="neither a banded nor a bordered"):
         hip.SparseBatchLCQP(1, n, nC, nK, Q, E)
+
+
+@pytest.mark.parametrize("n,nC,nK,extra", [(512, 256, 64, 1), (512, 256, 64, 3)])
+def test_sparse_banded_pattern_with_coupling_rows(hip, oracle, n, nC, nK, extra):
+    """the banded synthetic pattern plus `extra` coupling rows that touch every variable (a budget constraint over an OCP horizon): band of
+    half bandwidth 7 + border; the device matches the sparse oracle run with the device's ordering"""
+    import scipy.sparse as sp
+    B = 4
+    rng = np.random.default_rng(5)
+    insts, pats = [], None
+    for b in range(B):
+        d = P.sparse_instance(b, n, nC, nK)
+        E = d["E"].tocsr()
+        rows = rng.uniform(0.5, 1.5, (extra, n)) / n
+        A2 = sp.vstack([E[:nC], sp.csr_matrix(rows), E[nC:]], format="csc")
+        A2.sort_indices()
+        xs = np.linalg.lstsq(E[:nC].toarray(), 0.5 * (d["lbA"] + d["ubA"]), rcond=None)[0]
+        mid = rows @ xs
+        insts.append(dict(Q=d["Q"], E=A2, g=d["g"], lbA=np.concatenate([d["lbA"], mid - 5.0]), ubA=np.concatenate([d["ubA"], mid + 0.05 * (b + 1)])))
+    Qp, Ep = insts[0]["Q"], insts[0]["E"]
+    sb = hip.SparseBatchLCQP(B, n, nC + extra, nK, Qp, Ep, opt=hip.default_options(perturbStep=0, printLevel=0))
+    assert sb.border() == extra and sb.bandwidth() <= 15
+    assert sb.load(0, B, np.stack([d["Q"].data for d in insts]), np.stack([d["g"] for d in insts]), np.stack([d["E"].data for d in insts]),
+                   lbA=np.stack([d["lbA"] for d in insts]), ubA=np.stack([d["ubA"] for d in insts])) == 0
+    sb.run()
+    x, y, st = sb.solution()
+    perm = sb.ordering()
+    for b in range(B):
+        d = insts[b]
+        ro = oracle.sparse_lcqp_solve(n, nC + extra, nK, d["Q"].tocsr(), d["g"], d["E"].tocsr(), lbA=d["lbA"], ubA=d["ubA"], perm=perm, w=sb.bandwidth(), kb=extra,
+                                      opt=oracle.default_options(perturbStep=0))
+        assert st[b]["returnValue"] == ro["ret"] == 0
+        assert np.abs(x[b] - ro["x"]).max() < 1e-9 and np.abs(y[b] - ro["y"]).max() < 1e-7
+        assert abs(st[b]["iterTotal"] - ro["stats"]["iterTotal"]) <= 4
+    sb.close()
