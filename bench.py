@@ -289,7 +289,7 @@ def main():
     if main_proc and not sparse and not args.no_backsolve:
         # the factor-once / back-solve-many kernel pair on its own (bytes_bs(N) = 8 N (N+2)), cache-cold: 4096
         # factors of order n = 2 GiB at n = 256, far beyond the 256 MiB Infinity Cache, one right-hand side each; the in-situ
-        # rate of the same routine inside k_lcqp_run is in profiles/round2 (tools/gpu_phase_profile.py)
+        # rate of the same routine inside k_lcqp_run is in profiles/round2 (tools/gpu.py phase_profile)
         rng = np.random.default_rng(0)
         nb = 4096 if n <= 256 else 1024
         K0 = rng.standard_normal((64, n, n)) * 0.05

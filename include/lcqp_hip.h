@@ -134,11 +134,6 @@ int  lcqp_hip_batch_setup(lcqp_hip_batch_t* b);
 /* LCQProblem::runSolver for all instances, src/LCQProblem.cpp:444-560.  Asynchronous on the batch
  * stream; includes setup if it has not run since the last load. */
 int  lcqp_hip_batch_run(lcqp_hip_batch_t* b);
-/* second chance for the instances the last run returned with SUBPROBLEM_SOLVER_ERROR because the subsolver gave up
- * (exit flag 1; not for infeasible bounds): the same homotopy from the same start with the subsolver variant that handles
- * linearly dependent active rows (k_lcqp_rerun; costs the first pass nothing).  *count = instances repeated; their
- * solutions, statistics and work counters replace the failed ones.  Asynchronous like lcqp_hip_batch_run. */
-int  lcqp_hip_batch_rerun_failed(lcqp_hip_batch_t* b, int* count);
 int  lcqp_hip_batch_synchronize(lcqp_hip_batch_t* b);
 /* time of the last run (setup + homotopy kernel) measured with HIP events on the batch stream, ms */
 int  lcqp_hip_batch_last_timing(lcqp_hip_batch_t* b, float* setup_ms, float* solve_ms);
@@ -151,7 +146,7 @@ int  lcqp_hip_batch_get_solution(lcqp_hip_batch_t* b, double* x, double* y, lcqp
  * every pass of the loop; at most cap rows are copied. */
 int  lcqp_hip_batch_get_trace(lcqp_hip_batch_t* b, int instance, int cap, double* scalars, double* x, int* len);
 /* per-instance cycle counters of the homotopy kernel's phases, out[B][16]; all zero unless the library was
- * built with -DLCQP_PROFILE (tools/gpu_phase_profile.py) */
+ * built with -DLCQP_PROFILE (tools/gpu.py phase_profile) */
 int  lcqp_hip_batch_read_profile(lcqp_hip_batch_t* b, unsigned long long* out);
 /* raw HIP stream (hipStream_t) the batch launches on, for event timing by the caller */
 void* lcqp_hip_batch_stream(lcqp_hip_batch_t* b);

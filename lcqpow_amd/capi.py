@@ -78,7 +78,6 @@ def lib():
         L.lcqp_hip_batch_setup.argtypes = [C.c_void_p]
         L.lcqp_hip_batch_run.argtypes = [C.c_void_p]
         L.lcqp_hip_batch_synchronize.argtypes = [C.c_void_p]
-        L.lcqp_hip_batch_rerun_failed.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.lcqp_hip_batch_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.lcqp_hip_batch_get_solution.argtypes = [C.c_void_p, c_double_p, c_double_p, C.POINTER(Stats)]
         L.lcqp_hip_batch_get_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, C.POINTER(C.c_int)]
@@ -225,12 +224,6 @@ class BatchLCQP:
 
     def run(self):
         _check(lib().lcqp_hip_batch_run(self.h), "run")
-
-    def rerun_failed(self):
-        """repeat the instances whose subsolver gave up with the dependent-row rules on; returns how many were repeated"""
-        n = C.c_int(0)
-        _check(lib().lcqp_hip_batch_rerun_failed(self.h, C.byref(n)), "rerun_failed")
-        return n.value
 
     def synchronize(self):
         _check(lib().lcqp_hip_batch_synchronize(self.h), "synchronize")

@@ -43,15 +43,6 @@ class BatchLCQProblem {
         st.assign(B, lcqp_stats_t());
         return (ReturnValue)lcqp_hip_batch_get_solution(h, x.data(), y.data(), st.data());
     }
-    // second pass for the instances whose QP subsolver gave up (SUBPROBLEM_SOLVER_ERROR, exit flag 1): the same homotopy with
-    // the subsolver variant that handles linearly dependent active rows; returns how many instances were repeated
-    int rerunFailed()
-    {
-        int count = 0;
-        if (lcqp_hip_batch_rerun_failed(h, &count) != 0 || count == 0) return 0;
-        lcqp_hip_batch_get_solution(h, x.data(), y.data(), st.data());
-        return count;
-    }
     ReturnValue getReturnValue(int i) const { return (ReturnValue)st[i].returnValue; }
     AlgorithmStatus getPrimalSolution(int i, double* xOpt) const
     {

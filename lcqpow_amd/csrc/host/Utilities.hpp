@@ -1,7 +1,7 @@
 // Host-side enums, constants and dense helpers with the names and argument meaning of the reference's
 // Utilities (include/Utilities.hpp:37-129,140-328,350-362; src/Utilities.cpp:38-265).  Written from
-// scratch for this backend: std::vector-free, row-major, no qpOASES/OSQP types.  The sparse (csc) half
-// of the reference's Utilities is out of scope for the dense hot path.
+// scratch for this backend: std::vector-free, row-major, no qpOASES/OSQP types.  The sparse (csc) half of the
+// reference's Utilities (src/Utilities.cpp:49-59,75-82,118-173,189-199,228-241,593-650) is declared below as well.
 #ifndef LCQPOW_AMD_UTILITIES_HPP
 #define LCQPOW_AMD_UTILITIES_HPP
 

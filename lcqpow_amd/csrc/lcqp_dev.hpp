@@ -104,7 +104,7 @@ __device__ __forceinline__ Ctx<NCH> make_ctx(const DevBatch& db, int b, Lds lds)
     return c;
 }
 
-// phase buckets of the diagnostic build (tools/gpu_phase_profile.py)
+// phase buckets of the diagnostic build (tools/gpu.py phase_profile)
 enum { P_LCQP = 0, P_RESID = 1, P_GRAM = 2, P_CHOL = 3, P_CORR_L1 = 4, P_CORR_ROWS = 5, P_CORR_S = 6, P_ADMM = 7, P_MISC = 8, P_DEL = 9, P_UPD_PRE = 10 };
 #if defined(LCQP_PROFILE) && !defined(LCQP_PROFILE_BULK)
 #define PROF(c, k) do { unsigned long long t_ = clock64(); (c).prof[k] += t_ - (c).tlast; (c).tlast = t_; } while (0)
@@ -310,8 +310,7 @@ __device__ __forceinline__ int qp_adapt_rho(Ctx<NCH>& c, const double* g)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Dependent-row rules of the single-QP kernel (k_qp_solve, ROBUST = true; oracle: q->robust).  k_lcqp_run runs without
-// them: inside the persistent kernel they cost 6 % through register allocation.
+// Dependent-row rules of the subsolver (ROBUST = true in every kernel since round 2: k_lcqp_run, k_qp_solve; oracle: q->robust).
 // (1) Rows the last factorisation of S flagged as linearly dependent on the rows before them: the correction neither
 //     moved their multipliers nor enforced their equations.  Strictly inside its bound: the row is not active.
 //     Violated: it must be active, so it is promoted to the front of the list and another row becomes the dependent
@@ -1174,8 +1173,8 @@ __device__ __forceinline__ void qp_export(Ctx<NCH>& c, double* xdst /*np or n*/,
 // ---------------------------------------------------------------------------------------------
 // LCQProblem::runSolver for one instance (oracle: orc_lcqp_solve).  src/LCQProblem.cpp:444-560.
 // ---------------------------------------------------------------------------------------------
-// ROBUST selects the QP subsolver variant (qp_solve<NCH, ROBUST>): false in k_lcqp_run, true in k_lcqp_rerun, which repeats
-// the instances that ended with SUBPROBLEM_SOLVER_ERROR.
+// ROBUST: the dependent-row rules of the subsolver (polish_dependent_rows); on in every kernel since round 2 (the switch stays for A/B builds).
+// LR: the row state of the subsolver lives in LDS (k_lcqp_run at np <= 256).
 template <int NCH, bool ROBUST, bool LR = false>
 __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
 {

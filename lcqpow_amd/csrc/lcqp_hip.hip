@@ -105,7 +105,6 @@ struct lcqp_hip_batch {
     size_t stageBytes;
     std::vector<void*> allocs;
     bool setupDone, ran, anyLoaded;
-    int* rerunList;     // device buffer of instance ids for k_lcqp_rerun (allocated on first use)
     int nch;
     size_t bytesTotal;
 };
@@ -157,7 +156,7 @@ try {
     if (!h) { g_err = "out of host memory"; return nullptr; }
     h->device = device; h->setupDone = false; h->ran = false; h->anyLoaded = false; h->bytesTotal = 0;
     h->stage[0] = h->stage[1] = nullptr; h->stageBytes = 0;
-    h->stream = nullptr; h->ev0 = h->ev1 = h->ev2 = nullptr; h->rerunList = nullptr;
+    h->stream = nullptr; h->ev0 = h->ev1 = h->ev2 = nullptr;
     DevBatch& d = h->db;
     memset(&d, 0, sizeof(d));
     hipError_t e0 = hipStreamCreate(&h->stream);
@@ -473,31 +472,6 @@ try {
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev2, h->stream));
     h->ran = true;
-    return 0;
-}
-catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
-
-extern "C" int lcqp_hip_batch_rerun_failed(lcqp_hip_batch_t* h, int* count)
-try {
-    if (!h || !count) return LCQP_INVALID_ARGUMENT;
-    *count = 0;
-    if (!h->ran) return LCQP_LCQPOBJECT_NOT_SETUP;
-    HIPCHK(hipSetDevice(h->device));
-    DevBatch& d = h->db;
-    HIPCHK(hipStreamSynchronize(h->stream));
-    std::vector<lcqp_stats_t> st(d.B);
-    HIPCHK(hipMemcpy(st.data(), d.stats, sizeof(lcqp_stats_t) * (size_t)d.B, hipMemcpyDeviceToHost));
-    std::vector<int> list;
-    for (int b = 0; b < d.B; b++) if (st[b].returnValue == LCQP_SUBPROBLEM_SOLVER_ERROR && st[b].qpSolverExitFlag == 1) list.push_back(b);
-    if (list.empty()) return 0;
-    if (!h->rerunList && dev_alloc(h, &h->rerunList, (size_t)d.B, false)) return LCQP_HIP_ERROR;
-    HIPCHK(hipMemcpy(h->rerunList, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice));
-    // the failed pass may have adapted rho and refactorised K for these instances: start again from the setup state
-    // (the setup kernels run over the whole batch, 5 ms; solutions and statistics of the other instances are not touched)
-    { const int rcs = launch_setup(h); if (rcs) return rcs; }
-    dispatch_db(h, ID_k_lcqp_rerun, (int)list.size(), (const int*)h->rerunList);
-    HIPCHK(hipGetLastError());
-    *count = (int)list.size();
     return 0;
 }
 catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary

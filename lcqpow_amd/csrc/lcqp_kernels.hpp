@@ -349,21 +349,6 @@ __global__ __launch_bounds__(WG, LCQP_MINWAVES) void k_lcqp_run(DevBatch db)
                                      // (A/B 73.0 vs 72.0 ms, profiles/round2), so the batched loop and the per-QP path are ONE algorithm
 }
 
-// ---- repeat the instances whose QP subsolver gave up (same algorithm as k_lcqp_run since round 2, from a clean subsolver state;
-// kept for the C ABI: lcqp_hip_batch_rerun_failed) -----------------------------------------------------------------------
-template <int NCH>
-__global__ __launch_bounds__(WG, 4) void k_lcqp_rerun(DevBatch db, const int* list)
-{
-    LCQP_LDS_N(NCH)
-    Ctx<NCH> c = make_ctx<NCH>(db, list[blockIdx.x], lds);
-    int *dep = c.I(I_DEP), *prio = c.I(I_PRIO), *rslot = c.I(I_SLOT);
-    for (int r = threadIdx.x; r < db.mEcap; r += WG) { dep[r] = 0; prio[r] = 0; rslot[r] = -1; }
-    for (int a = threadIdx.x; a < db.capS; a += WG) c.idx[a] = -1;
-    if (threadIdx.x == 0) { c.info->haveSolution = 0; c.info->nT = 0; c.info->ns = 0; c.info->prioCtr = 0; c.info->ndep = 0; }
-    __syncthreads();
-    lcqp_run<NCH, true>(c);
-}
-
 // ---- one QP per workgroup with the SubsolverBase semantics ----------------------------------------
 template <int NCH>
 __global__ __launch_bounds__(WG, 4) void k_qp_solve(DevBatch db, int initial)
@@ -536,7 +521,6 @@ static void launch_impl(int kid, int grid, hipStream_t s, const LaunchArgs& a)
             }
 #endif
             hipLaunchKernelGGL((k_lcqp_run<NCH, false>), dim3(grid), dim3(WG), 0, s, a.db); break;
-        case ID_k_lcqp_rerun: hipLaunchKernelGGL((k_lcqp_rerun<NCH>), dim3(grid), dim3(WG), 0, s, a.db, a.list); break;
         case ID_k_qp_solve:   hipLaunchKernelGGL((k_qp_solve<NCH>), dim3(grid), dim3(WG), 0, s, a.db, a.initial); break;
         case ID_k_synth_fill: hipLaunchKernelGGL((k_synth_fill<NCH>), dim3(grid), dim3(WG), 0, s, a.db, a.seed0, a.first); break;
         case ID_k_synth_Q:    hipLaunchKernelGGL((k_synth_Q<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;

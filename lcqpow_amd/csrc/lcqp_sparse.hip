@@ -1574,7 +1574,7 @@ extern "C" int lcqp_hip_sparse_get_solution(lcqp_hip_sparse_t* h, double* x, dou
     return 0;
 }
 
-// -DLCQP_PROFILE builds (tools/gpu_phase_profile.py --sparse): mean clock ticks per instance and phase of the last run
+// -DLCQP_PROFILE builds (tools/gpu.py sparse_profile): mean clock ticks per instance and phase of the last run
 // (products, assembly, factorisation, forward sweeps, backward sweeps, vector operations, LCQP level, -)
 extern "C" int lcqp_hip_sparse_read_profile(lcqp_hip_sparse_t* h, double* out)
 try {

@@ -165,34 +165,6 @@ static int chol_lower(double* M, int n, double* minpiv)
     return 0;
 }
 
-/* Cholesky of the Gram matrix of active rows; a pivot <= tau * (original diagonal) marks the row as
- * linearly dependent: its pivot is set to 1e150 and its column to 0, so its multiplier stays ~0. */
-static int safe_chol(double* S, int n, double tau)
-{
-    int ndep = 0;
-    for (int j = 0; j < n; j++) {
-        double d0 = S[j * n + j];
-        double d = d0;
-        for (int k = 0; k < j; k++) d -= S[j * n + k] * S[j * n + k];
-        if (!(d > tau * d0) || !(d > 0)) {
-            S[j * n + j] = 1e150;
-            for (int i = j + 1; i < n; i++) S[i * n + j] = 0.0;
-            ndep++;
-            continue;
-        }
-        double ljj = sqrt(d);
-        S[j * n + j] = ljj;
-        for (int i = j + 1; i < n; i++) {
-            double s = S[i * n + j];
-            const double* ri = S + (size_t)i * n;
-            const double* rj = S + (size_t)j * n;
-            for (int k = 0; k < j; k++) s -= ri[k] * rj[k];
-            S[i * n + j] = s / ljj;
-        }
-    }
-    return ndep;
-}
-
 static void trsv_lower(const double* L, int n, double* b) /* solves L y = b in place */
 {
     for (int i = 0; i < n; i++) {
@@ -1320,8 +1292,8 @@ int orc_lcqp_solve(int nV, int nC, int nComp,
         p->alphak = 1; p->rho = opt->initialPenaltyParameter;                  /* :999-1004 */
         p->algoStat = ORC_PROBLEM_NOT_SOLVED;
         p->qp = orc_qp_create(nV, m, p->Q, p->A, opt);                          /* :906-907 */
-        /* 0 mirrors k_lcqp_run; non-zero the kernels that also carry the dependent-row rules: k_qp_solve under the host
-         * loop over SubsolverHIP, and the second pass k_lcqp_rerun */
+        /* the dependent-row rules every device kernel carries since round 2 (k_lcqp_run, k_qp_solve); orc_lcqp_set_robust(0) selects the
+         * plain polish of round 1 */
         p->qp->robust = g_lcqp_robust != 0;
 
         /* runSolver :444-560 */

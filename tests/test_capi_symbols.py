@@ -65,7 +65,6 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert L.lcqp_hip_qp_create(2, 1, Q.ctypes.data_as(dp), None, None, 0) is None          # nC > 0 without A
     assert L.lcqp_hip_batch_run(None) != 0 and L.lcqp_hip_batch_setup(None) != 0
     n = ctypes.c_int(0)
-    assert L.lcqp_hip_batch_rerun_failed(None, ctypes.byref(n)) != 0
     if la.device_count() == 0:
         # no GPU here: creating a batch must fail with the HIP error, never fall back to anything
         assert L.lcqp_hip_batch_create(2, 4, 1, 1, 0, 0) is None and capi.last_error() != ""

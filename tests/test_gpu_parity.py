@@ -536,29 +536,6 @@ def test_lcqp_structure_fuzz(hip, oracle):
     assert rets.get((0, 0), 0) >= count // 2, rets          # the generator is not mostly producing failures
 
 
-def test_lcqp_second_pass_for_failed_instances(hip, oracle):
-    """lcqp_hip_batch_rerun_failed (k_lcqp_rerun): instances whose subsolver gave up are repeated with the dependent-row rules;
-    everything else is untouched.  Compared with the oracle doing the same (plain loop, then the robust loop for a failure with
-    exit flag 1) on the degenerate problems of tools/gpu_fuzz.py."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("gpu_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_fuzz.py"))
-    fz = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(fz)
-    count = 150
-    cats, rets = fz.run(count, seed=1, verbose=False, rerun=True)
-    assert cats["same"] + cats["same solution, other iterate count"] >= count - count // 20, (cats, rets)
-    _, rets_plain = fz.run(count, seed=1, verbose=False)
-    assert rets.get((0, 0), 0) >= rets_plain.get((0, 0), 0)          # the second pass only ever adds solved instances
-    # a batch without failures: nothing is repeated, results stay bit-identical
-    bt = hip.BatchLCQP(8, 64, 96, 16, opt=hip.default_options(perturbStep=0))
-    bt.generate_synthetic(0)
-    bt.run()
-    x, y, st = bt.solution()
-    assert bt.rerun_failed() == 0
-    x2, y2, st2 = bt.solution()
-    assert np.array_equal(x, x2) and np.array_equal(y, y2)
-    bt.close()
-
 
 @pytest.mark.parametrize("kw", [
     dict(solveZeroPenaltyFirst=0),                              # first QP already carries the penalty (src/LCQProblem.cpp:452-467)

@@ -143,7 +143,7 @@ def test_sparse_bounds_and_initial_guess(hip, oracle, case):
 
 def test_sparse_profile_entry_point_needs_a_profile_build(hip):
     """lcqp_hip_sparse_read_profile reports LCQP_HIP_UNSUPPORTED (901) on the product build: the phase stamps exist only in
-    -DLCQP_PROFILE builds (tools/gpu_sparse_profile.py)"""
+    -DLCQP_PROFILE builds (tools/gpu.py sparse_profile)"""
     import ctypes as C
     sb, inst, x, y, st = _run(hip, 64, 32, 8, 2)
     out = np.zeros(8)

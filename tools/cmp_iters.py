@@ -1,5 +1,5 @@
 """CPU side of the iterate-count comparison: the oracle on the first N synthetic instances against the iterate counts a GPU run
-dumped (tools/gpu_dump_iters.py).  usage: python tools/cmp_iters.py gpurun_out/r3/base_iters.npz [N]"""
+dumped (tools/gpu.py dump_iters).  usage: python tools/cmp_iters.py gpurun_out/r3/base_iters.npz [N]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

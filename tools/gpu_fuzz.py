@@ -2,7 +2,7 @@
 (rank-deficient Q, dense / overlapping complementarity rows, equalities, duplicate rows, finite upper complementarity
 bounds, shifted lower bounds, box bounds, warm-start duals), HIP single-instance batch vs the CPU oracle.
 
-usage: python tools/gpu_fuzz.py [count] [seed] [host|rerun]   (prints one line per divergence and a summary; exit code 1 when more
+usage: python tools/gpu_fuzz.py [count] [seed] [host]   (prints one line per divergence and a summary; exit code 1 when more
 than 5 % of the problems end differently)
 """
 import os
@@ -110,34 +110,9 @@ def host_solve(d):
                 stats=dict(iterTotal=st.getIterTotal(), iterOuter=st.getIterOuter(), status=int(st.getSolutionStatus())))
 
 
-def batch_solve_with_rerun(d):
-    """one-instance batch (k_lcqp_run), then lcqp_hip_batch_rerun_failed (k_lcqp_rerun) when the subsolver gave up"""
-    with_box = d.get("lb") is not None or d.get("ub") is not None
-    bt = la.BatchLCQP(1, d["nV"], d["nC"], d["nComp"], with_box=with_box, opt=la.default_options(perturbStep=0))
-    rc = bt.load(0, 1, d["Q"], d["g"], d["L"], d["R"], **{k: d.get(k) for k in P.KEYS})
-    if rc != 0:
-        bt.close()
-        return dict(ret=rc, x=None, y=None, stats=None)
-    bt.run()
-    bt.rerun_failed()
-    x, y, st = bt.solution()
-    bt.close()
-    return dict(ret=st[0]["returnValue"], x=x[0], y=y[0], stats=st[0])
-
-
-def oracle_solve_with_rerun(d):
-    ro = P.oracle_solve(O, d, O.default_options(perturbStep=0))
-    if ro["ret"] == 203 and ro["stats"]["qpSolverExitFlag"] == 1:
-        O.lcqp_set_robust(1)
-        ro = P.oracle_solve(O, d, O.default_options(perturbStep=0))
-        O.lcqp_set_robust(1)
-    return ro
-
-
-def run(count, seed, verbose=True, host=False, rerun=False):
+def run(count, seed, verbose=True, host=False):
     """host=False: batched device loop (k_lcqp_run) vs the oracle; host=True: host loop over SubsolverHIP (k_qp_solve, with the
-    dependent-row rules) vs the oracle with the same rules; rerun=True: batched loop followed by the second pass for failed
-    instances (k_lcqp_rerun) vs the oracle doing the same"""
+    dependent-row rules) vs the oracle with the same rules"""
     O.build(); O.lib()
     O.lcqp_set_robust(1)      # every kernel carries the dependent-row rules since round 2
     rng = np.random.default_rng(seed)
@@ -145,11 +120,8 @@ def run(count, seed, verbose=True, host=False, rerun=False):
     cats = {"same": 0, "same solution, other iterate count": 0, "other stationary point": 0, "return codes differ": 0}
     for k in range(count):
         d = make(rng)
-        if rerun:
-            ro, rh = oracle_solve_with_rerun(d), batch_solve_with_rerun(d)
-        else:
-            ro = P.oracle_solve(O, d, O.default_options(perturbStep=0))
-            rh = host_solve(d) if host else P.hip_solve(la, d, la.default_options(perturbStep=0))
+        ro = P.oracle_solve(O, d, O.default_options(perturbStep=0))
+        rh = host_solve(d) if host else P.hip_solve(la, d, la.default_options(perturbStep=0))
         rets[(ro["ret"], rh["ret"])] = rets.get((ro["ret"], rh["ret"]), 0) + 1
         msg, cat = None, "same"
         if ro["ret"] != rh["ret"]:
@@ -181,7 +153,7 @@ def run(count, seed, verbose=True, host=False, rerun=False):
             print(f"[{k}] n={d['nV']} nC={d['nC']} nComp={d['nComp']} keys={sorted(set(d) - {'Q', 'g', 'L', 'R', 'nV', 'nC', 'nComp'})}: {cat}: {msg}", flush=True)
     O.lcqp_set_robust(1)
     if verbose:
-        print(f"fuzz[{'host loop + SubsolverHIP' if host else 'batched device loop + second pass' if rerun else 'batched device loop'}]: {count} problems (seed {seed}): {cats}; (oracle ret, hip ret) histogram: {dict(sorted(rets.items()))}")
+        print(f"fuzz[{'host loop + SubsolverHIP' if host else 'batched device loop'}]: {count} problems (seed {seed}): {cats}; (oracle ret, hip ret) histogram: {dict(sorted(rets.items()))}")
     return cats, rets
 
 
@@ -189,7 +161,7 @@ def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     mode = sys.argv[3] if len(sys.argv) > 3 else ""
-    cats, _ = run(count, seed, host=mode == "host", rerun=mode == "rerun")
+    cats, _ = run(count, seed, host=mode == "host")
     return 1 if cats["return codes differ"] + cats["other stationary point"] > count // 20 else 0
 
 
