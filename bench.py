@@ -319,7 +319,8 @@ def main():
             inst = [S.sparse_values(i, n, nC, nComp, orders=(qo, eo)) for i in range(cnt)]
             csr = [(sp.csc_matrix((d["Qx"], Qpat.indices, Qpat.indptr), shape=Qpat.shape).tocsr(),
                     sp.csc_matrix((d["Ex"], Apat.indices, Apat.indptr), shape=Apat.shape).tocsr()) for d in inst]
-            perm, w, kb = O.kkt_ordering(n, csr[0][0].indptr, csr[0][0].indices, csr[0][1].indptr, csr[0][1].indices)
+            perm, w, kb = O.kkt_ordering(n, csr[0][0].indptr, csr[0][0].indices, csr[0][1].indptr, csr[0][1].indices,
+                                          rows_follow=all(O.hessian_is_definite_by_diagonal(c[0]) for c in csr))
             res = [None] * cnt
 
             def work(lo, hi):

@@ -210,7 +210,9 @@ const char* lcqp_hip_sparse_last_error(void);
 int  lcqp_hip_sparse_bandwidth(const lcqp_hip_sparse_t* s);              /* half bandwidth of the KKT band */
 int  lcqp_hip_sparse_lanes(const lcqp_hip_sparse_t* s);                  /* lanes of a wavefront per instance: 8, 16, 32 or 64 */
 int  lcqp_hip_sparse_border(const lcqp_hip_sparse_t* s);                 /* border nodes of the bordered band: the last positions of the ordering (0: plain band) */
-int  lcqp_hip_sparse_get_ordering(const lcqp_hip_sparse_t* s, int* perm); /* perm[nV + nC + 2 nComp]: position -> node */
+/* perm[nV + nC + 2 nComp]: position -> node.  Two orderings of the band are prepared (the second, for Hessians that are safely definite by
+ * their diagonals, puts every row behind one of its variables); this is the one the instances loaded so far select (before any load: the first) */
+int  lcqp_hip_sparse_get_ordering(const lcqp_hip_sparse_t* s, int* perm);
 int  lcqp_hip_sparse_set_options(lcqp_hip_sparse_t* s, const lcqp_options_t* opt);
 /* loadLCQP, sparse overload (src/LCQProblem.cpp:390-441), values only: Qx [count][nnzQ], Ax [count][nnzA] in the CSC order of
  * the pattern; y0 [count][nC + 2 nComp]; NULL as in the reference */

@@ -48,8 +48,9 @@ enum { MV_L, MV_U, MV_RHOV, MV_YQ, MV_YA, MV_ZA, MV_YT, MV_EX, MV_EXS, MV_YK, MV
 enum { MI_ST, MI_STT, MI_STF, MI_NEW, MI_NUM };
 
 struct SpInfo {
-    int haveSolution, stfValid, hasY0, pad;
+    int haveSolution, stfValid, hasY0, bigReg;     // bigReg: this instance needs the safe regularisation of the polish (a Hessian that is only semidefinite)
     double scale, sigma, delta, delta2, phiConst;
+    double deltaS, delta2S;                        // the light level tried first (sp_polish)
     double hist[64];
     double bytes;        // algorithmic bytes counted by the kernel
     double prof[8];      // -DLCQP_PROFILE: clock ticks per phase (SP_* below)
@@ -77,6 +78,7 @@ struct SpBatch {
     // position, Usrc: entry of Q (k < nnzQ) or of E (nnzQ + k, CSR order), Ugate: the row of E whose membership in the working set gates
     // the entry, -1 none); C: the entries among border nodes, lower triangle (Cb2: the other border node).
     int kb, nU, nCb;
+    int lightOK;     // the ordering puts every row behind one of its variables and every Hessian of the batch is safely definite: the polish tries its light regularisation first
     const int *bnode, *Uptr, *Upos, *Usrc, *Ugate, *Cptr, *Cb2, *Csrc, *Cgate;
     double *bW, *bUv, *bS;   // [B][2][kb][Np] W rows, [B][2][nU] gated values of U, [B][2][kb][kb] factor of S   (index 0: polish, 1: ADMM)
     double *lbL, *lbR;       // [B][nComp]
@@ -176,14 +178,16 @@ template <int G> __device__ __forceinline__ double g_sum(double v)
     if (G >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
+// maximum that keeps a NaN (fmax drops it): a residual with a NaN in it must not pass an acceptance test
+__device__ __forceinline__ double nmax(double a, double b) { return (b > a || b != b) ? b : a; }
 template <int G> __device__ __forceinline__ double g_max(double v)
 {
-    v = fmax(v, dpp_d<0xB1>(v));
-    v = fmax(v, dpp_d<0x4E>(v));
-    v = fmax(v, dpp_d<0x141>(v));
-    if (G >= 16) v = fmax(v, dpp_d<0x140>(v));
-    if (G >= 32) v = fmax(v, __shfl_xor(v, 16, 64));
-    if (G >= 64) v = fmax(v, __shfl_xor(v, 32, 64));
+    v = nmax(v, dpp_d<0xB1>(v));
+    v = nmax(v, dpp_d<0x4E>(v));
+    v = nmax(v, dpp_d<0x141>(v));
+    if (G >= 16) v = nmax(v, dpp_d<0x140>(v));
+    if (G >= 32) v = nmax(v, __shfl_xor(v, 16, 64));
+    if (G >= 64) v = nmax(v, __shfl_xor(v, 32, 64));
     return v;
 }
 template <int G> __device__ __forceinline__ int g_sum_i(int v)
@@ -349,7 +353,7 @@ template <int G, class Pre, class Base> __device__ __forceinline__ double sp_ETy
     SPROF(c, SP_VECTORS);
     double mx = 0.0;
     sp_ell<G>(c.db->ellT, c.gl, c.Ex(), [&](int r) { return D2{y[r], 0.0}; }, pre,
-              [&](int i, double s, double, typename val_of<decltype(pre(0))>::type pv) { const double v = base(pv) - s; out[i] = v; mx = fmax(mx, fabs(v)); });
+              [&](int i, double s, double, typename val_of<decltype(pre(0))>::type pv) { const double v = base(pv) - s; out[i] = v; mx = nmax(mx, fabs(v)); });
     g_sync();
     SPROF(c, SP_PRODUCTS);
     return g_max<G>(mx);
@@ -363,7 +367,7 @@ template <int G> __device__ __forceinline__ double sp_residual(SpCtx<G>& c, GD g
     g_sync();
     double mx = 0.0;
     sp_ell<G>(c.db->ellT, c.gl, c.Ex(), [&](int r) { return D2{y[r], 0.0}; }, [&](int i) { return D2{g[i], qx[i]}; },
-              [&](int i, double s, double, D2 pv) { const double v = (-pv.a - pv.b) - s; r1[i] = v; mx = fmax(mx, fabs(v)); });
+              [&](int i, double s, double, D2 pv) { const double v = (-pv.a - pv.b) - s; r1[i] = v; mx = nmax(mx, fabs(v)); });
     g_sync();
     SPROF(c, SP_PRODUCTS);
     return g_max<G>(mx);
@@ -811,6 +815,7 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
     const double gs = 1.0 + sp_maxabs<G>(c, g, n);
     const double ytol = o.feasTol * gs;
     int fact_valid = 0, borderTodo = 0;
+    double dpUsed = c.info->delta, d2Used = c.info->delta2;      // regularisation of the factorisation in use
     for (int trial = 0; trial < o.maxTrials; trial++) {
         c.cTrials++;
         double res_stat;
@@ -818,7 +823,7 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
             GD r1s = c.V(NV_R1S), gs0 = c.V(NV_GS), exs = c.M(MV_EXS);
             double mx = 0.0;
             g_map<G, 8>(n, t, [&](int i) { return D3{r1s[i], gs0[i], g[i]}; },
-                        [&](int i, D3 v) { const double r = v.a + (v.b - v.c); r1[i] = r; mx = fmax(mx, fabs(r)); });
+                        [&](int i, D3 v) { const double r = v.a + (v.b - v.c); r1[i] = r; mx = nmax(mx, fabs(r)); });
             g_map<G, 8>(m, t, [&](int r) { return exs[r]; }, [&](int r, double v) { ex[r] = v; });
             g_sync();
             res_stat = g_max<G>(mx);
@@ -839,7 +844,7 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
                             else if (v.e > v.hi + ftol) ns = ST_UPPER;
                         } else {
                             const double bb = (v.s == ST_UPPER) ? v.hi : v.lo;
-                            res_eq = fmax(res_eq, fabs(bb - v.e));
+                            res_eq = nmax(res_eq, fabs(bb - v.e));
                             bmax = fmax(bmax, fabs(bb));
                             if (v.s == ST_LOWER && v.y > ytol) ns = ST_INACT;
                             if (v.s == ST_UPPER && v.y < -ytol) ns = ST_INACT;
@@ -875,8 +880,35 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
 #pragma unroll 8
             for (int r = t; r < m; r += G) diff |= ((stf[r] != ST_INACT) != (st[r] != ST_INACT));
             if (g_any<G>(diff)) {
-                const double d2 = c.info->delta2;
-                sp_factor_band<G>(c, c.KF(false), c.KD(false), c.info->delta, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; });
+                // Two levels of regularisation, as on the dense path (proxSmall / proxBig).  A correction with the safe level leaves
+                // delta dx and delta2 dy (1e-8, 1e-9 relative) in the true residuals: every QP paid one refinement trial -- a sweep, a band
+                // solve, the vector passes -- for the regularisation alone.  The light level (1e-12, 1e-14) is accepted at once.  The band
+                // LDL' is not pivoted, so the light level needs an ordering in which every row follows one of its variables (lightOK, chosen
+                // by the host when every Hessian of the batch is safely definite) and is only kept when every pivot has the sign its node
+                // prescribes and a safe size; a variable's pivot failing makes the safe level permanent for the instance.
+                int level = (db.lightOK && !c.info->bigReg) ? 0 : 1;
+                for (;;) {
+                    dpUsed = level ? c.info->delta : c.info->deltaS;
+                    d2Used = level ? c.info->delta2 : c.info->delta2S;
+                    const double d2 = d2Used;
+                    sp_factor_band<G>(c, c.KF(false), c.KD(false), dpUsed, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; });
+                    if (level == 1) break;
+                    int badVar = 0, badRow = 0;
+                    GD Kd = c.KD(false);
+                    const double sc = c.info->scale, vmax = 1.0 / (1e-8 * sc), rmax = sc / 1e-8;
+                    const int Nb = db.N - db.kb;
+#pragma unroll 4
+                    for (int p = t; p < Nb; p += G) {
+                        const double kd = Kd[p];            // 1 / D
+                        const int node = db.pnode[p];
+                        if (node < n) badVar |= !(kd > 0.0 && kd < vmax);
+                        else if (st[node - n] != ST_INACT) badRow |= !(kd < 0.0 && kd > -rmax);
+                    }
+                    const bool bv = g_any<G>(badVar), br = g_any<G>(badRow);
+                    if (!bv && !br) break;
+                    if (bv && t == 0) c.info->bigReg = 1;
+                    level = 1;
+                }
                 if (db.kb > 0) { sp_border_prepare<G>(c, false, [=](int r) { return st[r] != ST_INACT; }); borderTodo = db.kb; }
                 g_map<G, 8>(m, t, [&](int r) { return st[r]; }, [&](int r, int v) { stf[r] = v; });
                 if (t == 0) c.info->stfValid = 1;
@@ -895,7 +927,7 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
         for (int jb = 0; jb <= borderTodo; jb++) {
             GD vec = b;
             if (jb < borderTodo) vec = sp_border_column<G>(c, false, jb);
-            else if (borderTodo > 0) { const double d2 = c.info->delta2; sp_border_schur<G>(c, false, c.info->delta, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; }); }
+            else if (borderTodo > 0) { const double d2 = d2Used; sp_border_schur<G>(c, false, dpUsed, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; }); }
             sp_solve_band<G>(c, false, vec);
         }
         borderTodo = 0;
@@ -1035,6 +1067,7 @@ __global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db)
     if (t == 0) {
         c.info->scale = scale; c.info->sigma = db.opt.admmSigma * scale; c.info->delta = db.opt.proxBig * scale; c.info->delta2 = 1e-9 / scale;
         c.info->phiConst = phiConst; c.info->haveSolution = 0; c.info->stfValid = 0; c.info->bytes = 0.0;
+        c.info->deltaS = db.opt.proxSmall * scale; c.info->delta2S = 1e-14 / scale; c.info->bigReg = 0;
     }
     g_sync();
     sp_factor_band<G>(c, c.KF(true), c.KD(true), db.opt.admmSigma * scale, [=](int r) { return 1.0 / rhov[r]; }, [](int) { return true; });
@@ -1218,9 +1251,28 @@ struct lcqp_hip_sparse {
     hipEvent_t ev0, ev1, ev2;
     std::vector<void*> allocs;
     std::vector<int> csr2csc;      // value order: E (CSR) entry k comes from entry csr2csc[k] of the caller's CSC arrays
-    std::vector<int> perm;
+    // two orderings of the band (lcqp_hip_sparse_create): [0] reverse Cuthill-McKee, [1] the same with every row behind its first variable
+    struct Ord { std::vector<int> perm; int *iperm, *bandQ, *bandE, *bsrc, *pnode, *Upos; bool rowsFollow; } ord[2];
+    bool hasB;
+    int useB;                      // ordering of the last sp_choose_ordering
+    std::vector<int> qdiagHost;    // entry of Q_ii in the value array
+    std::vector<double> diagRatio; // per instance: min_i Q_ii / max_i Q_ii of the loaded Hessian (1: not loaded yet)
     bool loaded, ran;
 };
+
+// Ordering [1] and the light regularisation of the polish are for batches whose Hessians are safely definite, judged by their diagonals
+// (min Q_ii >= 1e-6 max Q_ii in every loaded instance); the pivot check of sp_polish covers what the diagonals do not show.
+static void sp_choose_ordering(lcqp_hip_sparse* h)
+{
+    bool definite = h->loaded;      // nothing loaded yet: the plain ordering
+    for (double r : h->diagRatio) definite = definite && (r >= 1e-6);
+    const int k = (definite && h->hasB) ? 1 : 0;
+    const lcqp_hip_sparse::Ord& o = h->ord[k];
+    SpBatch& d = h->db;
+    d.iperm = o.iperm; d.bandQ = o.bandQ; d.bandE = o.bandE; d.bsrc = o.bsrc; d.pnode = o.pnode; d.Upos = o.Upos;
+    d.lightOK = (definite && o.rowsFollow) ? 1 : 0;
+    h->useB = k;
+}
 
 #define SPCHK(call)                                                                             \
     do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_sp_err = std::string(#call) + ": " + hipGetErrorString(e_); return LCQP_HIP_ERROR; } } while (0)
@@ -1307,23 +1359,28 @@ try {
     // Ordering: reverse Cuthill-McKee; while the half bandwidth exceeds what a lane group covers, the node of highest degree moves to the
     // border (at most SP_KBMAX nodes), the positions behind the band.  Arrow-shaped KKT matrices (a coupling row, a shared variable:
     // examples/OptimizeOnCircle.cpp:44) become a narrow band plus a few border nodes.
-    std::vector<int> perm, iperm(N), border;
+    std::vector<int> permA, border;
     std::vector<char> isBorder(N, 0);
-    int w = 0;
+    std::vector<std::vector<int>> sub(N);
+    auto bandwidth = [&](const std::vector<int>& pm) {
+        std::vector<int> ip(N);
+        for (int p = 0; p < N; p++) ip[pm[p]] = p;
+        int wv = 0;
+        for (int v = 0; v < N; v++) if (!isBorder[v]) for (int u : sub[v]) wv = std::max(wv, std::abs(ip[v] - ip[u]));
+        return wv;
+    };
+    int wA = 0;
     for (;;) {
-        std::vector<std::vector<int>> sub(N);
-        for (int v = 0; v < N; v++) if (!isBorder[v]) for (int u : adj[v]) if (!isBorder[u]) sub[v].push_back(u);
+        for (int v = 0; v < N; v++) { sub[v].clear(); if (!isBorder[v]) for (int u : adj[v]) if (!isBorder[u]) sub[v].push_back(u); }
         std::vector<int> full;
         rcm_order(N, sub, full);
-        perm.clear();
-        for (int v : full) if (!isBorder[v]) perm.push_back(v);
-        for (int v : border) perm.push_back(v);
-        for (int p = 0; p < N; p++) iperm[perm[p]] = p;
-        w = 0;
-        for (int v = 0; v < N; v++) if (!isBorder[v]) for (int u : sub[v]) w = std::max(w, std::abs(iperm[v] - iperm[u]));
-        if (w <= SP_WMAX) break;
+        permA.clear();
+        for (int v : full) if (!isBorder[v]) permA.push_back(v);
+        for (int v : border) permA.push_back(v);
+        wA = bandwidth(permA);
+        if (wA <= SP_WMAX) break;
         if ((int)border.size() >= SP_KBMAX) {
-            g_sp_err = "KKT band of this pattern has half bandwidth " + std::to_string(w) + " > " + std::to_string(SP_WMAX) + " after reverse Cuthill-McKee with " +
+            g_sp_err = "KKT band of this pattern has half bandwidth " + std::to_string(wA) + " > " + std::to_string(SP_WMAX) + " after reverse Cuthill-McKee with " +
                        std::to_string(SP_KBMAX) + " border nodes: neither a banded nor a bordered problem (use the dense kernels)";
             return nullptr;
         }
@@ -1333,27 +1390,57 @@ try {
         isBorder[best] = 1; border.push_back(best);
     }
     const int kb = (int)border.size(), Nband = N - kb;
+    // A second ordering of the same band nodes for batches whose Hessians are safely definite (chosen at run time, sp_choose_ordering): a
+    // constraint row eliminated before every variable it touches gets the bare dual regularisation as its pivot (the LDL' is not pivoted),
+    // which rules out the light regularisation of the polish (sp_polish).  Here such rows move to just behind their first variable, so that
+    // every row pivot is -(delta2 + e D^-1 e').  With a Hessian that is nearly flat in that variable the same move is harmful (two active
+    // rows that hinge on it cancel), hence the choice by the data.
+    // Reverse Cuthill-McKee happens to put most multiplier nodes in front of their variables, and a band is as wide backwards: the second
+    // ordering is the first one reversed, and what rows are still in front of all their variables move behind the first of them.
+    std::vector<int> permB(permA);
+    std::reverse(permB.begin(), permB.begin() + Nband);
+    {
+        std::vector<int> pos(N, -1), base(permB);
+        for (int p = 0; p < Nband; p++) pos[base[p]] = p;
+        std::vector<std::pair<double, int>> key(Nband);
+        for (int p = 0; p < Nband; p++) {
+            const int v = base[p];
+            double k = p;
+            if (v >= n) {
+                int first = 1 << 30;
+                for (int u : sub[v]) if (u < n && pos[u] >= 0) first = std::min(first, pos[u]);
+                if (first != (1 << 30) && first > p) k = first + 0.5;
+            }
+            key[p] = {k, v};
+        }
+        std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
+        for (int p = 0; p < Nband; p++) permB[p] = key[p].second;
+    }
+    const int wB = bandwidth(permB);
+    auto lanes_for = [](int wv) { return wv < 8 ? 8 : (wv < 16 ? 16 : (wv < 32 ? 32 : 64)); };
+    const bool hasB = wB <= SP_WMAX && lanes_for(wB) == lanes_for(wA);      // not at the price of a wider lane group
+    int w = hasB ? std::max(wA, wB) : wA;
     if (w < 1) w = 1;
     // lanes per instance: the smallest of 8, 16, 32, 64 above the half bandwidth (LCQP_SPARSE_LANES raises it: test hook)
-    int G = w < 8 ? 8 : (w < 16 ? 16 : (w < 32 ? 32 : 64));
+    int G = lanes_for(w);
     if (const char* e = std::getenv("LCQP_SPARSE_LANES")) { const int v = std::atoi(e); if ((v == 16 || v == 32 || v == 64) && v > G) G = v; }
     const int ld = G, wS = G - 1;          // band rows are stored G wide: entry k of row i is K[i][i - (G-1) + k] (zero outside the true band)
-    std::vector<int> bandQ(nnzQ, -1), bandE(nnzA, -1);      // (-1: not in the band -- an upper-triangle entry of Q, or an entry of the border)
-    for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) { const int pi = iperm[i], pj = iperm[Qi[k]]; if (pj <= pi && pi < Nband) bandQ[k] = pi * ld + wS - (pi - pj); }
-    for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { const int pr = iperm[n + r], pc = iperm[Ei[k]]; const int hi = std::max(pr, pc), lo = std::min(pr, pc); if (hi < Nband) bandE[k] = hi * ld + wS - (hi - lo); }
-    // where every off-diagonal band entry comes from (assembly inside the factorisation): -1 nothing, k < nnzQ the entry k of Q,
-    // nnzQ + k the entry k of E (CSR order); the node behind a band position; the entry of Q_ii; the row of an entry of E
-    std::vector<int> bsrc((size_t)N * ld, -1), pnode(perm.begin(), perm.end()), qdiag(n, -1), Erow(nnzA);
-    for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) { if (Qi[k] == i) qdiag[i] = k; else if (bandQ[k] >= 0) bsrc[bandQ[k]] = k; }
-    for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { if (bandE[k] >= 0) bsrc[bandE[k]] = nnzQ + k; Erow[k] = r; }
-    // the border: per border node its entries with band nodes (U) and with border nodes of lower index (C)
-    std::vector<int> Uptr(kb + 1, 0), Upos, Usrc, Ugate, Cptr(kb + 1, 0), Cb2, Csrc, Cgate;
+    // what depends on the ordering: inverse permutation, band slot of every entry of Q and E (-1: not in the band -- an upper-triangle entry
+    // of Q, or an entry of the border), where every off-diagonal band entry comes from (assembly inside the factorisation: -1 nothing,
+    // k < nnzQ the entry k of Q, nnzQ + k the entry k of E in CSR order), the node behind a band position, the band positions of U
+    struct OrdMaps { std::vector<int> perm, iperm, bandQ, bandE, bsrc, Upos; };
+    std::vector<int> qdiag(n, -1), Erow(nnzA);
+    for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) if (Qi[k] == i) qdiag[i] = k;
+    for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) Erow[k] = r;
+    // the border: per border node its entries with band nodes (U) and with border nodes of lower index (C); the enumeration order does not
+    // depend on the ordering of the band
+    std::vector<int> Uptr(kb + 1, 0), Uother, Usrc, Ugate, Cptr(kb + 1, 0), Cb2, Csrc, Cgate, bidx(N, -1);
+    for (int b = 0; b < kb; b++) bidx[border[b]] = b;
     for (int b = 0; b < kb; b++) {
         const int v = border[b];
         auto put = [&](int other, int src, int gate) {
-            const int po = iperm[other];
-            if (po < Nband) { Upos.push_back(po); Usrc.push_back(src); Ugate.push_back(gate); }
-            else if (po - Nband < b) { Cb2.push_back(po - Nband); Csrc.push_back(src); Cgate.push_back(gate); }
+            if (bidx[other] < 0) { Uother.push_back(other); Usrc.push_back(src); Ugate.push_back(gate); }
+            else if (bidx[other] < b) { Cb2.push_back(bidx[other]); Csrc.push_back(src); Cgate.push_back(gate); }
         };
         if (v < n) {
             for (int k = Qp[v]; k < Qp[v + 1]; k++) if (Qi[k] != v) put(Qi[k], k, -1);                       // Q is symmetric: row v = column v
@@ -1362,14 +1449,28 @@ try {
             const int r = v - n;
             for (int k = Ep[r]; k < Ep[r + 1]; k++) put(Ei[k], nnzQ + k, r);
         }
-        Uptr[b + 1] = (int)Upos.size(); Cptr[b + 1] = (int)Cb2.size();
+        Uptr[b + 1] = (int)Uother.size(); Cptr[b + 1] = (int)Cb2.size();
     }
-    const int nU = (int)Upos.size(), nCb = (int)Cb2.size();
+    const int nU = (int)Uother.size(), nCb = (int)Cb2.size();
+    auto build_maps = [&](const std::vector<int>& pm) {
+        OrdMaps M;
+        M.perm = pm; M.iperm.assign(N, 0);
+        for (int p = 0; p < N; p++) M.iperm[pm[p]] = p;
+        M.bandQ.assign(nnzQ, -1); M.bandE.assign(nnzA, -1); M.bsrc.assign((size_t)N * ld, -1);
+        for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) { const int pi = M.iperm[i], pj = M.iperm[Qi[k]]; if (pj <= pi && pi < Nband) M.bandQ[k] = pi * ld + wS - (pi - pj); }
+        for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { const int pr = M.iperm[n + r], pc = M.iperm[Ei[k]]; const int hi = std::max(pr, pc), lo = std::min(pr, pc); if (hi < Nband) M.bandE[k] = hi * ld + wS - (hi - lo); }
+        for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) if (Qi[k] != i && M.bandQ[k] >= 0) M.bsrc[M.bandQ[k]] = k;
+        for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) if (M.bandE[k] >= 0) M.bsrc[M.bandE[k]] = nnzQ + k;
+        M.Upos.resize(nU);
+        for (int e = 0; e < nU; e++) M.Upos[e] = M.iperm[Uother[e]];
+        return M;
+    };
+    OrdMaps mapsA = build_maps(permA), mapsB = hasB ? build_maps(permB) : OrdMaps();
     if (hipSetDevice(device) != hipSuccess) { g_sp_err = "hipSetDevice failed"; return nullptr; }
     lcqp_hip_sparse* h = new (std::nothrow) lcqp_hip_sparse();
     if (!h) return nullptr;
     struct Guard { lcqp_hip_sparse* h; ~Guard() { if (h) lcqp_hip_sparse_destroy(h); } } guard{h};      // an exception below must not leak the handle
-    h->device = device; h->nnzA = nnzA; h->loaded = false; h->ran = false; h->csr2csc = csr2csc; h->perm = perm;
+    h->device = device; h->nnzA = nnzA; h->loaded = false; h->ran = false; h->csr2csc = csr2csc; h->hasB = hasB; h->useB = 0; h->qdiagHost = qdiag; h->diagRatio.assign(batch, 1.0);
     h->stream = nullptr; h->ev0 = h->ev1 = h->ev2 = nullptr;
     SpBatch& d = h->db;
     memset(&d, 0, sizeof(d));
@@ -1381,12 +1482,27 @@ try {
     const size_t B = batch;
     ok = ok && (d.Qp = sp_alloc<int>(h, n + 1, Qp)) && (d.Qi = sp_alloc<int>(h, nnzQ, Qi)) && (d.Ep = sp_alloc<int>(h, m + 1, Ep.data())) &&
          (d.Ei = sp_alloc<int>(h, nnzA, Ei.data())) && (d.ETp = sp_alloc<int>(h, n + 1, ETp.data())) && (d.ETi = sp_alloc<int>(h, nnzA, ETi.data())) &&
-         (d.ETmap = sp_alloc<int>(h, nnzA, ETmap.data())) && (d.iperm = sp_alloc<int>(h, N, iperm.data())) &&
-         (d.bandQ = sp_alloc<int>(h, nnzQ, bandQ.data())) && (d.bandE = sp_alloc<int>(h, nnzA, bandE.data())) &&
-         (d.bsrc = sp_alloc<int>(h, bsrc.size(), bsrc.data())) && (d.pnode = sp_alloc<int>(h, N, pnode.data())) &&
+         (d.ETmap = sp_alloc<int>(h, nnzA, ETmap.data())) &&
          (d.qdiag = sp_alloc<int>(h, n, qdiag.data())) && (d.Erow = sp_alloc<int>(h, nnzA, Erow.data()));
+    for (int k = 0; k < (hasB ? 2 : 1); k++) {
+        OrdMaps& M = k ? mapsB : mapsA;
+        lcqp_hip_sparse::Ord& o = h->ord[k];
+        // the light regularisation needs every row of the band behind one of its variables (sp_polish)
+        o.rowsFollow = true;
+        for (int r = 0; r < m; r++) {
+            if (M.iperm[n + r] >= Nband) continue;
+            bool follows = false;
+            for (int e = Ep[r]; e < Ep[r + 1]; e++) follows = follows || M.iperm[Ei[e]] < M.iperm[n + r];
+            o.rowsFollow = o.rowsFollow && follows;
+        }
+        ok = ok && (o.iperm = sp_alloc<int>(h, N, M.iperm.data())) && (o.bandQ = sp_alloc<int>(h, nnzQ, M.bandQ.data())) &&
+             (o.bandE = sp_alloc<int>(h, nnzA, M.bandE.data())) && (o.bsrc = sp_alloc<int>(h, M.bsrc.size(), M.bsrc.data())) &&
+             (o.pnode = sp_alloc<int>(h, N, M.perm.data())) && (o.Upos = sp_alloc<int>(h, nU, M.Upos.data()));
+        o.perm = std::move(M.perm);
+    }
+    if (ok) sp_choose_ordering(h);
     if (kb > 0)
-        ok = ok && (d.bnode = sp_alloc<int>(h, kb, border.data())) && (d.Uptr = sp_alloc<int>(h, kb + 1, Uptr.data())) && (d.Upos = sp_alloc<int>(h, nU, Upos.data())) &&
+        ok = ok && (d.bnode = sp_alloc<int>(h, kb, border.data())) && (d.Uptr = sp_alloc<int>(h, kb + 1, Uptr.data())) &&
              (d.Usrc = sp_alloc<int>(h, nU, Usrc.data())) && (d.Ugate = sp_alloc<int>(h, nU, Ugate.data())) && (d.Cptr = sp_alloc<int>(h, kb + 1, Cptr.data())) &&
              (d.Cb2 = sp_alloc<int>(h, nCb, Cb2.data())) && (d.Csrc = sp_alloc<int>(h, nCb, Csrc.data())) && (d.Cgate = sp_alloc<int>(h, nCb, Cgate.data())) &&
              (d.bW = sp_alloc<double>(h, (size_t)batch * 2 * kb * d.Np)) && (d.bUv = sp_alloc<double>(h, (size_t)batch * 2 * nU)) &&
@@ -1438,7 +1554,8 @@ extern "C" int lcqp_hip_sparse_border(const lcqp_hip_sparse_t* h) { return h ? h
 extern "C" int lcqp_hip_sparse_get_ordering(const lcqp_hip_sparse_t* h, int* perm)
 {
     if (!h || !perm) return LCQP_INVALID_ARGUMENT;
-    memcpy(perm, h->perm.data(), sizeof(int) * h->perm.size());
+    const std::vector<int>& pm = h->ord[h->useB].perm;      // the ordering the loaded Hessians select (sp_choose_ordering)
+    memcpy(perm, pm.data(), sizeof(int) * pm.size());
     return 0;
 }
 
@@ -1513,6 +1630,9 @@ try {
         }
         if (y0) for (int r = 0; r < m; r++) mvb[(size_t)MV_Y0 * m + r] = y0[(size_t)k * m + r];
         SpInfo info; memset(&info, 0, sizeof(info)); info.hasY0 = y0 ? 1 : 0;
+        double dmin = INFINITY, dmax = 0.0;
+        for (int i = 0; i < n; i++) { const double q = h->qdiagHost[i] >= 0 ? Qx[(size_t)k * d.nnzQ + h->qdiagHost[i]] : 0.0; dmin = std::min(dmin, q); dmax = std::max(dmax, std::fabs(q)); }
+        h->diagRatio[b] = (dmax > 0.0 && dmin > 0.0) ? dmin / dmax : 0.0;
         SPCHK(hipMemcpy(d.Qx + b * d.nnzQ, Qx + (size_t)k * d.nnzQ, sizeof(double) * d.nnzQ, hipMemcpyHostToDevice));
         SPCHK(hipMemcpy(d.Ex + b * d.nnzE, ex.data(), sizeof(double) * d.nnzE, hipMemcpyHostToDevice));
         SPCHK(hipMemcpy(d.nv + b * NV_NUM * n, nvb.data(), sizeof(double) * nvb.size(), hipMemcpyHostToDevice));
@@ -1522,6 +1642,7 @@ try {
         SPCHK(hipMemcpy(d.info + b, &info, sizeof(info), hipMemcpyHostToDevice));
     }
     h->loaded = true;
+    sp_choose_ordering(h);
     return 0;
 }
 catch (...) { g_sp_err = "out of host memory"; return LCQP_HIP_ERROR; }
@@ -1530,6 +1651,7 @@ extern "C" int lcqp_hip_sparse_run(lcqp_hip_sparse_t* h)
 try {
     if (!h || !h->loaded) return LCQP_LCQPOBJECT_NOT_SETUP;
     SPCHK(hipSetDevice(h->device));
+    sp_choose_ordering(h);
     SPCHK(hipEventRecord(h->ev0, h->stream));
     switch (h->db.G) {
         case 8: sp_launch<8>(h->db, h->stream, h->ev1); break;

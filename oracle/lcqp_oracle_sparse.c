@@ -41,7 +41,8 @@ typedef struct {
     const int *Ep, *Ei; const double* Ex;      /* CSR of E = [A; L; R] */
     const int *perm; int* iperm;
     double *l, *u, *rhov;
-    double scale, sigma, delta, delta2;
+    double scale, sigma, delta, delta2;        /* regularisation of the polish KKT matrix, safe level (PSD Hessians, dependent active rows) */
+    double delta_s, delta2_s; int big_reg;     /* the light level tried first (round 3), and whether this problem has needed the safe one */
     band_t Ka, Kp;
     int* stf; int stf_valid;                   /* working set the polish factor was built for */
     double *x, *y; int* st; int have_solution;
@@ -212,6 +213,32 @@ static int sqp_setup(sqp_t* q, const double* lbE, const double* ubE)
     q->sigma = o->admmSigma * scale;
     q->delta = o->proxBig * scale;          /* primal regularisation of the polish KKT matrix */
     q->delta2 = 1e-9 / scale;               /* dual regularisation: makes the matrix quasi-definite whatever the rank of Ea */
+    /* Round 3: two levels, as on the dense path (proxSmall / proxBig).  A correction with the safe level leaves delta * dx and delta2 * dy
+     * (1e-8, 1e-9 relative) in the true residuals, so every QP paid one refinement trial -- a sweep, a band solve and the vector passes --
+     * for the regularisation alone.  The light level leaves 1e-12 / 1e-14 and the first correction is accepted.  The band LDL' is not
+     * pivoted, so the light level is only kept when every pivot has the sign its node prescribes (variables +, active rows -) and
+     * a safe size; otherwise this factorisation uses the safe level -- and every later one of the problem when a variable's pivot was the
+     * reason (a Hessian that is only semidefinite). */
+    q->delta_s = o->proxSmall * scale; q->delta2_s = 1e-14 / scale; q->big_reg = 0;
+    /* The light level is not even tried (big_reg from the start) unless the Hessian is safely definite by its diagonal
+     * (min Q_ii >= 1e-6 max Q_ii) and the ordering puts every band row behind one of its variables -- a row eliminated before all of them
+     * has the bare -delta2 as its pivot.  (lcqp_hip_sparse.hip: sp_choose_ordering makes the same test, there over the whole batch.) */
+    {
+        double dmin = INFINITY;
+        for (int i = 0; i < n; i++) {
+            double qii = 0.0;
+            for (int k = q->Qp[i]; k < q->Qp[i + 1]; k++) if (q->Qi[k] == i) qii = q->Qx[k];
+            if (qii < dmin) dmin = qii;
+        }
+        int follow = 1;
+        for (int r = 0; r < m; r++) {
+            if (q->iperm[n + r] >= N - q->kb) continue;
+            int f = 0;
+            for (int k = q->Ep[r]; k < q->Ep[r + 1]; k++) f |= (q->iperm[q->Ei[k]] < q->iperm[n + r]);
+            follow &= f;
+        }
+        if (!(dmin >= 1e-6 * scale) || !follow) q->big_reg = 1;
+    }
     const double rho = o->admmRho * scale;
     double* dd = dal(m);
     for (int r = 0; r < m; r++) {
@@ -283,7 +310,7 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
             sp_Ex(q, x, Ex);
         }
         double res_stat = 0, res_eq = 0, bmax = 0;
-        for (int i = 0; i < n; i++) if (fabs(r1[i]) > res_stat) res_stat = fabs(r1[i]);
+        for (int i = 0; i < n; i++) if (fabs(r1[i]) > res_stat || r1[i] != r1[i]) res_stat = fabs(r1[i]);      /* a NaN stays (and is never accepted) */
         int changed = 0, nact = 0;
         const double ytol = o->feasTol * gs;
         for (int r = 0; r < m; r++) {
@@ -294,7 +321,7 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
                 else if (Ex[r] > q->u[r] + ftol) ns = SP_UPPER;
             } else {
                 const double bb = (s == SP_UPPER) ? q->u[r] : q->l[r];
-                if (fabs(bb - Ex[r]) > res_eq) res_eq = fabs(bb - Ex[r]);
+                if (fabs(bb - Ex[r]) > res_eq || Ex[r] != Ex[r]) res_eq = fabs(bb - Ex[r]);
                 if (fabs(bb) > bmax) bmax = fabs(bb);
                 if (s == SP_LOWER && y[r] > ytol) ns = SP_INACT;
                 if (s == SP_UPPER && y[r] < -ytol) ns = SP_INACT;
@@ -325,9 +352,25 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
             if (!same) {
                 int* use = q->newst;
                 double* d2 = (double*)malloc(sizeof(double) * (m ? m : 1));
-                for (int r = 0; r < m; r++) { use[r] = (st[r] != SP_INACT); d2[r] = q->delta2; }
-                kkt_assemble(q, &q->Kp, q->delta, d2, use);
-                kkt_factor(&q->Kp);
+                for (int r = 0; r < m; r++) use[r] = (st[r] != SP_INACT);
+                for (int level = q->big_reg; level < 2; level++) {
+                    const double dp = level ? q->delta : q->delta_s, dd = level ? q->delta2 : q->delta2_s;
+                    for (int r = 0; r < m; r++) d2[r] = dd;
+                    kkt_assemble(q, &q->Kp, dp, d2, use);
+                    kkt_factor(&q->Kp);
+                    if (level == 1) break;
+                    /* pivots of the band (the border is not examined): variables must be > 1e-8 scale, active rows < -1e-8 / scale */
+                    int badVar = 0, badRow = 0;
+                    const int Nb = q->Kp.N, ld = q->w + 1;
+                    for (int pp = 0; pp < Nb; pp++) {
+                        const double D = q->Kp.B[(size_t)pp * ld + q->w];
+                        const int node = q->perm[pp];
+                        if (node < n) badVar |= !(D > 1e-8 * q->scale);
+                        else if (use[node - n]) badRow |= !(D < -1e-8 / q->scale);
+                    }
+                    if (!badVar && !badRow) break;
+                    if (badVar) q->big_reg = 1;      /* the Hessian is not safely definite: every later factorisation too; dependent rows come and go */
+                }
                 free(d2);
                 memcpy(q->stf, st, sizeof(int) * m); q->stf_valid = 1;
                 q->c_fact++;

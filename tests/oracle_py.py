@@ -313,10 +313,18 @@ def dns_to_csc(full):
     return L.orc_dns_to_csc(_p(full), full.shape[0], full.shape[1])
 
 
-def kkt_ordering(nV, Qp, Qi, Ep, Ei, wmax=63, kbmax=16):
+def hessian_is_definite_by_diagonal(Qcsr):
+    """the test that selects the ordering and the light regularisation of the sparse polish: min Q_ii >= 1e-6 max Q_ii"""
+    d = np.asarray(Qcsr.diagonal(), dtype=float)
+    return bool(d.size and d.max() > 0 and d.min() >= 1e-6 * np.abs(d).max())
+
+
+def kkt_ordering(nV, Qp, Qi, Ep, Ei, wmax=63, kbmax=16, rows_follow=False):
     """Ordering of the KKT graph [Q E'; E .] with scipy (independent of the product's own analysis): reverse Cuthill-McKee; while the
-    half bandwidth exceeds wmax, the node of highest degree moves to the border (the last positions).  Returns (perm, w, kb):
-    perm[position] = node (node < nV: variable, else row node - nV), w = half bandwidth of the first N - kb positions."""
+    half bandwidth exceeds wmax, the node of highest degree moves to the border (the last positions).  rows_follow: the band is taken backwards and every row that
+    would still be eliminated before all of its variables moves to just behind the first of them (the ordering the product uses for batches
+    of safely definite Hessians, lcqp_hip_sparse_create); if that widens the band beyond wmax the plain ordering is kept.
+    Returns (perm, w, kb): perm[position] = node (node < nV: variable, else row node - nV), w = half bandwidth of the first N - kb positions."""
     import scipy.sparse as sp
     from scipy.sparse.csgraph import reverse_cuthill_mckee
     m = len(Ep) - 1
@@ -325,17 +333,38 @@ def kkt_ordering(nV, Qp, Qi, Ep, Ei, wmax=63, kbmax=16):
     Es = sp.csr_matrix((np.ones(len(Ei)), np.asarray(Ei), np.asarray(Ep)), shape=(m, nV))
     K = sp.csr_matrix(sp.bmat([[Qs, Es.T], [Es, None]], format="csr") + sp.identity(N, format="csr"))
     border = []
+
+    def width(Kk, p):
+        ip = np.empty(len(p), dtype=np.int64); ip[p] = np.arange(len(p))
+        coo = Kk.tocoo()
+        return int(np.abs(ip[coo.row] - ip[coo.col]).max()) if coo.nnz else 0
+
     while True:
         keep = np.setdiff1d(np.arange(N), border)
-        Kk = K[keep][:, keep]
-        p = np.asarray(reverse_cuthill_mckee(sp.csr_matrix(Kk), symmetric_mode=True), dtype=np.int64)
-        ip = np.empty(len(keep), dtype=np.int64); ip[p] = np.arange(len(keep))
-        coo = Kk.tocoo()
-        w = int(np.abs(ip[coo.row] - ip[coo.col]).max()) if coo.nnz else 0
+        Kk = sp.csr_matrix(K[keep][:, keep])
+        p = np.asarray(reverse_cuthill_mckee(Kk, symmetric_mode=True), dtype=np.int64)
+        w = width(Kk, p)
         if w <= wmax or len(border) >= kbmax:
             break
         deg = np.asarray(Kk.getnnz(axis=1)).ravel()
         border.append(int(keep[int(np.argmax(deg))]))
+    if rows_follow:
+        p = p[::-1].copy()      # reverse Cuthill-McKee leaves the multiplier nodes in front of their variables; the band width is the same backwards
+        ip = np.empty(len(keep), dtype=np.int64); ip[p] = np.arange(len(keep))
+        isrow = keep >= nV
+        key = np.arange(len(keep), dtype=float)
+        for pos in range(len(keep)):
+            loc = p[pos]
+            if not isrow[loc]:
+                continue
+            nb = Kk.indices[Kk.indptr[loc]:Kk.indptr[loc + 1]]
+            nb = nb[~isrow[nb]]
+            if nb.size and ip[nb].min() > pos:
+                key[pos] = ip[nb].min() + 0.5
+        p2 = p[np.argsort(key, kind="stable")]
+        w2 = width(Kk, p2)
+        if w2 <= wmax:
+            p, w = p2, w2
     perm = np.concatenate([keep[p], np.array(border, dtype=np.int64)]).astype(np.int32)
     return perm, w, len(border)
 
@@ -351,7 +380,7 @@ def sparse_lcqp_solve(nV, nC, nComp, Qcsr, g, Ecsr, lbA=None, ubA=None, lbL=None
     Qp = np.ascontiguousarray(Qcsr.indptr, dtype=np.int32); Qi = np.ascontiguousarray(Qcsr.indices, dtype=np.int32); Qx = _arr(Qcsr.data)
     Ep = np.ascontiguousarray(Ecsr.indptr, dtype=np.int32); Ei = np.ascontiguousarray(Ecsr.indices, dtype=np.int32); Ex = _arr(Ecsr.data)
     if perm is None:
-        perm, w, kb = kkt_ordering(nV, Qp, Qi, Ep, Ei)
+        perm, w, kb = kkt_ordering(nV, Qp, Qi, Ep, Ei, rows_follow=hessian_is_definite_by_diagonal(Qcsr))
     perm = np.ascontiguousarray(perm, dtype=np.int32)
     opt = opt or default_options()
     m = nC + 2 * nComp
