@@ -1,25 +1,31 @@
-"""Copy the summaries of tools/run_profiles.sh (gpurun_out/r2) into profiles/round2/final and write profiles/latest_traffic.json
-(HBM bytes per k_lcqp_run launch by the guide's recipe, tagged with the hash of the kernel sources it was measured on)."""
+"""Copy the summaries of tools/run_profiles.sh (gpurun_out/<tag>) into profiles/<round>/final and write profiles/latest_traffic.json
+(HBM bytes per k_lcqp_run launch by the guide's recipe, tagged with the hash of the kernel sources it was measured on).
+usage: python tools/collect_profiles.py [tag=r3] [round=round3]"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
-src = os.path.join(ROOT, "gpurun_out", "r2")
-dst = os.path.join(ROOT, "profiles", "round2", "final")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r3"
+ROUND = sys.argv[2] if len(sys.argv) > 2 else "round3"
+src = os.path.join(ROOT, "gpurun_out", TAG)
+dst = os.path.join(ROOT, "profiles", ROUND, "final")
 os.makedirs(dst, exist_ok=True)
-for name, pat in (("kernel_stats.csv", "trace/runc/*kernel_stats.csv"), ("kernel_trace.csv", "trace/runc/*kernel_trace.csv"),
-                  ("kernel_stats_sparse.csv", "trace_sparse/runc/*kernel_stats.csv"), ("pmc_fetch_size.csv", "fetch/runc/*counter_collection.csv"),
-                  ("pmc_write_size.csv", "write/runc/*counter_collection.csv"), ("pmc_sq.csv", "sq/runc/*counter_collection.csv"),
-                  ("pmc_fetch_size_sparse.csv", "fetch_sparse/runc/*counter_collection.csv"), ("pmc_write_size_sparse.csv", "write_sparse/runc/*counter_collection.csv"),
-                  ("pmc_sq_sparse.csv", "sq_sparse/runc/*counter_collection.csv")):
-    f = glob.glob(os.path.join(src, pat))[0]
+for name, pat in (("kernel_stats.csv", "trace/*/*kernel_stats.csv"), ("kernel_trace.csv", "trace/*/*kernel_trace.csv"),
+                  ("kernel_stats_sparse.csv", "trace_sparse/*/*kernel_stats.csv"), ("pmc_fetch_size.csv", "fetch/*/*counter_collection.csv"),
+                  ("pmc_write_size.csv", "write/*/*counter_collection.csv"), ("pmc_sq.csv", "sq/*/*counter_collection.csv"),
+                  ("pmc_fetch_size_sparse.csv", "fetch_sparse/*/*counter_collection.csv"), ("pmc_write_size_sparse.csv", "write_sparse/*/*counter_collection.csv"),
+                  ("pmc_sq_sparse.csv", "sq_sparse/*/*counter_collection.csv"), ("pmc_mfma.csv", "mfma/*/*counter_collection.csv")):
+    f = glob.glob(os.path.join(src, pat))
+    if not f:
+        print("missing:", pat); continue
+    f = f[0]
     rows = list(csv.DictReader(open(f)))
     if "counter_collection" in f or "kernel_trace" in f:      # keep the product kernels only (the copies of the generator run are noise)
         rows = [r for r in rows if any(k in r.get("Kernel_Name", "") for k in ("k_lcqp_run", "k_backsolve", "k_build", "k_factor", "k_trsm", "k_prepare", "k_sparse"))]
     with open(os.path.join(dst, name), "w", newline="") as fh:
         w = csv.DictWriter(fh, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
-for name in ("bench_default.json", "bench_under_rocprof.json", "bench_sparse.json"):
-    shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+for name in ("bench_default.json", "bench_under_rocprof.json", "bench_sparse.json", "summary.txt"):
+    if os.path.exists(os.path.join(src, name)): shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 def mean_counter(fname, kernel, counter):
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(dst, fname))) if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter]
     return sum(v) / len(v)

@@ -1,4 +1,4 @@
-"""Print what a tools/run_profiles_dense.sh directory holds: average duration per kernel, FETCH_SIZE / WRITE_SIZE / SQ counters of the
+"""Print what a tools/run_profiles.sh / run_profiles_dense.sh directory holds: average duration per kernel, FETCH_SIZE / WRITE_SIZE / SQ counters of the
 product kernels (per launch), the traffic by the guide's recipe.  usage: python tools/prof_summary.py gpurun_out/<tag>"""
 import csv, glob, json, os, sys
 d = sys.argv[1]
@@ -6,11 +6,11 @@ def rows(pat):
     f = glob.glob(os.path.join(d, pat))
     return list(csv.DictReader(open(f[0]))) if f else []
 KEYS = ("k_lcqp_run", "k_backsolve", "k_build", "k_factor", "k_trsm", "k_prepare", "k_sparse", "k_compress", "k_setup")
-for r in rows("trace/*/*kernel_stats.csv"):
+for r in rows("trace/*/*kernel_stats.csv") + rows("trace_sparse/*/*kernel_stats.csv"):
     if any(k in r["Name"] for k in KEYS):
         print(f"{r['Name'][:60]:60s} calls {r['Calls']:>4s} avg {float(r['AverageNs']) / 1e6:9.4f} ms  total {float(r['TotalDurationNs']) / 1e6:9.3f} ms")
 out = {}
-for tag in ("fetch", "write", "sq"):
+for tag in ("fetch", "write", "sq", "mfma", "fetch_sparse", "write_sparse", "sq_sparse"):
     acc = {}
     for r in rows(f"{tag}/*/*counter_collection.csv"):
         if any(k in r["Kernel_Name"] for k in KEYS):
