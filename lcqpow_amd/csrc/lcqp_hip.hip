@@ -99,6 +99,9 @@ struct lcqp_hip_batch {
     int device;
     hipStream_t stream;
     hipEvent_t ev0, ev1, ev2;
+    // the setup has two independent branches (C = L'R + R'L and its compression; L1 -> Et -> M): the short one runs beside the long one
+    hipStream_t side;
+    hipEvent_t evFork, evJoin;
     // two pinned staging slots for loadLCQP: instance k is packed into slot k&1 while slot (k-1)&1 is in flight
     void* stage[2];
     hipEvent_t stageDone[2];
@@ -127,11 +130,11 @@ static void lcqp_dispatch(int nch, int kid, int grid, hipStream_t s, const Launc
     }
 #endif
 }
-static void dispatch_db(lcqp_hip_batch* h, int kid, int grid, const int* list = nullptr, int initial = 0, uint64_t seed0 = 0, uint64_t first = 0)
+static void dispatch_db(lcqp_hip_batch* h, int kid, int grid, const int* list = nullptr, int initial = 0, uint64_t seed0 = 0, uint64_t first = 0, hipStream_t on = nullptr)
 {
     LaunchArgs a;
     a.db = h->db; a.list = list; a.initial = initial; a.seed0 = seed0; a.first = first;
-    lcqp_dispatch(h->nch, kid, grid, h->stream, a);
+    lcqp_dispatch(h->nch, kid, grid, on ? on : h->stream, a);
 }
 
 template <class T>
@@ -156,13 +159,16 @@ try {
     if (!h) { g_err = "out of host memory"; return nullptr; }
     h->device = device; h->setupDone = false; h->ran = false; h->anyLoaded = false; h->bytesTotal = 0;
     h->stage[0] = h->stage[1] = nullptr; h->stageBytes = 0;
-    h->stream = nullptr; h->ev0 = h->ev1 = h->ev2 = nullptr;
+    h->stream = nullptr; h->ev0 = h->ev1 = h->ev2 = nullptr; h->side = nullptr; h->evFork = h->evJoin = nullptr;
     DevBatch& d = h->db;
     memset(&d, 0, sizeof(d));
     hipError_t e0 = hipStreamCreate(&h->stream);
     if (e0 == hipSuccess) e0 = hipEventCreate(&h->ev0);
     if (e0 == hipSuccess) e0 = hipEventCreate(&h->ev1);
     if (e0 == hipSuccess) e0 = hipEventCreate(&h->ev2);
+    if (e0 == hipSuccess) e0 = hipStreamCreate(&h->side);
+    if (e0 == hipSuccess) e0 = hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming);
+    if (e0 == hipSuccess) e0 = hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming);
     if (e0 != hipSuccess) { set_err("stream/event creation", e0); lcqp_hip_batch_destroy(h); return nullptr; }
     d.B = batch; d.n = nV; d.nC = nC; d.nComp = nComp; d.mA = nC + 2 * nComp;
     h->nch = (nV + 127) / 128;
@@ -229,6 +235,9 @@ try {
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
+    if (h->evFork) (void)hipEventDestroy(h->evFork);
+    if (h->evJoin) (void)hipEventDestroy(h->evJoin);
+    if (h->side) (void)hipStreamDestroy(h->side);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -443,9 +452,21 @@ static int launch_setup(lcqp_hip_batch* h)
     DevBatch& d = h->db;
     const int ntile = d.nblk * (d.nblk + 1) / 2;
     dispatch_db(h, ID_k_prepare, d.B);
-    if (d.nComp > 0) { dispatch_db(h, ID_k_build_C, d.B * ntile); dispatch_db(h, ID_k_compress_C, d.B); }
+    // C and its compressed rows depend on L and R only, the chain L1 -> Et -> M on Q and E: two branches.  The short one goes to the side
+    // stream and fills the machine while k_factor (one workgroup per instance, chains of 64-step diagonal blocks) leaves most of it idle.
+    const bool fork = d.nComp > 0;
+    if (fork) {
+        HIPCHK(hipEventRecord(h->evFork, h->stream));
+        HIPCHK(hipStreamWaitEvent(h->side, h->evFork, 0));
+        dispatch_db(h, ID_k_build_C, d.B * ntile, nullptr, 0, 0, 0, h->side);
+        dispatch_db(h, ID_k_compress_C, d.B, nullptr, 0, 0, 0, h->side);
+        HIPCHK(hipEventRecord(h->evJoin, h->side));
+    }
     dispatch_db(h, ID_k_factor, d.B);
     dispatch_db(h, ID_k_trsm, d.B * ((d.mEcap + 63) / 64));
+    // the join sits in front of the last setup kernel, not behind it: an event recorded right after a stream wait carried a late time stamp
+    // (the homotopy kernel appeared 2 ms shorter than rocprofv3 and the wall clock say), and the side branch has long finished by then
+    if (fork) HIPCHK(hipStreamWaitEvent(h->stream, h->evJoin, 0));
     { const int nb = (d.mMld + 127) / 128; dispatch_db(h, ID_k_build_M, d.B * (nb * (nb + 1) / 2)); }      // 128 x 128 tiles of the lower triangle
     HIPCHK(hipGetLastError());
     h->setupDone = true;

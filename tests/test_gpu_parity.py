@@ -275,6 +275,28 @@ def test_lcqp_iterate_level_match(hip, oracle, name):
     assert np.abs(so[:, 0] - sh[:, 0]).max() < 10 * tol                         # stationarity per iterate
 
 
+def test_iterate_counts_against_the_oracle_are_unbiased(hip, oracle):
+    """whether an inner loop ends at an iterate or one cycle of four iterates later is a coin flip at the rounding
+    floor, so the two sides differ in the iterate count of about a third of the instances -- but with no bias (round 2 had +4 four times
+    as often as -4; the whole-workload log is profiles/round3/full_parity_8192.log), by whole inner cycles, with identical return
+    codes and the same solutions."""
+    import os
+    N = 512
+    bt = hip.BatchLCQP(N, 256, 512, 64, opt=hip.default_options(perturbStep=0, printLevel=0))
+    bt.generate_synthetic(0)
+    bt.run()
+    x, y, st = bt.solution()
+    ok, xo, yo, so = oracle.synth_batch_solve(0, N, 256, 512, 64, opt=oracle.default_options(perturbStep=0, printLevel=0),
+                                              threads=len(os.sched_getaffinity(0)))
+    assert ok == N and all(s["returnValue"] == 0 for s in st)
+    assert np.abs(x - xo).max() < X_TOL and np.abs(y - yo).max() < Y_TOL
+    d = np.array([s["iterTotal"] for s in st]) - np.array([s["iterTotal"] for s in so])
+    assert (d % 4 == 0).mean() >= 0.99                       # whole inner cycles (a +-1 needs a flip in the very last iterate)
+    assert abs(d.mean()) < 0.6, d.mean()                     # 5 sigma of the mean of 512 fair +-4 flips at rate 0.35
+    assert (d == 0).mean() > 0.5
+    bt.close()
+
+
 def test_lcqp_run_warm_up(hip):
     """SolverTest.RunWarmUp (test/RunUnitTests.cpp:505-551) on the HIP path, 20 seeds"""
     d = P.warm_up()
