@@ -755,6 +755,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
         return 0;
     };
 
+    int capOn = 0;      // the cap on entering rows applies to polishes that start from an empty working set (oracle: cap_on)
     for (int trial = 0; trial < o.maxTrials; trial++) {
         c.cTrials++;
         int changed = 0, nlv = 0, have_true = 0, need_true = 0;
@@ -774,8 +775,10 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                     wg_row_norms<NCH>(c.E, mE, rn);
                     if (t == 0) c.info->rnReady = 1;
                 }
+                int cntA = 0;
                 wg_map<4>(mE, [&](int r) { return MapID{st[r], yt[r]}; },
-                          [&](int r, MapID v) { if (ROBUST && v.s == ST_INACT && v.a != 0.0) yt[r] = 0.0; ylv[r] = 0.0; });
+                          [&](int r, MapID v) { if (ROBUST && v.s == ST_INACT && v.a != 0.0) yt[r] = 0.0; ylv[r] = 0.0; cntA += (v.s != ST_INACT); });
+                capOn = (block_sum_i(cntA, c.lds) == 0);
                 (void)sweep_distance();
                 need_true = 1;
             }
@@ -805,12 +808,12 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                 nread = mE;
                 wg_rows<NCH>(c.E, nullptr, mE, x, ex, nullptr, c.lds, [](int, double) {});
             }
-            // Entering rows are capped (oracle: qp_polish, same arithmetic): when more than max(n/4, 16) inactive rows are violated -- a cold
+            // Entering rows are capped (oracle: qp_polish, same arithmetic): when more than max(n/8, 16) inactive rows are violated -- a cold
             // start, where every violated row would enter at once, overshoot and oscillate for eight to ten trials with a factor rebuild
             // each -- only those at or above a cut enter (twelve bisection steps on [0, largest violation]); the others stay inactive with
             // a negative margin, i.e. they are read again in the next trial.
             double vcut = 0.0;
-            {
+            if (capOn) {
                 auto violation = [&](int r) -> double {
                     if (st[r] != ST_INACT) return 0.0;
                     const double e = ex[r], ftol = o.feasTol * (1.0 + fabs(e));
@@ -819,7 +822,10 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                 double vm = 0.0, cv = 0.0, vmax, nviol;
                 for (int a = t; a < nread; a += WG) { const double v = violation(LISTS ? list[a] : a); if (v > 0.0) { cv += 1.0; vm = fmax(vm, v); } }
                 block_max_sum(vm, cv, vmax, nviol, c.lds);
-                const int cap = max(c.n / 4, 16);
+#ifndef LCQP_CAP_DIV
+#define LCQP_CAP_DIV 8      // (experiment switch; the oracle uses 8.  Same-box A/B of n/3, /4, /5, /6, /8, /12, /16: 31.3, 31.5-32.0, 30.6, 30.3-30.6, 30.0-30.2, 31.1, 31.9 ms)
+#endif
+                const int cap = max(c.n / LCQP_CAP_DIV, 16);
                 if (nviol > (double)cap) {
                     double lo = 0.0, hi = vmax;
                     for (int it = 0; it < 12; it++) {
@@ -828,7 +834,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                         for (int a = t; a < nread; a += WG) cnt += (violation(LISTS ? list[a] : a) >= mid);
                         if (block_sum_i(cnt, c.lds) > cap) lo = mid; else hi = mid;
                     }
-                    vcut = hi;
+                    vcut = lo;      // the lower end: a few more than cap rows (with the upper end a tie of many equally violated rows would never enter)
                 }
             }
             // violated rows enter; fresh margins for the others; the two rules for rows flagged dependent

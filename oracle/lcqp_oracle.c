@@ -765,6 +765,11 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
     int fact_valid = 0;
     const double spv = q->spv;
     for (int r = 0; r < mE; r++) ylv[r] = 0.0;
+    /* the cap on entering rows (below) is for polishes that start from an EMPTY working set: with a guess in hand -- the previous QP's set,
+     * the one ADMM proposes -- the full primal-dual update is the better step (and degenerate problems such as example_data, where rows
+     * flagged dependent are re-tried every trial, need it) */
+    int cap_on = 0;
+    if (!reuse) { cap_on = 1; for (int r = 0; r < mE; r++) if (st[r] != ST_INACT) cap_on = 0; }
 
     for (int trial = 0; trial < o->maxTrials; trial++) {
         q->c_trials++;
@@ -810,15 +815,15 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
                 else { double s = 0; for (int k = 0; k < n; k++) s += e[k] * x[k]; Ex[r] = s; }
                 q->rows_swept++;
             }
-            /* Entering rows are capped (round 3): when more than max(n/4, 16) inactive rows are violated -- a cold start, where the
+            /* Entering rows are capped (round 3): when more than max(n/8, 16) inactive rows are violated -- a cold start, where the
              * primal-dual update would put every violated row into the working set at once, overshoot, and oscillate for eight to ten
              * trials with a factor rebuild each -- only the most violated ones enter: those at or above a cut found by twelve bisection
              * steps on [0, largest violation] (the same arithmetic on the device: qp_polish in lcqp_dev.hpp).  The others stay
-             * inactive and are looked at again in the next trial.  On the synthetic workload the first QP of a homotopy then takes 6.4
-             * instead of 8.4 trials and 3.3 instead of 5.3 rebuilds, of smaller factors. */
+             * inactive and are looked at again in the next trial.  On the synthetic workload the first QP of a homotopy then takes fewer
+             * trials (8.4 -> 6.4 with n/4) and fewer, smaller rebuilds; n/8 is the device's optimum (same-box A/B of n/3 ... n/16). */
             double vcut = 0.0;
-            {
-                const int cap = (n / 4 > 16) ? n / 4 : 16;
+            if (cap_on) {
+                const int cap = (n / 8 > 16) ? n / 8 : 16;
                 int nviol = 0; double vmax = 0.0;
                 for (int r = 0; r < mE; r++) if (st[r] == ST_INACT) {
                     const double v = row_violation(Ex[r], q->l[r], q->u[r], o->feasTol);
@@ -832,7 +837,7 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
                         for (int r = 0; r < mE; r++) if (st[r] == ST_INACT) cnt += (row_violation(Ex[r], q->l[r], q->u[r], o->feasTol) >= mid);
                         if (cnt > cap) lo = mid; else hi = mid;
                     }
-                    vcut = hi;
+                    vcut = lo;      /* the lower end: a few more than cap rows -- with the upper end a tie of many equally violated rows would never enter */
                 }
             }
             for (int r = 0; r < mE; r++) {
