@@ -389,6 +389,19 @@ template <int G> __device__ __forceinline__ void sp_Cx2(SpCtx<G>& c, GD v0, GD v
     g_sync();
     SPROF(c, SP_PRODUCTS);
 }
+// C v from lx = E v that somebody else has computed (the polish leaves E x of its solution), for one vector or two:
+// out(i, (C v0)[i], (C v1)[i], pre(i))
+template <int G, bool TWO, class Pre, class Out> __device__ __forceinline__ void sp_C_from_Ex(SpCtx<G>& c, GD lx0, GD lx1, Pre pre, Out out)
+{
+    SPROF(c, SP_VECTORS);
+    const int nC = c.db->nC, nK = c.db->nComp;
+    sp_ell<G>(c.db->ellT, c.gl, c.Ex(),
+              [&](int r) { const int rr = r >= nC + nK ? r - nK : (r >= nC ? r + nK : -1);
+                           return rr >= 0 ? D2{lx0[rr], TWO ? (double)lx1[rr] : 0.0} : D2{0.0, 0.0}; },
+              pre, [&](int i, double s0, double s1, typename val_of<decltype(pre(0))>::type pv) { out(i, s0, s1, pv); });
+    g_sync();
+    SPROF(c, SP_PRODUCTS);
+}
 template <int G> __device__ __forceinline__ double sp_maxabs(const SpCtx<G>& c, GD a, int n)
 {
     double s = 0.0;
@@ -818,7 +831,12 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
     double dpUsed = c.info->delta, d2Used = c.info->delta2;      // regularisation of the factorisation in use
     for (int trial = 0; trial < o.maxTrials; trial++) {
         c.cTrials++;
-        double res_stat;
+        // Two stages, as on the dense path (oracle: sqp_polish).  Stage 1 is what every trial needs: E x, for the status test.  Stage 2 -- the
+        // true residual, one pass over Q and one over E' -- runs only when stage 1 changed nothing: after a correction the residual is zero on
+        // the old working set up to rounding and regularisation, so when the set changes the next right-hand side is known without it (the
+        // multipliers of the leaving rows, below); the trial that accepts always has the true residual.
+        double res_stat = 0.0;
+        int have_r1 = 0;
         if (trial == 0 && reuse) {
             GD r1s = c.V(NV_R1S), gs0 = c.V(NV_GS), exs = c.M(MV_EXS);
             double mx = 0.0;
@@ -827,11 +845,10 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
             g_map<G, 8>(m, t, [&](int r) { return exs[r]; }, [&](int r, double v) { ex[r] = v; });
             g_sync();
             res_stat = g_max<G>(mx);
+            have_r1 = 1;
         } else {
-            res_stat = sp_residual<G>(c, g, x, yt, r1, qx);
             sp_Ex<G>(c, x, ex);
-            c.cSweeps++;
-            c.bytes += 12.0 * (db.nnzQ + 2.0 * db.nnzE) + 8.0 * (4.0 * n + 2.0 * m);
+            c.bytes += 12.0 * db.nnzE + 8.0 * (n + m);
         }
         double res_eq = 0.0, bmax = 0.0;
         int chg = 0, act = 0;
@@ -857,6 +874,12 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
         res_eq = g_max<G>(res_eq);
         bmax = g_max<G>(bmax);
         SPROF(c, SP_VECTORS);
+        if (!have_r1 && (trial == 0 || !changed)) {
+            res_stat = sp_residual<G>(c, g, x, yt, r1, qx);
+            c.cSweeps++;
+            c.bytes += 12.0 * (db.nnzQ + db.nnzE) + 8.0 * (3.0 * n + m);
+            have_r1 = 1;
+        }
         if (trial > 0 && !changed && res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) {
             GD r1s = c.V(NV_R1S), gs0 = c.V(NV_GS), exs = c.M(MV_EXS);
             g_map<G, 8>(n, t, [&](int i) { return D2{r1[i], g[i]}; }, [&](int i, D2 v) { r1s[i] = v.a; gs0[i] = v.b; });
@@ -872,7 +895,9 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
             g_map<G, 8>(m, t, [&](int r) { return I2D{newst[r], st[r], yt[r]}; },
                         [&](int r, I2D v) { const bool leaves = (v.a == ST_INACT && v.b != ST_INACT); ytmp[r] = leaves ? -v.y : 0.0; st[r] = v.a; if (leaves && v.y != 0.0) yt[r] = 0.0; });
             g_sync();
-            sp_ETy<G>(c, ytmp, r1, [&](int i) { return r1[i]; }, [](double v) { return v; });             // r1 - E'(-y_leaving) = r1 + E'y_leaving
+            // r1 - E'(-y_leaving) = r1 + E'y_leaving; without a true residual r1 is the predicted one: nothing was left on the old working set
+            if (have_r1) sp_ETy<G>(c, ytmp, r1, [&](int i) { return r1[i]; }, [](double v) { return v; });
+            else sp_ETy<G>(c, ytmp, r1, [](int) { return NoPre{}; }, [](NoPre) { return 0.0; });
             fact_valid = 0;
         }
         if (!fact_valid) {
@@ -1089,7 +1114,7 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_run(SpBatch d
     const lcqp_options_t& o = db.opt;
     const int t = c.gl, n = db.n, m = db.m, nC = db.nC, nK = db.nComp;
     GD g = c.V(NV_G), gtil = c.V(NV_GTIL), gphi = c.V(NV_GPHI), xk = c.V(NV_XK), pk = c.V(NV_PK), xnew = c.V(NV_XNEW), gk = c.V(NV_GK);
-    GD Qx = c.V(NV_QX), Cx = c.V(NV_CX), Qp = c.V(NV_QP), Cp = c.V(NV_CP), tmp = c.V(NV_TMP);
+    GD Qx = c.V(NV_QX), Cx = c.V(NV_CX), Qp = c.V(NV_QP), Cp = c.V(NV_CP);
     GD yk = c.M(MV_YK), lx = c.M(MV_LX);
     const bool hasPhi = db.hasLbL || db.hasLbR;
     const double phiConst = c.info->phiConst;
@@ -1115,8 +1140,11 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_run(SpBatch d
         st.rhoOpt = rho;
         if (hasPhi) { for (int i = t; i < n; i += G) gtil[i] = g[i] + rho * gphi[i]; g_sync(); }
     };
+    // Q x0 and C x0 once; from here on both follow the steps (the loop below)
+    sp_Qx2<G>(c, xk, xk, Qx, Qp); sp_Cx2<G>(c, xk, xk, Cx, Cp);
+    c.bytes += 12.0 * db.nnzQ + 2.0 * 12.0 * db.nnzE;
     if (o.solveZeroPenaltyFirst) { for (int i = t; i < n; i += G) gk[i] = g[i]; g_sync(); }
-    else { sp_Cx2<G>(c, xk, xk, Cx, Cp); for (int i = t; i < n; i += G) gk[i] = rho * Cx[i] + gtil[i]; g_sync(); }
+    else { for (int i = t; i < n; i += G) gk[i] = rho * Cx[i] + gtil[i]; g_sync(); }
     int initial = 1;
     for (;;) {
         SPROF(c, SP_LCQP);
@@ -1124,14 +1152,22 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_run(SpBatch d
         SPROF(c, SP_VECTORS);
         st.subproblemIter += qpIter; st.qpSolverExitFlag = ef; st.qpSolves++;
         if (ef != 0) { rc = LCQP_SUBPROBLEM_SOLVER_ERROR; break; }
+        // What the subsolver's accepted trial leaves behind makes every product of this level but one unnecessary (the dense kernel does
+        // the same, lcqp_dev.hpp: lcqp_run): Q xq is in NV_TMP (sp_residual), E xq in MV_EXS, and its residual r1s = -gs0 - Q xq - E'yq
+        // gives E'yq.  So pk = xq - xk, Q pk = Q xq - Q xk with Q xk kept up to date below, C xq = L'(R xq) + R'(L xq) is one column
+        // gather over E with the entries of E xq, C pk = C xq - C xk, and the stationarity needs no pass over E' of its own.
+        // (round 2: one pass over Q, one over E, two over E' per iterate.)
+        GD qxs = c.V(NV_TMP), exs = c.M(MV_EXS), r1s = c.V(NV_R1S), gs0 = c.V(NV_GS);
         {
             GD xq = c.V(NV_XQ), yq = c.M(MV_YQ);
-            g_map<G, 8>(n, t, [&](int i) { return D2{xq[i], xk[i]}; }, [&](int i, D2 v) { xnew[i] = v.a; pk[i] = v.a - v.b; });
+            g_map<G, 4>(n, t, [&](int i) { return D4{xq[i], xk[i], qxs[i], Qx[i]}; }, [&](int i, D4 v) { xnew[i] = v.a; pk[i] = v.a - v.b; Qp[i] = v.c - v.d; });
             g_map<G, 8>(m, t, [&](int r) { return yq[r]; }, [&](int r, double v) { yk[r] = -v; });     // src/SubsolverOSQP.cpp:196-199
             g_sync();
         }
+        bool perturbed = false;
         if (initial) st.rhoOpt = rho;
         else if (o.perturbStep) {
+            perturbed = true;
             for (int i = t; i < n; i += G) {
                 uint64_t z = o.perturbSeed + (perturbCounter + (uint64_t)i + 1ULL) * 0x9E3779B97F4A7C15ULL;
                 z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z = z ^ (z >> 31);
@@ -1140,8 +1176,17 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_run(SpBatch d
             perturbCounter += (uint64_t)n;
             g_sync();
         }
-        sp_Qx2<G>(c, pk, xk, Qp, Qx); sp_Cx2<G>(c, pk, xk, Cp, Cx);
-        c.bytes += 2.0 * 12.0 * db.nnzQ + 4.0 * 12.0 * db.nnzE;
+        if (perturbed) {
+            // the perturbation has to reach the penalty gradient rho C xk -- it is there to break the symmetry of problems like warm_up
+            // (perturbStep :1353-1362) -- so C xk is taken from the perturbed xk: one more pass over E, the column gather carries two
+            // vectors.  (Q xk is not: 2.2e-16 per component is below its rounding; the dense kernel does the same.)
+            sp_Ex<G>(c, xk, lx);
+            sp_C_from_Ex<G, true>(c, exs, lx, [](int) { return NoPre{}; }, [&](int i, double cxq, double cxk, NoPre) { Cx[i] = cxk; Cp[i] = cxq - cxk; });
+            c.bytes += 3.0 * 12.0 * db.nnzE;
+        } else {
+            sp_C_from_Ex<G, false>(c, exs, exs, [&](int i) { return Cx[i]; }, [&](int i, double cxq, double, double cxk) { Cp[i] = cxq - cxk; });
+            c.bytes += 12.0 * db.nnzE;
+        }
         if (!initial) {
             double sq = 0.0, sl = 0.0;
 #pragma unroll 4
@@ -1151,13 +1196,18 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_run(SpBatch d
             if (qk > 0 && lk < 0) alphak = fmin(-lk / qk, 1.0);
         }
         initial = 0;
-        { struct D6 { double a, b, c, d, e, f; };
-          g_map<G, 4>(n, t, [&](int i) { return D6{xk[i], pk[i], Qx[i], Qp[i], Cx[i], Cp[i]}; },
-                      [&](int i, D6 v) { xk[i] = v.a + alphak * v.b; Qx[i] = v.c + alphak * v.d; Cx[i] = v.e + alphak * v.f; }); }
+        // the step, the products that follow it, and updateStationarity without a box term: statk = Qk xk + g_tilde - E'yk with
+        // E'yk = -E'yq = gs0 + Q xq + r1s
+        double statMax = 0.0;
+        { struct D10 { double a, b, c, d, e, f, g0, q, r, gt; };
+          g_map<G, 2>(n, t, [&](int i) { return D10{xk[i], pk[i], Qx[i], Qp[i], Cx[i], Cp[i], gs0[i], qxs[i], r1s[i], gtil[i]}; },
+                      [&](int i, D10 v) {
+                          const double qn = v.c + alphak * v.d, cn = v.e + alphak * v.f;
+                          xk[i] = v.a + alphak * v.b; Qx[i] = qn; Cx[i] = cn;
+                          statMax = nmax(statMax, fabs(((qn + rho * cn) + v.gt) - ((v.g0 + v.q) + v.r)));
+                      }); }
         g_sync();
-        // updateStationarity without a box term: statk = Qk xk + g_tilde - E'yk
-        const double statMax = sp_ETy<G>(c, yk, tmp, [&](int i) { return D3{Qx[i], Cx[i], gtil[i]}; }, [&](D3 v) { return (v.a + rho * v.b) + v.c; });
-        const double statInf = statMax;
+        const double statInf = g_max<G>(statMax);
         if (db.traceCap > 0 && totalIter < db.traceCap) {   // storeSteps :488-490, printIteration :1528-1576 (the host rebuilds both from this)
             const double phiNow = getPhi();
             double so = 0.0, sm = 0.0, pm = 0.0;

@@ -299,18 +299,19 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
     int fact_valid = 0;
     for (int trial = 0; trial < o->maxTrials; trial++) {
         q->c_trials++;
+        /* Two stages, as on the dense path (round 3).  Stage 1 is what every trial needs: E x, for the status test.  Stage 2 -- the true
+         * residual r1 = -g - Q x - E'y, one pass over Q and one over E' -- runs only when stage 1 changed nothing: after a correction the
+         * residual is zero on the old working set up to rounding and regularisation, so when the set changes the next right-hand side is
+         * known without it (the multipliers of the leaving rows, below); the trial that accepts always has the true residual. */
+        int have_r1 = 0;
         if (trial == 0 && reuse) {
             for (int i = 0; i < n; i++) r1[i] = q->r1_last[i] + (q->g_last[i] - g[i]);
             memcpy(Ex, q->ex_last, sizeof(double) * m);
+            have_r1 = 1;
         } else {
-            q->c_sweeps++;
-            sp_Qx(q, x, r1);
-            for (int i = 0; i < n; i++) r1[i] = -g[i] - r1[i];
-            sp_ETy_sub(q, y, r1);
             sp_Ex(q, x, Ex);
         }
         double res_stat = 0, res_eq = 0, bmax = 0;
-        for (int i = 0; i < n; i++) if (fabs(r1[i]) > res_stat || r1[i] != r1[i]) res_stat = fabs(r1[i]);      /* a NaN stays (and is never accepted) */
         int changed = 0, nact = 0;
         const double ytol = o->feasTol * gs;
         for (int r = 0; r < m; r++) {
@@ -330,12 +331,21 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
             if (ns != s) changed++;
             nact += (ns != SP_INACT);
         }
+        if (!have_r1 && (trial == 0 || !changed)) {
+            q->c_sweeps++;
+            sp_Qx(q, x, r1);
+            for (int i = 0; i < n; i++) r1[i] = -g[i] - r1[i];
+            sp_ETy_sub(q, y, r1);
+            have_r1 = 1;
+        }
+        if (have_r1) for (int i = 0; i < n; i++) if (fabs(r1[i]) > res_stat || r1[i] != r1[i]) res_stat = fabs(r1[i]);      /* a NaN stays (and is never accepted) */
         if (trial > 0 && !changed && res_stat <= o->resTol * gs && res_eq <= o->resTol * (1.0 + bmax)) {
             memcpy(q->r1_last, r1, sizeof(double) * n); memcpy(q->ex_last, Ex, sizeof(double) * m); memcpy(q->g_last, g, sizeof(double) * n);
             return 1;
         }
         if (changed && trial > 0) {
             if (trial >= 2 && nact > n && changed > (n / 2 > 32 ? n / 2 : 32)) return 0;       /* overshooting cold start: hand over to ADMM */
+            if (!have_r1) for (int i = 0; i < n; i++) r1[i] = 0.0;        /* predicted: the last correction left nothing on the old working set */
             for (int r = 0; r < m; r++) {
                 const int ns = q->newst[r];
                 if (ns == SP_INACT && st[r] != SP_INACT && y[r] != 0.0) {
