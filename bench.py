@@ -90,8 +90,8 @@ def run_devices(devices, make_batch, steps, warmup, barrier):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=("dense", "sparse"), default="dense")
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default 1024 dense; 16384 sparse: 8 instances per wavefront, 2 wavefronts per SIMD resident)")
     ap.add_argument("--n", type=int, default=None)
