@@ -980,23 +980,31 @@ __device__ __forceinline__ int sp_qp_solve(SpCtx<G>& c, int initial, GD g, int* 
     GD l = c.M(MV_L), u = c.M(MV_U);
     GI st = c.I(MI_ST), stt = c.I(MI_STT);
     *iterations = 0;
-    int bad = 0;
-#pragma unroll 8
-    for (int r = t; r < m; r += G) bad |= (l[r] > u[r]);
+    int n_admm = initial ? o.admmFirst : o.admmHot;
+    const int use_stored = (!initial && c.info->haveSolution && n_admm == 0);
+    // The ADMM iterate (xa, ya) starts as a copy of the stored solution.  A hot start hands the stored solution to the polish directly and
+    // the copy is made only if the polish fails and an ADMM round follows (one QP in a thousand on the synthetic workload).
+    int backup_pending = 0;
     if (initial) {
         GD x0 = c.V(NV_X0), y0 = c.M(MV_Y0);
         const int hasY0 = c.info->hasY0;
         g_map<G, 8>(n, t, [&](int i) { return x0[i]; }, [&](int i, double v) { xq[i] = v; xa[i] = v; });
         g_map<G, 8>(m, t, [&](int r) { return y0[r]; }, [&](int r, double v) { const double yv = hasY0 ? -v : 0.0; yq[r] = yv; ya[r] = yv; });
+    } else if (use_stored) {
+        backup_pending = 1;
     } else {
         g_map<G, 8>(n, t, [&](int i) { return xq[i]; }, [&](int i, double v) { xa[i] = v; });
         g_map<G, 8>(m, t, [&](int r) { return yq[r]; }, [&](int r, double v) { ya[r] = v; });
     }
     g_sync();
-    int n_admm = initial ? o.admmFirst : o.admmHot;
-    const int use_stored = (!initial && c.info->haveSolution && n_admm == 0);
     int solved = 0, admm_ready = 0;
     for (int round = 0; round < o.maxRounds && !solved; round++) {
+        if (backup_pending && round > 0) {
+            g_map<G, 8>(n, t, [&](int i) { return xq[i]; }, [&](int i, double v) { xa[i] = v; });
+            g_map<G, 8>(m, t, [&](int r) { return yq[r]; }, [&](int r, double v) { ya[r] = v; });
+            g_sync();
+            backup_pending = 0;
+        }
         if (!admm_ready && (n_admm > 0 || !(round == 0 && use_stored))) {
             sp_Ex<G>(c, xa, za);
             g_map<G, 8>(m, t, [&](int r) { return D3{za[r], l[r], u[r]}; },
@@ -1006,7 +1014,7 @@ __device__ __forceinline__ int sp_qp_solve(SpCtx<G>& c, int initial, GD g, int* 
         }
         if (n_admm > 0) sp_admm<G>(c, g, n_admm);
         if (round == 0 && use_stored) {
-            g_map<G, 4>(m, t, [&](int r) { return ID3{st[r], l[r], u[r], 0.0, ya[r]}; },
+            g_map<G, 4>(m, t, [&](int r) { return ID3{st[r], l[r], u[r], 0.0, yq[r]}; },
                         [&](int r, ID3 v) { const int s = (v.lo == v.hi) ? ST_EQ : v.s; stt[r] = s; yt[r] = (s != ST_INACT) ? v.y : 0.0; });
         } else {
             g_map<G, 4>(m, t, [&](int r) { return ID3{0, l[r], u[r], za[r], ya[r]}; },
@@ -1019,7 +1027,8 @@ __device__ __forceinline__ int sp_qp_solve(SpCtx<G>& c, int initial, GD g, int* 
                             yt[r] = (s != ST_INACT) ? v.y : 0.0;
                         });
         }
-        g_map<G, 8>(n, t, [&](int i) { return xa[i]; }, [&](int i, double v) { xt[i] = v; });
+        { GD xs = (round == 0 && use_stored) ? xq : xa;
+          g_map<G, 8>(n, t, [&](int i) { return xs[i]; }, [&](int i, double v) { xt[i] = v; }); }
         g_sync();
         if (sp_polish<G>(c, g, round == 0 && use_stored)) { solved = 1; break; }
         n_admm = 2 * n_admm;
