@@ -42,9 +42,9 @@ constexpr int WGS = 64;      // one wavefront per workgroup; 64 / G instances in
 #ifndef SP_SWEEP_RING
 #define SP_SWEEP_RING 4      // coefficient chunks (8 steps each) of a band sweep in flight at G = 8
 #endif
-enum { NV_G, NV_GTIL, NV_GPHI, NV_XK, NV_PK, NV_XNEW, NV_GK, NV_QX, NV_CX, NV_QP, NV_CP, NV_TMP, NV_XQ, NV_XA, NV_XT, NV_R1, NV_R1S, NV_GS,
+enum { NV_G, NV_GTIL, NV_GPHI, NV_XK, NV_PK, NV_XNEW, NV_GK, NV_QX, NV_CX, NV_QP, NV_CP, NV_TMP, NV_XQ, NV_XA, NV_XT, NV_R1,
        NV_X0, NV_NUM };
-enum { MV_L, MV_U, MV_RHOV, MV_YQ, MV_YA, MV_ZA, MV_YT, MV_EX, MV_EXS, MV_YK, MV_Y0, MV_LX, MV_LX2, MV_NUM };
+enum { MV_L, MV_U, MV_RHOV, MV_YQ, MV_YA, MV_ZA, MV_YT, MV_EX, MV_YK, MV_Y0, MV_LX, MV_LX2, MV_NUM };
 enum { MI_ST, MI_STT, MI_STF, MI_NEW, MI_NUM };
 
 struct SpInfo {
@@ -816,7 +816,7 @@ struct ID4 { int p, s; double lo, hi, e; };
 struct ID2 { int s; double v, y; };
 
 template <int G>
-__device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
+__device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse, double gmaxHint)
 {
     const SpBatch& db = *c.db;
     const lcqp_options_t& o = db.opt;
@@ -825,7 +825,7 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
     GD l = c.M(MV_L), u = c.M(MV_U);
     GI st = c.I(MI_STT), stf = c.I(MI_STF), newst = c.I(MI_NEW);
     const int* iperm = db.iperm;
-    const double gs = 1.0 + sp_maxabs<G>(c, g, n);
+    const double gs = 1.0 + ((reuse && gmaxHint >= 0.0) ? gmaxHint : sp_maxabs<G>(c, g, n));      // (the LCQP level knows max|g| of the vector it has just formed)
     const double ytol = o.feasTol * gs;
     int fact_valid = 0, borderTodo = 0;
     double dpUsed = c.info->delta, d2Used = c.info->delta2;      // regularisation of the factorisation in use
@@ -838,13 +838,8 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
         double res_stat = 0.0;
         int have_r1 = 0;
         if (trial == 0 && reuse) {
-            GD r1s = c.V(NV_R1S), gs0 = c.V(NV_GS), exs = c.M(MV_EXS);
-            double mx = 0.0;
-            g_map<G, 8>(n, t, [&](int i) { return D3{r1s[i], gs0[i], g[i]}; },
-                        [&](int i, D3 v) { const double r = v.a + (v.b - v.c); r1[i] = r; mx = nmax(mx, fabs(r)); });
-            g_map<G, 8>(m, t, [&](int r) { return exs[r]; }, [&](int r, double v) { ex[r] = v; });
-            g_sync();
-            res_stat = g_max<G>(mx);
+            // hot start with an unchanged (x, y): r1 = r1_last + (g_last - g) and E x are in place -- the residual and E x of the accepted
+            // trial stay where they are, and the LCQP level adds (g_last - g) to r1 in the pass that forms the new g (k_sparse_run)
             have_r1 = 1;
         } else {
             sp_Ex<G>(c, x, ex);
@@ -880,13 +875,7 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
             c.bytes += 12.0 * (db.nnzQ + db.nnzE) + 8.0 * (3.0 * n + m);
             have_r1 = 1;
         }
-        if (trial > 0 && !changed && res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) {
-            GD r1s = c.V(NV_R1S), gs0 = c.V(NV_GS), exs = c.M(MV_EXS);
-            g_map<G, 8>(n, t, [&](int i) { return D2{r1[i], g[i]}; }, [&](int i, D2 v) { r1s[i] = v.a; gs0[i] = v.b; });
-            g_map<G, 8>(m, t, [&](int r) { return ex[r]; }, [&](int r, double v) { exs[r] = v; });
-            g_sync();
-            return 1;
-        }
+        if (trial > 0 && !changed && res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) return 1;
         if (changed && trial > 0) {
             if (trial >= 2 && nact > n && changed > max(n / 2, 32)) return 0;       // overshooting cold start: hand over to ADMM
             // leaving rows: their multipliers leave the residual (r1 += E_r' y_r), then the new working set takes over
@@ -969,7 +958,7 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse)
 struct ID3 { int s; double lo, hi, z, y; };
 
 template <int G>
-__device__ __forceinline__ int sp_qp_solve(SpCtx<G>& c, int initial, GD g, int* iterations)
+__device__ __forceinline__ int sp_qp_solve(SpCtx<G>& c, int initial, GD g, int* iterations, double gmaxHint)
 {
     const SpBatch& db = *c.db;
     const lcqp_options_t& o = db.opt;
@@ -1030,7 +1019,7 @@ __device__ __forceinline__ int sp_qp_solve(SpCtx<G>& c, int initial, GD g, int* 
         { GD xs = (round == 0 && use_stored) ? xq : xa;
           g_map<G, 8>(n, t, [&](int i) { return xs[i]; }, [&](int i, double v) { xt[i] = v; }); }
         g_sync();
-        if (sp_polish<G>(c, g, round == 0 && use_stored)) { solved = 1; break; }
+        if (sp_polish<G>(c, g, round == 0 && use_stored, gmaxHint)) { solved = 1; break; }
         n_admm = 2 * n_admm;
         if (n_admm < 10) n_admm = 10;
         if (n_admm > 400) n_admm = 400;
@@ -1155,18 +1144,19 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_run(SpBatch d
     if (o.solveZeroPenaltyFirst) { for (int i = t; i < n; i += G) gk[i] = g[i]; g_sync(); }
     else { for (int i = t; i < n; i += G) gk[i] = rho * Cx[i] + gtil[i]; g_sync(); }
     int initial = 1;
+    double gmaxNext = -1.0;      // max |gk| of the next QP when this level has formed it (-1: the subsolver looks)
     for (;;) {
         SPROF(c, SP_LCQP);
-        const int ef = sp_qp_solve<G>(c, initial, gk, &qpIter);
+        const int ef = sp_qp_solve<G>(c, initial, gk, &qpIter, gmaxNext);
         SPROF(c, SP_VECTORS);
         st.subproblemIter += qpIter; st.qpSolverExitFlag = ef; st.qpSolves++;
         if (ef != 0) { rc = LCQP_SUBPROBLEM_SOLVER_ERROR; break; }
         // What the subsolver's accepted trial leaves behind makes every product of this level but one unnecessary (the dense kernel does
-        // the same, lcqp_dev.hpp: lcqp_run): Q xq is in NV_TMP (sp_residual), E xq in MV_EXS, and its residual r1s = -gs0 - Q xq - E'yq
+        // the same, lcqp_dev.hpp: lcqp_run): Q xq is in NV_TMP (sp_residual), E xq in MV_EX, and its residual r1 = -gk - Q xq - E'yq (NV_R1, gk still the vector of that QP)
         // gives E'yq.  So pk = xq - xk, Q pk = Q xq - Q xk with Q xk kept up to date below, C xq = L'(R xq) + R'(L xq) is one column
         // gather over E with the entries of E xq, C pk = C xq - C xk, and the stationarity needs no pass over E' of its own.
         // (round 2: one pass over Q, one over E, two over E' per iterate.)
-        GD qxs = c.V(NV_TMP), exs = c.M(MV_EXS), r1s = c.V(NV_R1S), gs0 = c.V(NV_GS);
+        GD qxs = c.V(NV_TMP), exs = c.M(MV_EX), r1s = c.V(NV_R1), gs0 = gk;
         {
             GD xq = c.V(NV_XQ), yq = c.M(MV_YQ);
             g_map<G, 4>(n, t, [&](int i) { return D4{xq[i], xk[i], qxs[i], Qx[i]}; }, [&](int i, D4 v) { xnew[i] = v.a; pk[i] = v.a - v.b; Qp[i] = v.c - v.d; });
@@ -1271,7 +1261,12 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_run(SpBatch d
         }
         if (totalIter > o.maxIterations) { rc = LCQP_MAX_ITERATIONS_REACHED; break; }
         if (rho > o.maxPenaltyParameter) { rc = LCQP_MAX_PENALTY_REACHED; break; }
-        g_map<G, 8>(n, t, [&](int i) { return D2{Cx[i], gtil[i]}; }, [&](int i, D2 v) { gk[i] = rho * v.a + v.b; });
+        // the next QP's linear term; its hot start needs r1 = r1_last + (g_last - g): the residual of the accepted trial is still in NV_R1
+        { GD r1 = c.V(NV_R1);
+          double gm = 0.0;
+          g_map<G, 8>(n, t, [&](int i) { return D4{Cx[i], gtil[i], gk[i], r1[i]}; },
+                      [&](int i, D4 v) { const double gn = rho * v.a + v.b; gk[i] = gn; r1[i] = v.d + (v.c - gn); gm = fmax(gm, fabs(gn)); });
+          gmaxNext = g_max<G>(gm); }
         g_sync();
     }
     st.status = algoStat; st.returnValue = rc;
