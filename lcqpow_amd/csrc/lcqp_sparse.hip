@@ -868,7 +868,7 @@ __device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse, double gm
         const int changed = g_sum_i<G>(chg), nact = g_sum_i<G>(act);
         res_eq = g_max<G>(res_eq);
         bmax = g_max<G>(bmax);
-        SPROF(c, SP_VECTORS);
+        SPROF(c, SP_ASSEMBLE);      // (profile builds: the status test on its own)
         if (!have_r1 && (trial == 0 || !changed)) {
             res_stat = sp_residual<G>(c, g, x, yt, r1, qx);
             c.cSweeps++;

@@ -734,7 +734,7 @@ def cmd_sparse_profile():
     if rc != 0:
         print("library was not built with -DLCQP_PROFILE (rc %d)" % rc)
     else:
-        names = ["sparse products", "KKT assembly", "band factorisation", "forward sweeps", "backward sweeps", "vector operations", "LCQP level", "rhs of a correction (2 passes)"]
+        names = ["sparse products", "status test", "band factorisation", "forward sweeps", "backward sweeps", "vector operations", "LCQP level", "rhs of a correction (2 passes)"]
         print("mean ticks per instance %.3e (100 MHz clock: %.1f ms)" % (out.sum(), out.sum() / 1e5))
         for k in range(8):
             print("  %-20s %6.2f %%" % (names[k], 100 * out[k] / out.sum()))
