@@ -699,6 +699,10 @@ static void ti_delete(orc_qp_t* q, int p)
  * (tests/test_oracle_solver.py uses it to show that the oracle differs from ITSELF in the same way when only this order changes). */
 static int g_sum_order = 1;
 void orc_qp_set_sum_order(int device_order) { g_sum_order = device_order; }
+/* divisor of the cap on entering rows of a cold polish (qp_polish): max(n / div, 16) rows per trial; 0 switches the cap off (test hook:
+ * tests/test_oracle_solver.py::test_capped_cold_start_reaches_the_same_qp_solutions).  The device uses 8. */
+static int g_enter_cap_div = 8;
+void orc_qp_set_enter_cap(int div) { g_enter_cap_div = div; }
 static double dot_lanes(const double* a, const double* x, int n)
 {
     double v[64];
@@ -769,7 +773,7 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
      * the one ADMM proposes -- the full primal-dual update is the better step (and degenerate problems such as example_data, where rows
      * flagged dependent are re-tried every trial, need it) */
     int cap_on = 0;
-    if (!reuse) { cap_on = 1; for (int r = 0; r < mE; r++) if (st[r] != ST_INACT) cap_on = 0; }
+    if (!reuse && g_enter_cap_div > 0) { cap_on = 1; for (int r = 0; r < mE; r++) if (st[r] != ST_INACT) cap_on = 0; }
 
     for (int trial = 0; trial < o->maxTrials; trial++) {
         q->c_trials++;
@@ -823,7 +827,7 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
              * trials (8.4 -> 6.4 with n/4) and fewer, smaller rebuilds; n/8 is the device's optimum (same-box A/B of n/3 ... n/16). */
             double vcut = 0.0;
             if (cap_on) {
-                const int cap = (n / 8 > 16) ? n / 8 : 16;
+                const int cap = (n / g_enter_cap_div > 16) ? n / g_enter_cap_div : 16;
                 int nviol = 0; double vmax = 0.0;
                 for (int r = 0; r < mE; r++) if (st[r] == ST_INACT) {
                     const double v = row_violation(Ex[r], q->l[r], q->u[r], o->feasTol);

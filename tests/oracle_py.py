@@ -134,6 +134,11 @@ def qp_set_sum_order(device_order):
     lib().orc_qp_set_sum_order(int(device_order))
 
 
+def qp_set_enter_cap(div):
+    """cap on entering rows of a cold polish: max(n / div, 16) rows per trial (default 8, the device's value); 0 switches it off"""
+    lib().orc_qp_set_enter_cap(int(div))
+
+
 def synth_generate(instance, n=256, nC=512, nComp=64, seed0=SEED0):
     Q = np.empty((n, n)); g = np.empty(n); L = np.empty((nComp, n)); R = np.empty((nComp, n))
     A = np.empty((nC, n)); lbA = np.empty(nC); ubA = np.empty(nC)

@@ -179,3 +179,26 @@ def test_iterate_path_is_a_coin_flip_at_the_rounding_floor(oracle):
     d = np.array([a["iterTotal"] - b["iterTotal"] for a, b in zip(s0, s1)])
     assert np.all(d % 4 == 0)                                               # ... reached over whole cycles more or less
     assert 0.05 < np.mean(d != 0) < 0.6, np.mean(d != 0)                    # on a sizeable share (measured: 0.27 of 1024)
+
+
+def test_capped_cold_start_reaches_the_same_qp_solutions(oracle):
+    """Round 3: a polish that starts from an empty working set lets at most max(n/8, 16) rows enter per trial (the most violated first)
+    instead of all violated rows at once.  The QPs are strictly convex, so the cap cannot change their solutions -- hence not the
+    homotopy either -- only the way there: fewer trials and far fewer factor rebuilds in the first QP."""
+    import os
+    n_inst = 32
+    opt = oracle.default_options(perturbStep=0, printLevel=0)
+    threads = min(8, len(os.sched_getaffinity(0)))
+    try:
+        oracle.qp_set_enter_cap(0)
+        _, x0, y0, s0 = oracle.synth_batch_solve(0, n_inst, 256, 512, 64, opt=opt, threads=threads)
+        oracle.qp_set_enter_cap(8)
+        _, x1, y1, s1 = oracle.synth_batch_solve(0, n_inst, 256, 512, 64, opt=opt, threads=threads)
+    finally:
+        oracle.qp_set_enter_cap(8)
+    assert all(s["returnValue"] == 0 for s in s0) and all(s["returnValue"] == 0 for s in s1)
+    assert np.abs(x0 - x1).max() < 1e-11 and np.abs(y0 - y1).max() < 1e-8
+    d = np.array([a["iterTotal"] - b["iterTotal"] for a, b in zip(s0, s1)])
+    assert np.all(d % 4 == 0)                                               # the same homotopy up to the coin flips of the test above
+    mean = lambda S, k: float(np.mean([s[k] for s in S]))
+    assert mean(s1, "trials") < mean(s0, "trials") and mean(s1, "factorizations") < mean(s0, "factorizations")
