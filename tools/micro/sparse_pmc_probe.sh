@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOT USABLE AS IS on this pool: the texture-addresser / L1 counter groups slowed the 13 s sparse run beyond a 25-minute limit (nothing came
+# back).  Kept as a record of the counter names; run single groups under `timeout` on a small batch if at all.
 # Which unit bounds k_sparse_run?  Texture-addresser / L1 / L2 counters of the sparse workload, one rocprofv3 --pmc pass per group.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/sp_pmc
