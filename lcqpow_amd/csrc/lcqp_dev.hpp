@@ -382,13 +382,23 @@ __device__ __forceinline__ void ti_reset(Ctx<NCH>& c, int& nT, int& ns)
 
 // The fused pass for up to 64*NK slots: a wave takes rows j = w, w+4, ..., keeps D rows (D*NK loads of 512 bytes) in flight, and
 // for each row forms u = row.t (one wavefront reduction) and accumulates u*row -- the row is read once.
+// Column s of Ti is zero in the rows above crow[s] (Ti is triangular in creation order), and a lane does not load what it knows to be zero:
+// half the bytes of the pass (-DLCQP_TI_FULL_ROWS reads the full rows: cross-check).
 template <int NK, int D>
-__device__ __forceinline__ void ti_apply_fast(const double* __restrict__ Ti, int ld, const double* tv, double* out, int nT, int ns, double* red)
+__device__ __forceinline__ void ti_apply_fast(const double* __restrict__ Ti, int ld, const double* tv, double* out, int nT, int ns, double* red, const int* crow, const int* slotRow)
 {
     const int l = lane_id(), w = wave_id(), t = tid_here();
     double tr[NK], acc[NK];
+    int first[NK];
 #pragma unroll
-    for (int k = 0; k < NK; k++) { const int sl = 64 * k + l; tr[k] = (sl < ns) ? tv[sl] : 0.0; acc[k] = 0.0; }
+    for (int k = 0; k < NK; k++) {
+        const int sl = 64 * k + l; tr[k] = (sl < ns) ? tv[sl] : 0.0; acc[k] = 0.0;
+#ifdef LCQP_TI_FULL_ROWS
+        first[k] = (sl < ns) ? 0 : (1 << 30);
+#else
+        first[k] = (sl < ns && slotRow[sl] >= 0) ? crow[sl] : (1 << 30);      // (a free slot: its column is zero everywhere)
+#endif
+    }
     for (int j0 = w; j0 < nT; j0 += NWAVE * D) {
         double rv[D][NK];
 #pragma unroll
@@ -397,7 +407,7 @@ __device__ __forceinline__ void ti_apply_fast(const double* __restrict__ Ti, int
 #pragma unroll
             for (int k = 0; k < NK; k++) {
                 const int sl = 64 * k + l;
-                rv[d][k] = (j < nT && sl < ns) ? Ti[(size_t)j * ld + sl] : 0.0;
+                rv[d][k] = (j < nT && j >= first[k]) ? Ti[(size_t)j * ld + sl] : 0.0;
             }
         }
 #pragma unroll
@@ -427,10 +437,10 @@ __device__ __forceinline__ void ti_apply(Ctx<NCH>& c, const double* tv, double* 
     const double* Ti = c.S;
     if (nk <= TI_FAST_CHUNKS) {
         double* red = c.lds.arena;     // 4 waves x 256 partial sums
-        if (nk <= 1) ti_apply_fast<1, 16>(Ti, ld, tv, out, nT, ns, red);
-        else if (nk == 2) ti_apply_fast<2, 8>(Ti, ld, tv, out, nT, ns, red);
-        else if (nk == 3) ti_apply_fast<3, 6>(Ti, ld, tv, out, nT, ns, red);
-        else ti_apply_fast<4, 4>(Ti, ld, tv, out, nT, ns, red);
+        if (nk <= 1) ti_apply_fast<1, 16>(Ti, ld, tv, out, nT, ns, red, c.crow, c.idx);
+        else if (nk == 2) ti_apply_fast<2, 8>(Ti, ld, tv, out, nT, ns, red, c.crow, c.idx);
+        else if (nk == 3) ti_apply_fast<3, 6>(Ti, ld, tv, out, nT, ns, red, c.crow, c.idx);
+        else ti_apply_fast<4, 4>(Ti, ld, tv, out, nT, ns, red, c.crow, c.idx);
     } else {
         // wide working sets (more than 256 slots; only after an ADMM round guessed many rows): two passes, u = Ti tv staged in LDS
         constexpr int MAXK = (max_active(NCH) + 63) / 64;
@@ -595,7 +605,7 @@ __device__ __forceinline__ int ti_append(Ctx<NCH>& c, int r, double tau, int cap
     } else {
         d2 = srr;
     }
-    if (t == 0) c.info->work[2] += 8.0 * ((double)nT * ns + 3.0 * ns);
+    if (t == 0) c.info->work[2] += 8.0 * (((ns <= 64 * TI_FAST_CHUNKS) ? 0.5 * (double)nT * (nT + 1) : (double)nT * ns) + 3.0 * ns);
     int snew = -block_max((double)(-freeSlot), c.lds) + 0.5;      // smallest free slot (exact in double), 2^30: none
     if (!(d2 > tau * srr) || !(d2 > 0.0)) return 0;
     if (snew >= ns) {
@@ -653,8 +663,15 @@ __device__ __forceinline__ void ti_delete(Ctx<NCH>& c, int p, int& nT, int& ns)
         __syncthreads();
     }
     for (int col = t; col < ns; col += WG) {
-        double carry = Ti[(size_t)i0 * ld + col];
-        for (int j = 1; j < m; j += 16) {
+        // column col is zero above row crow[col] (everywhere for a free slot): rotations of zeros are skipped, in whole blocks of 16 rows
+#ifdef LCQP_TI_FULL_ROWS
+        const int cr = i0;
+#else
+        const int cr = (col == p) ? i0 : ((idx[col] >= 0) ? crow[col] : (1 << 30));
+#endif
+        double carry = (cr <= i0) ? Ti[(size_t)i0 * ld + col] : 0.0;
+        const int jz = max(1, min(cr - i0, m));                 // rows i0 + 1 ... i0 + jz - 1 of this column are zero, and so is the carry
+        for (int j = 1 + 16 * ((jz - 1) / 16); j < m; j += 16) {
             double rv[16];
 #pragma unroll
             for (int q = 0; q < 16; q++) rv[q] = (j + q < m) ? Ti[(size_t)(i0 + j + q) * ld + col] : 0.0;
@@ -1079,7 +1096,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             const int r = idx[a];
             if (r >= 0) { yt[r] += dy[a]; ex[r] = (st[r] == ST_UPPER) ? u[r] : l[r]; }      // the rows of the factor now sit on their bounds (up to rounding)
         }
-        if (t == 0) c.info->work[1] += (double)na * nsl;
+        if (t == 0) c.info->work[1] += (nsl <= 64 * TI_FAST_CHUNKS) ? 0.5 * (double)na * (na + 1) : (double)na * nsl;      // entries of Ti read: its triangle (full rows beyond 256 slots)
         __syncthreads();
         c.cCorr++;
     }
