@@ -153,8 +153,8 @@ void* lcqp_hip_batch_stream(lcqp_hip_batch_t* b);
 /* algorithmic HBM bytes of the last run, from the work counters the kernels keep */
 double lcqp_hip_batch_algorithmic_bytes(lcqp_hip_batch_t* b);
 /* the work sums that enter it, summed over the batch (counted by the kernel): out[0] = rows of Et read by the corrections (twice the
- * rows of the factor for a full correction, once plus the rows that left for a predicted one), out[1] = sum of (rows x slots of the
- * inverse factor) over corrections, out[2] = bytes moved by the working-set updates (and the entries of M a predicted correction
+ * rows of the factor for a full correction, once plus the rows that left for a predicted one), out[1] = entries of the inverse factor read by
+ * the corrections (its triangle, n_T (n_T + 1) / 2 per pass; full rows beyond 256 slots), out[2] = bytes moved by the working-set updates (and the entries of M a predicted correction
  * reads), out[3] = number of working-set updates, out[4] = rows of E read by the residual sweeps (stage 1: unscreened inactive rows;
  * stage 2: active rows), out[5] = triangular solves with L1 (two per full correction, one per predicted correction) */
 int    lcqp_hip_batch_work_sums(lcqp_hip_batch_t* b, double out[6]);

@@ -410,7 +410,7 @@ def test_lcqp_full_batch_properties(hip, oracle):
     m = nC + 2 * nComp
     bs = 8.0 * n * (n + 2)
     tot = lambda k: float(sum(s[k] for s in st2))
-    # ws = (rows of Et read by the corrections, sum of nT * slots, bytes moved by working-set updates, number of updates, rows of E read by
+    # ws = (rows of Et read by the corrections, entries of the inverse factor read by the corrections, bytes moved by working-set updates, number of updates, rows of E read by
     #       the sweeps, triangular solves with L1)
     expect = (tot("reserved") * 8.0 * n * n + 8.0 * n * ws[4] + ws[5] * 0.5 * bs + 8.0 * ws[0] * n + 8.0 * (ws[1] + ws[0])
               + ws[2] + tot("admmIter") * (bs + 16.0 * m * n) + B * 16.0 * n * n + (tot("iterTotal") + B) * 12.0 * (2 * nComp))
