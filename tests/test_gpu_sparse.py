@@ -39,6 +39,29 @@ def test_sparse_hip_matches_oracle(hip, oracle, shape, B):
     sb.close()
 
 
+def test_sparse_with_perturbed_steps(hip, oracle):
+    """perturbStep on (the reference's default, src/LCQProblem.cpp:1353-1362): the LCQP level then takes C xk from the perturbed iterate
+    (one more pass over E), so that the perturbation reaches the penalty gradient; Q xk is carried along the steps.  The oracle
+    recomputes both from the perturbed iterate -- the two sides may differ in the last bits of an iterate, not in where they end."""
+    n, nC, nK, B = 512, 256, 64, 4
+    Qp, Ap = P.sparse_pattern(n, nC, nK)
+    inst = [P.sparse_instance(i, n, nC, nK) for i in range(B)]
+    sb = hip.SparseBatchLCQP(B, n, nC, nK, Qp, Ap, opt=hip.default_options(perturbStep=1, perturbSeed=7, printLevel=0))
+    assert sb.load(0, B, np.stack([d["Q"].data for d in inst]), np.stack([d["g"] for d in inst]), np.stack([d["E"].data for d in inst]),
+                   lbA=np.stack([d["lbA"] for d in inst]), ubA=np.stack([d["ubA"] for d in inst])) == 0
+    sb.run()
+    x, y, st = sb.solution()
+    opt = oracle.default_options(perturbStep=1, perturbSeed=7)
+    for b in range(B):
+        d = inst[b]
+        ro = oracle.sparse_lcqp_solve(n, nC, nK, d["Q"].tocsr(), d["g"], d["E"].tocsr(), lbA=d["lbA"], ubA=d["ubA"], opt=opt)
+        assert st[b]["returnValue"] == ro["ret"] == 0
+        assert np.abs(x[b] - ro["x"]).max() < 1e-7 and np.abs(y[b] - ro["y"]).max() < 1e-5
+        L = d["E"].tocsr()[nC:nC + nK] @ x[b]; R = d["E"].tocsr()[nC + nK:] @ x[b]
+        assert abs(L @ R) < 1e-10 and L.min() > -1e-9 and R.min() > -1e-9
+    sb.close()
+
+
 @pytest.mark.parametrize("lanes", [16, 32, 64])
 def test_sparse_lane_group_widths(hip, oracle, monkeypatch, lanes):
     """the engine gives every instance G lanes of a wavefront, G the smallest of 8, 16, 32, 64 above the half bandwidth (here 7 -> 8);
