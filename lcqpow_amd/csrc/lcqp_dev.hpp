@@ -15,14 +15,14 @@ namespace lcqp {
 enum { V_G, V_GPHI, V_GTIL, V_XK, V_PK, V_XNEW, V_GK, V_QX, V_CX, V_QP, V_CP, V_STATK, V_TMP,
        V_XQ, V_XA, V_XT, V_R1, V_C, V_DU, V_W, V_RHS, V_LB, V_UB, V_X0, V_R1S, V_GS, V_ATY, V_QXN, V_XS, V_XREF, V_NUM };   // V_QXN: Q x at the last verified QP solution; V_XS: x of the last residual sweep; V_XREF: anchor of the proximal term (the point the solve started from)
 // per-instance vectors of length mEcap (rows of E = [A; L; R; box rows])
-enum { M_L, M_U, M_RHOV, M_YQ, M_YA, M_ZA, M_YT, M_EX, M_COEF, M_EXS, M_DY, M_RN, M_MG, M_YLV, M_NUM };   // M_DY: change of ya in the last ADMM iteration; M_RN: |E_r|; M_MG: safe margins of the inactive rows (row screening); M_YLV: multipliers of the rows that left the working set in the current trial (zero otherwise)
-enum { I_ST, I_STT, I_DEP, I_PRIO, I_SLOT, I_LIST, I_LIST2, I_NUM };   // I_DEP: row is active but linearly dependent on the rows of the factor; I_PRIO: promotion stamp (0: none); I_SLOT: slot of the row in the inverse factor (-1: none); I_LIST, I_LIST2: scratch lists of rows / slots
+enum { M_L, M_U, M_RHOV, M_YQ, M_YA, M_ZA, M_YT, M_EX, M_COEF, M_EXS, M_DY, M_RN, M_MG, M_YLV, M_HOTV, M_NUM };   // M_DY: change of ya in the last ADMM iteration; M_RN: |E_r|; M_MG: safe margins of the inactive rows (row screening); M_YLV: multipliers of the rows that left the working set in the current trial (zero otherwise)
+enum { I_ST, I_STT, I_DEP, I_PRIO, I_SLOT, I_LIST, I_LIST2, I_HOTC, I_NUM };   // I_HOTC / M_HOTV: column and value of a row of E with a single non-zero (-1: any other row; wg_row_norms)   // I_DEP: row is active but linearly dependent on the rows of the factor; I_PRIO: promotion stamp (0: none); I_SLOT: slot of the row in the inverse factor (-1: none); I_LIST, I_LIST2: scratch lists of rows / slots
 enum { S_R2, S_DY, S_D0, S_SV, S_W, S_NUM };   // slot-space vectors (length capS): S_SV / S_W: column of S and inv(S) times it when a row is appended
 
 struct InstInfo {
     int mE, nfin, hasY0, setupFail, haveSolution, isSetup, nT, prioCtr;   // nT: rows of the inverse factor Ti (= rows of the working set it holds); prioCtr: promotion stamps in use (I_PRIO)
     int ndep, ns;                                                         // ndep: active rows flagged dependent (I_DEP); ns: slots of Ti in use (high-water mark, free slots inside count)
-    int cNnz, kReady, rnReady, pad4;                                                   // cNnz: non-zeros of C held in compressed rows (k_compress_C), -1: C is swept as a dense matrix; kReady: L_K exists (qp_build_K); rnReady: M_RN holds the row norms of E
+    int cNnz, kReady, rnReady, nHot;                                                   // cNnz: non-zeros of C held in compressed rows (k_compress_C), -1: C is swept as a dense matrix; kReady: L_K exists (qp_build_K); rnReady: M_RN holds the row norms of E (and I_HOTC / M_HOTV the rows with a single non-zero, nHot of them)
     double scale, sigma, spv, rhoAdmm, phiConst;
     double hist[64];     // the last nDynamicPenalty complementarity values (src/LCQProblem.cpp:1344-1375; the reference's default is 3)
     double work[6];   // exact work sums for the byte accounting: [0] rows of Et read by the corrections, [1] sum(nT*ns) over corrections (pass over Ti), [2] bytes of Ti and M moved by working-set updates and predicted corrections, [3] number of updates, [4] rows of E read by the residual sweeps (both stages), [5] triangular solves with L1
@@ -747,6 +747,8 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
     double* mg = LR ? c.lds.arena + LDS_ROWS_OFF + 2 * LDS_ROWS_MAX : c.M(M_MG);
     int* st = LR ? reinterpret_cast<int*>(c.lds.arena + LDS_ROWS_OFF + 3 * LDS_ROWS_MAX) : c.I(I_STT);
     double *ylv = c.M(M_YLV), *rn = c.M(M_RN);
+    int* hotc = c.I(I_HOTC);
+    const double* hotv = c.M(M_HOTV);
     const double *l = c.M(M_L), *u = c.M(M_U);
     int *dep = c.I(I_DEP), *prio = c.I(I_PRIO), *list = c.I(I_LIST), *rslot = c.I(I_SLOT);
     double *r2 = c.Sv(S_R2), *dy = c.Sv(S_DY);
@@ -789,8 +791,11 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                 // cold entry: the whole residual, every row of E, fresh margins.  (Whatever ran before -- ADMM, rho adaptation, a solve
                 // with other bounds -- may have left M_EX and the margins in any state.)
                 if (!uniform_i(c.info->rnReady)) {
-                    wg_row_norms<NCH>(c.E, mE, rn);
-                    if (t == 0) c.info->rnReady = 1;
+                    wg_row_norms<NCH>(c.E, mE, rn, hotc, c.M(M_HOTV));
+                    int nh = 0;
+                    for (int r = t; r < mE; r += WG) nh += (hotc[r] >= 0);
+                    nh = block_sum_i(nh, c.lds);
+                    if (t == 0) { c.info->rnReady = 1; c.info->nHot = nh; }
                 }
                 int cntA = 0;
                 wg_map<4>(mE, [&](int r) { return MapID{st[r], yt[r]}; },
@@ -820,10 +825,10 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
 #else
                 nread = wg_compact(mE, [&](int r) { return (st[r] == ST_INACT) ? !(mg[r] > 1e-10) : (depRows && dep[r] != 0); }, list, c.lds);
 #endif
-                wg_rows<NCH, true>(c.E, list, nread, x, ex, nullptr, c.lds, [](int, double) {});
+                wg_rows<NCH, true>(c.E, list, nread, x, ex, nullptr, c.lds, [](int, double) {}, hotc, hotv);
             } else {
                 nread = mE;
-                wg_rows<NCH>(c.E, nullptr, mE, x, ex, nullptr, c.lds, [](int, double) {});
+                wg_rows<NCH>(c.E, nullptr, mE, x, ex, nullptr, c.lds, [](int, double) {}, hotc, hotv);
             }
             // Entering rows are capped (oracle: qp_polish, same arithmetic): when more than max(n/8, 16) inactive rows are violated -- a cold
             // start, where every violated row would enter at once, overshoot and oscillate for eight to ten trials with a factor rebuild
@@ -855,10 +860,11 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                 }
             }
             // violated rows enter; fresh margins for the others; the two rules for rows flagged dependent
-            int chg = 0, cntLv2 = 0;
+            int chg = 0, cntLv2 = 0, nDense = 0;
             for (int a = t; a < nread; a += WG) {
                 const int r = LISTS ? list[a] : a;
                 const int s = st[r];
+                nDense += (hotc[r] < 0);
                 const double e = ex[r], ftol = o.feasTol * (1.0 + fabs(e));
                 if (s == ST_INACT) {
                     if (e < l[r] - ftol && l[r] - e >= vcut) { st[r] = ST_LOWER; chg |= 1; }
@@ -873,9 +879,11 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                     else if (viol) { prio[r] = prioCtr + 1; chg |= 2; }
                 }
             }
-            if (t == 0) c.info->work[4] += (double)nread;
             if (depRows) nlv += block_sum_i(cntLv2, c.lds);
-            const int chgBits = block_or_bits(chg, c.lds);
+            // one reduction for the two change flags and the number of rows that were really read (rows with one non-zero are made up)
+            const int packed = block_sum_i((chg & 1) | (((chg >> 1) & 1) << 10) | (nDense << 20), c.lds);
+            const int chgBits = ((packed & 1023) ? 1 : 0) | (((packed >> 10) & 1023) ? 2 : 0);
+            if (t == 0) c.info->work[4] += (double)(packed >> 20);
             if (ROBUST && (chgBits & 2)) { prioCtr++; if (t == 0) c.info->prioCtr = prioCtr; }
             changed |= (chgBits != 0);
             need_true = !changed;
@@ -889,13 +897,13 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             if (LISTS) {
                 nact = wg_compact(mE, [&](int r) { return cold || st[r] != ST_INACT; }, lact, c.lds);
                 // du: the residual of the QP as given (the next hot start and A'y need it without the proximal term); r1: with it
-                wg_rows<NCH, true>(c.E, lact, nact, x, ex, yt, c.lds, [&](int i, double s) { const double ro = -g[i] - qx[i] - s; du[i] = ro; r1[i] = ro - spv * (x[i] - xref[i]); });
+                wg_rows<NCH, true>(c.E, lact, nact, x, ex, yt, c.lds, [&](int i, double s) { const double ro = -g[i] - qx[i] - s; du[i] = ro; r1[i] = ro - spv * (x[i] - xref[i]); }, hotc, hotv);
             } else {
-                wg_rows<NCH>(c.E, nullptr, mE, x, ex, yt, c.lds, [&](int i, double s) { const double ro = -g[i] - qx[i] - s; du[i] = ro; r1[i] = ro - spv * (x[i] - xref[i]); });
+                wg_rows<NCH>(c.E, nullptr, mE, x, ex, yt, c.lds, [&](int i, double s) { const double ro = -g[i] - qx[i] - s; du[i] = ro; r1[i] = ro - spv * (x[i] - xref[i]); }, hotc, hotv);
             }
-            if (t == 0) c.info->work[4] += (double)nact;
             c.cSweeps++;
             if (cold) {
+                if (t == 0) c.info->work[4] += (double)(nact - uniform_i(c.info->nHot));
                 if (LISTS) {
                     wg_map<4>(mE, [&](int r) { return MapID3{st[r], ex[r], l[r], u[r]}; },
                               [&](int r, MapID3 v) {
@@ -906,16 +914,17 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                 }
             } else {
                 const double res_stat = wg_maxabs(r1, np, c.lds);
-                double res_eq = 0.0, bmax = 0.0;
+                double res_eq = 0.0, bmax = 0.0, nDense2 = 0.0;
                 for (int a = t; a < nact; a += WG) {
                     const int r = LISTS ? lact[a] : a;
                     const int s = st[r];
+                    nDense2 += (hotc[r] < 0) ? 1.0 : 0.0;
                     if (s == ST_INACT) continue;
                     const double bb = (s == ST_UPPER) ? u[r] : l[r];
                     res_eq = fmax(res_eq, fabs(bb - ex[r]));
                     bmax = fmax(bmax, fabs(bb));
                 }
-                res_eq = block_max(res_eq, c.lds);
+                { double re, nd; block_max_sum(res_eq, nDense2, re, nd, c.lds); res_eq = re; if (t == 0) c.info->work[4] += nd; }
                 bmax = block_max(bmax, c.lds);
                 // the proximal QP is solved: is it the QP as given (sigma_p |x - xref| below the tolerance too)?  Else (PSD Hessians far from
                 // xref) the next step of the proximal-point iteration is anchored here

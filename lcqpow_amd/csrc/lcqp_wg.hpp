@@ -84,6 +84,12 @@ __device__ __forceinline__ double wave_bcast(double v, int src)
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int wave_bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 
 // make a value the compiler cannot prove wave-uniform live in scalar registers
 __device__ __forceinline__ double uniform_d(double v)
@@ -330,9 +336,11 @@ __device__ __forceinline__ void wg_symv(const double* __restrict__ M0, const dou
     else wg_symv_t<NCH, false, false>(M0, nullptr, n, v0, nullptr, o00, nullptr, nullptr, nullptr, lds);
 }
 
-// Euclidean norms of the m rows of an m x np row-major matrix (one wave per row, four rows in flight).
+// Euclidean norms of the m rows of an m x np row-major matrix (one wave per row, four rows in flight).  hotc / hotv (optional): rows with a
+// single non-zero -- complementarity selectors, box rows, simple bounds written as constraints -- are noted with their column and value
+// (hotc[r] = -1 for all others), so that the sweeps can make such a row up instead of reading np doubles of it (wg_rows).
 template <int NCH>
-__device__ __forceinline__ void wg_row_norms(const double* __restrict__ Mx, int m, double* out)
+__device__ __forceinline__ void wg_row_norms(const double* __restrict__ Mx, int m, double* out, int* hotc = nullptr, double* hotv = nullptr)
 {
     constexpr int np = 128 * NCH;
     const int l = lane_id(), w = wave_id();
@@ -352,6 +360,17 @@ __device__ __forceinline__ void wg_row_norms(const double* __restrict__ Mx, int 
             s2 = wave_sum(s2);
             const int r = r0 + NWAVE * d;
             if (l == 0 && r < m) out[r] = sqrt(s2);
+            if (hotc && r < m) {
+                int cnt = 0, col = -1; double val = 0.0;
+#pragma unroll
+                for (int k = 0; k < NCH; k++) {
+                    if (mm[d][k].x != 0.0) { cnt++; col = 128 * k + 2 * l; val = mm[d][k].x; }
+                    if (mm[d][k].y != 0.0) { cnt++; col = 128 * k + 2 * l + 1; val = mm[d][k].y; }
+                }
+                const int tot = wave_sum_i(cnt);
+                if (tot == 1) { if (cnt == 1) { hotc[r] = col; hotv[r] = val; } }
+                else if (l == 0) hotc[r] = -1;
+            }
         }
     }
     __syncthreads();
@@ -372,8 +391,11 @@ __device__ __forceinline__ void wg_row_norms(const double* __restrict__ Mx, int 
 template <int NCH, bool BYROW = false, bool KEEP = false, class Post>
 __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int* __restrict__ idx, int m,
                         const double* __restrict__ x, double* dots,
-                        const double* __restrict__ coef, Lds lds, Post post)
+                        const double* __restrict__ coef, Lds lds, Post post,
+                        const int* __restrict__ hotc = nullptr, const double* __restrict__ hotv = nullptr)
 {
+    // hotc / hotv (wg_row_norms): a row with a single non-zero is made up from its column and value instead of being read -- the same
+    // registers, the same sums, no bytes (bit-identical results; a typical working set is half complementarity selectors and box rows)
     constexpr int np = 128 * NCH;
     static_assert(5 * np <= arena_doubles(NCH), "wg_rows: four partial copies and the staged vector must fit the LDS arena");
     double* sx = lds.arena + 4 * np;
@@ -397,6 +419,8 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
         const bool mine = (l < 16) && (mya < m);
         int myrow = mine ? (idx ? idx[mya] : mya) : -1;
         double mycoef = (mine && coef && (!BYROW || myrow >= 0)) ? coef[BYROW ? myrow : mya] : 0.0;
+        const int myhc = (hotc && myrow >= 0) ? hotc[myrow] : -1;
+        const double myhv = (myhc >= 0) ? hotv[myrow] : 0.0;
         double mydot = 0.0;
         const int cnt = min(16, m - a0);
         for (int j0 = 0; j0 < cnt; j0 += D) {
@@ -408,7 +432,15 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
                 // lanes >= 16 hold row -1: entries beyond the chunk and padded list entries load nothing and contribute nothing
                 rows[d] = wave_bcast_i(myrow, (j0 + d) & 63);
                 cfs[d] = wave_bcast(mycoef, (j0 + d) & 63);
-                if (rows[d] >= 0) {
+                const int hc = hotc ? wave_bcast_i(myhc, (j0 + d) & 63) : -1;
+                if (hc >= 0) {
+                    const double hv = wave_bcast(myhv, (j0 + d) & 63);
+#pragma unroll
+                    for (int k = 0; k < NCH; k++) {
+                        mm[d][k] = double2{0.0, 0.0};
+                        if ((hc >> 7) == k && ((hc & 127) >> 1) == l) { if (hc & 1) mm[d][k].y = hv; else mm[d][k].x = hv; }
+                    }
+                } else if (rows[d] >= 0) {
                     const double2* rp = reinterpret_cast<const double2*>(Mx + (size_t)rows[d] * np) + l;
 #pragma unroll
                     for (int k = 0; k < NCH; k++) mm[d][k] = KEEP ? rp[64 * k] : ld_stream(rp + 64 * k);
