@@ -231,6 +231,10 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, B, shape),
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
+    tr = out["roofline"]["traffic"]
+    if tr is not None:
+        # the measured HBM bytes over the same duration: how busy the memory system is, whatever share of the bytes is algorithmic
+        out["roofline"]["traffic_frac"] = tr / kernel_s / 1e9 / HBM_PEAK_GBS
     main_proc = (rank == 0)
 
     if main_proc and world == 1 and not sparse and not args.no_pipelined:
