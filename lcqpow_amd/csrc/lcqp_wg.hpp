@@ -271,6 +271,7 @@ __device__ __forceinline__ void wg_combine(const double (&acc)[2 * NCH], Lds lds
 #ifndef LCQP_DEPTH
 #define LCQP_DEPTH 4
 #endif
+static_assert(LCQP_DEPTH == 1 || LCQP_DEPTH == 2 || LCQP_DEPTH == 4 || LCQP_DEPTH == 8, "LCQP_DEPTH: the sweeps read NWAVE * LCQP_DEPTH rows per step and rely on that dividing the padded sizes (a build with 3, 5 or 6 reads past the matrix)");
 template <int NCH, bool TWO_M, bool TWO_V>
 __device__ __forceinline__ void wg_symv_t(const double* __restrict__ M0, const double* __restrict__ M1, int n,
                         const double* __restrict__ v0, const double* __restrict__ v1,
