@@ -881,9 +881,11 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             }
             if (depRows) nlv += block_sum_i(cntLv2, c.lds);
             // one reduction for the two change flags and the number of rows that were really read (rows with one non-zero are made up)
-            const int packed = block_sum_i((chg & 1) | (((chg >> 1) & 1) << 10) | (nDense << 20), c.lds);
-            const int chgBits = ((packed & 1023) ? 1 : 0) | (((packed >> 10) & 1023) ? 2 : 0);
-            if (t == 0) c.info->work[4] += (double)(packed >> 20);
+            // (twelve bits for the count: with more than 4000 rows it is left out of the sum and every row read counts as dense)
+            const bool countDense = mE <= 4000;
+            const unsigned packed = (unsigned)block_sum_i((chg & 1) | (((chg >> 1) & 1) << 10) | ((countDense ? nDense : 0) << 20), c.lds);
+            const int chgBits = ((packed & 1023u) ? 1 : 0) | (((packed >> 10) & 1023u) ? 2 : 0);
+            if (t == 0) c.info->work[4] += countDense ? (double)(packed >> 20) : (double)nread;
             if (ROBUST && (chgBits & 2)) { prioCtr++; if (t == 0) c.info->prioCtr = prioCtr; }
             changed |= (chgBits != 0);
             need_true = !changed;
