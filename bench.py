@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--nC", type=int, default=None)
     ap.add_argument("--nComp", type=int, default=None)
-    ap.add_argument("--cpu-sample", type=int, default=64, help="instances of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="CPU baseline: 8 x instances per worker of the steady-state run (64 = 8 per physical core; 0 = skip)")
     ap.add_argument("--no-backsolve", action="store_true", help="skip the standalone back-solve kernel measurement")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-batches-in-flight measurement")
     ap.add_argument("--no-resident", action="store_true", help="skip the 8192-resident-instances measurement")
@@ -211,7 +211,9 @@ def main():
         n_corr = max(1, sum(s["corrections"] for s in st)); n_fact = max(1, sum(s["factorizations"] for s in st))
         cfg_extra = {"mean_backsolve_pairs": mean("corrections"), "mean_factor_updates": mean("factorizations"),
                      "mean_active_rows_per_backsolve": float(ws[0] / n_corr), "mean_factor_update_kbytes": float(ws[2] / n_fact / 1e3),
-                     "mean_E_rows_read_per_sweep": float(ws[4] / max(1.0, sum(s_["reserved"] for s_ in st)))}
+                     "mean_E_rows_read_per_sweep": float(ws[4] / max(1.0, sum(s_["reserved"] for s_ in st))),
+                     "mean_triangular_solves": float(ws[5] / B), "mean_Et_rows_read": float(ws[0] / B), "mean_dense_E_rows_read": float(ws[4] / B),
+                     "mean_T_entries_read": float(ws[1] / B), "mean_factor_update_bytes": float(ws[2] / B)}
         wl = (f"synthetic dense batch={B}/GPU n={n} nC={nC} nComp={nComp} (BASELINE configs[2]; SplitMix64 seed0=0x4C43515000000001, "
               f"perturbStep=0, printLevel=NONE)")
         metric = ("LCQPs/sec (batched dense n=256,nC=512,nComp=64)" if shape == (256, 512, 64)
@@ -341,26 +343,36 @@ def main():
             t1 = time.perf_counter(); work(0, 2); single = 2 / (time.perf_counter() - t1)
             ok = sum(1 for r_ in res if r_ is not None and r_["ret"] == 0)
             dx = float(max(np.abs(res[i]["x"] - x[i]).max() for i in range(min(cnt, B))))
-            out["cpu_baseline"] = {"value": cnt / dtc, "unit": "LCQPs/s", "cores": nth, "kind": "port",
+            out["cpu_baseline"] = {"value": cnt / dtc, "unit": "LCQPs/s", "cores": len(O.host_cpu_topology()[0]), "threads": nth, "kind": "port",
                                    "sample": f"instances 0..{cnt - 1} of the same sparse workload, CPU oracle (oracle/lcqp_oracle_sparse.c, the "
                                              f"same ADMM-KKT + polish algorithm with band LDL' in scalar C; the reference's OSQP path cannot be "
                                              f"built: external/osqp is empty), one LCQP per thread, {ok}/{cnt} solved in {dtc:.2f} s",
                                    "single_core_value": single, "max_abs_dx_vs_gpu": dx}
         else:
-            cnt = max(args.cpu_sample, threads)      # at least one LCQP per host core
-            tc = time.perf_counter()
-            ok, xo, yo, so = O.synth_batch_solve(0, cnt, n, nC, nComp, opt=oopt, threads=threads)
-            dtc = time.perf_counter() - tc
-            t1 = time.perf_counter()
-            O.synth_batch_solve(0, 4, n, nC, nComp, opt=oopt, threads=1, want_xy=False)     # one core, no contention
-            single = 4 / (time.perf_counter() - t1)
-            dx = float(np.abs(xo[: min(cnt, B)] - x[: min(cnt, B)]).max())
-            out["cpu_baseline"] = {"value": cnt / dtc, "unit": "LCQPs/s", "cores": threads, "kind": "port",
-                                   "sample": f"instances 0..{cnt - 1} of the same synthetic workload, CPU oracle "
-                                             f"(oracle/lcqp_oracle.c, same algorithm in scalar C; the reference's qpOASES "
-                                             f"path cannot be built: external/qpOASES is empty), one LCQP per thread, "
-                                             f"{ok}/{cnt} solved in {dtc:.2f} s",
-                                   "single_core_value": single, "max_abs_dx_vs_gpu": dx}
+            # steady state (oracle/lcqp_oracle.c::orc_synth_bench): pinned workers, `per` instances each, generated and one warm-up solve
+            # done before the clock starts, the allocator keeps the workers' buffers; one run with a worker per physical core, one with a
+            # worker per hardware thread; the reference itself is single-threaded (one LCQProblem = one thread), so "all cores" means
+            # independent instances side by side, as on the GPU
+            phys, allc = O.host_cpu_topology()
+            per = max(1, args.cpu_sample // 8)                       # default 8 instances per worker
+            okc, secc, xo, yo, so = O.synth_bench(0, len(phys), per, cpus=phys, n=n, nC=nC, nComp=nComp, opt=oopt)
+            per_t = max(1, per // 2) if len(allc) > len(phys) else per
+            okt, sect, _, _, _ = O.synth_bench(0, len(allc), per_t, cpus=allc, n=n, nC=nC, nComp=nComp, opt=oopt, want_xy=False)
+            ok1, sec1, _, _, _ = O.synth_bench(0, 1, 8, cpus=phys[:1], n=n, nC=nC, nComp=nComp, opt=oopt, want_xy=False)
+            v_cores, v_threads, single = len(phys) * per / secc, len(allc) * per_t / sect, 8 / sec1
+            ncmp = min(len(phys) * per, B)
+            dx = float(np.abs(xo[:ncmp] - x[:ncmp]).max())
+            out["cpu_baseline"] = {"value": max(v_cores, v_threads), "unit": "LCQPs/s", "cores": len(phys), "threads": len(allc), "kind": "port",
+                                   "value_one_worker_per_core": v_cores, "value_one_worker_per_thread": v_threads,
+                                   "single_core_value": single, "parallel_efficiency_vs_single_core": v_cores / (single * len(phys)),
+                                   "gpu_over_cpu": value / max(v_cores, v_threads),
+                                   "sample": f"steady state: CPU oracle (oracle/lcqp_oracle.c, same algorithm in scalar C; the reference's qpOASES path "
+                                             f"cannot be built: external/qpOASES is empty) on the same synthetic workload; workers pinned, instances "
+                                             f"generated and one warm-up solve per worker before the clock, buffers reused; "
+                                             f"{len(phys)} workers (one per physical core) x {per} instances: {okc}/{len(phys) * per} solved in {secc:.2f} s; "
+                                             f"{len(allc)} workers (one per hardware thread) x {per_t}: {okt}/{len(allc) * per_t} in {sect:.2f} s; "
+                                             f"one worker alone x 8: {sec1:.2f} s",
+                                   "max_abs_dx_vs_gpu": dx}
     for b_ in bts:
         b_.close()
     if dist is not None:

@@ -137,6 +137,7 @@ __device__ __forceinline__ void qp_admm(Ctx<NCH>& c, const double* g, int n_it)
     const double *l = c.M(M_L), *u = c.M(M_U);
     PROF(c, P_MISC);
     for (int it = 0; it < n_it; it++) {
+        const int t = tid_here();      // per iteration (nothing derived from the thread number is carried around a loop: it would be hoisted and spilled)
         for (int r = t; r < mE; r += WG) coef[r] = rhov[r] * za[r] - ya[r];
         __syncthreads();
         // rhs = sigma*xa - g + E'(rho.z - y)
@@ -725,7 +726,7 @@ __device__ __forceinline__ void ti_delete(Ctx<NCH>& c, int p, int& nT, int& ns)
 // r1 = r1_last + (g_last - g) and E x = ex_last hold exactly for an unchanged (x, y).
 // ---------------------------------------------------------------------------------------------
 template <int NCH, bool ROBUST, bool LR>
-__device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse, double gs)
+__device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse, double ytol, double rtolG)
 {
     constexpr int np = 128 * NCH;
     // every size sweeps through row lists (round 2 kept the plain sweep at np = 1024 because the list sweep returned wrong residuals in that
@@ -753,7 +754,8 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
     int *dep = c.I(I_DEP), *prio = c.I(I_PRIO), *list = c.I(I_LIST), *rslot = c.I(I_SLOT);
     double *r2 = c.Sv(S_R2), *dy = c.Sv(S_DY);
     int* idx = c.idx;
-    const double ytol = o.feasTol * gs;      // gs = 1 + |g|_inf
+    // ytol = feasTol (1 + |g|_inf), rtolG = resTol (1 + |g|_inf): formed by the caller, once per QP (long-lived uniform doubles are held in scalar registers: uniform_d)
+    const double shrinkF = uniform_d(1.0 + 1e-6 + o.feasTol);
     int na = 0, nsl = 0, fact_valid = 0;
     int prioCtr = ROBUST ? uniform_i(c.info->prioCtr) : 0;
     const int capNa = min(min(min(max(2 * c.n, 64), mE), capS), max_active(NCH));   // room for the degenerate vertices of small problems
@@ -761,21 +763,22 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
     // |x - x_last sweep| for the margins; x becomes the x of the last sweep.  Returns the shrink of the margins per unit row norm.
     auto sweep_distance = [&]() -> double {
         double d2 = 0.0, x2 = 0.0;
-        for (int i = t; i < c.n; i += WG) { const double xv = x[i], dd = xv - xs[i]; d2 += dd * dd; x2 += xv * xv; xs[i] = xv; }     // the n variables, not the padding
+        for (int i = tid_here(); i < c.n; i += WG) { const double xv = x[i], dd = xv - xs[i]; d2 += dd * dd; x2 += xv * xv; xs[i] = xv; }     // the n variables, not the padding
         // |E_r (x - x_last)| <= |E_r| |x - x_last|; the factor covers the tolerance that moves with E_r x (feasTol (1 + |E_r x|)),
         // the second term the rounding of a computed E_r x (~ eps |E_r| |x|)
-        return sqrt(block_sum(d2, c.lds)) * (1.0 + 1e-6 + o.feasTol) + 1e-13 * sqrt(block_sum(x2, c.lds));
+        return uniform_d(sqrt(block_sum(d2, c.lds)) * shrinkF + 1e-13 * sqrt(block_sum(x2, c.lds)));
     };
 
     // a polish that gives up leaves no multipliers of leaving rows behind (M_YLV is zero between trials)
     auto give_up = [&]() -> int {
-        for (int r = t; r < mE; r += WG) ylv[r] = 0.0;
+        for (int r = tid_here(); r < mE; r += WG) ylv[r] = 0.0;
         __syncthreads();
         return 0;
     };
 
     int capOn = 0;      // the cap on entering rows applies to polishes that start from an empty working set (oracle: cap_on)
     for (int trial = 0; trial < o.maxTrials; trial++) {
+        const int t = tid_here();      // per trial: nothing derived from the thread number is carried around the loop (it would be hoisted and spilled)
         c.cTrials++;
         int changed = 0, nlv = 0, have_true = 0, need_true = 0;
         const bool cold = (trial == 0 && !reuse);
@@ -856,7 +859,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                         for (int a = t; a < nread; a += WG) cnt += (violation(LISTS ? list[a] : a) >= mid);
                         if (block_sum_i(cnt, c.lds) > cap) lo = mid; else hi = mid;
                     }
-                    vcut = lo;      // the lower end: a few more than cap rows (with the upper end a tie of many equally violated rows would never enter)
+                    vcut = uniform_d(lo);      // the lower end: a few more than cap rows (with the upper end a tie of many equally violated rows would never enter)
                 }
             }
             // violated rows enter; fresh margins for the others; the two rules for rows flagged dependent
@@ -930,11 +933,11 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                 bmax = block_max(bmax, c.lds);
                 // the proximal QP is solved: is it the QP as given (sigma_p |x - xref| below the tolerance too)?  Else (PSD Hessians far from
                 // xref) the next step of the proximal-point iteration is anchored here
-                if (res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax) && !(wg_maxabs(du, np, c.lds) <= o.resTol * gs)) {
+                if (res_stat <= rtolG && res_eq <= o.resTol * (1.0 + bmax) && !(wg_maxabs(du, np, c.lds) <= rtolG)) {
                     for (int i = t; i < np; i += WG) { xref[i] = x[i]; r1[i] = du[i]; }
                     __syncthreads();
                 } else
-                if (res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) {
+                if (res_stat <= rtolG && res_eq <= o.resTol * (1.0 + bmax)) {
                     double *r1s = c.V(V_R1S), *gs0 = c.V(V_GS), *exs = c.M(M_EXS), *aty = c.V(V_ATY);
                     // A'y_A + y_box = -E'y = g + Qx + r1 at the verified point (all three are direct sums of this trial)
                     double* qxn = c.V(V_QXN);
@@ -1130,7 +1133,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
     const int t = tid_here(), mE = c.mE, n = c.n, nC = c.mA;
     const int trials0 = c.cTrials, admm0 = c.cAdmm;
     *iterations = 0;
-    if (c.info->setupFail) return 3;
+    if (uniform_i(c.info->setupFail)) return 3;
     double *xq = c.V(V_XQ), *xa = c.V(V_XA), *xt = c.V(V_XT);
     double *yq = c.M(M_YQ), *ya = c.M(M_YA), *za = c.M(M_ZA), *ex = c.M(M_EX);      // (M_EX here: scratch of the ADMM start)
     double* yt = LR ? c.lds.arena + LDS_ROWS_OFF : c.M(M_YT);                               // working multipliers / working set of the polish
@@ -1143,7 +1146,8 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         if (block_or(bad, c.lds)) return 2;
     }
     // the tolerances scale with 1 + |g|_inf: handed over by a caller that has just formed g, else one pass
-    const double gsc = 1.0 + (gmaxHint >= 0.0 ? gmaxHint : wg_maxabs(g, c.n, c.lds));
+    const double gsc = uniform_d(1.0 + (gmaxHint >= 0.0 ? gmaxHint : wg_maxabs(g, c.n, c.lds)));
+    const double ytolQ = uniform_d(o.feasTol * gsc), rtolQ = uniform_d(o.resTol * gsc);
     if (ROBUST && uniform_i(c.info->prioCtr) != 0) {     // promotions of dependent rows last for one solve
         int* prio = c.I(I_PRIO);
         for (int r = t; r < mE; r += WG) prio[r] = 0;
@@ -1165,9 +1169,10 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
     wg_map<4>(mE, [&](int r) { return yq[r]; }, [&](int r, double v) { ya[r] = v; });
     __syncthreads();
     int n_admm = initial ? o.admmFirst : o.admmHot;
-    const int use_stored = (!initial && c.info->haveSolution && n_admm == 0);
+    const int use_stored = (!initial && uniform_i(c.info->haveSolution) && n_admm == 0);
     int solved = 0, admm_ready = 0, certificate = 0;   // za = clip(E xa) is only needed once ADMM runs
     for (int round = 0; round < o.maxRounds && !solved; round++) {
+        const int t = tid_here();      // per round (see qp_admm)
         if (!admm_ready && (n_admm > 0 || !(round == 0 && use_stored))) {
             wg_rows<NCH>(c.E, nullptr, mE, xa, ex, nullptr, c.lds, [](int, double) {});
             for (int r = t; r < mE; r += WG) {
@@ -1198,7 +1203,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         }
         for (int i = t; i < np; i += WG) xt[i] = xa[i];
         __syncthreads();
-        if (qp_polish<NCH, ROBUST, LR>(c, g, round == 0 && use_stored, gsc)) { solved = 1; break; }
+        if (qp_polish<NCH, ROBUST, LR>(c, g, round == 0 && use_stored, ytolQ, rtolQ)) { solved = 1; break; }
         if (ADAPT && round >= 1 && n_admm > 0 && qp_adapt_rho<NCH>(c, g) < 0) return 3;      // no usable ADMM factor left
         if (round >= 2) {    // at least 20 ADMM iterations behind us: is the QP infeasible or unbounded?
             certificate = qp_certificate<NCH>(c, g);
@@ -1208,11 +1213,11 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         if (n_admm < 10) n_admm = 10;
         if (n_admm > 400) n_admm = 400;
     }
-    *iterations = (c.cTrials - trials0) + (c.cAdmm - admm0);
+    *iterations = uniform_i((c.cTrials - trials0) + (c.cAdmm - admm0));
     if (!solved) return certificate ? certificate : 1;
-    for (int i = t; i < np; i += WG) xq[i] = xt[i];
+    for (int i = tid_here(); i < np; i += WG) xq[i] = xt[i];
     wg_map<4>(mE, [&](int r) { return MapID{stt[r], yt[r]}; }, [&](int r, MapID v) { yq[r] = v.a; st[r] = v.s; });
-    if (t == 0) c.info->haveSolution = 1;
+    if (tid_here() == 0) c.info->haveSolution = 1;
     __syncthreads();
     return 0;
 }
@@ -1252,7 +1257,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
     st.admmIter = st.trials = st.factorizations = st.corrections = st.qpSolves = st.reserved = 0;
     int rc = 0, qpIter = 0, histLen = 0, algoStat = 0, totalIter = 0;
     double alphak = 1.0, rho = o.initialPenaltyParameter;                     // :999-1000
-    const double phiConst = c.info->phiConst;
+    const double phiConst = uniform_d(c.info->phiConst);
     uint64_t perturbCounter = 0;
     double* hist = c.info->hist;
     if (t == 0) {
@@ -1266,14 +1271,15 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
 
     auto updatePenalty = [&]() {      // :1199-1214 (Qk = Q + rho C is never materialised: Qk v = Qv + rho Cv; g_tilde follows in the fused pass)
         if (o.nDynamicPenalty > 0) histLen = 0;
-        rho *= o.penaltyUpdateFactor;
+        rho = uniform_d(rho * o.penaltyUpdateFactor);      // (uniform scalars of the homotopy live in scalar registers)
         st.rhoOpt = rho;
     };
     double gmax = -1.0;      // max |gk| over the n variables, handed to the subsolver (it scales its tolerances with 1 + |g|_inf); < 0: not known
     auto solveQP = [&](int initial) -> int {   // :1115-1148 (getSolution, yk_A and pk = xnew - xk follow in the fused pass / at the exit)
         const double* y0 = (initial && c.info->hasY0) ? db.y0 + (size_t)c.b * db.nd : nullptr;
         PROF(c, P_LCQP);
-        const int ef = qp_solve<NCH, ROBUST, true, LR>(c, initial, gk, y0, &qpIter, gmax, /*checkBounds=*/initial);
+        const int ef = uniform_i(qp_solve<NCH, ROBUST, true, LR>(c, initial, gk, y0, &qpIter, gmax, /*checkBounds=*/initial));
+        qpIter = uniform_i(qpIter);
         PROF(c, P_MISC);
         st.subproblemIter += qpIter;
         st.qpSolverExitFlag = ef;
@@ -1304,6 +1310,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
         double* sP = c.lds.arena;                     // pk for the gather through the rows of C
         for (;;) {
             rc = solveQP(initial);
+            const int t = tid_here();      // per iterate (see qp_polish)
             if (rc != 0) break;
             if (initial) st.rhoOpt = rho;   // :473
             const int cnz = uniform_i(c.info->cNnz);
@@ -1325,9 +1332,9 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
                 vp[e] = xn - vx[e];                             // pk = xnew - xk :1145
                 if (!initial && o.perturbStep && i < n) {
                     // perturbStep :1353-1362 (seeded SplitMix64 instead of time-seeded rand()); pk is the unperturbed difference
-                    uint64_t z = o.perturbSeed + (perturbCounter + (uint64_t)i + 1ULL) * 0x9E3779B97F4A7C15ULL;
-                    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-                    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+                    uint64_t z = o.perturbSeed + (perturbCounter + (uint64_t)i + 1ULL) * opaque_u64(0x9E3779B97F4A7C15ULL);
+                    z = (z ^ (z >> 30)) * opaque_u64(0xBF58476D1CE4E5B9ULL);
+                    z = (z ^ (z >> 27)) * opaque_u64(0x94D049BB133111EBULL);
                     z = z ^ (z >> 31);
                     vx[e] += ((int)(z % 3ULL) - 1) * 2.221e-16;
                 }
@@ -1364,7 +1371,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
                 double qk, lk;
                 block_sum2(sq, sl, qk, lk, c.lds);
                 alphak = 1.0;
-                if (qk > 0 && lk < 0) alphak = fmin(-lk / qk, 1.0);
+                if (qk > 0 && lk < 0) alphak = uniform_d(fmin(-lk / qk, 1.0));
             }
             initial = 0;
             // updateStep :1240-1243, updateStationarity :1246-1272 (statk = Qk xk + g_tilde - A' yk_A - yk_box), getPhi :1172-1185
@@ -1382,7 +1389,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
             }
             double statInf, phiNow;
             block_max_sum(smax, sphi, statInf, phiNow, c.lds);
-            phiNow += phiConst;
+            phiNow = uniform_d(phiNow + phiConst);
             if (db.traceCap > 0 && totalIter < db.traceCap) {   // storeSteps :488-490
                 // getObj :1161-1169, getMerit :1188-1196 and the step size of updateTrackingVectors (src/OutputStatistics.cpp:131-164)
                 double so = 0.0, sm = 0.0;
@@ -1422,7 +1429,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
                         __syncthreads();
                     } else {
                         leyffer = true;
-                        for (int i = 0; i < nd; i++) if (cur < o.etaDynamicPenalty * hist[i]) { leyffer = false; break; }
+                        for (int i = 0; i < nd; i++) if (cur < o.etaDynamicPenalty * uniform_d(hist[i])) { leyffer = false; break; }
                         __syncthreads();
                         if (t == 0) { for (int i = 0; i + 1 < nd; i++) hist[i] = hist[i + 1]; hist[nd - 1] = cur; }
                         __syncthreads();
@@ -1459,6 +1466,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
         }
         // getSolution (:1138-1142): the duals of the last QP that was solved, whatever the exit
         if (uniform_i(c.info->haveSolution)) qp_export<NCH>(c, xnew, np, yk);
+        const int t = tid_here();
         if (algoStat == -1) {
             // transformDuals :1381-1409 (rows of L, R are rows nC.., nC+nComp.. of E)
             double* lx = c.M(M_COEF);      // scratch (M_EX belongs to the subsolver's hot start)
@@ -1487,15 +1495,16 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
             __syncthreads();
         }
     }
+    const int tx = tid_here();
     st.status = algoStat;
     st.returnValue = rc;
     st.admmIter = c.cAdmm; st.trials = c.cTrials; st.factorizations = c.cFact; st.corrections = c.cCorr; st.reserved = c.cSweeps;
-    for (int i = t; i < n; i += WG) db.xout[(size_t)c.b * n + i] = xk[i];
-    for (int i = t; i < db.nd; i += WG) db.yout[(size_t)c.b * db.nd + i] = yk[i];
-    if (t == 0) db.stats[c.b] = st;
+    for (int i = tx; i < n; i += WG) db.xout[(size_t)c.b * n + i] = xk[i];
+    for (int i = tx; i < db.nd; i += WG) db.yout[(size_t)c.b * db.nd + i] = yk[i];
+    if (tx == 0) db.stats[c.b] = st;
     PROF(c, P_LCQP);
 #ifdef LCQP_PROFILE
-    if (t == 0) for (int k = 0; k < 16; k++) db.prof[(size_t)c.b * 16 + k] = c.prof[k];
+    if (tx == 0) for (int k = 0; k < 16; k++) db.prof[(size_t)c.b * 16 + k] = c.prof[k];
 #endif
     __syncthreads();
 }

@@ -99,6 +99,8 @@ __device__ __forceinline__ double uniform_d(double v)
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a 64-bit constant the compiler materialises where it is used (scalar registers) instead of hoisting it into a vector register pair
+__device__ __forceinline__ uint64_t opaque_u64(uint64_t v) { asm volatile("" : "+s"(v)); return v; }
 
 // Element-wise loop over n entries by the workgroup: all the loads of a tile of U*WG entries (load(i) returns them by value) are
 // issued before the first store of the tile (store(i, v)).  Written as load - store - load ... the compiler has to keep the order
@@ -662,14 +664,15 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
     const int t = tid_here();
     double* tile = lds.arena;
     double* dl = lds.arena + 64 * TILE_LD;
-    double minpiv = INFINITY;
-    int fail = 0;
+    // the smallest pivot and the failure flag are kept in LDS (dl[8], dl[9]; thread 0 writes them), not in registers around the loops
+    if (t == 0) { dl[8] = INFINITY; dl[9] = 0.0; }
     const int nn = 64 * nblk;
     if (tau > 0.0) {
         for (int i = t; i < nn; i += WG) d0[i] = F[(size_t)i * ld + i];
         __syncthreads();
     }
     for (int J = 0; J < nblk; J++) {
+        const int t = tid_here();      // per block column: nothing derived from the thread number is carried around the loop
         const int o = 64 * J;
         double* dscr = dscr0 + (size_t)J * dscrStride;
         for (int e = t; e < 64 * 64; e += WG) {
@@ -693,6 +696,8 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
             if (t < 64) {
                 __builtin_amdgcn_s_setprio(3);   // the only sequential stretch: let it win issue slots from streaming waves
                 const int l = t;
+                double minpiv = INFINITY;
+                int fail = 0;
                 double a[16], dcol[16];
                 double d0v = (tau > 0.0 && l < 16) ? d0[o + c0 + l] : 0.0;
 #pragma unroll
@@ -727,12 +732,10 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
                     for (int i = 0; i < 16; i++)
                         if (i >= l) tile[(c0 + i) * TILE_LD + c0 + l] = dcol[i];   // Dd[i][l]
                 }
-                if (l == 0) { dl[jb] = minpiv; dl[4 + jb] = (double)fail; }
+                if (l == 0) { dl[8] = fmin(dl[8], minpiv); if (fail) dl[9] = 1.0; }
                 __builtin_amdgcn_s_setprio(0);
             }
             __syncthreads();
-            minpiv = fmin(minpiv, dl[jb]);
-            if (dl[4 + jb] != 0.0) fail = 1;
             const int nrem = 16 * nsub - (c0 + 16);     // (non-padded) rows below the diagonal sub-block
             if (nrem > 0) {
                 // (2) panel: outputs (r, j), r in [c0+16, 64), j in [0,16)
@@ -830,9 +833,11 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
                 __syncthreads();
             }
     }
-    if (info_fail && fail) *info_fail = 1;   // benign same-value race
     __syncthreads();
-    return minpiv;
+    const double minpiv = dl[8];
+    if (info_fail && dl[9] != 0.0) *info_fail = 1;   // benign same-value race
+    __syncthreads();
+    return uniform_d(minpiv);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -4,7 +4,7 @@
 cd "$(dirname "$0")"
 NCH=${1:-2}; shift
 for f in "lcqp_nch.hip -DLCQP_TU_NCH=$NCH" "lcqp_sparse.hip"; do
-hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -c -o /tmp/resusage_$$.o $f -Rpass-analysis=kernel-resource-usage "$@" 2>&1 | python3 -c "
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -mllvm -disable-machine-licm -c -o /tmp/resusage_$$.o $f -Rpass-analysis=kernel-resource-usage "$@" 2>&1 | python3 -c "
 import sys,re,subprocess
 cur=None;rows={}
 for line in sys.stdin:

@@ -2,6 +2,7 @@
  * lcqp_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See lcqp_oracle.h.
  * Every function cites the reference file:line (under /root/reference) it restates.
  */
+#define _GNU_SOURCE      /* pthread_setaffinity_np, CPU_SET (orc_synth_bench) */
 #include "lcqp_oracle.h"
 #include "../include/lcqp_synth.h"
 
@@ -1497,6 +1498,82 @@ int orc_synth_batch_solve(uint64_t seed0, int first, int count, int n, int nC, i
     free(th);
     pthread_mutex_destroy(&c.mu);
     return c.ok;
+}
+
+/* Steady-state CPU baseline (bench.py's cpu_baseline leg; what the reference's own timer brackets is load + solve,
+ * interfaces/matlab/LCQPow.cpp:882,915-916).  `threads` workers, worker t pinned to cpus[t] (cpus may be NULL: no pinning), each with
+ * its own `perThread` instances first + t*perThread ... generated BEFORE the clock starts; the allocator is told to keep freed blocks
+ * (no mmap / munmap per solve) and every worker runs one untimed warm-up solve, so that the timed solves reuse the worker's buffers
+ * instead of faulting fresh pages in.  All workers start the timed part together (barrier); secondsOut = start to the last
+ * worker's finish.  xOut / yOut / statsOut (may be NULL) are indexed by instance - first.  Returns the number of timed instances that
+ * returned SUCCESSFUL_RETURN. */
+#include <malloc.h>
+#include <sched.h>
+#include <time.h>
+typedef struct {
+    uint64_t seed0; int first, perThread, n, nC, nComp; const orc_options_t* opt;
+    double *xOut, *yOut; orc_stats_t* statsOut;
+    pthread_barrier_t* bar; int tid, cpu, ok; double tEnd;
+} bench_worker_t;
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+
+static void* bench_worker(void* arg)
+{
+    bench_worker_t* w = (bench_worker_t*)arg;
+    if (w->cpu >= 0) {
+        cpu_set_t set; CPU_ZERO(&set); CPU_SET(w->cpu, &set);
+        pthread_setaffinity_np(pthread_self(), sizeof(set), &set);      /* (best effort: a refused mask leaves the worker unpinned) */
+    }
+    const int n = w->n, nC = w->nC, nComp = w->nComp, nd = n + nC + 2 * nComp, K = w->perThread;
+    const size_t szQ = (size_t)n * n, szL = (size_t)nComp * n, szA = (size_t)nC * n;
+    double *Q = dalloc(szQ * K), *g = dalloc((size_t)n * K), *L = dalloc(szL * K), *R = dalloc(szL * K);
+    double *A = dalloc(szA * K), *lbA = dalloc((size_t)nC * K), *ubA = dalloc((size_t)nC * K), *x = dalloc(n), *y = dalloc(nd);
+    for (int k = 0; k < K; k++)
+        orc_synth_generate(w->seed0, (uint64_t)(w->first + w->tid * K + k), n, nC, nComp, Q + szQ * k, g + (size_t)n * k, L + szL * k, R + szL * k,
+                           A + szA * k, lbA + (size_t)nC * k, ubA + (size_t)nC * k);
+    orc_stats_t st;
+    (void)orc_lcqp_solve(n, nC, nComp, Q, g, L, R, NULL, NULL, NULL, NULL, A, lbA, ubA, NULL, NULL, NULL, NULL, w->opt, x, y, &st, 0, NULL, NULL, NULL);   /* warm-up */
+    pthread_barrier_wait(w->bar);      /* the clock starts here (taken by the caller between two barriers) */
+    pthread_barrier_wait(w->bar);
+    for (int k = 0; k < K; k++) {
+        const int rc = orc_lcqp_solve(n, nC, nComp, Q + szQ * k, g + (size_t)n * k, L + szL * k, R + szL * k, NULL, NULL, NULL, NULL,
+                                      A + szA * k, lbA + (size_t)nC * k, ubA + (size_t)nC * k, NULL, NULL, NULL, NULL, w->opt, x, y, &st, 0, NULL, NULL, NULL);
+        const size_t id = (size_t)w->tid * K + k;
+        if (w->xOut) memcpy(w->xOut + id * n, x, sizeof(double) * n);
+        if (w->yOut) memcpy(w->yOut + id * nd, y, sizeof(double) * nd);
+        if (w->statsOut) w->statsOut[id] = st;
+        w->ok += (rc == 0);
+    }
+    w->tEnd = now_s();
+    free(Q); free(g); free(L); free(R); free(A); free(lbA); free(ubA); free(x); free(y);
+    return NULL;
+}
+
+int orc_synth_bench(uint64_t seed0, int first, int threads, int perThread, const int* cpus, int n, int nC, int nComp, const orc_options_t* opt,
+                    double* xOut, double* yOut, orc_stats_t* statsOut, double* secondsOut)
+{
+    if (threads < 1 || perThread < 1) return -1;
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);      /* matrices come from the worker's heap arena and go back to it: no page faults per solve */
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)threads + 1);
+    bench_worker_t* w = (bench_worker_t*)calloc((size_t)threads, sizeof(bench_worker_t));
+    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    for (int t = 0; t < threads; t++) {
+        w[t].seed0 = seed0; w[t].first = first; w[t].perThread = perThread; w[t].n = n; w[t].nC = nC; w[t].nComp = nComp; w[t].opt = opt;
+        w[t].xOut = xOut; w[t].yOut = yOut; w[t].statsOut = statsOut; w[t].bar = &bar; w[t].tid = t; w[t].cpu = cpus ? cpus[t] : -1;
+        pthread_create(&th[t], NULL, bench_worker, &w[t]);
+    }
+    pthread_barrier_wait(&bar);      /* every worker has generated its instances and finished its warm-up solve */
+    const double t0 = now_s();
+    pthread_barrier_wait(&bar);      /* release */
+    int ok = 0; double tEnd = t0;
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); ok += w[t].ok; if (w[t].tEnd > tEnd) tEnd = w[t].tEnd; }
+    if (secondsOut) *secondsOut = tEnd - t0;
+    pthread_barrier_destroy(&bar);
+    free(w); free(th);
+    return ok;
 }
 
 /* ------------------------------------------------------------------------------------------------

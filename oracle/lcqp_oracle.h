@@ -138,6 +138,10 @@ void orc_synth_generate(uint64_t seed0, uint64_t instance, int n, int nC, int nC
  * outputs may be NULL. Returns the number of instances that returned SUCCESSFUL_RETURN. */
 int orc_synth_batch_solve(uint64_t seed0, int first, int count, int n, int nC, int nComp, const orc_options_t* opt,
                           int threads, double* xOut, double* yOut, orc_stats_t* statsOut);
+/* steady-state timing of the same solver: `threads` pinned workers (cpus[t], NULL = unpinned) with `perThread` pre-generated instances
+ * each (instance ids first + t*perThread + k), buffers warm, common start; *secondsOut = start to last finish.  Returns the solved count. */
+int orc_synth_bench(uint64_t seed0, int first, int threads, int perThread, const int* cpus, int n, int nC, int nComp, const orc_options_t* opt,
+                    double* xOut, double* yOut, orc_stats_t* statsOut, double* secondsOut);
 
 
 /* ---- sparse arm (lcqp_oracle_sparse.c): LCQProblem::runSolver with the OSQP_SPARSE conventions of src/LCQProblem.cpp:929-960

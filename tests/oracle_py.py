@@ -94,6 +94,8 @@ def lib():
         L.orc_synth_generate.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int] + [c_double_p] * 7
         L.orc_synth_batch_solve.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Options),
                                             C.c_int, c_double_p, c_double_p, C.POINTER(Stats)]
+        L.orc_synth_bench.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(Options),
+                                      c_double_p, c_double_p, C.POINTER(Stats), c_double_p]
         _lib = L
     return _lib
 
@@ -210,6 +212,40 @@ def synth_batch_solve(first, count, n=256, nC=512, nComp=64, opt=None, threads=1
     st = (Stats * count)()
     ok = lib().orc_synth_batch_solve(seed0, first, count, n, nC, nComp, C.byref(opt), threads, _p(x), _p(y), st)
     return ok, x, y, [s.asdict() for s in st]
+
+
+def host_cpu_topology():
+    """(one cpu id per physical core, all cpu ids) of the cpus this process may run on, from the sibling lists in sysfs"""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores, seen = [], set()
+    for c in allowed:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                txt = f.read().strip()
+            sib = []
+            for part in txt.split(","):
+                lo, _, hi = part.partition("-")
+                sib += list(range(int(lo), int(hi or lo) + 1))
+            key = tuple(sorted(sib))
+        except OSError:
+            key = (c,)
+        if key not in seen:
+            seen.add(key)
+            cores.append(c)
+    return cores, allowed
+
+
+def synth_bench(first, threads, per_thread, cpus=None, n=256, nC=512, nComp=64, opt=None, seed0=SEED0, want_xy=True):
+    """steady-state CPU timing (orc_synth_bench): returns (solved, seconds, x, y, stats)"""
+    opt = opt or default_options()
+    count, nd = threads * per_thread, n + nC + 2 * nComp
+    x = np.zeros((count, n)) if want_xy else None
+    y = np.zeros((count, nd)) if want_xy else None
+    st = (Stats * count)()
+    sec = np.zeros(1)
+    cp = (C.c_int * threads)(*[int(c) for c in cpus[:threads]]) if cpus is not None else None
+    ok = lib().orc_synth_bench(seed0, first, threads, per_thread, cp, n, nC, nComp, C.byref(opt), _p(x), _p(y), st, _p(sec))
+    return ok, float(sec[0]), x, y, [s.asdict() for s in st]
 
 
 # ---- Utilities (orc_util_*) ---------------------------------------------------------------------

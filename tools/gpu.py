@@ -518,8 +518,8 @@ def cmd_phase_profile():
     if pre:
         so = os.path.abspath(pre[0])
     elif not os.path.exists(so) or "--rebuild" in sys.argv:
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-DLCQP_PROFILE", *extra,
-                               "-Wno-pass-failed", "-o", so, os.path.join(ROOT, "lcqpow_amd", "csrc", "lcqp_hip.hip")])
+        import __graft_entry__ as ge      # the product's own build recipe (host unit + per-size kernel units), with the profile switch
+        ge.build_hip(force=True, out=so, defines=["-DLCQP_PROFILE", *extra], only_nch=2)
     import lcqpow_amd.capi as capi
     capi._SO = so
     la = capi
