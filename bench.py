@@ -355,23 +355,40 @@ def main():
             # independent instances side by side, as on the GPU
             phys, allc = O.host_cpu_topology()
             per = max(1, args.cpu_sample // 8)                       # default 8 instances per worker
-            okc, secc, xo, yo, so = O.synth_bench(0, len(phys), per, cpus=phys, n=n, nC=nC, nComp=nComp, opt=oopt)
-            per_t = max(1, per // 2) if len(allc) > len(phys) else per
-            okt, sect, _, _, _ = O.synth_bench(0, len(allc), per_t, cpus=allc, n=n, nC=nC, nComp=nComp, opt=oopt, want_xy=False)
+            doms = O.l3_domains(phys)
+            # worker placements: one and two workers per L3 domain (an instance's working set, ~15 MB, then stays in its L3), one per physical
+            # core, one per hardware thread -- the baseline is the best of them
+            plans = [("one worker per L3 domain", [d[0] for d in doms], per), ("two workers per L3 domain", [c for d in doms for c in d[:2]], per),
+                     ("one worker per physical core", phys, per), ("one worker per hardware thread", allc, max(1, per // 2))]
+            runs, seen = [], set()
+            xo = None
+            for tag, cpus, k_ in plans:
+                if len(cpus) in seen:
+                    continue
+                seen.add(len(cpus))
+                ok_, sec_, xr, _, _ = O.synth_bench(0, len(cpus), k_, cpus=cpus, n=n, nC=nC, nComp=nComp, opt=oopt, want_xy=(cpus is phys))
+                if cpus is phys:
+                    xo = xr
+                runs.append({"placement": tag, "workers": len(cpus), "instances_per_worker": k_, "solved": ok_, "seconds": sec_, "value": len(cpus) * k_ / sec_})
             ok1, sec1, _, _, _ = O.synth_bench(0, 1, 8, cpus=phys[:1], n=n, nC=nC, nComp=nComp, opt=oopt, want_xy=False)
-            v_cores, v_threads, single = len(phys) * per / secc, len(allc) * per_t / sect, 8 / sec1
+            single = 8 / sec1
+            best = max(runs, key=lambda r_: r_["value"])
+            v_cores = [r_["value"] for r_ in runs if r_["workers"] == len(phys)][0]
+            stream = O.host_stream_gbps(phys, 256, 2)
             ncmp = min(len(phys) * per, B)
             dx = float(np.abs(xo[:ncmp] - x[:ncmp]).max())
-            out["cpu_baseline"] = {"value": max(v_cores, v_threads), "unit": "LCQPs/s", "cores": len(phys), "threads": len(allc), "kind": "port",
-                                   "value_one_worker_per_core": v_cores, "value_one_worker_per_thread": v_threads,
-                                   "single_core_value": single, "parallel_efficiency_vs_single_core": v_cores / (single * len(phys)),
-                                   "gpu_over_cpu": value / max(v_cores, v_threads),
+            out["cpu_baseline"] = {"value": best["value"], "unit": "LCQPs/s", "cores": len(phys), "threads": len(allc), "kind": "port",
+                                   "best_placement": best["placement"], "workers_at_best": best["workers"], "runs": runs,
+                                   "value_one_worker_per_core": v_cores, "single_core_value": single,
+                                   "single_core_times_cores": single * len(phys), "parallel_efficiency_vs_single_core": best["value"] / (single * len(phys)),
+                                   "host_stream_read_GBps_all_cores": stream, "gpu_over_cpu": value / best["value"],
                                    "sample": f"steady state: CPU oracle (oracle/lcqp_oracle.c, same algorithm in scalar C; the reference's qpOASES path "
-                                             f"cannot be built: external/qpOASES is empty) on the same synthetic workload; workers pinned, instances "
-                                             f"generated and one warm-up solve per worker before the clock, buffers reused; "
-                                             f"{len(phys)} workers (one per physical core) x {per} instances: {okc}/{len(phys) * per} solved in {secc:.2f} s; "
-                                             f"{len(allc)} workers (one per hardware thread) x {per_t}: {okt}/{len(allc) * per_t} in {sect:.2f} s; "
-                                             f"one worker alone x 8: {sec1:.2f} s",
+                                             f"cannot be built: external/qpOASES is empty) on the same synthetic workload; workers pinned, their instances "
+                                             f"generated and one warm-up solve done before the clock starts, buffers reused (no mmap per solve); "
+                                             f"{per} instances per worker ({max(1, per // 2)} with a worker per hardware thread); best of "
+                                             f"{len(runs)} placements = {best['placement']} ({best['workers']} workers, {best['seconds']:.2f} s). One worker alone: "
+                                             f"{single:.1f} LCQPs/s; beyond one or two workers per L3 domain the oracle is bound by host memory "
+                                             f"(an instance's working set exceeds a core's L3 share; stream read rate of all cores in this run: {stream:.0f} GB/s)",
                                    "max_abs_dx_vs_gpu": dx}
     for b_ in bts:
         b_.close()

@@ -199,8 +199,10 @@ int lcqp_hip_chol_solve(int batch, int n, const double* K, const double* b, doub
  * (src/LCQProblem.cpp:929-960: no box constraints, nC + 2 nComp duals) on the device -- ADMM on the quasi-definite KKT
  * matrix + active-set polish (the role of SubsolverOSQP, src/SubsolverOSQP.cpp:124-200), CSR/CSC products, band LDL' in a
  * reverse Cuthill-McKee ordering computed here once per pattern.  Pattern arrays are the CSC arrays the reference holds
- * (Q_sparse and the stacked A_sparse = [A; L; R], src/LCQProblem.cpp:629-723; Q full symmetric).  Returns NULL when the
- * KKT band of the pattern is wider than 63 (lcqp_hip_sparse_last_error() says so): such problems run on the dense kernels.
+ * (Q_sparse and the stacked A_sparse = [A; L; R], src/LCQProblem.cpp:629-723; Q full symmetric).  The KKT graph may be a band of
+ * half width <= 63 plus at most 16 dense border nodes (rows or variables that touch many others: the arrow of
+ * examples/OptimizeOnCircle.cpp).  Returns NULL for any other pattern (lcqp_hip_sparse_last_error() says why): the host layer runs
+ * such problems on the dense kernels, which take nV <= 1024.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct lcqp_hip_sparse lcqp_hip_sparse_t;
 lcqp_hip_sparse_t* lcqp_hip_sparse_create(int batch, int nV, int nC, int nComp, const int* Qp, const int* Qi,

@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liblcqpow_hip.so")
+# LCQPOW_HIP_LIBRARY: another build of the same HIP library (experiment variants under ab_tmp/); there is no CPU fallback either way
+_SO = os.environ.get("LCQPOW_HIP_LIBRARY") or os.path.join(_HERE, "liblcqpow_hip.so")
 c_double_p = C.POINTER(C.c_double)
 
 SEED0 = 0x4C43515000000001

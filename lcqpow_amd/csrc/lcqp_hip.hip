@@ -3,6 +3,7 @@
 #include "lcqp_launch.hpp"
 #include "../../include/lcqp_synth.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -153,7 +154,7 @@ static int dev_alloc(lcqp_hip_batch* h, T** p, size_t count, bool zero)
 extern "C" lcqp_hip_batch_t* lcqp_hip_batch_create(int batch, int nV, int nC, int nComp, int withBox, int device)
 try {
     if (batch <= 0 || nV <= 0 || nC < 0 || nComp < 0) { g_err = "invalid dimensions"; return nullptr; }
-    if (nV > 1024) { g_err = "nV > 1024 is not supported by this build"; return nullptr; }
+    if (nV > 1024) { g_err = "nV > 1024 is not supported by the dense kernels of this build (padded sizes 128 ... 1024; the sparse engine takes larger banded / bordered problems)"; return nullptr; }
     HIPCHKN(hipSetDevice(device));
     lcqp_hip_batch* h = new (std::nothrow) lcqp_hip_batch();
     if (!h) { g_err = "out of host memory"; return nullptr; }
@@ -256,9 +257,12 @@ try {
         if (opt->storeSteps && have < want) {
             HIPCHK(hipSetDevice(h->device));
             HIPCHK(hipStreamSynchronize(h->stream));
+            for (void* old : {(void*)d.traceS, (void*)d.traceX})      // a regrow frees the smaller buffers
+                if (old) { (void)hipFree(old); h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), old), h->allocs.end()); }
+            d.traceS = d.traceX = nullptr; d.traceCap = 0;
             if (dev_alloc(h, &d.traceS, (size_t)d.B * want * 8, true) || dev_alloc(h, &d.traceX, (size_t)d.B * want * d.n, true)) return LCQP_HIP_ERROR;
             if (!d.traceLen && dev_alloc(h, &d.traceLen, (size_t)d.B, true)) return LCQP_HIP_ERROR;
-            d.traceCap = want;    // (the smaller buffers stay in the allocation list until the batch is destroyed)
+            d.traceCap = want;
         } else if (opt->storeSteps) d.traceCap = have;
         else if (have > 0) d.traceCap = -have;                    // keep the buffers, stop recording
     }

@@ -171,8 +171,11 @@ __global__ __launch_bounds__(WG) void k_compress_C(DevBatch db)
 }
 
 // ---- k_factor: the constant factorisation L1 of Q + sp I (L_K of the ADMM fallback is built on demand, qp_build_K) ----
+#ifndef LCQP_FACTOR_MINWAVES
+#define LCQP_FACTOR_MINWAVES 4      // 4 workgroups per CU: the 1024 instances of the BASELINE batch are one residency wave (at 3 a second, quarter-full wave follows)
+#endif
 template <int NCH>
-__global__ __launch_bounds__(WG) void k_factor(DevBatch db)
+__global__ __launch_bounds__(WG, LCQP_FACTOR_MINWAVES) void k_factor(DevBatch db)
 {
     LCQP_LDS_N(NCH)
     constexpr int np = 128 * NCH;
@@ -517,7 +520,10 @@ static void launch_impl(int kid, int grid, hipStream_t s, const LaunchArgs& a)
         case ID_k_lcqp_run:
 #ifndef LCQP_NO_LDS_ROWS      // experiment switch: the row state in global memory for every size
             if constexpr (NCH <= 2) {
-                if (a.db.mEcap <= LDS_ROWS_MAX) { hipLaunchKernelGGL((k_lcqp_run<NCH, true>), dim3(grid), dim3(WG), 0, s, a.db); break; }
+                // the row state sits behind the routines' scratch (arena[0, LDS_ROWS_OFF)): the sweeps need 6 np doubles there, the triangular solves
+                // 5 np, the widest pass over the inverse factor 4 capS, the rotations 3 capS
+                static_assert(6 * 128 * NCH <= LDS_ROWS_OFF, "k_lcqp_run<NCH, true>: the sweeps' scratch must end below the row state");
+                if (a.db.mEcap <= LDS_ROWS_MAX && 4 * a.db.capS <= LDS_ROWS_OFF) { hipLaunchKernelGGL((k_lcqp_run<NCH, true>), dim3(grid), dim3(WG), 0, s, a.db); break; }
             }
 #endif
             hipLaunchKernelGGL((k_lcqp_run<NCH, false>), dim3(grid), dim3(WG), 0, s, a.db); break;

@@ -1618,16 +1618,22 @@ extern "C" int lcqp_hip_sparse_set_options(lcqp_hip_sparse_t* h, const lcqp_opti
     if (!h || !opt) return LCQP_INVALID_ARGUMENT;
     if (opt->nDynamicPenalty > 64) { g_sp_err = "nDynamicPenalty > 64 unsupported"; return LCQP_HIP_UNSUPPORTED; }
     h->db.opt = *opt;
-    // per-iterate tracking buffers, sized once for the largest trace this handle is asked for
+    // per-iterate tracking buffers: kept at the largest trace this handle was asked for (a regrow frees the smaller ones); the kernel records
+    // only while storeSteps is on -- traceCap < 0 keeps the buffers of a handle whose tracking has been switched off again
+    SpBatch& d = h->db;
     const int want = opt->storeSteps ? std::min(std::max(opt->maxIterations + 1, 1), 4096) : 0;
-    if (want > h->db.traceCap) {
+    const int have = d.traceCap < 0 ? -d.traceCap : d.traceCap;
+    if (want > have) {
         if (hipSetDevice(h->device) != hipSuccess) { g_sp_err = "hipSetDevice failed"; return LCQP_HIP_ERROR; }
-        SpBatch& d = h->db;
+        (void)hipStreamSynchronize(h->stream);
+        for (void* old : {(void*)d.traceS, (void*)d.traceX, (void*)d.traceLen})
+            if (old) { (void)hipFree(old); h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), old), h->allocs.end()); }
+        d.traceS = d.traceX = nullptr; d.traceLen = nullptr; d.traceCap = 0;
         double *ts = sp_alloc<double>(h, (size_t)d.B * want * 8), *tx = sp_alloc<double>(h, (size_t)d.B * want * d.n);
         int* tl = sp_alloc<int>(h, (size_t)d.B);
         if (!ts || !tx || !tl) { g_sp_err = "out of device memory for the iterate trace"; return LCQP_HIP_ERROR; }
         d.traceS = ts; d.traceX = tx; d.traceLen = tl; d.traceCap = want;
-    }
+    } else d.traceCap = opt->storeSteps ? have : -have;
     return 0;
 }
 
@@ -1638,7 +1644,7 @@ extern "C" int lcqp_hip_sparse_get_trace(lcqp_hip_sparse_t* h, int instance, int
     SpBatch& d = h->db;
     *len = 0;
     if (instance < 0 || instance >= d.B) return LCQP_INVALID_ARGUMENT;
-    if (d.traceCap == 0) return 0;
+    if (d.traceCap <= 0) return 0;      // no buffers, or tracking switched off: an empty trace
     SPCHK(hipSetDevice(h->device));
     SPCHK(hipStreamSynchronize(h->stream));
     int n = 0;

@@ -201,6 +201,7 @@ struct orc_qp {
     orc_options_t opt;
     /* setup */
     int is_setup, mE, nfin;
+    int k_ready;      /* LK exists (qp_build_K): the ADMM factor is built when the first ADMM iteration needs it, as on the device (lcqp_dev.hpp: qp_build_K) */
     int* boxidx;
     double *E, *Et, *l, *u, *rhov;
     double scale, sigma, spv, rho;
@@ -346,22 +347,10 @@ static int qp_setup(orc_qp_t* q, const double* lbA, const double* ubA, const dou
         memcpy(t, q->E + (size_t)r * n, sizeof(double) * n);
         trsv_lower(q->L1, n, t);
     }
-    /* LK = chol(Q + sigma I + E' diag(rhov) E) */
+    /* LK = chol(Q + sigma I + E' diag(rhov) E) is only needed when the active-set iteration fails (one instance in a hundred of the synthetic
+     * workload): built on demand by qp_build_K, like the device does -- an eager build was half of a solve's time for nothing */
     q->LK = dalloc((size_t)n * n);
-    memcpy(q->LK, q->Q, sizeof(double) * n * n);
-    for (int i = 0; i < n; i++) q->LK[(size_t)i * n + i] += q->sigma;
-    for (int r = 0; r < mE; r++) {
-        double rv = q->rhov[r];
-        if (rv == 0.0) continue;
-        const double* e = q->E + (size_t)r * n;
-        for (int i = 0; i < n; i++) {
-            double ei = rv * e[i];
-            if (ei == 0.0) continue;
-            double* row = q->LK + (size_t)i * n;
-            for (int j = 0; j < n; j++) row[j] += ei * e[j];
-        }
-    }
-    if (chol_lower(q->LK, n, NULL) != 0) return 3;
+    q->k_ready = 0;
 
     q->x = dalloc(n); q->y = dalloc(mE); q->st = (int*)calloc(mE ? mE : 1, sizeof(int));
     q->xa = dalloc(n); q->ya = dalloc(mE); q->za = dalloc(mE);
@@ -421,6 +410,28 @@ static void qp_update_bounds(orc_qp_t* q, const double* lbA, const double* ubA, 
 }
 
 static double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* LK = chol(Q + sigma I + E' diag(rhov) E); returns non-zero when a pivot is not positive (device: qp_build_K) */
+static int qp_build_K(orc_qp_t* q)
+{
+    const int n = q->nV, mE = q->mE;
+    memcpy(q->LK, q->Q, sizeof(double) * n * n);
+    for (int i = 0; i < n; i++) q->LK[(size_t)i * n + i] += q->sigma;
+    for (int r = 0; r < mE; r++) {
+        const double rv = q->rhov[r];
+        if (rv == 0.0) continue;
+        const double* e = q->E + (size_t)r * n;
+        for (int i = 0; i < n; i++) {
+            const double ei = rv * e[i];
+            if (ei == 0.0) continue;
+            double* row = q->LK + (size_t)i * n;
+            for (int j = 0; j < n; j++) row[j] += ei * e[j];
+        }
+    }
+    const int rc = chol_lower(q->LK, n, NULL);
+    q->k_ready = (rc == 0);
+    return rc;
+}
 
 /* n_it ADMM iterations on (xa, za, ya) with the constant factor LK (OSQP iteration, reduced KKT form):
  *   xt = K^-1 (sigma x - g + E'(rho.z - y));  zt = E xt;  relaxation alpha;  z = clip;  y += rho (zr - z). */
@@ -565,20 +576,7 @@ static int qp_adapt_rho(orc_qp_t* q, const double* g)
     if (!(fac > 5.0 || fac < 0.2)) return 0;
     for (int r = 0; r < mE; r++) q->rhov[r] *= fac;
     q->rho *= fac;
-    memcpy(q->LK, q->Q, sizeof(double) * n * n);
-    for (int i = 0; i < n; i++) q->LK[(size_t)i * n + i] += q->sigma;
-    for (int r = 0; r < mE; r++) {
-        const double rv = q->rhov[r];
-        if (rv == 0.0) continue;
-        const double* e = q->E + (size_t)r * n;
-        for (int i = 0; i < n; i++) {
-            const double ei = rv * e[i];
-            if (ei == 0.0) continue;
-            double* row = q->LK + (size_t)i * n;
-            for (int j = 0; j < n; j++) row[j] += ei * e[j];
-        }
-    }
-    chol_lower(q->LK, n, NULL);
+    (void)qp_build_K(q);
     q->c_fact++;
     return 1;
 }
@@ -1075,7 +1073,10 @@ int orc_qp_solve(orc_qp_t* q, int initialSolve, int* iterations, int* exit_flag,
             }
             admm_ready = 1;
         }
-        if (n_admm > 0) qp_admm(q, g, n_admm);
+        if (n_admm > 0) {
+            if (!q->k_ready && qp_build_K(q) != 0) { free(xt); free(yt); free(stt); *exit_flag = 3; return ORC_SUBPROBLEM_SOLVER_ERROR; }   /* first ADMM iteration: LK is built now */
+            qp_admm(q, g, n_admm);
+        }
         if (round == 0 && use_stored_set) {
             memcpy(stt, q->st, sizeof(int) * mE);
             for (int r = 0; r < mE; r++) if (q->l[r] == q->u[r]) stt[r] = ST_EQ;
@@ -1254,7 +1255,7 @@ static void lcqp_determineStationarityType(lcqp_t* p)
     p->algoStat = ORC_C_STATIONARY;
 }
 
-static int g_lcqp_robust = 1;   /* every kernel carries the dependent-row rules since round 2 (k_lcqp_run, k_lcqp_rerun, k_qp_solve) */
+static int g_lcqp_robust = 1;   /* every kernel carries the dependent-row rules since round 2 (k_lcqp_run, k_qp_solve) */
 void orc_lcqp_set_robust(int on) { g_lcqp_robust = on; }
 
 int orc_lcqp_solve(int nV, int nC, int nComp,
@@ -1554,8 +1555,11 @@ int orc_synth_bench(uint64_t seed0, int first, int threads, int perThread, const
                     double* xOut, double* yOut, orc_stats_t* statsOut, double* secondsOut)
 {
     if (threads < 1 || perThread < 1) return -1;
-    mallopt(M_MMAP_THRESHOLD, 1 << 30);      /* matrices come from the worker's heap arena and go back to it: no page faults per solve */
+    /* matrices come from the worker's heap arena and go back to it: no mmap / munmap / page faults per solve (they would serialise the
+     * workers on the address-space lock of the process: 128 workers then reach what 20 do).  32 MiB is the largest threshold glibc takes. */
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);
     mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 64 << 20);
     pthread_barrier_t bar;
     pthread_barrier_init(&bar, NULL, (unsigned)threads + 1);
     bench_worker_t* w = (bench_worker_t*)calloc((size_t)threads, sizeof(bench_worker_t));
@@ -1574,6 +1578,45 @@ int orc_synth_bench(uint64_t seed0, int first, int threads, int perThread, const
     pthread_barrier_destroy(&bar);
     free(w); free(th);
     return ok;
+}
+
+/* Read bandwidth of the host memory seen by `threads` pinned workers streaming `bytesPerThread` each (private arrays, first touched by their
+ * worker), `reps` passes: GB/s.  bench.py prints it beside the cpu_baseline: with every core busy the oracle is bound by this, not by its
+ * arithmetic (its working set per instance, ~15 MB, exceeds a core's share of the L3). */
+typedef struct { pthread_barrier_t* bar; int cpu, reps; size_t n; double sum, tEnd; } stream_worker_t;
+static void* stream_worker(void* arg)
+{
+    stream_worker_t* w = (stream_worker_t*)arg;
+    if (w->cpu >= 0) { cpu_set_t set; CPU_ZERO(&set); CPU_SET(w->cpu, &set); pthread_setaffinity_np(pthread_self(), sizeof(set), &set); }
+    double* a = (double*)malloc(sizeof(double) * w->n);
+    for (size_t i = 0; i < w->n; i++) a[i] = (double)(i & 7);
+    pthread_barrier_wait(w->bar);
+    pthread_barrier_wait(w->bar);
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int r = 0; r < w->reps; r++)
+        for (size_t i = 0; i + 3 < w->n; i += 4) { s0 += a[i]; s1 += a[i + 1]; s2 += a[i + 2]; s3 += a[i + 3]; }
+    w->sum = (s0 + s1) + (s2 + s3);
+    w->tEnd = now_s();
+    free(a);
+    return NULL;
+}
+double orc_host_stream_gbps(int threads, const int* cpus, size_t bytesPerThread, int reps)
+{
+    if (threads < 1 || reps < 1) return 0.0;
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)threads + 1);
+    stream_worker_t* w = (stream_worker_t*)calloc((size_t)threads, sizeof(stream_worker_t));
+    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    for (int t = 0; t < threads; t++) { w[t].bar = &bar; w[t].cpu = cpus ? cpus[t] : -1; w[t].reps = reps; w[t].n = bytesPerThread / sizeof(double); pthread_create(&th[t], NULL, stream_worker, &w[t]); }
+    pthread_barrier_wait(&bar);
+    const double t0 = now_s();
+    pthread_barrier_wait(&bar);
+    double tEnd = t0, chk = 0;
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); if (w[t].tEnd > tEnd) tEnd = w[t].tEnd; chk += w[t].sum; }
+    const double gbps = (chk >= 0.0 && tEnd > t0) ? (double)threads * (double)(bytesPerThread / sizeof(double)) * sizeof(double) * reps / (tEnd - t0) / 1e9 : 0.0;
+    pthread_barrier_destroy(&bar);
+    free(w); free(th);
+    return gbps;
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -23,6 +23,7 @@
 #ifndef LCQP_ORACLE_H
 #define LCQP_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -123,9 +124,8 @@ int orc_lcqp_solve(int nV, int nC, int nComp,
                    const orc_options_t* opt, double* xOpt, double* yOpt, orc_stats_t* stats,
                    int traceCap, double* traceScalars /* traceCap x 8 */, double* traceX /* traceCap x nV */, int* traceLen);
 
-/* which QP path orc_lcqp_solve mirrors: 0 (default) the batched homotopy kernel k_lcqp_run; non-zero the kernels that also
- * apply the dependent-row rules of orc_qp_*: k_qp_solve under the reference's host loop over SubsolverHIP, and the second pass
- * for failed batch instances, k_lcqp_rerun */
+/* the dependent-row rules of orc_qp_* inside orc_lcqp_solve: on (1, the default) since every device kernel carries them (k_lcqp_run,
+ * k_qp_solve); 0 switches them off for A/B runs of the oracle against itself */
 void orc_lcqp_set_robust(int on);
 /* 1 (default): the QP solver sums E x in the device's order (64 lanes + butterfly); 0: left to right.  See dot_lanes in lcqp_oracle.c. */
 void orc_qp_set_sum_order(int device_order);
@@ -142,6 +142,8 @@ int orc_synth_batch_solve(uint64_t seed0, int first, int count, int n, int nC, i
  * each (instance ids first + t*perThread + k), buffers warm, common start; *secondsOut = start to last finish.  Returns the solved count. */
 int orc_synth_bench(uint64_t seed0, int first, int threads, int perThread, const int* cpus, int n, int nC, int nComp, const orc_options_t* opt,
                     double* xOut, double* yOut, orc_stats_t* statsOut, double* secondsOut);
+/* read bandwidth (GB/s) of the host memory under `threads` pinned streaming workers: the figure bench.py prints beside the cpu_baseline */
+double orc_host_stream_gbps(int threads, const int* cpus, size_t bytesPerThread, int reps);
 
 
 /* ---- sparse arm (lcqp_oracle_sparse.c): LCQProblem::runSolver with the OSQP_SPARSE conventions of src/LCQProblem.cpp:929-960

@@ -96,6 +96,8 @@ def lib():
                                             C.c_int, c_double_p, c_double_p, C.POINTER(Stats)]
         L.orc_synth_bench.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(Options),
                                       c_double_p, c_double_p, C.POINTER(Stats), c_double_p]
+        L.orc_host_stream_gbps.restype = C.c_double
+        L.orc_host_stream_gbps.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_size_t, C.c_int]
         _lib = L
     return _lib
 
@@ -233,6 +235,24 @@ def host_cpu_topology():
             seen.add(key)
             cores.append(c)
     return cores, allowed
+
+
+def l3_domains(cpus):
+    """the given cpu ids grouped by the L3 cache they share (sysfs); one group when sysfs does not say"""
+    doms = {}
+    for c in cpus:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/cache/index3/shared_cpu_list") as f:
+                key = f.read().strip()
+        except OSError:
+            key = "all"
+        doms.setdefault(key, []).append(c)
+    return list(doms.values())
+
+
+def host_stream_gbps(cpus, mbytes_per_thread=256, reps=3):
+    cp = (C.c_int * len(cpus))(*[int(c) for c in cpus])
+    return float(lib().orc_host_stream_gbps(len(cpus), cp, int(mbytes_per_thread) << 20, reps))
 
 
 def synth_bench(first, threads, per_thread, cpus=None, n=256, nC=512, nComp=64, opt=None, seed0=SEED0, want_xy=True):

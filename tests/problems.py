@@ -159,6 +159,45 @@ def branch_qp_solution(O, d, x, tol=1e-7):
     return q.solution()[0]
 
 
+def stationarity_type(d, x, y, rho, ctol=1e3 * 2.221e-16, merge_box=False):
+    """determineStationarityType + getWeakComplementarities (src/LCQProblem.cpp:1412-1482) restated in numpy on a RETURNED solution:
+    y holds the transformed duals (transformDuals :1381-1409), so the multipliers of L and R are shifted back by rho R x / rho L x first.
+    Returns 1 (W), 2 (C), 3 (M), 4 (S).
+    merge_box: a complementarity row that is +-e_v while variable v also carries a finite box bound is the same constraint normal twice
+    (examples/example_data: lb = 0 on the variables L selects), so only the SUM of the two multipliers' contributions to the stationarity
+    in v is defined; with merge_box the whole contribution is attributed to the complementarity row -- a classification that does not depend
+    on how a solver happened to split it."""
+    n, nC, nK = d["nV"], d["nC"], d["nComp"]
+    L, R = d["L"], d["R"]
+    Lx, Rx = L @ x, R @ x
+    yL = y[n + nC:n + nC + nK] + rho * Rx
+    yR = y[n + nC + nK:] + rho * Lx
+    if merge_box:
+        lb = d.get("lb"); ub = d.get("ub")
+        boxed = np.zeros(n, dtype=bool)
+        if lb is not None: boxed |= np.isfinite(lb)
+        if ub is not None: boxed |= np.isfinite(ub)
+        yL, yR = yL.copy(), yR.copy()
+        for M_, ym in ((L, yL), (R, yR)):
+            for i in range(nK):
+                nz = np.nonzero(M_[i])[0]
+                if nz.size == 1 and boxed[nz[0]]:
+                    ym[i] += y[nz[0]] / M_[i, nz[0]]
+    sflag, mflag = True, True
+    for i in range(nK):
+        if not (Lx[i] <= ctol and Rx[i] <= ctol):
+            continue
+        a, b = yL[i], yR[i]
+        prod, mn = a * b, min(a, b)
+        if mn < 0:
+            sflag = False
+        if abs(prod) >= ctol and mn <= 0:
+            if prod <= ctol:
+                return 1
+            mflag = False
+    return 4 if sflag else (3 if mflag else 2)
+
+
 # ---- sparse synthetic workload (BASELINE config 5): banded, OCP-like, one pattern for the whole batch ------------------------------
 from lcqpow_amd.synth_sparse import SPARSE_SEED0  # noqa: E402
 

@@ -30,9 +30,10 @@ def test_bench_json_contract():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["traffic"] is None          # the PMC figure belongs to the BASELINE workload only
     cb = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
+    for k in ("value", "unit", "cores", "threads", "kind", "sample", "runs", "value_one_worker_per_core", "single_core_value", "host_stream_read_GBps_all_cores"):
         assert k in cb, k
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["max_abs_dx_vs_gpu"] < 1e-9
+    assert cb["kind"] == "port" and 1 <= cb["cores"] <= cb["threads"] and cb["value"] > 0 and cb["max_abs_dx_vs_gpu"] < 1e-9
+    assert cb["value"] == max(r_["value"] for r_ in cb["runs"]) and all(r_["solved"] == r_["workers"] * r_["instances_per_worker"] for r_ in cb["runs"])
 
 
 def test_bench_refuses_a_smaller_run_than_asked_for():
@@ -54,3 +55,42 @@ def test_bench_sparse_workload_line():
     assert d["unit"] == "LCQPs/s" and d["config"]["solved"] == 8 and "sparse" in d["config"]["workload"]
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0 and d["roofline"]["traffic"] is None
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["max_abs_dx_vs_gpu"] < 1e-8
+
+
+@pytest.mark.gpu
+def test_bench_under_the_drivers_launcher():
+    """the launcher path on a GPU box: bench.py as a fresh child of `python -m torch.distributed.run` with one rank --
+    gloo process group (control plane) and HIP in the same process -- prints the one JSON line with n_gpus = 1"""
+    port = 29600 + (os.getpid() % 300)
+    env = dict(os.environ); env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "16",
+                        "--cpu-sample", "0", "--no-backsolve"],      # (the default shape: torch.distributed.run's own parser would take "--n" as a prefix of its options)
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["config"]["solved"] == 16 and d["config"]["global_batch"] == 16
+    assert "no collective" in d["config"]["parallelism"] and d["scaling"] == "weak" and d["roofline"]["achieved"] > 0
+
+
+@pytest.mark.gpu
+def test_cpp_shards_on_one_device_equal_one_batch():
+    """examples/multi_gpu_batch (the sharding of SURVEY.md §8e from C++: one host thread, batch object and stream per shard): two shards of
+    1024 instances on one device give the checksum of a single 2048-instance batch -- shard boundaries change nothing"""
+    exe = os.path.join(ROOT, "examples", "bin", "multi_gpu_batch")
+    if not os.path.exists(exe):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as ge
+        ge.build_examples()
+    out = {}
+    for shards in (1, 2):
+        r = subprocess.run([exe, "2048", str(shards)], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        line = [l for l in r.stdout.splitlines() if "checksum" in l][-1]
+        assert "2048/2048 LCQPs solved" in line, line
+        out[shards] = float(line.split("checksum")[1].split(",")[0].strip())
+    assert abs(out[1] - out[2]) <= 1e-10 * abs(out[1]), out      # (the sum of 2048 x 256 solution entries, associated per shard)

@@ -213,7 +213,17 @@ def test_lcqp_reference_problems(hip, oracle, name):
         # (the stationarity TYPE, src/LCQProblem.cpp:1412-1453, is read off the signs of the multipliers of L and R; on biactive pairs whose
         # rows are duplicated by a box bound it depends on how the unique SUM is split between the duplicates -- S or W for the same point)
         _cmp(ro, rh, xtol=1e-7, ytol=np.inf, status=False)
-        assert rh["stats"]["status"] in (1, 4) and ro["stats"]["status"] in (1, 4)
+        # Stationarity type (a parity output, row (a)13): each side reports what the reference's rule (src/LCQProblem.cpp:1412-1482) gives on ITS
+        # multipliers, and the oracle's answer is the committed one (W).  The two raw answers differ -- W on the oracle, S on the device -- and
+        # legitimately so: pair 25 has L_25 = -e_38 while variable 38 carries the box bound lb = 0, the same normal twice, so only
+        # -y_L25 + y_box38 = -0.0538 is defined (equal on both sides, asserted below through `comb`); the oracle happens to put -5e-11 on the
+        # row (W: a negative multiplier on a biactive pair), the device +0.029 (S).  With the whole contribution attributed to the
+        # complementarity row the rule gives the SAME type on both sides (S), and that is what is asserted.
+        for r in (ro, rh):
+            assert r["stats"]["status"] == P.stationarity_type(d, r["x"], r["y"], r["stats"]["rhoOpt"])
+        assert ro["stats"]["status"] == int(GOLD["example_data_stats"][3]) == 1
+        assert P.stationarity_type(d, ro["x"], ro["y"], ro["stats"]["rhoOpt"], merge_box=True) == \
+               P.stationarity_type(d, rh["x"], rh["y"], rh["stats"]["rhoOpt"], merge_box=True) == 4
         n, nC, nComp = d["nV"], d["nC"], d["nComp"]
         for r in (ro, rh):
             yy = r["y"]
@@ -293,7 +303,22 @@ def test_iterate_counts_against_the_oracle_are_unbiased(hip, oracle):
     d = np.array([s["iterTotal"] for s in st]) - np.array([s["iterTotal"] for s in so])
     assert (d % 4 == 0).mean() >= 0.99                       # whole inner cycles (a +-1 needs a flip in the very last iterate)
     assert abs(d.mean()) < 0.6, d.mean()                     # 5 sigma of the mean of 512 fair +-4 flips at rate 0.35
-    assert (d == 0).mean() > 0.5
+    # measured: 36.5 % of 8192 instances differ (profiles/round3/full_parity_8192.log); 512 draws at that rate stay below 0.45 at 4 sigma
+    assert (d != 0).mean() < 0.45, (d != 0).mean()
+    # everything that does not hinge on the coin is equal: return codes (above), and -- for the instances that took the same number of
+    # iterates -- the number of penalty updates and the final penalty parameter
+    same = d == 0
+    assert all(st[i]["iterOuter"] == so[i]["iterOuter"] and st[i]["rhoOpt"] == so[i]["rhoOpt"] and st[i]["status"] == so[i]["status"] for i in np.nonzero(same)[0])
+    # Parity does not hinge on the summation order the oracle shares with the device (oracle/lcqp_oracle.c: dot_lanes): the same 512 instances
+    # against the PLAIN-order oracle (E x summed left to right), solutions only
+    oracle.qp_set_sum_order(0)
+    try:
+        ok0, xo0, yo0, so0 = oracle.synth_batch_solve(0, N, 256, 512, 64, opt=oracle.default_options(perturbStep=0, printLevel=0),
+                                                      threads=len(os.sched_getaffinity(0)))
+    finally:
+        oracle.qp_set_sum_order(1)
+    assert ok0 == N and np.abs(x - xo0).max() < X_TOL and np.abs(y - yo0).max() < Y_TOL
+    assert all(a["status"] == b_["status"] for a, b_ in zip(st, so0))
     bt.close()
 
 
@@ -387,19 +412,42 @@ def test_lcqp_full_batch_properties(hip, oracle):
     Lx = x[:, :nComp]; Rx = x[:, nComp:2 * nComp]          # one-hot selectors of the generator
     assert np.abs((Lx * Rx).sum(axis=1)).max() < 1e3 * 2.221e-16
     assert Lx.min() > -1e-9 and Rx.min() > -1e-9
-    for b in (0, 17, 511, 1023):
-        d = bt.read_problem(b)
-        Ax = d["A"] @ x[b]
-        assert (Ax >= d["lbA"] - 1e-8).all() and (Ax <= d["ubA"] + 1e-8).all()
-        yA = y[b, n:n + nC]; yL = y[b, n + nC:n + nC + nComp]; yR = y[b, n + nC + nComp:]
-        stat = d["Q"] @ x[b] + d["g"] - d["A"].T @ yA - d["L"].T @ yL - d["R"].T @ yR - y[b, :n]
-        assert np.abs(stat).max() < 1e-8
-        # S-stationary points minimise the convex QP of their complementarity branch (biactive pairs as inequalities);
-        # the branch QP is solved by the QP solver alone, no homotopy involved
+    # The independent property check over the WHOLE batch (nothing here shares code with the homotopy): primal feasibility, LCQP stationarity
+    # of the returned (transformed) duals, sign and complementary slackness of the row multipliers -- a few einsums per chunk of instances
+    # read back from HBM (bit-identical to the host generator: test_lcqp_synthetic_vs_oracle).
+    worst = dict(feas=0.0, stat=0.0, slack=0.0, sign=0.0)
+    probs = {}
+    for c0 in range(0, B, 128):
+        ds = [bt.read_problem(b) for b in range(c0, c0 + 128)]
+        for k_, b in enumerate(range(c0, c0 + 128)):
+            if b % 16 == 0:
+                probs[b] = ds[k_]                                             # the 64-instance sample of the branch-QP check below
+        Qs = np.stack([d["Q"] for d in ds]); As = np.stack([d["A"] for d in ds]); gs = np.stack([d["g"] for d in ds])
+        lo = np.stack([d["lbA"] for d in ds]); hi = np.stack([d["ubA"] for d in ds])
+        xs, ys = x[c0:c0 + 128], y[c0:c0 + 128]
+        Ax = np.einsum("brc,bc->br", As, xs)
+        yA, yL, yR, ybox = ys[:, n:n + nC], ys[:, n + nC:n + nC + nComp], ys[:, n + nC + nComp:], ys[:, :n]
+        stat = np.einsum("bij,bj->bi", Qs, xs) + gs - np.einsum("brc,br->bc", As, yA) - ybox
+        stat[:, :nComp] -= yL; stat[:, nComp:2 * nComp] -= yR                 # L = [I 0 0], R = [0 I 0] (checked against the read-back below)
+        assert all(np.array_equal(d["L"], np.eye(nComp, n)) and np.array_equal(d["R"], np.eye(nComp, n, nComp)) for d in ds[:4])
+        worst["feas"] = max(worst["feas"], float(np.maximum(lo - Ax, Ax - hi).max()))
+        worst["stat"] = max(worst["stat"], float(np.abs(stat).max()))
+        # dual layout of SURVEY.md §8(b): y >= 0 on a row at its lower bound, <= 0 at its upper bound, zero strictly inside
+        dlo, dhi = Ax - lo, hi - Ax
+        worst["slack"] = max(worst["slack"], float((np.abs(yA) * np.minimum(dlo, dhi)).max()))
+        worst["sign"] = max(worst["sign"], float(np.maximum(np.where(dlo > 1e-7, yA, 0.0).max(), np.where(dhi > 1e-7, -yA, 0.0).max())))
+        assert np.abs(ybox).max() == 0.0                                      # no box bounds in this workload
+    assert worst["feas"] < 1e-8 and worst["stat"] < 1e-8 and worst["slack"] < 1e-8 and worst["sign"] < 1e-8, worst
+    # S-stationary points minimise the convex QP of their complementarity branch (biactive pairs as inequalities); the branch QP is solved
+    # by the QP solver alone, no homotopy involved: every S-stationary instance of a 64-instance sample
+    nS = 0
+    for b, d in probs.items():
         if st[b]["status"] == 4:
             dd = dict(d); dd.update(nV=n, nC=nC, nComp=nComp)
             xb = P.branch_qp_solution(oracle, dd, x[b])
-            assert xb is not None and np.abs(xb - x[b]).max() < 1e-7
+            assert xb is not None and np.abs(xb - x[b]).max() < 1e-7, b
+            nS += 1
+    assert nS >= 32
     # second run on the same handle reproduces the first bit for bit (determinism with perturbStep = 0)
     bt.run()
     x2, y2, st2 = bt.solution()

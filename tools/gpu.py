@@ -26,7 +26,7 @@ def command(name, doc):
 def cmd_bias():
     """Where do the HIP batch loop and the CPU oracle part ways on the synthetic workload?
 
-        python tools/gpu_bias.py [--count N] [name=lib.so ...]
+        python tools/gpu.py bias [--count N] [name=lib.so ...]
 
     For every library variant (default: the product library): solve instances 0..N-1 with the device trace on, solve the same
     instances with the oracle (trace on, all host cores), print the histogram of iterTotal(gpu) - iterTotal(cpu), and for the
@@ -134,7 +134,7 @@ def cmd_bulk_profile():
 @command("checks", "Run every GPU building block against the CPU oracle / numpy and print the errors (no asserts).")
 def cmd_checks():
     """Run every GPU building block against the CPU oracle / numpy and print the errors (no asserts).
-    Used for bring-up on a gpurun box:  python tools/gpu_checks.py [quick]"""
+    Used for bring-up on a gpurun box:  python tools/gpu.py checks [quick]"""
     import os, sys, time
     import numpy as np
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -279,7 +279,7 @@ def cmd_dual_diff():
 @command("dump_iters", "Dump iterTotal / iterOuter / rhoOpt / x of the first N synthetic instances solved by a library variant to gpurun_out/r3/<tag>_iters.npz.")
 def cmd_dump_iters():
     """Dump iterTotal / iterOuter / rhoOpt / x of the first N synthetic instances solved by a library variant to gpurun_out/r3/<tag>_iters.npz.
-    usage: python tools/gpu_dump_iters.py lib.so tag [N]"""
+    usage: python tools/gpu.py dump_iters lib.so tag [N]"""
     import os, sys
     import numpy as np
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -302,7 +302,7 @@ def cmd_dump_iters():
 @command("dump_prof", "Dump the per-instance phase cycle counters of a -DLCQP_PROFILE library and the instance statistics to gpurun_out/r3/<tag>_prof.npz.")
 def cmd_dump_prof():
     """Dump the per-instance phase cycle counters of a -DLCQP_PROFILE library and the instance statistics to gpurun_out/r3/<tag>_prof.npz.
-    usage: python tools/gpu_dump_prof.py lib.so tag [B]"""
+    usage: python tools/gpu.py dump_prof lib.so tag [B]"""
     import ctypes as C, os, sys
     import numpy as np
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -345,7 +345,7 @@ def cmd_dump_stamps():
 @command("dump_traces", "Dump the device traces (scalars and xk per iterate) of some synthetic instances to gpurun_out/r3/traces.npz.")
 def cmd_dump_traces():
     """Dump the device traces (scalars and xk per iterate) of some synthetic instances to gpurun_out/r3/traces.npz.
-    usage: python tools/gpu_dump_traces.py lib.so id id ..."""
+    usage: python tools/gpu.py dump_traces lib.so id id ..."""
     import os, sys
     import numpy as np
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -371,7 +371,7 @@ def cmd_dump_traces():
 def cmd_full_parity():
     """Whole-workload parity: every instance of the node-sized synthetic job (8192 LCQPs, BASELINE configs[3]) solved by the
     batched HIP path on one GPU and by the CPU oracle on all host cores; prints the largest primal / dual difference and how
-    many instances took a different number of iterates.   usage: python tools/gpu_full_parity.py [instances] [chunk]"""
+    many instances took a different number of iterates.   usage: python tools/gpu.py full_parity [instances] [chunk]"""
     import os
     import sys
     import time
@@ -554,7 +554,7 @@ def cmd_phase_profile():
 @command("quick", "Quick check of a library variant on the synthetic workload against the oracle: solved counts, max|dx|, iterate histogram,")
 def cmd_quick():
     """Quick check of a library variant on the synthetic workload against the oracle: solved counts, max|dx|, iterate histogram,
-    work counters.  usage: python tools/gpu_quick.py lib.so [N]"""
+    work counters.  usage: python tools/gpu.py quick lib.so [N]"""
     import os, sys, time
     import numpy as np
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -580,9 +580,9 @@ def cmd_quick():
     print("  work sums per LCQP:", ws, " alg MB per LCQP %.1f" % (bt.algorithmic_bytes() / N / 1e6))
 
 
-@command("quick_parity", "Quick check of a library variant against the CPU oracle: python tools/gpu_quick_parity.py path/to/lib.so [B] [n nC nComp]")
+@command("quick_parity", "Quick check of a library variant against the CPU oracle: python tools/gpu.py quick_parity path/to/lib.so [B] [n nC nComp]")
 def cmd_quick_parity():
-    """Quick check of a library variant against the CPU oracle: python tools/gpu_quick_parity.py path/to/lib.so [B] [n nC nComp]"""
+    """Quick check of a library variant against the CPU oracle: python tools/gpu.py quick_parity path/to/lib.so [B] [n nC nComp]"""
     import os, sys
     import numpy as np
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -635,7 +635,7 @@ def cmd_shape_sweep():
 @command("single_latency", "Latency of one LCQP on the two single-problem paths: the reference's host loop over SubsolverHIP (one kernel launch per QP) and")
 def cmd_single_latency():
     """Latency of one LCQP on the two single-problem paths: the reference's host loop over SubsolverHIP (one kernel launch per QP) and
-    a batch of one (whole homotopy in one launch).   usage: python tools/gpu_single_latency.py"""
+    a batch of one (whole homotopy in one launch).   usage: python tools/gpu.py single_latency"""
     import os, sys, time
     import numpy as np
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -667,9 +667,9 @@ def cmd_single_latency():
         print(f"{name:18s} host loop {1e3 * h[0]:8.1f} ms (ret {h[1]}, {h[2]} iterates, {h[3]} subproblem its)   batch of one {1e3 * b[0]:8.1f} ms ({b[2]} iterates)   CPU oracle {1e3 * to:8.1f} ms")
 
 
-@command("sparse_check", "Sparse arm on the GPU against the sparse CPU oracle: python tools/gpu_sparse_check.py [B] [n nC nComp]")
+@command("sparse_check", "Sparse arm on the GPU against the sparse CPU oracle: python tools/gpu.py sparse_check [B] [n nC nComp]")
 def cmd_sparse_check():
-    """Sparse arm on the GPU against the sparse CPU oracle: python tools/gpu_sparse_check.py [B] [n nC nComp]"""
+    """Sparse arm on the GPU against the sparse CPU oracle: python tools/gpu.py sparse_check [B] [n nC nComp]"""
     import os, sys, time
     import numpy as np
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -704,7 +704,7 @@ def cmd_sparse_check():
 def cmd_sparse_profile():
     """Diagnostic: where does k_sparse_run spend its time?  Runs a -DLCQP_PROFILE build of the library (s_memtime stamps between phases,
     per instance) on the sparse BASELINE workload and prints the share of each phase.  Shares only -- the stamped build is not the
-    measured build.   usage: python tools/gpu_sparse_profile.py --so=ab_tmp/libprof.so [B]
+    measured build.   usage: python tools/gpu.py sparse_profile --so=ab_tmp/libprof.so [B]
     (build the library first, here or on the box:  python -c "import __graft_entry__ as g; g.build_hip(True, 'ab_tmp/libprof.so', ['-DLCQP_PROFILE'], 2)")"""
     import ctypes as C, os, sys
     import numpy as np
@@ -747,7 +747,7 @@ def cmd_sparse_profile():
 def cmd_spmv_bench():
     """SpMV rate of the device CSC products (lcqp_hip_csc_apply) at the sizes of BASELINE config 5 (n = 4096) and beyond.
     Bytes per product: 12 per non-zero (8 value + 4 index) + 4 per column pointer + 8 per input and output entry.
-    usage: python tools/gpu_spmv_bench.py"""
+    usage: python tools/gpu.py spmv_bench"""
     import os, sys
     import numpy as np
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -801,7 +801,7 @@ def cmd_trace_check():
 @command("trace_diff", "Print the per-iterate trace (|stat|, phi, rho, alpha, obj, merit, |p|, qp iterations) of one named test problem from the HIP")
 def cmd_trace_diff():
     """Print the per-iterate trace (|stat|, phi, rho, alpha, obj, merit, |p|, qp iterations) of one named test problem from the HIP
-    batch loop beside the oracle's.  usage: python tools/gpu_trace_diff.py warm_up_w_A"""
+    batch loop beside the oracle's.  usage: python tools/gpu.py trace_diff warm_up_w_A"""
     import os, sys
     import numpy as np
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -827,8 +827,8 @@ def cmd_trace_diff():
 @command("trace_tail", "Where the HIP and oracle homotopies of one synthetic instance part: [stat, phi, rho, alpha] per stored iterate around the")
 def cmd_trace_tail():
     """Where the HIP and oracle homotopies of one synthetic instance part: [stat, phi, rho, alpha] per stored iterate around the
-    first iterate whose scalars differ (diagnostic for the one-cycle differences reported by tools/gpu_full_parity.py).
-    usage: python tools/gpu_trace_tail.py [instance ...]"""
+    first iterate whose scalars differ (diagnostic for the one-cycle differences reported by `python tools/gpu.py full_parity`).
+    usage: python tools/gpu.py trace_tail [instance ...]"""
     import os, sys
     import numpy as np
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -862,6 +862,56 @@ def cmd_ab():
 def cmd_fuzz():
     import gpu_fuzz
     sys.exit(gpu_fuzz.main())
+
+
+@command("fuzz_diverge", "first diverging iterate of HIP and oracle on chosen fuzz problems: python tools/gpu.py fuzz_diverge SEED ID [ID ...]")
+def cmd_fuzz_diverge():
+    """Root cause of the fuzz problems that end at another stationary point on the two sides (tools/gpu_fuzz.py): regenerates problem ID of
+    the given seed, solves it with per-iterate traces on both sides and prints the iterates around the first one where the traces part:
+    |xk_hip - xk_orc|, rho, alpha, stationarity, complementarity, QP iterations of either side, and how many candidate next points the QP
+    of that iterate has (the QP is re-solved by the oracle's QP solver from both sides' xk: a PSD Hessian has a face of minimisers)."""
+    import os
+    import numpy as np
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lcqpow_amd as la, oracle_py as O, problems as P, gpu_fuzz
+    seed = int(sys.argv[1]); ids = [int(a) for a in sys.argv[2:]]
+    O.build(); O.lib(); O.lcqp_set_robust(1)
+    rng = np.random.default_rng(seed)
+    probs = {}
+    for k in range(max(ids) + 1):
+        d = gpu_fuzz.make(rng)
+        if k in ids:
+            probs[k] = d
+    np.set_printoptions(linewidth=200, precision=3)
+    for k in ids:
+        d = probs[k]
+        ro = P.oracle_solve(O, d, O.default_options(perturbStep=0), trace=1000)
+        rh = P.hip_solve(la, d, la.default_options(perturbStep=0, storeSteps=1), trace=True)
+        so, sh, xo, xh = ro["trace_scalars"], rh["trace_scalars"], ro["trace_x"], rh["trace_x"]
+        Qe = np.linalg.eigvalsh(d["Q"])
+        print(f"=== seed {seed} id {k}: n={d['nV']} nC={d['nC']} nComp={d['nComp']} keys={sorted(set(d) - {'Q','g','L','R','nV','nC','nComp'})} "
+              f"eig(Q) min {Qe.min():.2e} max {Qe.max():.2e} rank-deficient dims {(Qe < 1e-9 * max(Qe.max(), 1e-300)).sum()}")
+        print(f"    ret {ro['ret']}/{rh['ret']} iter {len(so)}/{len(sh)} final |dx| {np.abs(ro['x'] - rh['x']).max():.2e} status {ro['stats']['status']}/{rh['stats']['status']}")
+        kk = min(len(so), len(sh))
+        dxs = np.array([np.abs(xo[i] - xh[i]).max() for i in range(kk)])
+        first = int(np.argmax(dxs > 1e-6 * (1 + np.abs(xo[:kk]).max()))) if (dxs > 1e-6 * (1 + np.abs(xo[:kk]).max())).any() else kk
+        for i in range(max(0, first - 2), min(kk, first + 3)):
+            print(f"    it {i}: |dx| {dxs[i]:.2e}  orc [stat {so[i,0]:.2e} phi {so[i,1]:.2e} rho {so[i,2]:g} alpha {so[i,3]:.6g} obj {so[i,4]:.10g} |p| {so[i,6]:.2e} qpit {so[i,7]:g}]"
+                  f"  hip [stat {sh[i,0]:.2e} phi {sh[i,1]:.2e} rho {sh[i,2]:g} alpha {sh[i,3]:.6g} obj {sh[i,4]:.10g} |p| {sh[i,6]:.2e} qpit {sh[i,7]:g}]")
+        if 0 < first < kk:
+            # the QP that produced iterate `first`: min 1/2 x'Qx + (g_tilde + rho C xk)'x at xk = iterate first-1 -- objective values of the
+            # two sides' next points in the penalised merit of THAT iterate: equal values = two minimisers of one QP (a face), not an error
+            i = first - 1
+            rho = so[i + 1, 2] if so[i + 1, 2] == sh[i + 1, 2] else so[i, 2]
+            Cm = d["L"].T @ d["R"] + d["R"].T @ d["L"]
+            lbL = d.get("lbL", np.zeros(d["nComp"])); lbR = d.get("lbR", np.zeros(d["nComp"]))
+            gphi = -(d["R"].T @ lbL + d["L"].T @ lbR)
+            for side, xs in (("orc", xo), ("hip", xh)):
+                xk, xn = xs[i], xs[i + 1]
+                gk = d["g"] + rho * gphi + rho * (Cm @ xk)
+                f = lambda v: 0.5 * v @ d["Q"] @ v + gk @ v
+                print(f"    {side}: QP at iterate {i} (rho {rho:g}): f(xk) {f(xk):.12g} f(x_next) {f(xn):.12g}; f(other side's x_next) {f((xh if side == 'orc' else xo)[i + 1]):.12g}; |xk_orc - xk_hip| {np.abs(xo[i] - xh[i]).max():.2e}")
 
 
 if __name__ == "__main__":
