@@ -240,22 +240,29 @@ def main():
     main_proc = (rank == 0)
 
     if main_proc and world == 1 and not sparse and not args.no_pipelined:
-        # not the headline: the same K steps with two batch objects in flight on two streams (step k+1 is launched while step k
-        # still runs), so that the launch tail of one step -- its slowest instances -- overlaps with the bulk of the next
-        bt2 = make_batch(devices[0])
-        bt2.run(); bt2.synchronize()
-        pair = (bt, bt2)
+        # not the headline: the same K steps as a stream of batches through the product's pipeline (lcqpow_amd.BatchPipeline, the twin of
+        # LCQPow::BatchPipeline in lcqpow_amd/csrc/host/BatchLCQProblem.hpp): two batch objects, each with its own buffers and HIP stream, so
+        # that the launch tail of one step -- its slowest instances, most workgroup slots already idle -- overlaps with the setup kernels and
+        # the first instances of the next.  Every step still does setup + homotopy of a whole batch; results are bit-identical.
+        pipe = la.BatchPipeline(2, B, n, nC, nComp, device=devices[0], opt=opt)
+        for s_ in pipe.slots:
+            s_.generate_synthetic(0); s_.run(); s_.synchronize()
+        ksteps = max(2, args.steps)
+        solved_p, last = 0, None
         tp = time.perf_counter()
-        for k in range(max(2, args.steps)):
-            pair[k % 2].run()                 # asynchronous: returns after the launches
-        bt.synchronize(); bt2.synchronize()
+        for k in range(ksteps):
+            b_, done = pipe.acquire()
+            # (a caller consumes b_.solution() here when `done`, then loads its next batch of problems into b_)
+            pipe.launch(b_)
+        for b_ in pipe.drain():
+            last = b_
         dtp = time.perf_counter() - tp
-        x2, _, st2 = bt2.solution()
-        out["pipelined"] = {"depth": 2, "steps": max(2, args.steps), "value": B * max(2, args.steps) / dtp, "unit": "LCQPs/s",
-                            "ms_per_step": 1e3 * dtp / max(2, args.steps), "solved_last_step": sum(1 for s_ in st2 if s_["returnValue"] == 0),
+        x2, _, st2 = last.solution()
+        out["pipelined"] = {"depth": 2, "steps": ksteps, "value": B * ksteps / dtp, "unit": "LCQPs/s",
+                            "ms_per_step": 1e3 * dtp / ksteps, "solved_last_step": sum(1 for s_ in st2 if s_["returnValue"] == 0),
                             "bitwise_equal_to_sequential": bool(np.array_equal(x2, x)),
-                            "note": "two independent batches of the same workload in flight on two streams; every step still does setup + homotopy"}
-        bt2.close()
+                            "note": "product call: lcqpow_amd.BatchPipeline / LCQPow::BatchPipeline, two batch objects in flight on two streams; every step still does setup + homotopy"}
+        pipe.close()
 
     if main_proc and world == 1 and not sparse and not args.no_resident and shape == (256, 512, 64) and B == 1024:
         # the node-sized job of BASELINE configs[3] (8192 instances) resident on ONE GPU: shows what the tail of a launch that is

@@ -1,8 +1,9 @@
 // Throughput path: B independent dense LCQPs generated in HBM and solved by one launch of the homotopy kernel.
-//   batch_synthetic [B=1024] [nV=256] [nC=512] [nComp=64]
+//   batch_synthetic [B=1024] [nV=256] [nC=512] [nComp=64] [pipelined steps=8]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "BatchLCQProblem.hpp"
 
@@ -27,5 +28,28 @@ int main(int argc, char** argv)
     long iters = 0;
     for (int i = 0; i < B; i++) { ok += batch.getReturnValue(i) == SUCCESSFUL_RETURN; iters += batch.getStats(i).iterTotal; }
     std::printf("%d/%d LCQPs solved in %.1f ms (%.0f LCQPs/s), %.1f iterates per LCQP\n", ok, B, dt * 1e3, B / dt, (double)iters / B);
-    return ok == B ? 0 : 1;
+    if (ok != B) return 1;
+    // the same work as a stream of batches over two batch objects (BatchPipeline): batch k+1 is generated and launched while batch k runs
+    const int steps = argc > 5 ? std::atoi(argv[5]) : 8;
+    BatchPipeline pipe(2, B, nV, nC, nComp);
+    if (!pipe.ok()) { std::printf("could not create the pipeline: %s\n", lcqp_hip_last_error()); return 1; }
+    for (int k = 0; k < pipe.depth(); k++) { pipe.slot(k).setOptions(options); pipe.slot(k).generateSynthetic(0x4C43515000000001ULL, 0); pipe.slot(k).runSolver(); }
+    long solved = 0;
+    double check = 0.0;
+    std::vector<double> xv(nV);
+    auto consume = [&](BatchLCQProblem& b) {
+        for (int i = 0; i < B; i++) { solved += b.getReturnValue(i) == SUCCESSFUL_RETURN; }
+        b.getPrimalSolution(0, xv.data()); check += xv[0];
+    };
+    const auto t1 = std::chrono::steady_clock::now();
+    for (int k = 0; k < steps; k++) {
+        BatchLCQProblem& b = pipe.acquire();
+        if (pipe.hasResults()) consume(b);
+        // (a real caller loads the next batch of problems here: loadLCQP / generateSynthetic)
+        if (pipe.launch(b) != SUCCESSFUL_RETURN) { std::printf("launch failed: %s\n", lcqp_hip_last_error()); return 1; }
+    }
+    while (BatchLCQProblem* b = pipe.drain()) consume(*b);
+    const double dp = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    std::printf("pipelined, depth 2: %ld/%ld LCQPs solved in %.1f ms (%.0f LCQPs/s)\n", solved, (long)steps * B, dp * 1e3, steps * (double)B / dp);
+    return solved == (long)steps * B ? 0 : 1;
 }

@@ -209,6 +209,9 @@ lcqp_hip_sparse_t* lcqp_hip_sparse_create(int batch, int nV, int nC, int nComp, 
                                           const int* Ap, const int* Ai, int device);
 void lcqp_hip_sparse_destroy(lcqp_hip_sparse_t* s);
 const char* lcqp_hip_sparse_last_error(void);
+/* diagnostic (-DLCQP_SCHED_PROFILE builds, zeros otherwise): per phase of the scheduler (start, round, trial, factor, correct, QP end, idle polls)
+ * clock ticks, wavefront steps, instances served: 21 values */
+int  lcqp_hip_sparse_sched_profile(lcqp_hip_sparse_t* s, unsigned long long* out21);
 int  lcqp_hip_sparse_bandwidth(const lcqp_hip_sparse_t* s);              /* half bandwidth of the KKT band */
 int  lcqp_hip_sparse_lanes(const lcqp_hip_sparse_t* s);                  /* lanes of a wavefront per instance: 8, 16, 32 or 64 */
 int  lcqp_hip_sparse_border(const lcqp_hip_sparse_t* s);                 /* border nodes of the bordered band: the last positions of the ordering (0: plain band) */

@@ -182,6 +182,44 @@ class SubsolverHIP:
             pass
 
 
+class BatchPipeline:
+    """A stream of batches over `depth` BatchLCQP objects (each has its own HIP stream; run() only launches): the host-side twin of
+    LCQPow::BatchPipeline (lcqpow_amd/csrc/host/BatchLCQProblem.hpp, DESIGN.md section 8a).  acquire() hands out the object to fill next --
+    a free one, else the oldest one in flight after waiting for it (its results are then read with .solution())."""
+
+    def __init__(self, depth, batch, nV, nC, nComp, with_box=False, device=0, opt=None):
+        self.slots = [BatchLCQP(batch, nV, nC, nComp, with_box=with_box, device=device, opt=opt) for _ in range(depth)]
+        self.state = [0] * depth          # 0 free, 1 in flight, 2 finished
+        self.order = []
+
+    def acquire(self):
+        for k, s in enumerate(self.state):
+            if s == 0:
+                return self.slots[k], False
+        k = self.order.pop(0)
+        self.slots[k].synchronize()
+        self.state[k] = 2
+        return self.slots[k], True        # (object, it carries a finished run)
+
+    def launch(self, bt):
+        k = self.slots.index(bt)
+        bt.run()
+        self.state[k] = 1
+        self.order.append(k)
+
+    def drain(self):
+        """the batches still in flight, oldest first"""
+        while self.order:
+            k = self.order.pop(0)
+            self.slots[k].synchronize()
+            self.state[k] = 0
+            yield self.slots[k]
+
+    def close(self):
+        for s in self.slots:
+            s.close()
+
+
 class BatchLCQP:
     """B independent dense LCQPs of one shape solved on one GPU (lcqp_hip_batch_*)."""
 

@@ -36,8 +36,14 @@ class BatchLCQProblem {
     // runSolver for every instance; per-instance return values are in getReturnValue(i)
     ReturnValue runSolver()
     {
-        int rc = lcqp_hip_batch_run(h);
-        if (rc) return (ReturnValue)rc;
+        const ReturnValue rc = runSolverAsync();
+        return rc != SUCCESSFUL_RETURN ? rc : collect();
+    }
+    // the two halves of runSolver: the launches on this batch's own HIP stream (returns at once), and the wait + read-back.  Between the two
+    // the host is free -- e.g. to load and launch another batch object (BatchPipeline below).
+    ReturnValue runSolverAsync() { return (ReturnValue)lcqp_hip_batch_run(h); }
+    ReturnValue collect()
+    {
         x.assign((size_t)B * nV_, 0.0);
         y.assign((size_t)B * (nV_ + nC_ + 2 * nComp_), 0.0);
         st.assign(B, lcqp_stats_t());
@@ -65,6 +71,59 @@ class BatchLCQProblem {
     lcqp_hip_batch_t* h;
     std::vector<double> x, y;
     std::vector<lcqp_stats_t> st;
+};
+
+// A stream of batches over `depth` batch objects.  A launch whose batch fills the GPU exactly once ends with its
+// slowest instances while most workgroup slots are already idle (B = 1024: an average slot is busy 80 % of the launch); with a second batch
+// object in flight -- its own buffers, its own HIP stream -- the setup kernels and the first instances of batch k+1 run in that tail.  Every
+// batch still does all of runSolver's work; results are bit-identical to the sequential use.  Usage:
+//     BatchPipeline pipe(2, 1024, nV, nC, nComp);
+//     for (each batch of problems) { BatchLCQProblem& b = pipe.acquire();   // waits for (and hands back) the oldest batch when all are in flight
+//                                    if (b.hasResults()) consume(b);  load(b);  pipe.launch(b); }
+//     while (BatchLCQProblem* b = pipe.drain()) consume(*b);
+class BatchPipeline {
+  public:
+    BatchPipeline(int depth, int batch, int nV, int nC, int nComp, bool withBoxBounds = false, int device = 0)
+    {
+        for (int k = 0; k < depth; ++k) { slots.push_back(new BatchLCQProblem(batch, nV, nC, nComp, withBoxBounds, device)); state.push_back(0); }
+    }
+    ~BatchPipeline() { for (size_t k = 0; k < slots.size(); ++k) delete slots[k]; }
+    BatchPipeline(const BatchPipeline&) = delete;
+    BatchPipeline& operator=(const BatchPipeline&) = delete;
+    bool ok() const { for (size_t k = 0; k < slots.size(); ++k) if (!slots[k]->ok()) return false; return !slots.empty(); }
+    int depth() const { return (int)slots.size(); }
+    BatchLCQProblem& slot(int k) { return *slots[k]; }
+    // the batch object to fill next: a free one, else the oldest one in flight (waited for; its results are then in the object: resultsOf())
+    BatchLCQProblem& acquire()
+    {
+        for (size_t k = 0; k < slots.size(); ++k) if (state[k] == 0) { cur = (int)k; return *slots[k]; }
+        const int k = order.front(); order.erase(order.begin());
+        lastRc = slots[k]->collect(); state[k] = 2; cur = k;
+        return *slots[k];
+    }
+    bool hasResults() const { return cur >= 0 && state[cur] == 2; }     // the object acquire() returned carries a finished run
+    ReturnValue lastCollectStatus() const { return lastRc; }
+    ReturnValue launch(BatchLCQProblem& b)
+    {
+        for (size_t k = 0; k < slots.size(); ++k)
+            if (slots[k] == &b) { const ReturnValue rc = b.runSolverAsync(); if (rc == SUCCESSFUL_RETURN) { state[k] = 1; order.push_back((int)k); } return rc; }
+        return INVALID_ARGUMENT;
+    }
+    // after the last launch: the batches still in flight, oldest first (NULL when none is left)
+    BatchLCQProblem* drain()
+    {
+        if (order.empty()) return 0;
+        const int k = order.front(); order.erase(order.begin());
+        lastRc = slots[k]->collect(); state[k] = 0;
+        return slots[k];
+    }
+
+  private:
+    std::vector<BatchLCQProblem*> slots;
+    std::vector<int> state;      // 0 free, 1 in flight, 2 finished (results in the object)
+    std::vector<int> order;      // launch order of the batches in flight
+    int cur = -1;
+    ReturnValue lastRc = SUCCESSFUL_RETURN;
 };
 
 }  // namespace LCQPow

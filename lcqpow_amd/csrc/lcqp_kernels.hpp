@@ -171,11 +171,10 @@ __global__ __launch_bounds__(WG) void k_compress_C(DevBatch db)
 }
 
 // ---- k_factor: the constant factorisation L1 of Q + sp I (L_K of the ADMM fallback is built on demand, qp_build_K) ----
-#ifndef LCQP_FACTOR_MINWAVES
-#define LCQP_FACTOR_MINWAVES 4      // 4 workgroups per CU: the 1024 instances of the BASELINE batch are one residency wave (at 3 a second, quarter-full wave follows)
-#endif
+// (4 instead of 3 workgroups per CU -- __launch_bounds__(WG, 4): the batch in one residency wave -- changes nothing: 5.566 vs 5.567 ms of setup in a
+// same-box A/B; the kernel is bound by its 64-step chains, not by slots)
 template <int NCH>
-__global__ __launch_bounds__(WG, LCQP_FACTOR_MINWAVES) void k_factor(DevBatch db)
+__global__ __launch_bounds__(WG) void k_factor(DevBatch db)
 {
     LCQP_LDS_N(NCH)
     constexpr int np = 128 * NCH;

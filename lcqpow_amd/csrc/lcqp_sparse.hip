@@ -1,6 +1,6 @@
 // lcqp_sparse.hip -- the SPARSE arm of the hot path on gfx950: B independent LCQPs that share one sparsity pattern, behind
 // lcqp_hip_sparse_* (include/lcqp_hip.h).  G lanes of a wavefront per instance (G = 8, 16, 32 or 64: the smallest power of two
-// above the half bandwidth of the KKT band), 64 / G instances per wavefront, one wavefront per workgroup (k_sparse_run).
+// above the half bandwidth of the KKT band), 64 / G instances per wavefront, one wavefront per workgroup (k_sparse_sched).
 //
 // Restates, with the conventions of the reference's OSQP_SPARSE arm (src/LCQProblem.cpp:929-960: no box constraints, nC + 2 nComp
 // duals, no box term in the stationarity :1246-1272, dual sign of src/SubsolverOSQP.cpp:196-199):
@@ -37,7 +37,7 @@ constexpr int SP_WMAX = 63;
 constexpr int SP_KBMAX = 16;   // border nodes of the bordered band (rows / variables too dense for a band)
 constexpr int WGS = 64;      // one wavefront per workgroup; 64 / G instances in it
 #ifndef SP_WAVES_PER_SIMD
-#define SP_WAVES_PER_SIMD 2  // register budget of k_sparse_run: 512 / SP_WAVES_PER_SIMD per lane
+#define SP_WAVES_PER_SIMD 2  // register budget of k_sparse_sched: 512 / SP_WAVES_PER_SIMD per lane
 #endif
 #ifndef SP_SWEEP_RING
 #define SP_SWEEP_RING 4      // coefficient chunks (8 steps each) of a band sweep in flight at G = 8
@@ -56,6 +56,34 @@ struct SpInfo {
     double prof[8];      // -DLCQP_PROFILE: clock ticks per phase (SP_* below)
 };
 enum { SP_PRODUCTS, SP_ASSEMBLE, SP_FACTOR, SP_FORWARD, SP_BACKWARD, SP_VECTORS, SP_LCQP, SP_RHS, SP_NPHASE };
+
+// ---- the homotopy as a phase machine (round 4) ----------------------------------------------------------------------------------------
+// Round 3 ran the whole homotopy of an instance inside one persistent lane group: the 64 / G instances of a wavefront moved in lock step, an
+// instance was active in 74 % of its wavefront's trials and refactorised in 26 % of them while its wavefront did in 83 %.  Now an instance is
+// a record in memory (SpState + its vectors) that moves through QUEUES, one per phase; a wavefront pops up to 64 / G instances that are in
+// the SAME phase, runs that phase for them, and pushes each to the queue of its next phase (k_sparse_sched).  A wavefront therefore only
+// ever holds instances doing the same thing; nobody waits for a neighbour's factorisation or for the slowest polish of eight.
+enum { PH_START, PH_ROUND, PH_TRIAL, PH_FACTOR, PH_CORRECT, PH_QPEND, PH_NUM };
+struct SpState {
+    // LCQProblem::runSolver (src/LCQProblem.cpp:444-560)
+    int initial, histLen, algoStat, totalIter, rc, qpIter;
+    double alphak, rho, gmaxNext;
+    unsigned long long perturbCounter;
+    lcqp_stats_t st;
+    // the subsolver call (oracle: sqp_solve)
+    int round, n_admm, use_stored, backup_pending, admm_ready, trials0, admm0;
+    // the polish (oracle: sqp_polish)
+    int trial, reuse, fact_valid, borderTodo;
+    double gs, ytol, dpUsed, d2Used;
+    // work counters
+    int cAdmm, cTrials, cFact, cCorr, cSweeps;
+    double bytes;
+};
+// Queues: the batch is cut into pools of `poolSize` consecutive instances (a power of two; the byte offset of an instance inside its pool fits
+// 32 bits for every per-instance array: the saddr + 32-bit offset addressing of SpCtx::arr); wavefront w serves pool w % nPools.  Per pool
+// and phase a ring of poolSize entries (an instance is in at most one queue) and three counters: tail (next slot to write), head (next slot to
+// read), count (entries published).  ctl[pool][PH_NUM] = instances of the pool not finished yet.
+constexpr int QCTL = 4;      // ints per (pool, phase): tail, head, count, pad
 
 struct EllMat { const int *eidx, *epos, *ptr, *cidx, *cmap; int rows, W, tails; };   // see g_ell
 
@@ -91,6 +119,11 @@ struct SpBatch {
     double *traceS, *traceX;
     int* traceLen;
     int traceCap;
+    // phase machine
+    SpState* state;          // [B]
+    int *qring, *qctl;       // [nPools][PH_NUM][poolSize], [nPools][PH_NUM + 1][QCTL]
+    int poolSize, nPools;
+    unsigned long long* qprof;   // [PH_NUM + 1][3] (-DLCQP_SCHED_PROFILE): clock ticks, wavefront steps, instances served per phase; row PH_NUM: ticks / polls without work
 };
 
 // ---- addressing: uniform base pointer + 32-bit lane offset -------------------------------------------------------------------------
@@ -123,8 +156,8 @@ template <int G>
 struct SpCtx {
     const SpBatch* db;
     int b, gl;               // instance, lane inside the group
-    unsigned gi;             // group (instance) inside the wave
-    int w0;                  // first instance of the wave (uniform)
+    unsigned gi;             // this instance's index relative to w0
+    int w0;                  // first instance of the block of instances the wave addresses (uniform): its own 64 / G instances (k_sparse_setup) or its pool (k_sparse_sched)
     SpInfo* info;
     double* win;             // LDS of this group: G x G window + 16 staged rows
     int cAdmm, cTrials, cFact, cCorr, cSweeps;
@@ -808,238 +841,500 @@ __device__ __forceinline__ void sp_admm(SpCtx<G>& c, GD g, int n_it)
     }
 }
 
-// ---- primal-dual active-set polish in correction form (oracle: sqp_polish) ---------------------------------------------------
+// ---- the phases of an instance's homotopy (k_sparse_sched runs them) -----------------------------------------------------------------------
+// Every routine below is called by the G lanes of one instance with that instance's context and state record (all values uniform inside the
+// group) and returns the phase the instance enters next (PH_NUM: finished).  Together they are runSolver (src/LCQProblem.cpp:444-560), the
+// subsolver call (oracle: sqp_solve) and the polish (oracle: sqp_polish) of round 3, cut at the points where instances of one wavefront used
+// to part: before a trial, before a factorisation, before a correction, at the end of a QP.
 struct StRow { int s; double e, lo, hi, y; };
 struct I2 { int a, b; };
 struct I2D { int a, b; double y; };
 struct ID4 { int p, s; double lo, hi, e; };
 struct ID2 { int s; double v, y; };
-
-template <int G>
-__device__ __forceinline__ int sp_polish(SpCtx<G>& c, GD g, int reuse, double gmaxHint)
-{
-    const SpBatch& db = *c.db;
-    const lcqp_options_t& o = db.opt;
-    const int t = c.gl, n = db.n, m = db.m;
-    GD x = c.V(NV_XT), r1 = c.V(NV_R1), qx = c.V(NV_TMP), yt = c.M(MV_YT), ex = c.M(MV_EX), b = c.Nv();
-    GD l = c.M(MV_L), u = c.M(MV_U);
-    GI st = c.I(MI_STT), stf = c.I(MI_STF), newst = c.I(MI_NEW);
-    const int* iperm = db.iperm;
-    const double gs = 1.0 + ((reuse && gmaxHint >= 0.0) ? gmaxHint : sp_maxabs<G>(c, g, n));      // (the LCQP level knows max|g| of the vector it has just formed)
-    const double ytol = o.feasTol * gs;
-    int fact_valid = 0, borderTodo = 0;
-    double dpUsed = c.info->delta, d2Used = c.info->delta2;      // regularisation of the factorisation in use
-    for (int trial = 0; trial < o.maxTrials; trial++) {
-        c.cTrials++;
-        // Two stages, as on the dense path (oracle: sqp_polish).  Stage 1 is what every trial needs: E x, for the status test.  Stage 2 -- the
-        // true residual, one pass over Q and one over E' -- runs only when stage 1 changed nothing: after a correction the residual is zero on
-        // the old working set up to rounding and regularisation, so when the set changes the next right-hand side is known without it (the
-        // multipliers of the leaving rows, below); the trial that accepts always has the true residual.
-        double res_stat = 0.0;
-        int have_r1 = 0;
-        if (trial == 0 && reuse) {
-            // hot start with an unchanged (x, y): r1 = r1_last + (g_last - g) and E x are in place -- the residual and E x of the accepted
-            // trial stay where they are, and the LCQP level adds (g_last - g) to r1 in the pass that forms the new g (k_sparse_run)
-            have_r1 = 1;
-        } else {
-            sp_Ex<G>(c, x, ex);
-            c.bytes += 12.0 * db.nnzE + 8.0 * (n + m);
-        }
-        double res_eq = 0.0, bmax = 0.0;
-        int chg = 0, act = 0;
-        g_map<G, 4>(m, t, [&](int r) { return StRow{st[r], ex[r], l[r], u[r], yt[r]}; },
-                    [&](int r, StRow v) {
-                        int ns = v.s;
-                        if (v.s == ST_INACT) {
-                            const double ftol = o.feasTol * (1.0 + fabs(v.e));
-                            if (v.e < v.lo - ftol) ns = ST_LOWER;
-                            else if (v.e > v.hi + ftol) ns = ST_UPPER;
-                        } else {
-                            const double bb = (v.s == ST_UPPER) ? v.hi : v.lo;
-                            res_eq = nmax(res_eq, fabs(bb - v.e));
-                            bmax = fmax(bmax, fabs(bb));
-                            if (v.s == ST_LOWER && v.y > ytol) ns = ST_INACT;
-                            if (v.s == ST_UPPER && v.y < -ytol) ns = ST_INACT;
-                        }
-                        newst[r] = ns;
-                        chg += (ns != v.s);
-                        act += (ns != ST_INACT);
-                    });
-        const int changed = g_sum_i<G>(chg), nact = g_sum_i<G>(act);
-        res_eq = g_max<G>(res_eq);
-        bmax = g_max<G>(bmax);
-        SPROF(c, SP_ASSEMBLE);      // (profile builds: the status test on its own)
-        if (!have_r1 && (trial == 0 || !changed)) {
-            res_stat = sp_residual<G>(c, g, x, yt, r1, qx);
-            c.cSweeps++;
-            c.bytes += 12.0 * (db.nnzQ + db.nnzE) + 8.0 * (3.0 * n + m);
-            have_r1 = 1;
-        }
-        if (trial > 0 && !changed && res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) return 1;
-        if (changed && trial > 0) {
-            if (trial >= 2 && nact > n && changed > max(n / 2, 32)) return 0;       // overshooting cold start: hand over to ADMM
-            // leaving rows: their multipliers leave the residual (r1 += E_r' y_r), then the new working set takes over
-            GD ytmp = c.M(MV_LX);
-            g_sync();
-            g_map<G, 8>(m, t, [&](int r) { return I2D{newst[r], st[r], yt[r]}; },
-                        [&](int r, I2D v) { const bool leaves = (v.a == ST_INACT && v.b != ST_INACT); ytmp[r] = leaves ? -v.y : 0.0; st[r] = v.a; if (leaves && v.y != 0.0) yt[r] = 0.0; });
-            g_sync();
-            // r1 - E'(-y_leaving) = r1 + E'y_leaving; without a true residual r1 is the predicted one: nothing was left on the old working set
-            if (have_r1) sp_ETy<G>(c, ytmp, r1, [&](int i) { return r1[i]; }, [](double v) { return v; });
-            else sp_ETy<G>(c, ytmp, r1, [](int) { return NoPre{}; }, [](NoPre) { return 0.0; });
-            fact_valid = 0;
-        }
-        if (!fact_valid) {
-            int diff = (c.info->stfValid == 0);
-#pragma unroll 8
-            for (int r = t; r < m; r += G) diff |= ((stf[r] != ST_INACT) != (st[r] != ST_INACT));
-            if (g_any<G>(diff)) {
-                // Two levels of regularisation, as on the dense path (proxSmall / proxBig).  A correction with the safe level leaves
-                // delta dx and delta2 dy (1e-8, 1e-9 relative) in the true residuals: every QP paid one refinement trial -- a sweep, a band
-                // solve, the vector passes -- for the regularisation alone.  The light level (1e-12, 1e-14) is accepted at once.  The band
-                // LDL' is not pivoted, so the light level needs an ordering in which every row follows one of its variables (lightOK, chosen
-                // by the host when every Hessian of the batch is safely definite) and is only kept when every pivot has the sign its node
-                // prescribes and a safe size; a variable's pivot failing makes the safe level permanent for the instance.
-                int level = (db.lightOK && !c.info->bigReg) ? 0 : 1;
-                for (;;) {
-                    dpUsed = level ? c.info->delta : c.info->deltaS;
-                    d2Used = level ? c.info->delta2 : c.info->delta2S;
-                    const double d2 = d2Used;
-                    sp_factor_band<G>(c, c.KF(false), c.KD(false), dpUsed, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; });
-                    if (level == 1) break;
-                    int badVar = 0, badRow = 0;
-                    GD Kd = c.KD(false);
-                    const double sc = c.info->scale, vmax = 1.0 / (1e-8 * sc), rmax = sc / 1e-8;
-                    const int Nb = db.N - db.kb;
-#pragma unroll 4
-                    for (int p = t; p < Nb; p += G) {
-                        const double kd = Kd[p];            // 1 / D
-                        const int node = db.pnode[p];
-                        if (node < n) badVar |= !(kd > 0.0 && kd < vmax);
-                        else if (st[node - n] != ST_INACT) badRow |= !(kd < 0.0 && kd > -rmax);
-                    }
-                    const bool bv = g_any<G>(badVar), br = g_any<G>(badRow);
-                    if (!bv && !br) break;
-                    if (bv && t == 0) c.info->bigReg = 1;
-                    level = 1;
-                }
-                if (db.kb > 0) { sp_border_prepare<G>(c, false, [=](int r) { return st[r] != ST_INACT; }); borderTodo = db.kb; }
-                g_map<G, 8>(m, t, [&](int r) { return st[r]; }, [&](int r, int v) { stf[r] = v; });
-                if (t == 0) c.info->stfValid = 1;
-                g_sync();
-            }
-            fact_valid = 1;
-        }
-        // correction: [Q + delta I, Ea'; Ea, -delta2 I][dx; dy] = [r1; ba - Ea x]
-        SPROF(c, SP_VECTORS);
-        g_map<G, 8>(n, t, [&](int i) { return ID{iperm[i], r1[i]}; }, [&](int, ID v) { b[v.i] = v.a; });
-        g_map<G, 4>(m, t, [&](int r) { return ID4{iperm[n + r], st[r], l[r], u[r], ex[r]}; },
-                    [&](int, ID4 v) { b[v.p] = (v.s != ST_INACT) ? ((v.s == ST_UPPER) ? v.hi : v.lo) - v.e : 0.0; });
-        g_sync();
-        SPROF(c, SP_RHS);
-        // one call site of the band solve: first the columns of W = U inv(Bd) a fresh factorisation owes (none for a plain band), then b
-        for (int jb = 0; jb <= borderTodo; jb++) {
-            GD vec = b;
-            if (jb < borderTodo) vec = sp_border_column<G>(c, false, jb);
-            else if (borderTodo > 0) { const double d2 = d2Used; sp_border_schur<G>(c, false, dpUsed, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; }); }
-            sp_solve_band<G>(c, false, vec);
-        }
-        borderTodo = 0;
-        if (db.kb > 0) sp_border_solve<G>(c, false, b);
-        g_map<G, 8>(n, t, [&](int i) { return D2{b[iperm[i]], x[i]}; }, [&](int i, D2 v) { x[i] = v.b + v.a; });
-        g_map<G, 8>(m, t, [&](int r) { return ID2{st[r], b[iperm[n + r]], yt[r]}; }, [&](int r, ID2 v) { if (v.s != ST_INACT) yt[r] = v.y + v.v; });
-        g_sync();
-        c.cCorr++;
-    }
-    return 0;
-}
-
-// ---- SubsolverBase::solve on the OSQP arm (oracle: sqp_solve) ------------------------------------------------------------------
 struct ID3 { int s; double lo, hi, z, y; };
 
+// the polish starts (oracle: sqp_polish, entry): tolerances scale with 1 + |g|_inf
 template <int G>
-__device__ __forceinline__ int sp_qp_solve(SpCtx<G>& c, int initial, GD g, int* iterations, double gmaxHint)
+__device__ __forceinline__ int sp_polish_begin(SpCtx<G>& c, SpState& S, GD g, int reuse)
+{
+    const lcqp_options_t& o = c.db->opt;
+    S.gs = 1.0 + ((reuse && S.gmaxNext >= 0.0) ? S.gmaxNext : sp_maxabs<G>(c, g, c.db->n));      // (the LCQP level knows max|g| of the vector it has just formed)
+    S.ytol = o.feasTol * S.gs;
+    S.fact_valid = 0; S.borderTodo = 0;
+    S.dpUsed = c.info->delta; S.d2Used = c.info->delta2;      // regularisation of the factorisation in use
+    S.trial = 0; S.reuse = reuse;
+    return PH_TRIAL;
+}
+
+// the instance is finished: statistics and solution go out
+template <int G>
+__device__ __forceinline__ int sp_finish(SpCtx<G>& c, SpState& S)
+{
+    const SpBatch& db = *c.db;
+    const int t = here(c.gl), n = db.n, m = db.m;
+    GD xk = c.V(NV_XK), yk = c.M(MV_YK);
+    S.st.status = S.algoStat; S.st.returnValue = S.rc;
+    S.st.admmIter = c.cAdmm; S.st.trials = c.cTrials; S.st.factorizations = c.cFact; S.st.corrections = c.cCorr; S.st.reserved = c.cSweeps;
+    for (int i = t; i < n; i += G) db.xout[(size_t)c.b * n + i] = xk[i];
+    for (int r = t; r < m; r += G) db.yout[(size_t)c.b * m + r] = yk[r];
+    if (t == 0) { db.stats[c.b] = S.st; c.info->bytes += c.bytes; }
+    c.bytes = 0.0;
+    return PH_NUM;
+}
+
+// a polish that did not settle (oracle: the tail of the round loop of sqp_solve): twice as many ADMM iterations, or the QP has failed
+template <int G>
+__device__ __forceinline__ int sp_polish_failed(SpCtx<G>& c, SpState& S)
+{
+    const lcqp_options_t& o = c.db->opt;
+    S.n_admm = 2 * S.n_admm;
+    if (S.n_admm < 10) S.n_admm = 10;
+    if (S.n_admm > 400) S.n_admm = 400;
+    S.round++;
+    if (S.round < o.maxRounds) return PH_ROUND;
+    S.qpIter = (c.cTrials - S.trials0) + (c.cAdmm - S.admm0);
+    S.st.subproblemIter += S.qpIter; S.st.qpSolverExitFlag = 1; S.st.qpSolves++;
+    S.rc = LCQP_SUBPROBLEM_SOLVER_ERROR;
+    return sp_finish<G>(c, S);
+}
+
+// PH_TRIAL: the head of one trial of the polish -- E x, the status test, the true residual when the working set did not change, acceptance;
+// else the leaving rows, and whether the factorisation still matches the working set
+template <int G>
+__device__ __forceinline__ int sp_ph_trial(SpCtx<G>& c, SpState& S, GD g)
 {
     const SpBatch& db = *c.db;
     const lcqp_options_t& o = db.opt;
+    const int t = c.gl, n = db.n, m = db.m, trial = S.trial;
+    GD x = c.V(NV_XT), r1 = c.V(NV_R1), qx = c.V(NV_TMP), yt = c.M(MV_YT), ex = c.M(MV_EX);
+    GD l = c.M(MV_L), u = c.M(MV_U);
+    GI st = c.I(MI_STT), stf = c.I(MI_STF), newst = c.I(MI_NEW);
+    const double gs = S.gs, ytol = S.ytol;
+    c.cTrials++;
+    // Two stages, as on the dense path (oracle: sqp_polish).  Stage 1 is what every trial needs: E x, for the status test.  Stage 2 -- the
+    // true residual, one pass over Q and one over E' -- runs only when stage 1 changed nothing: after a correction the residual is zero on
+    // the old working set up to rounding and regularisation, so when the set changes the next right-hand side is known without it (the
+    // multipliers of the leaving rows, below); the trial that accepts always has the true residual.
+    double res_stat = 0.0;
+    int have_r1 = 0;
+    if (trial == 0 && S.reuse) {
+        // hot start with an unchanged (x, y): r1 = r1_last + (g_last - g) and E x are in place -- the residual and E x of the accepted
+        // trial stay where they are, and the LCQP level adds (g_last - g) to r1 in the pass that forms the new g (sp_ph_qpend)
+        have_r1 = 1;
+    } else {
+        sp_Ex<G>(c, x, ex);
+        c.bytes += 12.0 * db.nnzE + 8.0 * (n + m);
+    }
+    double res_eq = 0.0, bmax = 0.0;
+    int chg = 0, act = 0;
+    g_map<G, 4>(m, t, [&](int r) { return StRow{st[r], ex[r], l[r], u[r], yt[r]}; },
+                [&](int r, StRow v) {
+                    int ns = v.s;
+                    if (v.s == ST_INACT) {
+                        const double ftol = o.feasTol * (1.0 + fabs(v.e));
+                        if (v.e < v.lo - ftol) ns = ST_LOWER;
+                        else if (v.e > v.hi + ftol) ns = ST_UPPER;
+                    } else {
+                        const double bb = (v.s == ST_UPPER) ? v.hi : v.lo;
+                        res_eq = nmax(res_eq, fabs(bb - v.e));
+                        bmax = fmax(bmax, fabs(bb));
+                        if (v.s == ST_LOWER && v.y > ytol) ns = ST_INACT;
+                        if (v.s == ST_UPPER && v.y < -ytol) ns = ST_INACT;
+                    }
+                    newst[r] = ns;
+                    chg += (ns != v.s);
+                    act += (ns != ST_INACT);
+                });
+    const int changed = g_sum_i<G>(chg), nact = g_sum_i<G>(act);
+    res_eq = g_max<G>(res_eq);
+    bmax = g_max<G>(bmax);
+    SPROF(c, SP_ASSEMBLE);      // (profile builds: the status test on its own)
+    if (!have_r1 && (trial == 0 || !changed)) {
+        res_stat = sp_residual<G>(c, g, x, yt, r1, qx);
+        c.cSweeps++;
+        c.bytes += 12.0 * (db.nnzQ + db.nnzE) + 8.0 * (3.0 * n + m);
+        have_r1 = 1;
+    }
+    if (trial > 0 && !changed && res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) return PH_QPEND;      // a verified KKT point
+    if (changed && trial > 0) {
+        if (trial >= 2 && nact > n && changed > max(n / 2, 32)) return sp_polish_failed<G>(c, S);       // overshooting cold start: hand over to ADMM
+        // leaving rows: their multipliers leave the residual (r1 += E_r' y_r), then the new working set takes over
+        GD ytmp = c.M(MV_LX);
+        g_sync();
+        g_map<G, 8>(m, t, [&](int r) { return I2D{newst[r], st[r], yt[r]}; },
+                    [&](int r, I2D v) { const bool leaves = (v.a == ST_INACT && v.b != ST_INACT); ytmp[r] = leaves ? -v.y : 0.0; st[r] = v.a; if (leaves && v.y != 0.0) yt[r] = 0.0; });
+        g_sync();
+        // r1 - E'(-y_leaving) = r1 + E'y_leaving; without a true residual r1 is the predicted one: nothing was left on the old working set
+        if (have_r1) sp_ETy<G>(c, ytmp, r1, [&](int i) { return r1[i]; }, [](double v) { return v; });
+        else sp_ETy<G>(c, ytmp, r1, [](int) { return NoPre{}; }, [](NoPre) { return 0.0; });
+        S.fact_valid = 0;
+    }
+    if (!S.fact_valid) {
+        int diff = (c.info->stfValid == 0);
+#pragma unroll 8
+        for (int r = t; r < m; r += G) diff |= ((stf[r] != ST_INACT) != (st[r] != ST_INACT));
+        if (g_any<G>(diff)) return PH_FACTOR;
+        S.fact_valid = 1;
+    }
+    return PH_CORRECT;
+}
+
+// PH_FACTOR: the band LDL' of [Q + delta I, Ea'; Ea, -delta2 I] for the working set in MI_STT
+template <int G>
+__device__ __forceinline__ int sp_ph_factor(SpCtx<G>& c, SpState& S)
+{
+    const SpBatch& db = *c.db;
     const int t = c.gl, n = db.n, m = db.m;
-    const int trials0 = c.cTrials, admm0 = c.cAdmm;
+    GI st = c.I(MI_STT), stf = c.I(MI_STF);
+    // Two levels of regularisation, as on the dense path (proxSmall / proxBig).  A correction with the safe level leaves
+    // delta dx and delta2 dy (1e-8, 1e-9 relative) in the true residuals: every QP paid one refinement trial -- a sweep, a band
+    // solve, the vector passes -- for the regularisation alone.  The light level (1e-12, 1e-14) is accepted at once.  The band
+    // LDL' is not pivoted, so the light level needs an ordering in which every row follows one of its variables (lightOK, chosen
+    // by the host when every Hessian of the batch is safely definite) and is only kept when every pivot has the sign its node
+    // prescribes and a safe size; a variable's pivot failing makes the safe level permanent for the instance.
+    int level = (db.lightOK && !c.info->bigReg) ? 0 : 1;
+    for (;;) {
+        S.dpUsed = level ? c.info->delta : c.info->deltaS;
+        S.d2Used = level ? c.info->delta2 : c.info->delta2S;
+        const double d2 = S.d2Used;
+        sp_factor_band<G>(c, c.KF(false), c.KD(false), S.dpUsed, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; });
+        if (level == 1) break;
+        int badVar = 0, badRow = 0;
+        GD Kd = c.KD(false);
+        const double sc = c.info->scale, vmax = 1.0 / (1e-8 * sc), rmax = sc / 1e-8;
+        const int Nb = db.N - db.kb;
+#pragma unroll 4
+        for (int p = t; p < Nb; p += G) {
+            const double kd = Kd[p];            // 1 / D
+            const int node = db.pnode[p];
+            if (node < n) badVar |= !(kd > 0.0 && kd < vmax);
+            else if (st[node - n] != ST_INACT) badRow |= !(kd < 0.0 && kd > -rmax);
+        }
+        const bool bv = g_any<G>(badVar), br = g_any<G>(badRow);
+        if (!bv && !br) break;
+        if (bv && t == 0) c.info->bigReg = 1;
+        level = 1;
+    }
+    if (db.kb > 0) { sp_border_prepare<G>(c, false, [=](int r) { return st[r] != ST_INACT; }); S.borderTodo = db.kb; }
+    g_map<G, 8>(m, t, [&](int r) { return st[r]; }, [&](int r, int v) { stf[r] = v; });
+    if (t == 0) c.info->stfValid = 1;
+    g_sync();
+    S.fact_valid = 1;
+    return PH_CORRECT;
+}
+
+// PH_CORRECT: [Q + delta I, Ea'; Ea, -delta2 I][dx; dy] = [r1; ba - Ea x], x += dx, y += dy; then the next trial (or the polish has run out of trials)
+template <int G>
+__device__ __forceinline__ int sp_ph_correct(SpCtx<G>& c, SpState& S)
+{
+    const SpBatch& db = *c.db;
+    const int t = c.gl, n = db.n, m = db.m;
+    GD x = c.V(NV_XT), r1 = c.V(NV_R1), yt = c.M(MV_YT), ex = c.M(MV_EX), b = c.Nv();
+    GD l = c.M(MV_L), u = c.M(MV_U);
+    GI st = c.I(MI_STT);
+    const int* iperm = db.iperm;
+    SPROF(c, SP_VECTORS);
+    g_map<G, 8>(n, t, [&](int i) { return ID{iperm[i], r1[i]}; }, [&](int, ID v) { b[v.i] = v.a; });
+    g_map<G, 4>(m, t, [&](int r) { return ID4{iperm[n + r], st[r], l[r], u[r], ex[r]}; },
+                [&](int, ID4 v) { b[v.p] = (v.s != ST_INACT) ? ((v.s == ST_UPPER) ? v.hi : v.lo) - v.e : 0.0; });
+    g_sync();
+    SPROF(c, SP_RHS);
+    // one call site of the band solve: first the columns of W = U inv(Bd) a fresh factorisation owes (none for a plain band), then b
+    const int borderTodo = S.borderTodo;
+    for (int jb = 0; jb <= borderTodo; jb++) {
+        GD vec = b;
+        if (jb < borderTodo) vec = sp_border_column<G>(c, false, jb);
+        else if (borderTodo > 0) { const double d2 = S.d2Used; sp_border_schur<G>(c, false, S.dpUsed, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; }); }
+        sp_solve_band<G>(c, false, vec);
+    }
+    S.borderTodo = 0;
+    if (db.kb > 0) sp_border_solve<G>(c, false, b);
+    g_map<G, 8>(n, t, [&](int i) { return D2{b[iperm[i]], x[i]}; }, [&](int i, D2 v) { x[i] = v.b + v.a; });
+    g_map<G, 8>(m, t, [&](int r) { return ID2{st[r], b[iperm[n + r]], yt[r]}; }, [&](int r, ID2 v) { if (v.s != ST_INACT) yt[r] = v.y + v.v; });
+    g_sync();
+    c.cCorr++;
+    S.trial++;
+    if (S.trial >= c.db->opt.maxTrials) return sp_polish_failed<G>(c, S);
+    return PH_TRIAL;
+}
+
+// the subsolver call starts (oracle: sqp_solve, entry): SubsolverBase::solve on the OSQP arm.  A hot start from the stored solution goes
+// straight to the polish; everything else takes the round preamble (PH_ROUND).
+template <int G>
+__device__ __forceinline__ int sp_qp_begin(SpCtx<G>& c, SpState& S, GD g)
+{
+    const SpBatch& db = *c.db;
+    const lcqp_options_t& o = db.opt;
+    const int t = c.gl, n = db.n, m = db.m, initial = S.initial;
     GD xq = c.V(NV_XQ), xa = c.V(NV_XA), xt = c.V(NV_XT);
-    GD yq = c.M(MV_YQ), ya = c.M(MV_YA), za = c.M(MV_ZA), yt = c.M(MV_YT);
+    GD yq = c.M(MV_YQ), ya = c.M(MV_YA), yt = c.M(MV_YT);
     GD l = c.M(MV_L), u = c.M(MV_U);
     GI st = c.I(MI_ST), stt = c.I(MI_STT);
-    *iterations = 0;
-    int n_admm = initial ? o.admmFirst : o.admmHot;
-    const int use_stored = (!initial && c.info->haveSolution && n_admm == 0);
+    S.trials0 = c.cTrials; S.admm0 = c.cAdmm; S.qpIter = 0;
+    S.n_admm = initial ? o.admmFirst : o.admmHot;
+    S.use_stored = (!initial && c.info->haveSolution && S.n_admm == 0);
     // The ADMM iterate (xa, ya) starts as a copy of the stored solution.  A hot start hands the stored solution to the polish directly and
     // the copy is made only if the polish fails and an ADMM round follows (one QP in a thousand on the synthetic workload).
-    int backup_pending = 0;
+    S.backup_pending = 0;
     if (initial) {
         GD x0 = c.V(NV_X0), y0 = c.M(MV_Y0);
         const int hasY0 = c.info->hasY0;
         g_map<G, 8>(n, t, [&](int i) { return x0[i]; }, [&](int i, double v) { xq[i] = v; xa[i] = v; });
         g_map<G, 8>(m, t, [&](int r) { return y0[r]; }, [&](int r, double v) { const double yv = hasY0 ? -v : 0.0; yq[r] = yv; ya[r] = yv; });
-    } else if (use_stored) {
-        backup_pending = 1;
+    } else if (S.use_stored) {
+        S.backup_pending = 1;
     } else {
         g_map<G, 8>(n, t, [&](int i) { return xq[i]; }, [&](int i, double v) { xa[i] = v; });
         g_map<G, 8>(m, t, [&](int r) { return yq[r]; }, [&](int r, double v) { ya[r] = v; });
     }
     g_sync();
-    int solved = 0, admm_ready = 0;
-    for (int round = 0; round < o.maxRounds && !solved; round++) {
-        if (backup_pending && round > 0) {
-            g_map<G, 8>(n, t, [&](int i) { return xq[i]; }, [&](int i, double v) { xa[i] = v; });
-            g_map<G, 8>(m, t, [&](int r) { return yq[r]; }, [&](int r, double v) { ya[r] = v; });
-            g_sync();
-            backup_pending = 0;
-        }
-        if (!admm_ready && (n_admm > 0 || !(round == 0 && use_stored))) {
-            sp_Ex<G>(c, xa, za);
-            g_map<G, 8>(m, t, [&](int r) { return D3{za[r], l[r], u[r]}; },
-                        [&](int r, D3 v) { za[r] = fmin(fmax(v.a, v.b), v.c); if (isinf(v.b) && isinf(v.c)) ya[r] = 0.0; });
-            g_sync();
-            admm_ready = 1;
-        }
-        if (n_admm > 0) sp_admm<G>(c, g, n_admm);
-        if (round == 0 && use_stored) {
-            g_map<G, 4>(m, t, [&](int r) { return ID3{st[r], l[r], u[r], 0.0, yq[r]}; },
-                        [&](int r, ID3 v) { const int s = (v.lo == v.hi) ? ST_EQ : v.s; stt[r] = s; yt[r] = (s != ST_INACT) ? v.y : 0.0; });
-        } else {
-            g_map<G, 4>(m, t, [&](int r) { return ID3{0, l[r], u[r], za[r], ya[r]}; },
-                        [&](int r, ID3 v) {
-                            int s = ST_INACT;
-                            if (isfinite(v.lo) && (v.z - v.lo < -v.y)) s = ST_LOWER;
-                            if (isfinite(v.hi) && (v.hi - v.z < v.y)) s = ST_UPPER;
-                            if (v.lo == v.hi) s = ST_EQ;
-                            stt[r] = s;
-                            yt[r] = (s != ST_INACT) ? v.y : 0.0;
-                        });
-        }
-        { GD xs = (round == 0 && use_stored) ? xq : xa;
-          g_map<G, 8>(n, t, [&](int i) { return xs[i]; }, [&](int i, double v) { xt[i] = v; }); }
-        g_sync();
-        if (sp_polish<G>(c, g, round == 0 && use_stored, gmaxHint)) { solved = 1; break; }
-        n_admm = 2 * n_admm;
-        if (n_admm < 10) n_admm = 10;
-        if (n_admm > 400) n_admm = 400;
-    }
-    *iterations = (c.cTrials - trials0) + (c.cAdmm - admm0);
-    if (!solved) return 1;
-    g_map<G, 8>(n, t, [&](int i) { return xt[i]; }, [&](int i, double v) { xq[i] = v; });
-    g_map<G, 8>(m, t, [&](int r) { return ID{stt[r], yt[r]}; }, [&](int r, ID v) { yq[r] = v.a; st[r] = v.i; });
-    if (t == 0) c.info->haveSolution = 1;
+    S.admm_ready = 0; S.round = 0;
+    if (!S.use_stored) return PH_ROUND;
+    g_map<G, 4>(m, t, [&](int r) { return ID3{st[r], l[r], u[r], 0.0, yq[r]}; },
+                [&](int r, ID3 v) { const int s = (v.lo == v.hi) ? ST_EQ : v.s; stt[r] = s; yt[r] = (s != ST_INACT) ? v.y : 0.0; });
+    g_map<G, 8>(n, t, [&](int i) { return xq[i]; }, [&](int i, double v) { xt[i] = v; });
     g_sync();
-    return 0;
+    return sp_polish_begin<G>(c, S, g, 1);
+}
+
+// PH_ROUND: the preamble of a round that does not start from the stored solution -- the first QP of a homotopy, and every round after a
+// polish that failed: ADMM iterations from (xa, ya), the working set they propose, the polish from there
+template <int G>
+__device__ __forceinline__ int sp_ph_round(SpCtx<G>& c, SpState& S, GD g)
+{
+    const SpBatch& db = *c.db;
+    const int t = c.gl, n = db.n, m = db.m;
+    GD xq = c.V(NV_XQ), xa = c.V(NV_XA), xt = c.V(NV_XT);
+    GD yq = c.M(MV_YQ), ya = c.M(MV_YA), za = c.M(MV_ZA), yt = c.M(MV_YT);
+    GD l = c.M(MV_L), u = c.M(MV_U);
+    GI stt = c.I(MI_STT);
+    if (S.backup_pending && S.round > 0) {
+        g_map<G, 8>(n, t, [&](int i) { return xq[i]; }, [&](int i, double v) { xa[i] = v; });
+        g_map<G, 8>(m, t, [&](int r) { return yq[r]; }, [&](int r, double v) { ya[r] = v; });
+        g_sync();
+        S.backup_pending = 0;
+    }
+    if (!S.admm_ready) {
+        sp_Ex<G>(c, xa, za);
+        g_map<G, 8>(m, t, [&](int r) { return D3{za[r], l[r], u[r]}; },
+                    [&](int r, D3 v) { za[r] = fmin(fmax(v.a, v.b), v.c); if (isinf(v.b) && isinf(v.c)) ya[r] = 0.0; });
+        g_sync();
+        S.admm_ready = 1;
+    }
+    if (S.n_admm > 0) sp_admm<G>(c, g, S.n_admm);
+    g_map<G, 4>(m, t, [&](int r) { return ID3{0, l[r], u[r], za[r], ya[r]}; },
+                [&](int r, ID3 v) {
+                    int s = ST_INACT;
+                    if (isfinite(v.lo) && (v.z - v.lo < -v.y)) s = ST_LOWER;
+                    if (isfinite(v.hi) && (v.hi - v.z < v.y)) s = ST_UPPER;
+                    if (v.lo == v.hi) s = ST_EQ;
+                    stt[r] = s;
+                    yt[r] = (s != ST_INACT) ? v.y : 0.0;
+                });
+    g_map<G, 8>(n, t, [&](int i) { return xa[i]; }, [&](int i, double v) { xt[i] = v; });
+    g_sync();
+    return sp_polish_begin<G>(c, S, g, 0);
+}
+// ---- LCQProblem::runSolver, OSQP_SPARSE arm (oracle: orc_sparse_lcqp_solve) ----------------------------------------------------
+// PH_START: everything in front of the first QP
+template <int G>
+__device__ __forceinline__ int sp_ph_start(SpCtx<G>& c, SpState& S)
+{
+    const SpBatch& db = *c.db;
+    const lcqp_options_t& o = db.opt;
+    const int t = c.gl, n = db.n;
+    GD g = c.V(NV_G), gtil = c.V(NV_GTIL), xk = c.V(NV_XK), gk = c.V(NV_GK);
+    GD Qx = c.V(NV_QX), Cx = c.V(NV_CX), Qp = c.V(NV_QP), Cp = c.V(NV_CP);
+    memset(&S.st, 0, sizeof(S.st));
+    S.rc = 0; S.qpIter = 0; S.histLen = 0; S.algoStat = 0; S.totalIter = 0;
+    S.alphak = 1.0; S.rho = o.initialPenaltyParameter;
+    S.perturbCounter = 0;
+    if (db.traceCap > 0 && t == 0) db.traceLen[c.b] = 0;     // a run that records nothing leaves an empty trace
+    { GD x0 = c.V(NV_X0);
+      g_map<G, 8>(n, t, [&](int i) { return D2{x0[i], g[i]}; }, [&](int i, D2 v) { xk[i] = v.a; gtil[i] = v.b; }); }
+    g_sync();
+    // Q x0 and C x0 once; from here on both follow the steps (sp_ph_qpend)
+    sp_Qx2<G>(c, xk, xk, Qx, Qp); sp_Cx2<G>(c, xk, xk, Cx, Cp);
+    c.bytes += 12.0 * db.nnzQ + 2.0 * 12.0 * db.nnzE;
+    if (o.solveZeroPenaltyFirst) { for (int i = t; i < n; i += G) gk[i] = g[i]; g_sync(); }
+    else { const double rho = S.rho; for (int i = t; i < n; i += G) gk[i] = rho * Cx[i] + gtil[i]; g_sync(); }
+    S.initial = 1;
+    S.gmaxNext = -1.0;      // max |gk| of the next QP when this level has formed it (-1: the subsolver looks)
+    return sp_qp_begin<G>(c, S, gk);
+}
+
+// PH_QPEND: the subsolver has a verified solution (oracle: the exit of sqp_solve), then one iterate of runSolver's loop up to the next QP
+template <int G>
+__device__ __forceinline__ int sp_ph_qpend(SpCtx<G>& c, SpState& S)
+{
+    const SpBatch& db = *c.db;
+    const lcqp_options_t& o = db.opt;
+    const int t = c.gl, n = db.n, m = db.m, nC = db.nC, nK = db.nComp;
+    GD g = c.V(NV_G), gtil = c.V(NV_GTIL), gphi = c.V(NV_GPHI), xk = c.V(NV_XK), pk = c.V(NV_PK), xnew = c.V(NV_XNEW), gk = c.V(NV_GK);
+    GD Qx = c.V(NV_QX), Cx = c.V(NV_CX), Qp = c.V(NV_QP), Cp = c.V(NV_CP);
+    GD yk = c.M(MV_YK), lx = c.M(MV_LX);
+    const bool hasPhi = db.hasLbL || db.hasLbR;
+    const double phiConst = c.info->phiConst;
+    double* hist = c.info->hist;
+    {   // the solution becomes the stored one (sqp_solve's exit)
+        GD xq = c.V(NV_XQ), xt = c.V(NV_XT), yq = c.M(MV_YQ), yt = c.M(MV_YT);
+        GI st = c.I(MI_ST), stt = c.I(MI_STT);
+        S.qpIter = (c.cTrials - S.trials0) + (c.cAdmm - S.admm0);
+        g_map<G, 8>(n, t, [&](int i) { return xt[i]; }, [&](int i, double v) { xq[i] = v; });
+        g_map<G, 8>(m, t, [&](int r) { return ID{stt[r], yt[r]}; }, [&](int r, ID v) { yq[r] = v.a; st[r] = v.i; });
+        if (t == 0) c.info->haveSolution = 1;
+        g_sync();
+    }
+    SPROF(c, SP_VECTORS);
+    S.st.subproblemIter += S.qpIter; S.st.qpSolverExitFlag = 0; S.st.qpSolves++;
+    double rho = S.rho, alphak = S.alphak;
+    auto getPhi = [&]() -> double {
+        double s = 0.0;
+#pragma unroll 8
+        for (int i = t; i < n; i += G) s += (hasPhi ? gphi[i] * xk[i] : 0.0) + 0.5 * xk[i] * Cx[i];
+        return phiConst + g_sum<G>(s);
+    };
+    auto updatePenalty = [&]() {
+        if (o.nDynamicPenalty > 0) S.histLen = 0;
+        rho *= o.penaltyUpdateFactor;
+        S.st.rhoOpt = rho;
+        if (hasPhi) { for (int i = t; i < n; i += G) gtil[i] = g[i] + rho * gphi[i]; g_sync(); }
+    };
+    // What the subsolver's accepted trial leaves behind makes every product of this level but one unnecessary (the dense kernel does
+    // the same, lcqp_dev.hpp: lcqp_run): Q xq is in NV_TMP (sp_residual), E xq in MV_EX, and its residual r1 = -gk - Q xq - E'yq (NV_R1, gk still the vector of that QP)
+    // gives E'yq.  So pk = xq - xk, Q pk = Q xq - Q xk with Q xk kept up to date below, C xq = L'(R xq) + R'(L xq) is one column
+    // gather over E with the entries of E xq, C pk = C xq - C xk, and the stationarity needs no pass over E' of its own.
+    // (round 2: one pass over Q, one over E, two over E' per iterate.)
+    GD qxs = c.V(NV_TMP), exs = c.M(MV_EX), r1s = c.V(NV_R1), gs0 = gk;
+    {
+        GD xq = c.V(NV_XQ), yq = c.M(MV_YQ);
+        g_map<G, 4>(n, t, [&](int i) { return D4{xq[i], xk[i], qxs[i], Qx[i]}; }, [&](int i, D4 v) { xnew[i] = v.a; pk[i] = v.a - v.b; Qp[i] = v.c - v.d; });
+        g_map<G, 8>(m, t, [&](int r) { return yq[r]; }, [&](int r, double v) { yk[r] = -v; });     // src/SubsolverOSQP.cpp:196-199
+        g_sync();
+    }
+    const int initial = S.initial;
+    bool perturbed = false;
+    if (initial) S.st.rhoOpt = rho;
+    else if (o.perturbStep) {
+        perturbed = true;
+        const uint64_t pc = S.perturbCounter;
+        for (int i = t; i < n; i += G) {
+            uint64_t z = o.perturbSeed + (pc + (uint64_t)i + 1ULL) * 0x9E3779B97F4A7C15ULL;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z = z ^ (z >> 31);
+            xk[i] += ((int)(z % 3ULL) - 1) * 2.221e-16;
+        }
+        S.perturbCounter += (uint64_t)n;
+        g_sync();
+    }
+    if (perturbed) {
+        // the perturbation has to reach the penalty gradient rho C xk -- it is there to break the symmetry of problems like warm_up
+        // (perturbStep :1353-1362) -- so C xk is taken from the perturbed xk: one more pass over E, the column gather carries two
+        // vectors.  (Q xk is not: 2.2e-16 per component is below its rounding; the dense kernel does the same.)
+        sp_Ex<G>(c, xk, lx);
+        sp_C_from_Ex<G, true>(c, exs, lx, [](int) { return NoPre{}; }, [&](int i, double cxq, double cxk, NoPre) { Cx[i] = cxk; Cp[i] = cxq - cxk; });
+        c.bytes += 3.0 * 12.0 * db.nnzE;
+    } else {
+        sp_C_from_Ex<G, false>(c, exs, exs, [&](int i) { return Cx[i]; }, [&](int i, double cxq, double, double cxk) { Cp[i] = cxq - cxk; });
+        c.bytes += 12.0 * db.nnzE;
+    }
+    if (!initial) {
+        double sq = 0.0, sl = 0.0;
+#pragma unroll 4
+        for (int i = t; i < n; i += G) { sq += pk[i] * (Qp[i] + rho * Cp[i]); sl += pk[i] * ((Qx[i] + rho * Cx[i]) + gtil[i]); }
+        const double qk = g_sum<G>(sq), lk = g_sum<G>(sl);
+        alphak = 1.0;
+        if (qk > 0 && lk < 0) alphak = fmin(-lk / qk, 1.0);
+    }
+    S.initial = 0;
+    // the step, the products that follow it, and updateStationarity without a box term: statk = Qk xk + g_tilde - E'yk with
+    // E'yk = -E'yq = gs0 + Q xq + r1s
+    double statMax = 0.0;
+    { struct D10 { double a, b, c, d, e, f, g0, q, r, gt; };
+      g_map<G, 2>(n, t, [&](int i) { return D10{xk[i], pk[i], Qx[i], Qp[i], Cx[i], Cp[i], gs0[i], qxs[i], r1s[i], gtil[i]}; },
+                  [&](int i, D10 v) {
+                      const double qn = v.c + alphak * v.d, cn = v.e + alphak * v.f;
+                      xk[i] = v.a + alphak * v.b; Qx[i] = qn; Cx[i] = cn;
+                      statMax = nmax(statMax, fabs(((qn + rho * cn) + v.gt) - ((v.g0 + v.q) + v.r)));
+                  }); }
+    g_sync();
+    const double statInf = g_max<G>(statMax);
+    int totalIter = S.totalIter;
+    if (db.traceCap > 0 && totalIter < db.traceCap) {   // storeSteps :488-490, printIteration :1528-1576 (the host rebuilds both from this)
+        const double phiNow = getPhi();
+        double so = 0.0, sm = 0.0, pm = 0.0;
+        for (int i = t; i < n; i += G) { const double xv = xk[i]; so += g[i] * xv + 0.5 * xv * Qx[i]; sm += 0.5 * rho * xv * Cx[i]; pm = fmax(pm, fabs(pk[i])); }
+        const double objNow = g_sum<G>(so), meritNow = objNow + g_sum<G>(sm), stepNow = g_max<G>(pm);
+        double* ts = db.traceS + ((size_t)c.b * db.traceCap + totalIter) * 8;
+        double* tx = db.traceX + ((size_t)c.b * db.traceCap + totalIter) * n;
+        if (t == 0) {
+            ts[0] = statInf; ts[1] = phiNow; ts[2] = rho; ts[3] = alphak; ts[4] = objNow; ts[5] = meritNow; ts[6] = stepNow; ts[7] = (double)S.qpIter;
+            db.traceLen[c.b] = totalIter + 1;
+        }
+        for (int i = t; i < n; i += G) tx[i] = xk[i];
+    }
+    totalIter++; S.totalIter = totalIter; S.st.iterTotal++;
+    bool leyffer = false;
+    const int nd = o.nDynamicPenalty;
+    if (nd > 0) {
+        const double cur = getPhi();
+        if (S.histLen < nd) { if (t == 0) hist[S.histLen] = cur; S.histLen++; g_sync(); }
+        else {
+            if (!(cur < o.complementarityTolerance)) {
+                leyffer = true;
+                for (int i = 0; i < nd; i++) if (cur < o.etaDynamicPenalty * hist[i]) { leyffer = false; break; }
+            }
+            g_sync();
+            if (t == 0) { for (int i = 0; i + 1 < nd; i++) hist[i] = hist[i + 1]; hist[nd - 1] = cur; }
+            g_sync();
+        }
+    }
+    if (leyffer) { updatePenalty(); S.st.iterOuter++; }
+    bool done = false;
+    if (statInf < o.stationarityTolerance) {
+        if (getPhi() < o.complementarityTolerance) {
+            sp_Ex<G>(c, xk, lx);
+            int sflag = 1, mflag = 1, wflag = 0;
+            const double ctol = o.complementarityTolerance;
+            for (int i = 0; i < nK; i++) {
+                const double Lx = lx[nC + i], Rx = lx[nC + nK + i];
+                if (!(Lx <= ctol && Rx <= ctol)) continue;
+                const double a = yk[nC + i], bq = yk[nC + nK + i];
+                const double dualProd = a * bq, dualMin = fmin(a, bq);
+                if (dualMin < 0) sflag = 0;
+                if (fabs(dualProd) >= ctol && dualMin <= 0) { if (dualProd <= ctol) { wflag = 1; break; } mflag = 0; }
+            }
+            S.algoStat = wflag ? 1 : (sflag ? 4 : (mflag ? 3 : 2));
+            g_sync();
+            for (int i = t; i < nK; i += G) { const double Lx = lx[nC + i], Rx = lx[nC + nK + i]; yk[nC + i] -= rho * Rx; yk[nC + nK + i] -= rho * Lx; }
+            g_sync();
+            S.rc = 0;
+            done = true;
+        } else {
+            updatePenalty(); S.st.iterOuter++;
+        }
+    }
+    if (!done && totalIter > o.maxIterations) { S.rc = LCQP_MAX_ITERATIONS_REACHED; done = true; }
+    if (!done && rho > o.maxPenaltyParameter) { S.rc = LCQP_MAX_PENALTY_REACHED; done = true; }
+    S.rho = rho; S.alphak = alphak;
+    if (done) return sp_finish<G>(c, S);
+    // the next QP's linear term; its hot start needs r1 = r1_last + (g_last - g): the residual of the accepted trial is still in NV_R1
+    { GD r1 = c.V(NV_R1);
+      double gm = 0.0;
+      g_map<G, 8>(n, t, [&](int i) { return D4{Cx[i], gtil[i], gk[i], r1[i]}; },
+                  [&](int i, D4 v) { const double gn = rho * v.a + v.b; gk[i] = gn; r1[i] = v.d + (v.c - gn); gm = fmax(gm, fabs(gn)); });
+      S.gmaxNext = g_max<G>(gm); }
+    g_sync();
+    SPROF(c, SP_LCQP);
+    return sp_qp_begin<G>(c, S, gk);
 }
 
 extern __shared__ double sp_dyn_lds[];
 
 template <int G>
-__device__ __forceinline__ SpCtx<G> sp_ctx(const SpBatch& db, int b)
+__device__ __forceinline__ SpCtx<G> sp_ctx(const SpBatch& db, int b, int w0)
 {
     SpCtx<G> c;
-    c.db = &db; c.b = b; c.gl = threadIdx.x & (G - 1); c.gi = threadIdx.x / G; c.w0 = blockIdx.x * (64 / G);
+    c.db = &db; c.b = b; c.gl = threadIdx.x & (G - 1); c.gi = (unsigned)(b - w0); c.w0 = w0;
     c.info = db.info + b;
     c.win = sp_dyn_lds + (size_t)(threadIdx.x / G) * (G * G + 16 * G);
     c.cAdmm = c.cTrials = c.cFact = c.cCorr = c.cSweeps = 0;
@@ -1057,8 +1352,11 @@ __global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db)
 {
     const int b = blockIdx.x * (64 / G) + threadIdx.x / G;
     if (b >= db.B) return;
-    SpCtx<G> c = sp_ctx<G>(db, b);
+    SpCtx<G> c = sp_ctx<G>(db, b, blockIdx.x * (64 / G));
     const int t = c.gl, n = db.n, m = db.m, nC = db.nC, nK = db.nComp;
+#ifdef LCQP_PROFILE
+    if (t == 0) for (int k = 0; k < SP_NPHASE; k++) c.info->prof[k] = 0.0;
+#endif
     double dmax = 0.0;
     for (int i = t; i < n; i += G)
         for (int k = db.Qp[i]; k < db.Qp[i + 1]; k++) if (db.Qi[k] == i) dmax = fmax(dmax, fabs(c.Qx()[k]));
@@ -1102,182 +1400,119 @@ __global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db)
     if (t == 0) c.info->bytes = c.bytes;
 }
 
-// ---- LCQProblem::runSolver, OSQP_SPARSE arm (oracle: orc_sparse_lcqp_solve) ----------------------------------------------------
+// ---- the scheduler: persistent wavefronts that serve the phase queues of their pool -------------------------------------------------------
+// Queue discipline (per pool and phase): push = take a slot (atomicAdd on tail), write the instance id into it, release fence, atomicAdd on
+// count; pop = claim up to 64 / G entries of count (compare-and-swap), take as many slots (atomicAdd on head), wait for each slot's id (a
+// pusher that holds a slot writes it a few instructions later; ids are stored +1, 0 = empty), clear it, acquire fence.  An instance is in at
+// most one queue, so a ring of poolSize entries never overflows.  Everything an instance's phase wrote to memory is released by the fence in
+// front of its push and acquired by the fence behind the pop of whichever wavefront runs its next phase.
+// agent scope: a pool is served by wavefronts of several XCDs, whose L2s are not coherent with each other -- the release writes the L2 back, the
+// acquire invalidates L1 and L2 (workgroup-scope fences in their place: stale vectors, more iterates, 15 - 25 % SLOWER; profiles/round4)
+#define SP_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define SP_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+__device__ __forceinline__ int q_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 template <int G>
-__global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_run(SpBatch db)
+__global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_sched(SpBatch db)
 {
-    const int b = blockIdx.x * (64 / G) + threadIdx.x / G;
-    if (b >= db.B) return;
-    SpCtx<G> c = sp_ctx<G>(db, b);
-    const lcqp_options_t& o = db.opt;
-    const int t = c.gl, n = db.n, m = db.m, nC = db.nC, nK = db.nComp;
-    GD g = c.V(NV_G), gtil = c.V(NV_GTIL), gphi = c.V(NV_GPHI), xk = c.V(NV_XK), pk = c.V(NV_PK), xnew = c.V(NV_XNEW), gk = c.V(NV_GK);
-    GD Qx = c.V(NV_QX), Cx = c.V(NV_CX), Qp = c.V(NV_QP), Cp = c.V(NV_CP);
-    GD yk = c.M(MV_YK), lx = c.M(MV_LX);
-    const bool hasPhi = db.hasLbL || db.hasLbR;
-    const double phiConst = c.info->phiConst;
-    double* hist = c.info->hist;
-    lcqp_stats_t st;
-    memset(&st, 0, sizeof(st));
-    int rc = 0, qpIter = 0, histLen = 0, algoStat = 0, totalIter = 0;
-    double alphak = 1.0, rho = o.initialPenaltyParameter;
-    uint64_t perturbCounter = 0;
-    if (db.traceCap > 0 && t == 0) db.traceLen[c.b] = 0;     // a run that records nothing leaves an empty trace
-    { GD x0 = c.V(NV_X0);
-      g_map<G, 8>(n, t, [&](int i) { return D2{x0[i], g[i]}; }, [&](int i, D2 v) { xk[i] = v.a; gtil[i] = v.b; }); }
-    g_sync();
-    auto getPhi = [&]() -> double {
-        double s = 0.0;
-#pragma unroll 8
-        for (int i = t; i < n; i += G) s += (hasPhi ? gphi[i] * xk[i] : 0.0) + 0.5 * xk[i] * Cx[i];
-        return phiConst + g_sum<G>(s);
-    };
-    auto updatePenalty = [&]() {
-        if (o.nDynamicPenalty > 0) histLen = 0;
-        rho *= o.penaltyUpdateFactor;
-        st.rhoOpt = rho;
-        if (hasPhi) { for (int i = t; i < n; i += G) gtil[i] = g[i] + rho * gphi[i]; g_sync(); }
-    };
-    // Q x0 and C x0 once; from here on both follow the steps (the loop below)
-    sp_Qx2<G>(c, xk, xk, Qx, Qp); sp_Cx2<G>(c, xk, xk, Cx, Cp);
-    c.bytes += 12.0 * db.nnzQ + 2.0 * 12.0 * db.nnzE;
-    if (o.solveZeroPenaltyFirst) { for (int i = t; i < n; i += G) gk[i] = g[i]; g_sync(); }
-    else { for (int i = t; i < n; i += G) gk[i] = rho * Cx[i] + gtil[i]; g_sync(); }
-    int initial = 1;
-    double gmaxNext = -1.0;      // max |gk| of the next QP when this level has formed it (-1: the subsolver looks)
-    for (;;) {
-        SPROF(c, SP_LCQP);
-        const int ef = sp_qp_solve<G>(c, initial, gk, &qpIter, gmaxNext);
-        SPROF(c, SP_VECTORS);
-        st.subproblemIter += qpIter; st.qpSolverExitFlag = ef; st.qpSolves++;
-        if (ef != 0) { rc = LCQP_SUBPROBLEM_SOLVER_ERROR; break; }
-        // What the subsolver's accepted trial leaves behind makes every product of this level but one unnecessary (the dense kernel does
-        // the same, lcqp_dev.hpp: lcqp_run): Q xq is in NV_TMP (sp_residual), E xq in MV_EX, and its residual r1 = -gk - Q xq - E'yq (NV_R1, gk still the vector of that QP)
-        // gives E'yq.  So pk = xq - xk, Q pk = Q xq - Q xk with Q xk kept up to date below, C xq = L'(R xq) + R'(L xq) is one column
-        // gather over E with the entries of E xq, C pk = C xq - C xk, and the stationarity needs no pass over E' of its own.
-        // (round 2: one pass over Q, one over E, two over E' per iterate.)
-        GD qxs = c.V(NV_TMP), exs = c.M(MV_EX), r1s = c.V(NV_R1), gs0 = gk;
-        {
-            GD xq = c.V(NV_XQ), yq = c.M(MV_YQ);
-            g_map<G, 4>(n, t, [&](int i) { return D4{xq[i], xk[i], qxs[i], Qx[i]}; }, [&](int i, D4 v) { xnew[i] = v.a; pk[i] = v.a - v.b; Qp[i] = v.c - v.d; });
-            g_map<G, 8>(m, t, [&](int r) { return yq[r]; }, [&](int r, double v) { yk[r] = -v; });     // src/SubsolverOSQP.cpp:196-199
-            g_sync();
-        }
-        bool perturbed = false;
-        if (initial) st.rhoOpt = rho;
-        else if (o.perturbStep) {
-            perturbed = true;
-            for (int i = t; i < n; i += G) {
-                uint64_t z = o.perturbSeed + (perturbCounter + (uint64_t)i + 1ULL) * 0x9E3779B97F4A7C15ULL;
-                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z = z ^ (z >> 31);
-                xk[i] += ((int)(z % 3ULL) - 1) * 2.221e-16;
-            }
-            perturbCounter += (uint64_t)n;
-            g_sync();
-        }
-        if (perturbed) {
-            // the perturbation has to reach the penalty gradient rho C xk -- it is there to break the symmetry of problems like warm_up
-            // (perturbStep :1353-1362) -- so C xk is taken from the perturbed xk: one more pass over E, the column gather carries two
-            // vectors.  (Q xk is not: 2.2e-16 per component is below its rounding; the dense kernel does the same.)
-            sp_Ex<G>(c, xk, lx);
-            sp_C_from_Ex<G, true>(c, exs, lx, [](int) { return NoPre{}; }, [&](int i, double cxq, double cxk, NoPre) { Cx[i] = cxk; Cp[i] = cxq - cxk; });
-            c.bytes += 3.0 * 12.0 * db.nnzE;
-        } else {
-            sp_C_from_Ex<G, false>(c, exs, exs, [&](int i) { return Cx[i]; }, [&](int i, double cxq, double, double cxk) { Cp[i] = cxq - cxk; });
-            c.bytes += 12.0 * db.nnzE;
-        }
-        if (!initial) {
-            double sq = 0.0, sl = 0.0;
-#pragma unroll 4
-            for (int i = t; i < n; i += G) { sq += pk[i] * (Qp[i] + rho * Cp[i]); sl += pk[i] * ((Qx[i] + rho * Cx[i]) + gtil[i]); }
-            const double qk = g_sum<G>(sq), lk = g_sum<G>(sl);
-            alphak = 1.0;
-            if (qk > 0 && lk < 0) alphak = fmin(-lk / qk, 1.0);
-        }
-        initial = 0;
-        // the step, the products that follow it, and updateStationarity without a box term: statk = Qk xk + g_tilde - E'yk with
-        // E'yk = -E'yq = gs0 + Q xq + r1s
-        double statMax = 0.0;
-        { struct D10 { double a, b, c, d, e, f, g0, q, r, gt; };
-          g_map<G, 2>(n, t, [&](int i) { return D10{xk[i], pk[i], Qx[i], Qp[i], Cx[i], Cp[i], gs0[i], qxs[i], r1s[i], gtil[i]}; },
-                      [&](int i, D10 v) {
-                          const double qn = v.c + alphak * v.d, cn = v.e + alphak * v.f;
-                          xk[i] = v.a + alphak * v.b; Qx[i] = qn; Cx[i] = cn;
-                          statMax = nmax(statMax, fabs(((qn + rho * cn) + v.gt) - ((v.g0 + v.q) + v.r)));
-                      }); }
-        g_sync();
-        const double statInf = g_max<G>(statMax);
-        if (db.traceCap > 0 && totalIter < db.traceCap) {   // storeSteps :488-490, printIteration :1528-1576 (the host rebuilds both from this)
-            const double phiNow = getPhi();
-            double so = 0.0, sm = 0.0, pm = 0.0;
-            for (int i = t; i < n; i += G) { const double xv = xk[i]; so += g[i] * xv + 0.5 * xv * Qx[i]; sm += 0.5 * rho * xv * Cx[i]; pm = fmax(pm, fabs(pk[i])); }
-            const double objNow = g_sum<G>(so), meritNow = objNow + g_sum<G>(sm), stepNow = g_max<G>(pm);
-            double* ts = db.traceS + ((size_t)c.b * db.traceCap + totalIter) * 8;
-            double* tx = db.traceX + ((size_t)c.b * db.traceCap + totalIter) * n;
-            if (t == 0) {
-                ts[0] = statInf; ts[1] = phiNow; ts[2] = rho; ts[3] = alphak; ts[4] = objNow; ts[5] = meritNow; ts[6] = stepNow; ts[7] = (double)qpIter;
-                db.traceLen[c.b] = totalIter + 1;
-            }
-            for (int i = t; i < n; i += G) tx[i] = xk[i];
-        }
-        totalIter++; st.iterTotal++;
-        bool leyffer = false;
-        const int nd = o.nDynamicPenalty;
-        if (nd > 0) {
-            const double cur = getPhi();
-            if (histLen < nd) { if (t == 0) hist[histLen] = cur; histLen++; g_sync(); }
-            else {
-                if (!(cur < o.complementarityTolerance)) {
-                    leyffer = true;
-                    for (int i = 0; i < nd; i++) if (cur < o.etaDynamicPenalty * hist[i]) { leyffer = false; break; }
-                }
-                g_sync();
-                if (t == 0) { for (int i = 0; i + 1 < nd; i++) hist[i] = hist[i + 1]; hist[nd - 1] = cur; }
-                g_sync();
+    constexpr int IPW = 64 / G;
+    const int pool = blockIdx.x % db.nPools;
+    const int w0 = pool * db.poolSize;
+    const int mask = db.poolSize - 1;
+    int* ring = db.qring + (size_t)pool * PH_NUM * db.poolSize;
+    int* ctl = db.qctl + (size_t)pool * (PH_NUM + 1) * QCTL;
+    int* remaining = ctl + PH_NUM * QCTL;
+    const int lane = threadIdx.x, grp = lane / G;
+    for (int idle = 0;;) {
+        // ---- pop: one phase for the whole wavefront (lane 0 decides; the queue with the most entries, a full wavefront's worth if there is one)
+        int ph = -1, take = 0, base = 0;
+        if (lane == 0) {
+            int best = 0;
+            for (int k = 0; k < PH_NUM; k++) { const int cnt = q_load(&ctl[k * QCTL + 2]); if (cnt > best) { best = cnt; ph = k; } }
+            if (ph >= 0) {
+                take = min(best, IPW);
+                if (atomicCAS(&ctl[ph * QCTL + 2], best, best - take) == best) base = atomicAdd(&ctl[ph * QCTL + 1], take);
+                else { ph = -1; take = 0; }      // somebody else moved the counter: look again
             }
         }
-        if (leyffer) { updatePenalty(); st.iterOuter++; }
-        if (statInf < o.stationarityTolerance) {
-            if (getPhi() < o.complementarityTolerance) {
-                sp_Ex<G>(c, xk, lx);
-                int sflag = 1, mflag = 1, wflag = 0;
-                const double ctol = o.complementarityTolerance;
-                for (int i = 0; i < nK; i++) {
-                    const double Lx = lx[nC + i], Rx = lx[nC + nK + i];
-                    if (!(Lx <= ctol && Rx <= ctol)) continue;
-                    const double a = yk[nC + i], bq = yk[nC + nK + i];
-                    const double dualProd = a * bq, dualMin = fmin(a, bq);
-                    if (dualMin < 0) sflag = 0;
-                    if (fabs(dualProd) >= ctol && dualMin <= 0) { if (dualProd <= ctol) { wflag = 1; break; } mflag = 0; }
-                }
-                algoStat = wflag ? 1 : (sflag ? 4 : (mflag ? 3 : 2));
-                g_sync();
-                for (int i = t; i < nK; i += G) { const double Lx = lx[nC + i], Rx = lx[nC + nK + i]; yk[nC + i] -= rho * Rx; yk[nC + nK + i] -= rho * Lx; }
-                g_sync();
-                rc = 0;
-                break;
-            }
-            updatePenalty(); st.iterOuter++;
-        }
-        if (totalIter > o.maxIterations) { rc = LCQP_MAX_ITERATIONS_REACHED; break; }
-        if (rho > o.maxPenaltyParameter) { rc = LCQP_MAX_PENALTY_REACHED; break; }
-        // the next QP's linear term; its hot start needs r1 = r1_last + (g_last - g): the residual of the accepted trial is still in NV_R1
-        { GD r1 = c.V(NV_R1);
-          double gm = 0.0;
-          g_map<G, 8>(n, t, [&](int i) { return D4{Cx[i], gtil[i], gk[i], r1[i]}; },
-                      [&](int i, D4 v) { const double gn = rho * v.a + v.b; gk[i] = gn; r1[i] = v.d + (v.c - gn); gm = fmax(gm, fabs(gn)); });
-          gmaxNext = g_max<G>(gm); }
-        g_sync();
-    }
-    st.status = algoStat; st.returnValue = rc;
-    st.admmIter = c.cAdmm; st.trials = c.cTrials; st.factorizations = c.cFact; st.corrections = c.cCorr; st.reserved = c.cSweeps;
-    for (int i = t; i < n; i += G) db.xout[(size_t)c.b * n + i] = xk[i];
-    for (int r = t; r < m; r += G) db.yout[(size_t)c.b * m + r] = yk[r];
-    if (t == 0) { db.stats[c.b] = st; c.info->bytes += c.bytes; }
-#ifdef LCQP_PROFILE
-    SPROF(c, SP_LCQP);
-    if (t == 0) for (int k = 0; k < SP_NPHASE; k++) c.info->prof[k] = (double)c.prof[k];
+        ph = __builtin_amdgcn_readfirstlane(ph); take = __builtin_amdgcn_readfirstlane(take); base = __builtin_amdgcn_readfirstlane(base);
+#ifdef LCQP_SCHED_PROFILE
+        const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #endif
+        if (take == 0) {
+            if (q_load(remaining) <= 0) break;
+            if (++idle > 4) __builtin_amdgcn_s_sleep(32);
+#ifdef LCQP_SCHED_PROFILE
+            if (lane == 0) { atomicAdd(&db.qprof[PH_NUM * 3 + 0], __builtin_amdgcn_s_memtime() - tq0); atomicAdd(&db.qprof[PH_NUM * 3 + 1], 1ull); }
+#endif
+            continue;
+        }
+        idle = 0;
+        int myid = -1;
+        if (lane < take) {
+            int* slot = &ring[(size_t)ph * db.poolSize + ((base + lane) & mask)];
+            int v;
+            while ((v = q_load(slot)) == 0) __builtin_amdgcn_s_sleep(1);
+            __hip_atomic_store(slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            myid = v - 1;
+        }
+        SP_ACQUIRE();
+        const int b = __shfl(myid, grp, 64);
+        // ---- run the phase for the instances popped (lane groups without one idle through it)
+        int next = -1;
+        if (b >= 0) {
+            SpCtx<G> c = sp_ctx<G>(db, b, w0);
+            SpState& S = db.state[b];
+            c.cAdmm = S.cAdmm; c.cTrials = S.cTrials; c.cFact = S.cFact; c.cCorr = S.cCorr; c.cSweeps = S.cSweeps; c.bytes = S.bytes;
+            GD gk = c.V(NV_GK);
+            switch (ph) {
+                case PH_START:   c.cAdmm = c.cTrials = c.cFact = c.cCorr = c.cSweeps = 0; c.bytes = 0.0; next = sp_ph_start<G>(c, S); break;
+                case PH_ROUND:   next = sp_ph_round<G>(c, S, gk); break;
+                case PH_TRIAL:   next = sp_ph_trial<G>(c, S, gk); break;
+                case PH_FACTOR:  next = sp_ph_factor<G>(c, S); break;
+                case PH_CORRECT: next = sp_ph_correct<G>(c, S); break;
+                default:         next = sp_ph_qpend<G>(c, S); break;
+            }
+            S.cAdmm = c.cAdmm; S.cTrials = c.cTrials; S.cFact = c.cFact; S.cCorr = c.cCorr; S.cSweeps = c.cSweeps; S.bytes = c.bytes;
+#ifdef LCQP_PROFILE
+            SPROF(c, SP_VECTORS);
+            if (c.gl == 0) for (int k = 0; k < SP_NPHASE; k++) c.info->prof[k] += (double)c.prof[k];
+#endif
+        }
+        // ---- push: what this wavefront wrote is released, then every instance goes to the queue of its next phase
+        SP_RELEASE();
+        if (b >= 0 && (lane & (G - 1)) == 0) {
+            if (next == PH_NUM) atomicSub(remaining, 1);
+            else {
+                const int s = atomicAdd(&ctl[next * QCTL + 0], 1);
+                __hip_atomic_store(&ring[(size_t)next * db.poolSize + (s & mask)], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                SP_RELEASE();
+                atomicAdd(&ctl[next * QCTL + 2], 1);
+            }
+        }
+#ifdef LCQP_SCHED_PROFILE
+        if (lane == 0) { atomicAdd(&db.qprof[ph * 3 + 0], __builtin_amdgcn_s_memtime() - tq0); atomicAdd(&db.qprof[ph * 3 + 1], 1ull); atomicAdd(&db.qprof[ph * 3 + 2], (unsigned long long)take); }
+#endif
+    }
+}
+
+// fills the queues of a run: every instance of every pool into PH_START
+__global__ void k_sparse_sched_init(SpBatch db)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = db.nPools * (PH_NUM + 1) * QCTL;
+    if (b < nq) {
+        const int pool = b / ((PH_NUM + 1) * QCTL), k = (b / QCTL) % (PH_NUM + 1), f = b % QCTL;
+        const int inPool = max(0, min(db.poolSize, db.B - pool * db.poolSize));
+        int v = 0;
+        if (k == PH_NUM) v = (f == 0) ? inPool : 0;                        // remaining
+        else if (k == PH_START) v = (f == 0 || f == 2) ? inPool : 0;       // tail = count = instances of the pool, head = 0
+        db.qctl[b] = v;
+    }
+    if (b < db.nPools * db.poolSize) {
+        const int pool = b / db.poolSize, i = b % db.poolSize;
+        for (int k = 0; k < PH_NUM; k++) db.qring[((size_t)pool * PH_NUM + k) * db.poolSize + i] = (k == PH_START && pool * db.poolSize + i < db.B) ? pool * db.poolSize + i + 1 : 0;
+    }
 }
 
 template <int G>
@@ -1287,7 +1522,16 @@ static void sp_launch(const SpBatch& db, hipStream_t stream, hipEvent_t mid)
     const size_t ldsBytes = G <= 16 ? 0 : sizeof(double) * (size_t)ipw * (G * G + 16 * G);       // LDS window of sp_factor_lds: per group G x G and 16 staged rows
     hipLaunchKernelGGL(k_sparse_setup<G>, dim3(grid), dim3(WGS), ldsBytes, stream, db);
     (void)hipEventRecord(mid, stream);
-    hipLaunchKernelGGL(k_sparse_run<G>, dim3(grid), dim3(WGS), ldsBytes, stream, db);
+    const int ninit = std::max(db.nPools * db.poolSize, db.nPools * (PH_NUM + 1) * QCTL);
+    hipLaunchKernelGGL(k_sparse_sched_init, dim3((ninit + 255) / 256), dim3(256), 0, stream, db);
+    // persistent wavefronts: as many as the batch has work for, at most what the device holds at once (they leave when their pool is done);
+    // a multiple of the number of pools so that every pool is served
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int waves = std::min(grid, cus * 4 * SP_WAVES_PER_SIMD);
+    waves = ((waves + db.nPools - 1) / db.nPools) * db.nPools;
+    hipLaunchKernelGGL(k_sparse_sched<G>, dim3(waves), dim3(WGS), ldsBytes, stream, db);
 }
 
 }  // namespace
@@ -1582,6 +1826,18 @@ try {
          (d.lbL = sp_alloc<double>(h, B * nComp)) && (d.lbR = sp_alloc<double>(h, B * nComp)) && (d.mi = sp_alloc<int>(h, B * MI_NUM * m)) &&
          (d.info = sp_alloc<SpInfo>(h, B)) && (d.stats = sp_alloc<lcqp_stats_t>(h, B)) && (d.xout = sp_alloc<double>(h, B * n)) &&
          (d.yout = sp_alloc<double>(h, B * m));
+    {
+        // pools of the phase machine (k_sparse_sched): the largest power of two of instances whose per-instance arrays all stay below 4 GiB
+        // (the 32-bit lane offsets of SpCtx::arr), at most the batch rounded up to a power of two
+        size_t perInst = sizeof(double) * std::max<size_t>({(size_t)nnzQ, (size_t)nnzA, 2 * Np, (size_t)(G > 16 ? (size_t)N * ld : 0), Np * (size_t)G,
+                                                            2 * (size_t)kb * Np, 2 * (size_t)nU, (size_t)NV_NUM * n, (size_t)MV_NUM * m, (size_t)nComp});
+        perInst = std::max(perInst, sizeof(int) * (size_t)MI_NUM * m);
+        int pool = 1;
+        while ((size_t)(2 * pool) * perInst < ((size_t)1 << 32) && pool < batch) pool *= 2;
+        d.poolSize = pool; d.nPools = (batch + pool - 1) / pool;
+        ok = ok && (d.state = sp_alloc<SpState>(h, B)) && (d.qring = sp_alloc<int>(h, (size_t)d.nPools * PH_NUM * pool)) &&
+             (d.qctl = sp_alloc<int>(h, (size_t)d.nPools * (PH_NUM + 1) * QCTL)) && (d.qprof = sp_alloc<unsigned long long>(h, (PH_NUM + 1) * 3));
+    }
     if (!ok) { g_sp_err = "device allocation failed"; return nullptr; }      // (the guard destroys the handle)
     guard.h = nullptr;
     return h;
@@ -1706,6 +1962,17 @@ try {
     return 0;
 }
 catch (...) { g_sp_err = "out of host memory"; return LCQP_HIP_ERROR; }
+
+/* -DLCQP_SCHED_PROFILE builds: per phase (rows 0 .. PH_NUM-1: start, round, trial, factor, correct, qp end; row PH_NUM: polls without work) the clock
+ * ticks (100 MHz), wavefront steps and instances served, summed over the wavefronts of all runs since the handle was created: 3 (PH_NUM + 1) values */
+extern "C" int lcqp_hip_sparse_sched_profile(lcqp_hip_sparse_t* h, unsigned long long* out)
+{
+    if (!h || !out) return LCQP_INVALID_ARGUMENT;
+    SPCHK(hipSetDevice(h->device));
+    SPCHK(hipStreamSynchronize(h->stream));
+    SPCHK(hipMemcpy(out, h->db.qprof, sizeof(unsigned long long) * 3 * (PH_NUM + 1), hipMemcpyDeviceToHost));
+    return 0;
+}
 
 extern "C" int lcqp_hip_sparse_run(lcqp_hip_sparse_t* h)
 try {

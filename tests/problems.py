@@ -163,32 +163,38 @@ def stationarity_type(d, x, y, rho, ctol=1e3 * 2.221e-16, merge_box=False):
     """determineStationarityType + getWeakComplementarities (src/LCQProblem.cpp:1412-1482) restated in numpy on a RETURNED solution:
     y holds the transformed duals (transformDuals :1381-1409), so the multipliers of L and R are shifted back by rho R x / rho L x first.
     Returns 1 (W), 2 (C), 3 (M), 4 (S).
-    merge_box: a complementarity row that is +-e_v while variable v also carries a finite box bound is the same constraint normal twice
-    (examples/example_data: lb = 0 on the variables L selects), so only the SUM of the two multipliers' contributions to the stationarity
-    in v is defined; with merge_box the whole contribution is attributed to the complementarity row -- a classification that does not depend
-    on how a solver happened to split it."""
+    merge_box: the reference's rule reads the signs of the multipliers a solver happened to return, but a complementarity row c e_v on a variable
+    whose box bound is active has the box bound's normal (up to sign): the two multipliers are not unique, only their combined contribution
+    c y_row + y_box to the stationarity in v is.  With merge_box the rule is applied to the most favourable admissible split -- which is what
+    "there EXIST multipliers with these signs" (the definition of the stationarity types) means:
+      same direction  (c > 0 at an active lower bound, c < 0 at an active upper bound): the row can carry the whole contribution, y_row + y_box / c;
+      opposite direction (the two constraints pin x_v from both sides): any amount can be added to both, the row's multiplier is unbounded above."""
     n, nC, nK = d["nV"], d["nC"], d["nComp"]
     L, R = d["L"], d["R"]
     Lx, Rx = L @ x, R @ x
     yL = y[n + nC:n + nC + nK] + rho * Rx
     yR = y[n + nC + nK:] + rho * Lx
     if merge_box:
-        lb = d.get("lb"); ub = d.get("ub")
-        boxed = np.zeros(n, dtype=bool)
-        if lb is not None: boxed |= np.isfinite(lb)
-        if ub is not None: boxed |= np.isfinite(ub)
+        lb = d.get("lb") if d.get("lb") is not None else np.full(n, -INF)
+        ub = d.get("ub") if d.get("ub") is not None else np.full(n, INF)
         yL, yR = yL.copy(), yR.copy()
         for M_, ym in ((L, yL), (R, yR)):
             for i in range(nK):
                 nz = np.nonzero(M_[i])[0]
-                if nz.size == 1 and boxed[nz[0]]:
-                    ym[i] += y[nz[0]] / M_[i, nz[0]]
+                if nz.size != 1:
+                    continue
+                v, c = nz[0], M_[i, nz[0]]
+                at_lo, at_hi = abs(x[v] - lb[v]) <= 1e-9, abs(x[v] - ub[v]) <= 1e-9
+                if (c > 0 and at_hi) or (c < 0 and at_lo):
+                    ym[i] = INF
+                elif (c > 0 and at_lo) or (c < 0 and at_hi):
+                    ym[i] += y[v] / c
     sflag, mflag = True, True
     for i in range(nK):
         if not (Lx[i] <= ctol and Rx[i] <= ctol):
             continue
         a, b = yL[i], yR[i]
-        prod, mn = a * b, min(a, b)
+        prod, mn = (0.0 if (a == 0 or b == 0) else a * b), min(a, b)
         if mn < 0:
             sflag = False
         if abs(prod) >= ctol and mn <= 0:
