@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=("dense", "sparse"), default="dense")
-    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default 1024 dense; 16384 sparse: 8 instances per wavefront, 2 wavefronts per SIMD resident)")
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default 1024 dense; 65536 sparse: four times what the 2048 resident wavefronts hold, so that the phase queues of k_sparse_sched stay filled)")
     ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--nC", type=int, default=None)
     ap.add_argument("--nComp", type=int, default=None)
@@ -102,10 +102,10 @@ def main():
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-batches-in-flight measurement")
     ap.add_argument("--no-resident", action="store_true", help="skip the 8192-resident-instances measurement")
     ap.add_argument("--no-sparse", action="store_true", help="skip the sparse_config5 object (BASELINE configs[4]) of the default line")
-    ap.add_argument("--sparse-batch", type=int, default=16384, help="instances of the sparse_config5 object")
+    ap.add_argument("--sparse-batch", type=int, default=65536, help="instances of the sparse_config5 object")
     args = ap.parse_args()
     sparse = args.workload == "sparse"
-    B = args.batch or (16384 if sparse else 1024)
+    B = args.batch or (65536 if sparse else 1024)
     n = args.n or (4096 if sparse else 256)
     nC = args.nC if args.nC is not None else (2048 if sparse else 512)
     nComp = args.nComp or (512 if sparse else 64)
@@ -198,7 +198,7 @@ def main():
 
     if sparse:
         kernel_s = (setup_ms + solve_ms) * 1e-3             # setup (the one KKT factorisation) + homotopy: both counted in the bytes
-        kname = "k_sparse_setup + k_sparse_run"
+        kname = "k_sparse_setup + k_sparse_sched"
         cfg_extra = {"kkt_half_bandwidth": bt.bandwidth(), "nnz_Q": bt.nnzQ, "nnz_E": bt.nnzA,
                      "mean_kkt_factorizations": mean("factorizations"), "mean_band_solves": mean("corrections") + mean("admmIter")}
         wl = (f"synthetic sparse batch={B}/GPU n={n} nC={nC} nComp={nComp} (BASELINE configs[4]; banded pattern of lcqpow_amd/synth_sparse.py, "
@@ -279,8 +279,9 @@ def main():
         btR.close()
 
     if main_proc and world == 1 and not sparse and not args.no_sparse and shape == (256, 512, 64) and B == 1024:
-        # BASELINE configs[4] in the default line: the sparse arm (OSQP-style ADMM KKT + polish on the banded KKT matrix) on the batch that
-        # fills the GPU once (8 instances per wavefront, 2 wavefronts per SIMD: 16 384 resident), one warm-up and one timed step;
+        # BASELINE configs[4] in the default line: the sparse arm (OSQP-style ADMM KKT + polish on the banded KKT matrix) on a batch of four times
+        # what the resident wavefronts hold (8 instances per wavefront, 2 wavefronts per SIMD: 16 384) -- the persistent wavefronts of
+        # k_sparse_sched regroup instances by phase, which needs filled queues; 150 GB of the 288 GB -- one warm-up and one timed step;
         # `python bench.py --workload sparse` runs the same workload as the headline with steps / warmup / cpu_baseline
         Bs, ns, nCs, nKs = args.sparse_batch, 4096, 2048, 512
         sb = make_sparse_batch(devices[0], 0, Bs, ns, nCs, nKs)
@@ -294,7 +295,7 @@ def main():
                                  "batch": Bs, "steps": 1, "ms_per_step": 1e3 * dts, "solved": sum(1 for s_ in sts if s_["returnValue"] == 0),
                                  "kkt_half_bandwidth": sb.bandwidth(), "lanes_per_instance": sb.lanes(),
                                  "mean_lcqp_iterates": float(np.mean([s_["iterTotal"] for s_ in sts])),
-                                 "roofline": {"bound": "hbm", "kernel": "k_sparse_setup + k_sparse_run", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "roofline": {"bound": "hbm", "kernel": "k_sparse_setup + k_sparse_sched", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("sparse", Bs, (ns, nCs, nKs)), "algorithmic_bytes_per_launch": sbytes},
                                  "data": "synthetic (lcqpow_amd/synth_sparse.py: banded pattern, numpy PCG64 seed0=0x4C43515000000005 ^ instance id)"}
         sb.close()

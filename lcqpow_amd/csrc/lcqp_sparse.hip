@@ -1219,8 +1219,8 @@ __device__ __forceinline__ int sp_ph_qpend(SpCtx<G>& c, SpState& S)
         perturbed = true;
         const uint64_t pc = S.perturbCounter;
         for (int i = t; i < n; i += G) {
-            uint64_t z = o.perturbSeed + (pc + (uint64_t)i + 1ULL) * 0x9E3779B97F4A7C15ULL;
-            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z = z ^ (z >> 31);
+            uint64_t z = o.perturbSeed + (pc + (uint64_t)i + 1ULL) * opaque_u64(0x9E3779B97F4A7C15ULL);
+            z = (z ^ (z >> 30)) * opaque_u64(0xBF58476D1CE4E5B9ULL); z = (z ^ (z >> 27)) * opaque_u64(0x94D049BB133111EBULL); z = z ^ (z >> 31);
             xk[i] += ((int)(z % 3ULL) - 1) * 2.221e-16;
         }
         S.perturbCounter += (uint64_t)n;
@@ -1331,12 +1331,12 @@ __device__ __forceinline__ int sp_ph_qpend(SpCtx<G>& c, SpState& S)
 extern __shared__ double sp_dyn_lds[];
 
 template <int G>
-__device__ __forceinline__ SpCtx<G> sp_ctx(const SpBatch& db, int b, int w0)
+__device__ __forceinline__ SpCtx<G> sp_ctx(const SpBatch& db, int b, int w0, int lane)
 {
     SpCtx<G> c;
-    c.db = &db; c.b = b; c.gl = threadIdx.x & (G - 1); c.gi = (unsigned)(b - w0); c.w0 = w0;
+    c.db = &db; c.b = b; c.gl = lane & (G - 1); c.gi = (unsigned)(b - w0); c.w0 = w0;
     c.info = db.info + b;
-    c.win = sp_dyn_lds + (size_t)(threadIdx.x / G) * (G * G + 16 * G);
+    c.win = sp_dyn_lds + (size_t)(lane / G) * (G * G + 16 * G);
     c.cAdmm = c.cTrials = c.cFact = c.cCorr = c.cSweeps = 0;
     c.bytes = 0.0;
 #ifdef LCQP_PROFILE
@@ -1352,7 +1352,7 @@ __global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db)
 {
     const int b = blockIdx.x * (64 / G) + threadIdx.x / G;
     if (b >= db.B) return;
-    SpCtx<G> c = sp_ctx<G>(db, b, blockIdx.x * (64 / G));
+    SpCtx<G> c = sp_ctx<G>(db, b, blockIdx.x * (64 / G), (int)threadIdx.x);
     const int t = c.gl, n = db.n, m = db.m, nC = db.nC, nK = db.nComp;
 #ifdef LCQP_PROFILE
     if (t == 0) for (int k = 0; k < SP_NPHASE; k++) c.info->prof[k] = 0.0;
@@ -1422,8 +1422,8 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_sched(SpBatch
     int* ring = db.qring + (size_t)pool * PH_NUM * db.poolSize;
     int* ctl = db.qctl + (size_t)pool * (PH_NUM + 1) * QCTL;
     int* remaining = ctl + PH_NUM * QCTL;
-    const int lane = threadIdx.x, grp = lane / G;
     for (int idle = 0;;) {
+        const int lane = here((int)threadIdx.x), grp = lane / G;      // per step: nothing derived from the lane number is carried around the loop (it would be hoisted and spilled)
         // ---- pop: one phase for the whole wavefront (lane 0 decides; the queue with the most entries, a full wavefront's worth if there is one)
         int ph = -1, take = 0, base = 0;
         if (lane == 0) {
@@ -1461,7 +1461,7 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_sched(SpBatch
         // ---- run the phase for the instances popped (lane groups without one idle through it)
         int next = -1;
         if (b >= 0) {
-            SpCtx<G> c = sp_ctx<G>(db, b, w0);
+            SpCtx<G> c = sp_ctx<G>(db, b, w0, lane);
             SpState& S = db.state[b];
             c.cAdmm = S.cAdmm; c.cTrials = S.cTrials; c.cFact = S.cFact; c.cCorr = S.cCorr; c.cSweeps = S.cSweeps; c.bytes = S.bytes;
             GD gk = c.V(NV_GK);

@@ -39,10 +39,10 @@ out = {"kernel": "k_lcqp_run<2>", "workload": ["dense", 1024, 256, 512, 64], "so
                "bench.kernel_source_hash() of the profiled sources: bench.py reports the figure only while it matches"}
 bs = json.load(open(os.path.join(dst, "bench_sparse.json")))
 Bs = bs["config"]["global_batch"]
-def sum_counter(fname, counter):      # k_sparse_setup + k_sparse_run of the one profiled step
+def sum_counter(fname, counter):      # k_sparse_setup + k_sparse_sched of the one profiled step
     return sum(float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(dst, fname))) if "k_sparse" in r["Kernel_Name"] and r["Counter_Name"] == counter)
 fs, ws = sum_counter("pmc_fetch_size_sparse.csv", "FETCH_SIZE"), sum_counter("pmc_write_size_sparse.csv", "WRITE_SIZE")
-sparse = {"kernel": "k_sparse_setup + k_sparse_run", "workload": ["sparse", Bs, 4096, 2048, 512], "source_hash": bench.kernel_source_hash(),
+sparse = {"kernel": "k_sparse_setup + k_sparse_sched", "workload": ["sparse", Bs, 4096, 2048, 512], "source_hash": bench.kernel_source_hash(),
           "FETCH_SIZE_KiB": fs, "WRITE_SIZE_KiB": ws, "traffic_bytes_guide_recipe": (2 * fs + ws) * 1024, "traffic_bytes_uncorrected": (fs + ws) * 1024,
           "note": "same recipe, `python3 bench.py --workload sparse --steps 1 --warmup 0 --cpu-sample 0`"}
 out["entries"] = [dict(out), sparse]

@@ -700,9 +700,9 @@ def cmd_sparse_check():
               {k: (st[b][k], ro["stats"][k]) for k in ("iterTotal", "trials", "factorizations", "corrections", "admmIter", "status")})
 
 
-@command("sparse_profile", "Diagnostic: where does k_sparse_run spend its time?  Runs a -DLCQP_PROFILE build of the library (s_memtime stamps between phases,")
+@command("sparse_profile", "Diagnostic: where does k_sparse_sched spend its time?  Runs a -DLCQP_PROFILE build of the library (s_memtime stamps between phases,")
 def cmd_sparse_profile():
-    """Diagnostic: where does k_sparse_run spend its time?  Runs a -DLCQP_PROFILE build of the library (s_memtime stamps between phases,
+    """Diagnostic: where does k_sparse_sched spend its time?  Runs a -DLCQP_PROFILE build of the library (s_memtime stamps between phases,
     per instance) on the sparse BASELINE workload and prints the share of each phase.  Shares only -- the stamped build is not the
     measured build.   usage: python tools/gpu.py sparse_profile --so=ab_tmp/libprof.so [B]
     (build the library first, here or on the box:  python -c "import __graft_entry__ as g; g.build_hip(True, 'ab_tmp/libprof.so', ['-DLCQP_PROFILE'], 2)")"""

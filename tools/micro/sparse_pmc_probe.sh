@@ -1,7 +1,7 @@
 #!/bin/bash
 # NOT USABLE AS IS on this pool: the texture-addresser / L1 counter groups slowed the 13 s sparse run beyond a 25-minute limit (nothing came
 # back).  Kept as a record of the counter names; run single groups under `timeout` on a small batch if at all.
-# Which unit bounds k_sparse_run?  Texture-addresser / L1 / L2 counters of the sparse workload, one rocprofv3 --pmc pass per group.
+# Which unit bounds k_sparse_sched?  Texture-addresser / L1 / L2 counters of the sparse workload, one rocprofv3 --pmc pass per group.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/sp_pmc
 mkdir -p $O
@@ -18,7 +18,7 @@ import csv, glob
 for f in sorted(glob.glob("$O/g*/*/*counter_collection.csv")):
     acc = {}
     for r in csv.DictReader(open(f)):
-        if "k_sparse_run" in r["Kernel_Name"]:
+        if "k_sparse_sched" in r["Kernel_Name"]:
             acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     for k, v in acc.items():
         print(f"{k:40s} {v:.6g}")
