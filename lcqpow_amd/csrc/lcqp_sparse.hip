@@ -21,6 +21,7 @@
 #include "../../include/lcqp_hip.h"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -93,6 +94,7 @@ struct SpBatch {
     lcqp_options_t opt;
     const int *Qp, *Qi, *Ep, *Ei, *ETp, *ETi, *ETmap, *iperm, *bandQ, *bandE;
     const int *bsrc, *pnode, *qdiag, *Erow;   // band entry -> value it comes from (sp_factor_reg), node of a band position, Q_ii, row of an E entry
+    const int *bgate, *bdiag;                 // band entry -> the row of E whose membership in the working set gates it (-1: none); band position -> its diagonal (sp_factor_reg)
     EllMat ellQ, ellE, ellT; // rows of Q, rows of E, columns of E in ELL slabs
     double *Qx, *Ex;         // [B][nnzQ], [B][nnzE] (CSR order)
     double *Kb;              // [B][N*ld] assembled band rows (input of a factorisation): Kb[i*ld + k] = K[i][i-w+k]
@@ -542,22 +544,28 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
     // band row r in band order (entry k: column r - (G-1) + k), assembled on the fly from the values of Q and E: variables carry
     // Q + dprim I; constraint row rr carries its entries of E and -ddual(rr) on the diagonal when it is in the working set, -1 alone
     // when it is not (the KKT matrix is never written to memory)
+    // Two levels of dependent loads per row (round 4; four before: code -> row of E -> status -> value, and position -> node -> Q_ii -> value):
+    // level 1, shared by the batch: where each band entry comes from (bsrc), which row of E gates it (bgate), what the diagonal is (bdiag:
+    // >= 0 the entry of Q, -1 a variable without a stored diagonal, -2 - rr the constraint row rr, INT_MIN a border position);
+    // level 2, this instance's values and working-set flags.  The factorisation was bound by this chain, not by its arithmetic.
+    const int* __restrict__ bgate = c.db->bgate;
+    const int* __restrict__ bdiag = c.db->bdiag;
     auto load_row = [&](double* dst, int r) {
         if (r < N) {
-            int code[G];
+            int code[G], gate[G];
 #pragma unroll
-            for (int k = 0; k < GM; k++) code[k] = bsrc[r * G + k];
-            const int node = c.db->pnode[r];
+            for (int k = 0; k < GM; k++) { code[k] = bsrc[r * G + k]; gate[k] = bgate[r * G + k]; }
+            const int bd = bdiag[r];
 #pragma unroll
             for (int k = 0; k < GM; k++) {
                 double v = 0.0;
-                if (code[k] >= nnzQ) { const int e = code[k] - nnzQ; if (use(c.db->Erow[e])) v = Ev[e]; }
+                if (code[k] >= nnzQ) { if (use(gate[k])) v = Ev[code[k] - nnzQ]; }
                 else if (code[k] >= 0) v = Qv[code[k]];
                 dst[k] = v;
             }
-            if (r >= N - c.db->kb) dst[GM] = 1.0;                       // a border position: an isolated unit pivot of the band
-            else if (node < nvar) { const int qd = c.db->qdiag[node]; dst[GM] = (qd >= 0 ? (double)Qv[qd] : 0.0) + dprim; }
-            else { const int rr = node - nvar; dst[GM] = use(rr) ? -ddual(rr) : -1.0; }
+            if (bd == INT_MIN) dst[GM] = 1.0;                           // a border position: an isolated unit pivot of the band
+            else if (bd >= -1) dst[GM] = (bd >= 0 ? (double)Qv[bd] : 0.0) + dprim;
+            else { const int rr = -2 - bd; dst[GM] = use(rr) ? -ddual(rr) : -1.0; }
         } else {
 #pragma unroll
             for (int k = 0; k < G; k++) dst[k] = (k == GM) ? 1.0 : 0.0;
@@ -1550,7 +1558,7 @@ struct lcqp_hip_sparse {
     std::vector<void*> allocs;
     std::vector<int> csr2csc;      // value order: E (CSR) entry k comes from entry csr2csc[k] of the caller's CSC arrays
     // two orderings of the band (lcqp_hip_sparse_create): [0] reverse Cuthill-McKee, [1] the same with every row behind its first variable
-    struct Ord { std::vector<int> perm; int *iperm, *bandQ, *bandE, *bsrc, *pnode, *Upos; bool rowsFollow; } ord[2];
+    struct Ord { std::vector<int> perm; int *iperm, *bandQ, *bandE, *bsrc, *bgate, *bdiag, *pnode, *Upos; bool rowsFollow; } ord[2];
     bool hasB;
     int useB;                      // ordering of the last sp_choose_ordering
     std::vector<int> qdiagHost;    // entry of Q_ii in the value array
@@ -1567,7 +1575,7 @@ static void sp_choose_ordering(lcqp_hip_sparse* h)
     const int k = (definite && h->hasB) ? 1 : 0;
     const lcqp_hip_sparse::Ord& o = h->ord[k];
     SpBatch& d = h->db;
-    d.iperm = o.iperm; d.bandQ = o.bandQ; d.bandE = o.bandE; d.bsrc = o.bsrc; d.pnode = o.pnode; d.Upos = o.Upos;
+    d.iperm = o.iperm; d.bandQ = o.bandQ; d.bandE = o.bandE; d.bsrc = o.bsrc; d.bgate = o.bgate; d.bdiag = o.bdiag; d.pnode = o.pnode; d.Upos = o.Upos;
     d.lightOK = (definite && o.rowsFollow) ? 1 : 0;
     h->useB = k;
 }
@@ -1726,7 +1734,7 @@ try {
     // what depends on the ordering: inverse permutation, band slot of every entry of Q and E (-1: not in the band -- an upper-triangle entry
     // of Q, or an entry of the border), where every off-diagonal band entry comes from (assembly inside the factorisation: -1 nothing,
     // k < nnzQ the entry k of Q, nnzQ + k the entry k of E in CSR order), the node behind a band position, the band positions of U
-    struct OrdMaps { std::vector<int> perm, iperm, bandQ, bandE, bsrc, Upos; };
+    struct OrdMaps { std::vector<int> perm, iperm, bandQ, bandE, bsrc, bgate, bdiag, Upos; };
     std::vector<int> qdiag(n, -1), Erow(nnzA);
     for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) if (Qi[k] == i) qdiag[i] = k;
     for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) Erow[k] = r;
@@ -1759,6 +1767,16 @@ try {
         for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { const int pr = M.iperm[n + r], pc = M.iperm[Ei[k]]; const int hi = std::max(pr, pc), lo = std::min(pr, pc); if (hi < Nband) M.bandE[k] = hi * ld + wS - (hi - lo); }
         for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) if (Qi[k] != i && M.bandQ[k] >= 0) M.bsrc[M.bandQ[k]] = k;
         for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) if (M.bandE[k] >= 0) M.bsrc[M.bandE[k]] = nnzQ + k;
+        // the same information one level of indirection shorter (sp_factor_reg: load_row): the gating row of every band entry, the diagonal of every position
+        M.bgate.assign((size_t)N * ld, -1);
+        for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) if (M.bandE[k] >= 0) M.bgate[M.bandE[k]] = r;
+        M.bdiag.assign(N, -1);
+        for (int p_ = 0; p_ < N; p_++) {
+            const int node = pm[p_];
+            if (p_ >= Nband) M.bdiag[p_] = INT_MIN;
+            else if (node < n) M.bdiag[p_] = qdiag[node];
+            else M.bdiag[p_] = -2 - (node - n);
+        }
         M.Upos.resize(nU);
         for (int e = 0; e < nU; e++) M.Upos[e] = M.iperm[Uother[e]];
         return M;
@@ -1795,6 +1813,7 @@ try {
         }
         ok = ok && (o.iperm = sp_alloc<int>(h, N, M.iperm.data())) && (o.bandQ = sp_alloc<int>(h, nnzQ, M.bandQ.data())) &&
              (o.bandE = sp_alloc<int>(h, nnzA, M.bandE.data())) && (o.bsrc = sp_alloc<int>(h, M.bsrc.size(), M.bsrc.data())) &&
+             (o.bgate = sp_alloc<int>(h, M.bgate.size(), M.bgate.data())) && (o.bdiag = sp_alloc<int>(h, M.bdiag.size(), M.bdiag.data())) &&
              (o.pnode = sp_alloc<int>(h, N, M.perm.data())) && (o.Upos = sp_alloc<int>(h, nU, M.Upos.data()));
         o.perm = std::move(M.perm);
     }
