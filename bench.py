@@ -244,9 +244,9 @@ def main():
         # LCQPow::BatchPipeline in lcqpow_amd/csrc/host/BatchLCQProblem.hpp): two batch objects, each with its own buffers and HIP stream, so
         # that the launch tail of one step -- its slowest instances, most workgroup slots already idle -- overlaps with the setup kernels and
         # the first instances of the next.  Every step still does setup + homotopy of a whole batch; results are bit-identical.
-        pipe = la.BatchPipeline(2, B, n, nC, nComp, device=devices[0], opt=opt)
-        for s_ in pipe.slots:
-            s_.generate_synthetic(0); s_.run(); s_.synchronize()
+        bt2 = make_batch(devices[0])
+        bt2.run(); bt2.synchronize()
+        pipe = la.BatchPipeline(2, B, n, nC, nComp, over=[bt, bt2])      # (over the batch object of the headline and one more: two objects alive, see capi.BatchPipeline)
         ksteps = max(2, args.steps)
         solved_p, last = 0, None
         tp = time.perf_counter()
@@ -262,7 +262,7 @@ def main():
                             "ms_per_step": 1e3 * dtp / ksteps, "solved_last_step": sum(1 for s_ in st2 if s_["returnValue"] == 0),
                             "bitwise_equal_to_sequential": bool(np.array_equal(x2, x)),
                             "note": "product call: lcqpow_amd.BatchPipeline / LCQPow::BatchPipeline, two batch objects in flight on two streams; every step still does setup + homotopy"}
-        pipe.close()
+        pipe.close(); bt2.close()
 
     if main_proc and world == 1 and not sparse and not args.no_resident and shape == (256, 512, 64) and B == 1024:
         # the node-sized job of BASELINE configs[3] (8192 instances) resident on ONE GPU: shows what the tail of a launch that is

@@ -187,9 +187,14 @@ class BatchPipeline:
     LCQPow::BatchPipeline (lcqpow_amd/csrc/host/BatchLCQProblem.hpp, DESIGN.md section 8a).  acquire() hands out the object to fill next --
     a free one, else the oldest one in flight after waiting for it (its results are then read with .solution())."""
 
-    def __init__(self, depth, batch, nV, nC, nComp, with_box=False, device=0, opt=None):
-        self.slots = [BatchLCQP(batch, nV, nC, nComp, with_box=with_box, device=device, opt=opt) for _ in range(depth)]
-        self.state = [0] * depth          # 0 free, 1 in flight, 2 finished
+    def __init__(self, depth, batch, nV, nC, nComp, with_box=False, device=0, opt=None, over=None):
+        # over: existing BatchLCQP objects to run the pipeline over (not closed by close()).  HIP maps the streams of a process onto a few
+        # hardware queues (4 by default, GPU_MAX_HW_QUEUES); every batch object has two streams, so a process that keeps more than two batch
+        # objects alive can find both slots of a pipeline on one queue -- and its batches run one after the other (tools/micro/pipeline_check.py:
+        # 35 200 LCQPs/s with two objects alive, 30 750 with an idle third one, 34 800 again with GPU_MAX_HW_QUEUES=8)
+        self.owned = over is None
+        self.slots = list(over) if over is not None else [BatchLCQP(batch, nV, nC, nComp, with_box=with_box, device=device, opt=opt) for _ in range(depth)]
+        self.state = [0] * len(self.slots)          # 0 free, 1 in flight, 2 finished
         self.order = []
 
     def acquire(self):
@@ -216,8 +221,9 @@ class BatchPipeline:
             yield self.slots[k]
 
     def close(self):
-        for s in self.slots:
-            s.close()
+        if self.owned:
+            for s in self.slots:
+                s.close()
 
 
 class BatchLCQP:

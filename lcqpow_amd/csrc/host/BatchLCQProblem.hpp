@@ -81,6 +81,9 @@ class BatchLCQProblem {
 //     for (each batch of problems) { BatchLCQProblem& b = pipe.acquire();   // waits for (and hands back) the oldest batch when all are in flight
 //                                    if (b.hasResults()) consume(b);  load(b);  pipe.launch(b); }
 //     while (BatchLCQProblem* b = pipe.drain()) consume(*b);
+// (HIP maps the streams of a process onto a few hardware queues -- 4 by default, GPU_MAX_HW_QUEUES -- and every batch object has two streams:
+//  a process that keeps more batch objects alive than the pipeline's can find both slots on one queue, and they then run one after the
+//  other; tools/micro/pipeline_check.py measures it.  Create the pipeline first, or raise GPU_MAX_HW_QUEUES.)
 class BatchPipeline {
   public:
     BatchPipeline(int depth, int batch, int nV, int nC, int nComp, bool withBoxBounds = false, int device = 0)

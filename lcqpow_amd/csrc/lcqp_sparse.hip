@@ -1420,10 +1420,53 @@ __global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db)
 #define SP_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
 __device__ __forceinline__ int q_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Lanes per instance depend on the phase (round 4, second step): the band phases (PH_FACTOR, PH_CORRECT, PH_ROUND with its ADMM band solves) need
+// the G lanes the folded band layout is made for and take 64 / G instances per wavefront; the STREAMING phases (PH_START, PH_TRIAL, PH_QPEND:
+// sparse products and element-wise loops, 60 % of the time) take ONE instance with all 64 lanes -- a wavefront instruction then reads 512
+// contiguous bytes of one instance instead of eight 64-byte pieces of eight instances, the access pattern this part streams best
+// (tools/micro/stream_pattern.py: 2.4 TB/s for eight far-apart pieces per wavefront, 5.8 TB/s for one stream).
+#ifndef SP_WIDE_LANES
+#define SP_WIDE_LANES 64      // (experiment switch: 0 = every phase with G lanes per instance, the first phase machine of round 4)
+#endif
+template <int G, int GP>
+__device__ __forceinline__ int sp_run_phase(const SpBatch& db, int ph, int b, int w0, int lane)
+{
+    SpCtx<GP> c = sp_ctx<GP>(db, b, w0, lane);
+    SpState& S = db.state[b];
+    c.cAdmm = S.cAdmm; c.cTrials = S.cTrials; c.cFact = S.cFact; c.cCorr = S.cCorr; c.cSweeps = S.cSweeps; c.bytes = S.bytes;
+    GD gk = c.V(NV_GK);
+    int next;
+    if constexpr (GP == G) {
+        // every phase can run with the band's lane group (the streaming ones do when SP_WIDE_LANES == 0 or G == 64)
+        switch (ph) {
+            case PH_START:   c.cAdmm = c.cTrials = c.cFact = c.cCorr = c.cSweeps = 0; c.bytes = 0.0; next = sp_ph_start<GP>(c, S); break;
+            case PH_ROUND:   next = sp_ph_round<GP>(c, S, gk); break;
+            case PH_TRIAL:   next = sp_ph_trial<GP>(c, S, gk); break;
+            case PH_FACTOR:  next = sp_ph_factor<GP>(c, S); break;
+            case PH_CORRECT: next = sp_ph_correct<GP>(c, S); break;
+            default:         next = sp_ph_qpend<GP>(c, S); break;
+        }
+    } else {
+        switch (ph) {
+            case PH_START:   c.cAdmm = c.cTrials = c.cFact = c.cCorr = c.cSweeps = 0; c.bytes = 0.0; next = sp_ph_start<GP>(c, S); break;
+            case PH_TRIAL:   next = sp_ph_trial<GP>(c, S, gk); break;
+            default:         next = sp_ph_qpend<GP>(c, S); break;
+        }
+    }
+    S.cAdmm = c.cAdmm; S.cTrials = c.cTrials; S.cFact = c.cFact; S.cCorr = c.cCorr; S.cSweeps = c.cSweeps; S.bytes = c.bytes;
+#ifdef LCQP_PROFILE
+    SPROF(c, SP_VECTORS);
+    if (c.gl == 0) for (int k = 0; k < SP_NPHASE; k++) c.info->prof[k] += (double)c.prof[k];
+#endif
+    return next;
+}
+
 template <int G>
 __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_sched(SpBatch db)
 {
     constexpr int IPW = 64 / G;
+    constexpr int GW = (SP_WIDE_LANES > G) ? SP_WIDE_LANES : G;      // lanes per instance of the streaming phases
+    constexpr int IPWW = 64 / GW;
     const int pool = blockIdx.x % db.nPools;
     const int w0 = pool * db.poolSize;
     const int mask = db.poolSize - 1;
@@ -1431,14 +1474,20 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_sched(SpBatch
     int* ctl = db.qctl + (size_t)pool * (PH_NUM + 1) * QCTL;
     int* remaining = ctl + PH_NUM * QCTL;
     for (int idle = 0;;) {
-        const int lane = here((int)threadIdx.x), grp = lane / G;      // per step: nothing derived from the lane number is carried around the loop (it would be hoisted and spilled)
-        // ---- pop: one phase for the whole wavefront (lane 0 decides; the queue with the most entries, a full wavefront's worth if there is one)
+        const int lane = here((int)threadIdx.x);      // per step: nothing derived from the lane number is carried around the loop (it would be hoisted and spilled)
+        // ---- pop: one phase for the whole wavefront (lane 0 decides).  A band phase with a full wavefront's worth of instances first (the long
+        // steps run at full width), else the fullest streaming queue, else whatever a band queue holds.
         int ph = -1, take = 0, base = 0;
         if (lane == 0) {
+            int cnt[PH_NUM];
+            for (int k = 0; k < PH_NUM; k++) cnt[k] = q_load(&ctl[k * QCTL + 2]);
+            auto isWide = [](int k) { return GW != G && (k == PH_START || k == PH_TRIAL || k == PH_QPEND); };
             int best = 0;
-            for (int k = 0; k < PH_NUM; k++) { const int cnt = q_load(&ctl[k * QCTL + 2]); if (cnt > best) { best = cnt; ph = k; } }
+            for (int k = 0; k < PH_NUM; k++) if (!isWide(k) && cnt[k] >= IPW && cnt[k] > best) { best = cnt[k]; ph = k; }
+            if (ph < 0) for (int k = 0; k < PH_NUM; k++) if (isWide(k) && cnt[k] > best) { best = cnt[k]; ph = k; }
+            if (ph < 0) for (int k = 0; k < PH_NUM; k++) if (cnt[k] > best) { best = cnt[k]; ph = k; }
             if (ph >= 0) {
-                take = min(best, IPW);
+                take = min(best, isWide(ph) ? IPWW : IPW);
                 if (atomicCAS(&ctl[ph * QCTL + 2], best, best - take) == best) base = atomicAdd(&ctl[ph * QCTL + 1], take);
                 else { ph = -1; take = 0; }      // somebody else moved the counter: look again
             }
@@ -1465,31 +1514,18 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_sched(SpBatch
             myid = v - 1;
         }
         SP_ACQUIRE();
-        const int b = __shfl(myid, grp, 64);
+        const bool wide = GW != G && (ph == PH_START || ph == PH_TRIAL || ph == PH_QPEND);
+        const int gw = wide ? GW : G;                       // lanes per instance in this step
+        const int b = __shfl(myid, lane / gw, 64);
         // ---- run the phase for the instances popped (lane groups without one idle through it)
         int next = -1;
         if (b >= 0) {
-            SpCtx<G> c = sp_ctx<G>(db, b, w0, lane);
-            SpState& S = db.state[b];
-            c.cAdmm = S.cAdmm; c.cTrials = S.cTrials; c.cFact = S.cFact; c.cCorr = S.cCorr; c.cSweeps = S.cSweeps; c.bytes = S.bytes;
-            GD gk = c.V(NV_GK);
-            switch (ph) {
-                case PH_START:   c.cAdmm = c.cTrials = c.cFact = c.cCorr = c.cSweeps = 0; c.bytes = 0.0; next = sp_ph_start<G>(c, S); break;
-                case PH_ROUND:   next = sp_ph_round<G>(c, S, gk); break;
-                case PH_TRIAL:   next = sp_ph_trial<G>(c, S, gk); break;
-                case PH_FACTOR:  next = sp_ph_factor<G>(c, S); break;
-                case PH_CORRECT: next = sp_ph_correct<G>(c, S); break;
-                default:         next = sp_ph_qpend<G>(c, S); break;
-            }
-            S.cAdmm = c.cAdmm; S.cTrials = c.cTrials; S.cFact = c.cFact; S.cCorr = c.cCorr; S.cSweeps = c.cSweeps; S.bytes = c.bytes;
-#ifdef LCQP_PROFILE
-            SPROF(c, SP_VECTORS);
-            if (c.gl == 0) for (int k = 0; k < SP_NPHASE; k++) c.info->prof[k] += (double)c.prof[k];
-#endif
+            if (wide) next = sp_run_phase<G, GW>(db, ph, b, w0, lane);
+            else next = sp_run_phase<G, G>(db, ph, b, w0, lane);
         }
         // ---- push: what this wavefront wrote is released, then every instance goes to the queue of its next phase
         SP_RELEASE();
-        if (b >= 0 && (lane & (G - 1)) == 0) {
+        if (b >= 0 && (lane & (gw - 1)) == 0) {
             if (next == PH_NUM) atomicSub(remaining, 1);
             else {
                 const int s = atomicAdd(&ctl[next * QCTL + 0], 1);
