@@ -1889,6 +1889,7 @@ try {
         perInst = std::max(perInst, sizeof(int) * (size_t)MI_NUM * m);
         int pool = 1;
         while ((size_t)(2 * pool) * perInst < ((size_t)1 << 32) && pool < batch) pool *= 2;
+        if (const char* e = std::getenv("LCQP_SPARSE_POOL")) { const int v = std::atoi(e); if (v >= 1 && v < pool && (v & (v - 1)) == 0) pool = v; }      // test hook: several small pools
         d.poolSize = pool; d.nPools = (batch + pool - 1) / pool;
         ok = ok && (d.state = sp_alloc<SpState>(h, B)) && (d.qring = sp_alloc<int>(h, (size_t)d.nPools * PH_NUM * pool)) &&
              (d.qctl = sp_alloc<int>(h, (size_t)d.nPools * (PH_NUM + 1) * QCTL)) && (d.qprof = sp_alloc<unsigned long long>(h, (PH_NUM + 1) * 3));

@@ -80,6 +80,30 @@ def test_sparse_lane_group_widths(hip, oracle, monkeypatch, lanes):
     sb.close()
 
 
+@pytest.mark.parametrize("pool,B", [(4, 21), (8, 40)])
+def test_sparse_phase_machine_pools(hip, oracle, monkeypatch, pool, B):
+    """k_sparse_sched (round 4): instances move through per-phase queues, in POOLS of a power-of-two number of consecutive instances (the
+    32-bit lane offsets); LCQP_SPARSE_POOL forces pools of 4 / 8 instances, so that a small batch spans several pools with a ragged last one and
+    more wavefronts than instances.  Whatever lanes run an instance and in whatever order, the results are those of the instance alone:
+    the same bits as a batch of one pool, and the oracle's solution."""
+    n, nC, nK = 512, 256, 64
+    sb0, inst, x0, y0, st0 = _run(hip, n, nC, nK, B)          # one pool
+    sb0.close()
+    monkeypatch.setenv("LCQP_SPARSE_POOL", str(pool))
+    sb, _, x, y, st = _run(hip, n, nC, nK, B)
+    assert np.array_equal(x, x0) and np.array_equal(y, y0)
+    assert [s["iterTotal"] for s in st] == [s["iterTotal"] for s in st0] and all(s["returnValue"] == 0 for s in st)
+    sb.run(); sb.synchronize()                               # a second run on the same handle: the queues are refilled
+    x2, y2, _ = sb.solution()
+    assert np.array_equal(x2, x)
+    opt = oracle.default_options(perturbStep=0)
+    for b in (0, B // 2, B - 1):
+        d = inst[b]
+        ro = oracle.sparse_lcqp_solve(n, nC, nK, d["Q"].tocsr(), d["g"], d["E"].tocsr(), lbA=d["lbA"], ubA=d["ubA"], opt=opt)
+        assert ro["ret"] == 0 and np.abs(x[b] - ro["x"]).max() < 1e-9 and np.abs(y[b] - ro["y"]).max() < 1e-7
+    sb.close()
+
+
 @pytest.mark.parametrize("span", [10, 18])
 def test_sparse_wider_bands(hip, oracle, span):
     """constraint rows over 10 / 18 variables: half bandwidths beyond 7 select wider lane groups by themselves"""
