@@ -114,6 +114,9 @@ struct lcqp_hip_batch {
 };
 
 // -DLCQP_ONLY_NCH=k (experiment builds, tools/gpu_ab.py): link only the kernels of one padded size
+// padded size of a problem with n variables in units of 128: 1, 2, 3, 4, then 8 (np = 1024) and 16 (np = 2048)
+static inline int padded_nch(int n) { const int k = (n + 127) / 128; return k > 8 ? 16 : (k > 4 ? 8 : k); }
+
 static void lcqp_dispatch(int nch, int kid, int grid, hipStream_t s, const LaunchArgs& a)
 {
 #ifdef LCQP_ONLY_NCH
@@ -127,7 +130,8 @@ static void lcqp_dispatch(int nch, int kid, int grid, hipStream_t s, const Launc
         case 2: lcqp_launch_2(kid, grid, s, a); break;
         case 3: lcqp_launch_3(kid, grid, s, a); break;
         case 4: lcqp_launch_4(kid, grid, s, a); break;
-        default: lcqp_launch_8(kid, grid, s, a); break;
+        case 8: lcqp_launch_8(kid, grid, s, a); break;
+        default: lcqp_launch_16(kid, grid, s, a); break;
     }
 #endif
 }
@@ -154,7 +158,7 @@ static int dev_alloc(lcqp_hip_batch* h, T** p, size_t count, bool zero)
 extern "C" lcqp_hip_batch_t* lcqp_hip_batch_create(int batch, int nV, int nC, int nComp, int withBox, int device)
 try {
     if (batch <= 0 || nV <= 0 || nC < 0 || nComp < 0) { g_err = "invalid dimensions"; return nullptr; }
-    if (nV > 1024) { g_err = "nV > 1024 is not supported by the dense kernels of this build (padded sizes 128 ... 1024; the sparse engine takes larger banded / bordered problems)"; return nullptr; }
+    if (nV > 2048) { g_err = "nV > 2048 is not supported by the dense kernels of this build (padded sizes 128 ... 2048; the sparse engine takes larger banded / bordered problems)"; return nullptr; }
     HIPCHKN(hipSetDevice(device));
     lcqp_hip_batch* h = new (std::nothrow) lcqp_hip_batch();
     if (!h) { g_err = "out of host memory"; return nullptr; }
@@ -172,8 +176,7 @@ try {
     if (e0 == hipSuccess) e0 = hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming);
     if (e0 != hipSuccess) { set_err("stream/event creation", e0); lcqp_hip_batch_destroy(h); return nullptr; }
     d.B = batch; d.n = nV; d.nC = nC; d.nComp = nComp; d.mA = nC + 2 * nComp;
-    h->nch = (nV + 127) / 128;
-    if (h->nch > 4) h->nch = 8;      // 512 < nV <= 1024 runs the np = 1024 instantiation
+    h->nch = padded_nch(nV);      // 512 < nV <= 1024 runs the np = 1024 instantiation; 1024 < nV <= 2048: np = 2048 (96 KiB of LDS, one workgroup per CU, one row in flight per wave)
     d.np = 128 * h->nch;
     d.nblk = d.np / 64;
     d.boxcap = withBox ? nV : 0;
@@ -785,8 +788,8 @@ static int download_padded(double* dst, const double* src, int batch, int rows, 
 
 extern "C" int lcqp_hip_util_symv(int batch, int n, double alpha, const double* A, const double* bv, const double* cv, double* dv)
 try {
-    if (n <= 0 || n > 1024 || batch <= 0) return LCQP_HIP_UNSUPPORTED;
-    const int nch = (n + 127) / 128 > 4 ? 8 : (n + 127) / 128, np = 128 * nch;
+    if (n <= 0 || n > 2048 || batch <= 0) return LCQP_HIP_UNSUPPORTED;
+    const int nch = padded_nch(n), np = 128 * nch;
     TmpBuf tb;
     double *dA = tb.get((size_t)batch * np * np), *db_ = tb.get((size_t)batch * np), *dc = tb.get((size_t)batch * np), *dd = tb.get((size_t)batch * np);
     if (!dA || !db_ || !dc || !dd) return set_err("hipMalloc", hipErrorOutOfMemory);
@@ -801,8 +804,8 @@ catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothin
 
 static int util_rows(int batch, int m, int n, const double* A, const double* x, double* dots, const double* coef, double* outT)
 {
-    if (n <= 0 || n > 1024 || batch <= 0 || m <= 0) return LCQP_HIP_UNSUPPORTED;
-    const int nch = (n + 127) / 128 > 4 ? 8 : (n + 127) / 128, np = 128 * nch;
+    if (n <= 0 || n > 2048 || batch <= 0 || m <= 0) return LCQP_HIP_UNSUPPORTED;
+    const int nch = padded_nch(n), np = 128 * nch;
     TmpBuf tb;
     double* dA = tb.get((size_t)batch * m * np);
     double* dx = x ? tb.get((size_t)batch * np) : nullptr;
@@ -823,8 +826,8 @@ static int util_rows(int batch, int m, int n, const double* A, const double* x, 
 extern "C" int lcqp_hip_util_rows_list(int batch, int m, int n, const double* A, const int* list, int nlist, const double* x, const double* coef,
                                        double* dots, double* outT)
 try {
-    if (n <= 0 || n > 1024 || batch <= 0 || m <= 0 || nlist < 0 || nlist > m || !list) return LCQP_HIP_UNSUPPORTED;
-    const int nch = (n + 127) / 128 > 4 ? 8 : (n + 127) / 128, np = 128 * nch;
+    if (n <= 0 || n > 2048 || batch <= 0 || m <= 0 || nlist < 0 || nlist > m || !list) return LCQP_HIP_UNSUPPORTED;
+    const int nch = padded_nch(n), np = 128 * nch;
     TmpBuf tb;
     double* dA = tb.get((size_t)batch * m * np);
     double* dx = x ? tb.get((size_t)batch * np) : nullptr;
@@ -999,8 +1002,8 @@ __global__ void k_fill_random(double* p, size_t n, uint64_t seed)
 
 extern "C" int lcqp_hip_bench_rows(int batch, int m, int n, int mode, int repeat, float* ms)
 try {
-    if (n <= 0 || n > 1024 || batch <= 0 || m <= 0) return LCQP_HIP_UNSUPPORTED;
-    const int nch = (n + 127) / 128 > 4 ? 8 : (n + 127) / 128, np = 128 * nch;
+    if (n <= 0 || n > 2048 || batch <= 0 || m <= 0) return LCQP_HIP_UNSUPPORTED;
+    const int nch = padded_nch(n), np = 128 * nch;
     TmpBuf tb;
     double *dA = tb.get((size_t)batch * m * np, false), *dx = tb.get((size_t)batch * np, false), *dd = tb.get((size_t)batch * m, false);
     double *dcf = tb.get((size_t)batch * m, false), *dout = tb.get((size_t)batch * np, false);

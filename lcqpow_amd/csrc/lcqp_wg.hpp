@@ -280,7 +280,7 @@ __device__ __forceinline__ void wg_symv_t(const double* __restrict__ M0, const d
                         double* o00, double* o10, double* o01, double* o11, Lds lds)
 {
     constexpr int np = 128 * NCH;
-    constexpr int D = (TWO_M ? (LCQP_DEPTH >= 2 ? LCQP_DEPTH / 2 : 1) : LCQP_DEPTH) * (NCH > 4 ? 1 : 1);
+    constexpr int D = (NCH > 8) ? 1 : (TWO_M ? (LCQP_DEPTH >= 2 ? LCQP_DEPTH / 2 : 1) : LCQP_DEPTH);      // (np = 2048: a row is 8 KiB per wave already)
     static_assert(6 * np <= arena_doubles(NCH), "wg_symv: four partial copies and two staged vectors must fit the LDS arena");
     double* sv0 = lds.arena + 4 * np;
     double* sv1 = lds.arena + 5 * np;
@@ -415,7 +415,7 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
         acc[2 * k] = acc[2 * k + 1] = 0.0;
     }
     const int nchunk = (m + 15) >> 4;
-    constexpr int D = LCQP_DEPTH;     // rows a wave keeps in flight (see wg_symv_t)
+    constexpr int D = (NCH > 8) ? 1 : LCQP_DEPTH;     // rows a wave keeps in flight (see wg_symv_t)
     for (int ch = w; ch < nchunk; ch += NWAVE) {
         const int a0 = ch << 4;
         const int mya = a0 + l;

@@ -167,7 +167,7 @@ def test_subsolver_warm_start_duals(hip, oracle):
     q1.close(); q2.close()
 
 
-@pytest.mark.parametrize("n", [100, 256, 300, 512, 700, 1024])
+@pytest.mark.parametrize("n", [100, 256, 300, 512, 700, 1024, 1500, 2048])
 def test_row_list_sweep(hip, n):
     """wg_rows through a row list with row-indexed scalars (stage 1 / stage 2 of the subsolver's trials) on its own, every padded size
     np = 128 ... 1024: row products for the listed rows only (the others keep their values), the weighted row sum over the list.
@@ -685,6 +685,37 @@ def test_lcqp_option_sweep(hip, oracle, kw):
         if ro["ret"] == 0:
             assert np.abs(ro["x"] - rh["x"]).max() < 1e-7, kw
             assert so["status"] == sh["status"]
+
+
+def test_dense_problems_between_1024_and_2048_variables(hip, oracle):
+    """Round 4 lifts the dense limit from nV = 1024 to 2048 (an np = 2048 instantiation: 96 KiB of LDS, one workgroup per CU, one row in flight
+    per wave -- meant for single large problems).  (a) a random strictly convex QP with nV = 1300 through SubsolverHIP: the oracle's solution,
+    KKT residuals; (b) the circle example at N = 700 (nV = 1402, nC = 701, nComp = 700) as a batch of one: the optimum the reference prints
+    (examples/OptimizeOnCircle.cpp:144), complementarity, stationarity of the returned duals."""
+    rng = np.random.default_rng(2048)
+    n, m = 1300, 300
+    Mx = rng.standard_normal((n, n)) / np.sqrt(n); Q = Mx.T @ Mx + np.eye(n)
+    A = rng.standard_normal((m, n)) / np.sqrt(n); xs = rng.standard_normal(n)
+    lbA = A @ xs - rng.uniform(0.05, 0.5, m); ubA = A @ xs + rng.uniform(0.05, 0.5, m); g = rng.standard_normal(n)
+    qh = hip.SubsolverHIP(n, m, Q, A)
+    ret, it, flag = qh.solve(True, g, lbA, ubA, np.zeros(n))
+    assert ret == 0 and flag == 0
+    x, y = qh.getSolution()
+    qh.close()
+    res = P.kkt_residuals(Q, g, A, lbA, ubA, np.full(n, -np.inf), np.full(n, np.inf), x, y)
+    assert max(res) < 1e-8, res
+    qo = oracle.QP(Q, A); ro = qo.solve(True, g, lbA, ubA, np.zeros(n)); xo, yo = qo.solution()
+    assert ro[0] == 0 and np.abs(x - xo).max() < X_TOL and np.abs(y - yo).max() < Y_TOL
+    d = P.circle(700)
+    assert d["nV"] == 1402
+    rh = P.hip_solve(hip, d, hip.default_options(perturbStep=0))
+    # (the optimum moves with the discretisation: (0.1811, -0.9835) is what the reference prints for N = 100, a polygon with 700 corners gives
+    #  (0.1798, -0.9837); both lie on the unit circle next to the unconstrained minimiser's direction)
+    assert rh["ret"] == 0 and np.abs(rh["x"][:2] - [0.1811, -0.9835]).max() < 3e-3 and abs(np.hypot(*rh["x"][:2]) - 1.0) < 1e-3
+    xx, yy, nV, nC, nK = rh["x"], rh["y"], d["nV"], d["nC"], d["nComp"]
+    assert abs((d["L"] @ xx) @ (d["R"] @ xx)) < 1e3 * 2.221e-16
+    stat = d["Q"] @ xx + d["g"] - d["A"].T @ yy[nV:nV + nC] - d["L"].T @ yy[nV + nC:nV + nC + nK] - d["R"].T @ yy[nV + nC + nK:] - yy[:nV]
+    assert np.abs(stat).max() < 1e-7
 
 
 def test_subsolver_active_row_capacity(hip, oracle):
