@@ -59,7 +59,7 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     L = la.lib()
     assert L.lcqp_hip_batch_create(0, 4, 1, 1, 0, 0) is None and "invalid" in capi.last_error()
     assert L.lcqp_hip_batch_create(4, 4, -1, 1, 0, 0) is None
-    assert L.lcqp_hip_batch_create(1, 1025, 0, 1, 0, 0) is None and "1024" in capi.last_error()
+    assert L.lcqp_hip_batch_create(1, 2049, 0, 1, 0, 0) is None and "2048" in capi.last_error()
     Q = np.eye(2); dp = ctypes.POINTER(ctypes.c_double)
     assert L.lcqp_hip_qp_create(0, 0, Q.ctypes.data_as(dp), None, None, 0) is None
     assert L.lcqp_hip_qp_create(2, 1, Q.ctypes.data_as(dp), None, None, 0) is None          # nC > 0 without A
