@@ -406,7 +406,9 @@ def test_python_osqp_sparse_runs_on_the_sparse_engine(hip, oracle, capfd):
     assert np.abs(lcqp.getDualSolution() - ro["y"]).max() < 1e-7
     stats = lcqpow.OutputStatistics()
     lcqp.getOutputStatistics(stats)
-    assert abs(stats.getIterTotal() - ro["stats"]["iterTotal"]) <= 4 and stats.getSolutionStatus() == ro["stats"]["status"]
+    # (one inner cycle of four iterates more or less: the step-length coin flip at the rounding floor, DESIGN.md section 2 -- nothing else may differ)
+    assert stats.getIterTotal() - ro["stats"]["iterTotal"] in (-4, 0, 4) and stats.getSolutionStatus() == ro["stats"]["status"]
+    assert stats.getRhoOpt() == ro["stats"]["rhoOpt"] or stats.getIterTotal() != ro["stats"]["iterTotal"]
     out = capfd.readouterr().out
     assert " outer |  inner |   station  |   complem  |     rho    |   norm p   |    alpha   | sub it" in out
     assert len([ln for ln in out.splitlines() if ln.strip() and ln.lstrip()[0].isdigit()]) == stats.getIterTotal()
