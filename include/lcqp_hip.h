@@ -202,7 +202,7 @@ int lcqp_hip_chol_solve(int batch, int n, const double* K, const double* b, doub
  * (Q_sparse and the stacked A_sparse = [A; L; R], src/LCQProblem.cpp:629-723; Q full symmetric).  The KKT graph may be a band of
  * half width <= 63 plus at most 16 dense border nodes (rows or variables that touch many others: the arrow of
  * examples/OptimizeOnCircle.cpp).  Returns NULL for any other pattern (lcqp_hip_sparse_last_error() says why): the host layer runs
- * such problems on the dense kernels, which take nV <= 2048.
+ * such problems on the dense kernels, which take nV <= 4096.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct lcqp_hip_sparse lcqp_hip_sparse_t;
 lcqp_hip_sparse_t* lcqp_hip_sparse_create(int batch, int nV, int nC, int nComp, const int* Qp, const int* Qi,

@@ -114,8 +114,8 @@ struct lcqp_hip_batch {
 };
 
 // -DLCQP_ONLY_NCH=k (experiment builds, tools/gpu_ab.py): link only the kernels of one padded size
-// padded size of a problem with n variables in units of 128: 1, 2, 3, 4, then 8 (np = 1024) and 16 (np = 2048)
-static inline int padded_nch(int n) { const int k = (n + 127) / 128; return k > 8 ? 16 : (k > 4 ? 8 : k); }
+// padded size of a problem with n variables in units of 128: 1, 2, 3, 4, then 8 (np = 1024), 16 (np = 2048) and 32 (np = 4096)
+static inline int padded_nch(int n) { const int k = (n + 127) / 128; return k > 16 ? 32 : (k > 8 ? 16 : (k > 4 ? 8 : k)); }
 
 static void lcqp_dispatch(int nch, int kid, int grid, hipStream_t s, const LaunchArgs& a)
 {
@@ -131,7 +131,8 @@ static void lcqp_dispatch(int nch, int kid, int grid, hipStream_t s, const Launc
         case 3: lcqp_launch_3(kid, grid, s, a); break;
         case 4: lcqp_launch_4(kid, grid, s, a); break;
         case 8: lcqp_launch_8(kid, grid, s, a); break;
-        default: lcqp_launch_16(kid, grid, s, a); break;
+        case 16: lcqp_launch_16(kid, grid, s, a); break;
+        default: lcqp_launch_32(kid, grid, s, a); break;
     }
 #endif
 }
@@ -158,7 +159,7 @@ static int dev_alloc(lcqp_hip_batch* h, T** p, size_t count, bool zero)
 extern "C" lcqp_hip_batch_t* lcqp_hip_batch_create(int batch, int nV, int nC, int nComp, int withBox, int device)
 try {
     if (batch <= 0 || nV <= 0 || nC < 0 || nComp < 0) { g_err = "invalid dimensions"; return nullptr; }
-    if (nV > 2048) { g_err = "nV > 2048 is not supported by the dense kernels of this build (padded sizes 128 ... 2048; the sparse engine takes larger banded / bordered problems)"; return nullptr; }
+    if (nV > 4096) { g_err = "nV > 4096 is not supported by the dense kernels of this build (padded sizes 128 ... 4096; the sparse engine takes larger banded / bordered problems)"; return nullptr; }
     HIPCHKN(hipSetDevice(device));
     lcqp_hip_batch* h = new (std::nothrow) lcqp_hip_batch();
     if (!h) { g_err = "out of host memory"; return nullptr; }
@@ -788,7 +789,7 @@ static int download_padded(double* dst, const double* src, int batch, int rows, 
 
 extern "C" int lcqp_hip_util_symv(int batch, int n, double alpha, const double* A, const double* bv, const double* cv, double* dv)
 try {
-    if (n <= 0 || n > 2048 || batch <= 0) return LCQP_HIP_UNSUPPORTED;
+    if (n <= 0 || n > 4096 || batch <= 0) return LCQP_HIP_UNSUPPORTED;
     const int nch = padded_nch(n), np = 128 * nch;
     TmpBuf tb;
     double *dA = tb.get((size_t)batch * np * np), *db_ = tb.get((size_t)batch * np), *dc = tb.get((size_t)batch * np), *dd = tb.get((size_t)batch * np);
@@ -804,7 +805,7 @@ catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothin
 
 static int util_rows(int batch, int m, int n, const double* A, const double* x, double* dots, const double* coef, double* outT)
 {
-    if (n <= 0 || n > 2048 || batch <= 0 || m <= 0) return LCQP_HIP_UNSUPPORTED;
+    if (n <= 0 || n > 4096 || batch <= 0 || m <= 0) return LCQP_HIP_UNSUPPORTED;
     const int nch = padded_nch(n), np = 128 * nch;
     TmpBuf tb;
     double* dA = tb.get((size_t)batch * m * np);
@@ -826,7 +827,7 @@ static int util_rows(int batch, int m, int n, const double* A, const double* x, 
 extern "C" int lcqp_hip_util_rows_list(int batch, int m, int n, const double* A, const int* list, int nlist, const double* x, const double* coef,
                                        double* dots, double* outT)
 try {
-    if (n <= 0 || n > 2048 || batch <= 0 || m <= 0 || nlist < 0 || nlist > m || !list) return LCQP_HIP_UNSUPPORTED;
+    if (n <= 0 || n > 4096 || batch <= 0 || m <= 0 || nlist < 0 || nlist > m || !list) return LCQP_HIP_UNSUPPORTED;
     const int nch = padded_nch(n), np = 128 * nch;
     TmpBuf tb;
     double* dA = tb.get((size_t)batch * m * np);
@@ -1002,7 +1003,7 @@ __global__ void k_fill_random(double* p, size_t n, uint64_t seed)
 
 extern "C" int lcqp_hip_bench_rows(int batch, int m, int n, int mode, int repeat, float* ms)
 try {
-    if (n <= 0 || n > 2048 || batch <= 0 || m <= 0) return LCQP_HIP_UNSUPPORTED;
+    if (n <= 0 || n > 4096 || batch <= 0 || m <= 0) return LCQP_HIP_UNSUPPORTED;
     const int nch = padded_nch(n), np = 128 * nch;
     TmpBuf tb;
     double *dA = tb.get((size_t)batch * m * np, false), *dx = tb.get((size_t)batch * np, false), *dd = tb.get((size_t)batch * m, false);

@@ -27,5 +27,6 @@ void lcqp_launch_3(int kid, int grid, hipStream_t s, const LaunchArgs& a);
 void lcqp_launch_4(int kid, int grid, hipStream_t s, const LaunchArgs& a);
 void lcqp_launch_8(int kid, int grid, hipStream_t s, const LaunchArgs& a);
 void lcqp_launch_16(int kid, int grid, hipStream_t s, const LaunchArgs& a);
+void lcqp_launch_32(int kid, int grid, hipStream_t s, const LaunchArgs& a);
 
 }  // namespace lcqp

@@ -1,8 +1,8 @@
-// lcqp_nch.hip -- one instantiation of the per-size kernels: compile with -DLCQP_TU_NCH=k, k in {1,2,3,4,8,16}.
+// lcqp_nch.hip -- one instantiation of the per-size kernels: compile with -DLCQP_TU_NCH=k, k in {1,2,3,4,8,16,32}.
 #include "lcqp_kernels.hpp"
 
 #ifndef LCQP_TU_NCH
-#error "compile lcqp_nch.hip with -DLCQP_TU_NCH=1|2|3|4|8|16"
+#error "compile lcqp_nch.hip with -DLCQP_TU_NCH=1|2|3|4|8|16|32"
 #endif
 #define LCQP_CAT2(a, b) a##b
 #define LCQP_CAT(a, b) LCQP_CAT2(a, b)

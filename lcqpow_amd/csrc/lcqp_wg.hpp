@@ -19,8 +19,10 @@ namespace lcqp {
 constexpr int WG = 256;          // threads per workgroup
 constexpr int NWAVE = 4;         // waves per workgroup
 // doubles of routine-private LDS: 35.25 KiB (4 workgroups per CU) up to np = 512; the np = 1024 instantiation (NCH = 8) needs room for
-// six vectors of length np (wg_symv) and takes 48 KiB (3 workgroups per CU)
-constexpr int arena_doubles(int nch) { return 6 * 128 * nch > 4512 ? 6 * 128 * nch : 4512; }
+// six vectors of length np (wg_symv) and takes 48 KiB (3 workgroups per CU), np = 2048 96 KiB.  np = 4096 (NCH = 32) would need 192 KiB that
+// way: its four waves combine their partial sums in TWO copies instead of four (wg_ncopy), four vectors of length np = 128 KiB.
+constexpr int wg_ncopy(int nch) { return nch > 16 ? 2 : 4; }
+constexpr int arena_doubles(int nch) { return (wg_ncopy(nch) + 2) * 128 * nch > 4512 ? (wg_ncopy(nch) + 2) * 128 * nch : 4512; }
 constexpr int ARENA = arena_doubles(4);
 constexpr int TILE_LD = 65;      // padded leading dimension of the 64x64 LDS tile
 // active rows the subsolver has room for: wg_trsv keeps the vector and four partial copies of it in the arena (896; 1216 at NCH = 8)
@@ -249,13 +251,28 @@ __device__ __forceinline__ void wg_combine(const double (&acc)[2 * NCH], Lds lds
     constexpr int np = 128 * NCH;
     double* red = lds.arena;
     const int l = lane_id(), w = wave_id();
+    if constexpr (wg_ncopy(NCH) == 4) {
 #pragma unroll
-    for (int k = 0; k < NCH; k++) {
-        red[w * np + 128 * k + 2 * l] = acc[2 * k];
-        red[w * np + 128 * k + 2 * l + 1] = acc[2 * k + 1];
+        for (int k = 0; k < NCH; k++) {
+            red[w * np + 128 * k + 2 * l] = acc[2 * k];
+            red[w * np + 128 * k + 2 * l + 1] = acc[2 * k + 1];
+        }
+        __syncthreads();
+        for (int c = tid_here(); c < np; c += WG) post(c, red[c] + red[np + c] + red[2 * np + c] + red[3 * np + c]);
+    } else {
+        // two copies: waves 0 and 1 write, waves 2 and 3 add their partial sums to them (wave 2 to copy 0, wave 3 to copy 1)
+        if (w < 2) {
+#pragma unroll
+            for (int k = 0; k < NCH; k++) { red[w * np + 128 * k + 2 * l] = acc[2 * k]; red[w * np + 128 * k + 2 * l + 1] = acc[2 * k + 1]; }
+        }
+        __syncthreads();
+        if (w >= 2) {
+#pragma unroll
+            for (int k = 0; k < NCH; k++) { red[(w - 2) * np + 128 * k + 2 * l] += acc[2 * k]; red[(w - 2) * np + 128 * k + 2 * l + 1] += acc[2 * k + 1]; }
+        }
+        __syncthreads();
+        for (int c = tid_here(); c < np; c += WG) post(c, red[c] + red[np + c]);
     }
-    __syncthreads();
-    for (int c = tid_here(); c < np; c += WG) post(c, red[c] + red[np + c] + red[2 * np + c] + red[3 * np + c]);
     __syncthreads();
 }
 
@@ -281,9 +298,9 @@ __device__ __forceinline__ void wg_symv_t(const double* __restrict__ M0, const d
 {
     constexpr int np = 128 * NCH;
     constexpr int D = (NCH > 8) ? 1 : (TWO_M ? (LCQP_DEPTH >= 2 ? LCQP_DEPTH / 2 : 1) : LCQP_DEPTH);      // (np = 2048: a row is 8 KiB per wave already)
-    static_assert(6 * np <= arena_doubles(NCH), "wg_symv: four partial copies and two staged vectors must fit the LDS arena");
-    double* sv0 = lds.arena + 4 * np;
-    double* sv1 = lds.arena + 5 * np;
+    static_assert((wg_ncopy(NCH) + 2) * np <= arena_doubles(NCH), "wg_symv: the partial copies and two staged vectors must fit the LDS arena");
+    double* sv0 = lds.arena + wg_ncopy(NCH) * np;
+    double* sv1 = lds.arena + (wg_ncopy(NCH) + 1) * np;
     for (int i = tid_here(); i < np; i += WG) {
         sv0[i] = (i < n) ? v0[i] : 0.0;
         sv1[i] = (TWO_V && i < n) ? v1[i] : 0.0;
@@ -400,8 +417,8 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
     // hotc / hotv (wg_row_norms): a row with a single non-zero is made up from its column and value instead of being read -- the same
     // registers, the same sums, no bytes (bit-identical results; a typical working set is half complementarity selectors and box rows)
     constexpr int np = 128 * NCH;
-    static_assert(5 * np <= arena_doubles(NCH), "wg_rows: four partial copies and the staged vector must fit the LDS arena");
-    double* sx = lds.arena + 4 * np;
+    static_assert((wg_ncopy(NCH) + 1) * np <= arena_doubles(NCH), "wg_rows: the partial copies and the staged vector must fit the LDS arena");
+    double* sx = lds.arena + wg_ncopy(NCH) * np;
     if (x) {
         for (int i = tid_here(); i < np; i += WG) sx[i] = x[i];
     }
@@ -518,19 +535,26 @@ __device__ __forceinline__ void wg_trsv(const double* __restrict__ F, int ld, in
         __syncthreads();
         const int cb0 = forward ? I + 1 : 0, cb1 = forward ? nblk : I;
         if (cb1 > cb0) {
-            for (int cb = cb0; cb < cb1; cb++) {
-                const double* Fp = F + (size_t)(64 * I + 16 * w) * ld + 64 * cb + l;
-                double f[16];
+            // (nn > 2048, the np = 4096 instantiation: two copies of the partial sums instead of four -- waves 0 and 1 write, waves 2 and 3 add)
+            const bool two = nn > 2048;
+            for (int pass = 0; pass < (two ? 2 : 1); pass++) {
+                if (!two || (w >> 1) == pass)
+                    for (int cb = cb0; cb < cb1; cb++) {
+                        const double* Fp = F + (size_t)(64 * I + 16 * w) * ld + 64 * cb + l;
+                        double f[16];
 #pragma unroll
-                for (int cc = 0; cc < 16; cc++) f[cc] = ld_stream(Fp + (size_t)cc * ld);
-                double acc = 0.0;
+                        for (int cc = 0; cc < 16; cc++) f[cc] = ld_stream(Fp + (size_t)cc * ld);
+                        double acc = 0.0;
 #pragma unroll
-                for (int cc = 0; cc < 16; cc++) acc += f[cc] * b[64 * I + 16 * w + cc];
-                red[w * nn + 64 * cb + l] = acc;
+                        for (int cc = 0; cc < 16; cc++) acc += f[cc] * b[64 * I + 16 * w + cc];
+                        if (!two) red[w * nn + 64 * cb + l] = acc;
+                        else if (pass == 0) red[(w & 1) * nn + 64 * cb + l] = acc;
+                        else red[(w & 1) * nn + 64 * cb + l] += acc;
+                    }
+                __syncthreads();
             }
-            __syncthreads();
             for (int c = 64 * cb0 + tid_here(); c < 64 * cb1; c += WG)
-                b[c] -= red[c] + red[nn + c] + red[2 * nn + c] + red[3 * nn + c];
+                b[c] -= two ? (red[c] + red[nn + c]) : (red[c] + red[nn + c] + red[2 * nn + c] + red[3 * nn + c]);
             __syncthreads();
         }
     }

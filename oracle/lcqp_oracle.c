@@ -357,7 +357,7 @@ static int qp_setup(orc_qp_t* q, const double* lbA, const double* ubA, const dou
     q->w_n1 = dalloc(n); q->w_n2 = dalloc(n); q->w_n3 = dalloc(n); q->w_m1 = dalloc(mE); q->w_m2 = dalloc(mE);
     q->cap_na = (2 * n > 64) ? 2 * n : 64;   /* room for the degenerate vertices of small problems (many rows, few variables) */
     if (q->cap_na > mE) q->cap_na = mE;
-    { const int lim = n > 1024 ? 2432 : (n > 512 ? 1216 : 896);   /* the device keeps the active-row solves in LDS (max_active(NCH)); binds for nV > 448 only */
+    { const int lim = n > 2048 ? 3264 : (n > 1024 ? 2432 : (n > 512 ? 1216 : 896));   /* the device keeps the active-row solves in LDS (max_active(NCH)); binds for nV > 448 only */
       if (q->cap_na > lim) q->cap_na = lim; }
     q->w_a1 = dalloc(q->cap_na); q->w_a2 = dalloc(q->cap_na); q->w_a3 = dalloc(q->cap_na); q->w_a4 = dalloc(q->cap_na);
     q->newst = (int*)calloc(mE ? mE : 1, sizeof(int));

@@ -204,6 +204,46 @@ def stationarity_type(d, x, y, rho, ctol=1e3 * 2.221e-16, merge_box=False):
     return 4 if sflag else (3 if mflag else 2)
 
 
+def grid_lcqp(g=44, nK=300, nC=200, seed=0):
+    """An LCQP whose KKT graph is a 2-D grid: g x g variables coupled by a 5-point stencil Hessian, complementarity between horizontally
+    adjacent cells, constraint rows that couple vertically adjacent cells.  Reverse Cuthill-McKee leaves a band of half width ~ 2 g, far beyond
+    the 63 the sparse engine's lane groups cover, and no handful of border nodes fixes that: the pattern that is "neither banded nor
+    bordered".  Returns scipy CSC matrices Q (n x n), E = [A; L; R] and the dense vectors."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    n = g * g
+    idx = lambda r, c: r * g + c
+    rows, cols, vals = [], [], []
+    for r in range(g):
+        for c in range(g):
+            i = idx(r, c)
+            rows.append(i); cols.append(i); vals.append(4.5 + rng.uniform(0, 1))
+            for dr, dc in ((0, 1), (1, 0)):
+                if r + dr < g and c + dc < g:
+                    j = idx(r + dr, c + dc)
+                    rows += [i, j]; cols += [j, i]; vals += [-1.0, -1.0]
+    Q = sp.csc_matrix((vals, (rows, cols)), shape=(n, n))
+    cells = [(r, c) for r in range(g) for c in range(0, g - 1, 2)]
+    pick = rng.choice(len(cells), nK, replace=False)
+    Lr, Lc, Rr, Rc = [], [], [], []
+    xs = rng.uniform(-1, 1, n)
+    for k, p in enumerate(pick):
+        r, c = cells[p]
+        i, j = idx(r, c), idx(r, c + 1)
+        Lr.append(k); Lc.append(i); Rr.append(k); Rc.append(j)
+        if rng.random() < 0.5: xs[i], xs[j] = 0.0, rng.uniform(0, 1)
+        else: xs[i], xs[j] = rng.uniform(0, 1), 0.0
+    Lm = sp.csc_matrix((np.ones(nK), (Lr, Lc)), shape=(nK, n)); Rm = sp.csc_matrix((np.ones(nK), (Rr, Rc)), shape=(nK, n))
+    ar, ac, av = [], [], []
+    for k in range(nC):
+        r, c = int(rng.integers(0, g - 1)), int(rng.integers(0, g))
+        ar += [k, k]; ac += [idx(r, c), idx(r + 1, c)]; av += [rng.uniform(0.5, 1.5), rng.uniform(-1.5, -0.5)]
+    A = sp.csc_matrix((av, (ar, ac)), shape=(nC, n))
+    ax = A @ xs
+    return dict(nV=n, nC=nC, nComp=nK, Q=Q, g=rng.uniform(-2, 2, n), A=A, L=Lm, R=Rm, E=sp.vstack([A, Lm, Rm]).tocsc(),
+                lbA=ax - rng.uniform(0.1, 1, nC), ubA=ax + rng.uniform(0.1, 1, nC))
+
+
 # ---- sparse synthetic workload (BASELINE config 5): banded, OCP-like, one pattern for the whole batch ------------------------------
 from lcqpow_amd.synth_sparse import SPARSE_SEED0  # noqa: E402
 

@@ -59,7 +59,7 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     L = la.lib()
     assert L.lcqp_hip_batch_create(0, 4, 1, 1, 0, 0) is None and "invalid" in capi.last_error()
     assert L.lcqp_hip_batch_create(4, 4, -1, 1, 0, 0) is None
-    assert L.lcqp_hip_batch_create(1, 2049, 0, 1, 0, 0) is None and "2048" in capi.last_error()
+    assert L.lcqp_hip_batch_create(1, 4097, 0, 1, 0, 0) is None and "4096" in capi.last_error()
     Q = np.eye(2); dp = ctypes.POINTER(ctypes.c_double)
     assert L.lcqp_hip_qp_create(0, 0, Q.ctypes.data_as(dp), None, None, 0) is None
     assert L.lcqp_hip_qp_create(2, 1, Q.ctypes.data_as(dp), None, None, 0) is None          # nC > 0 without A
@@ -115,8 +115,8 @@ def test_sparse_pattern_validation_needs_no_gpu():
 
 
 def test_dense_size_limit_is_reported_not_hidden():
-    """Limits the reference does not have: the dense kernels take nV <= 2048 (padded sizes 128 ... 2048; round 3: 1024) and at most
-    min(max(2 nV, 64), rows, 896 / 1216 / 2432) simultaneously active rows (tests/test_gpu_parity.py::test_subsolver_active_row_capacity).  A larger
+    """Limits the reference does not have: the dense kernels take nV <= 4096 (padded sizes 128 ... 4096; round 3: 1024) and at most
+    min(max(2 nV, 64), rows, 896 / 1216 / 2432 / 3264) simultaneously active rows (tests/test_gpu_parity.py::test_subsolver_active_row_capacity).  A larger
     problem is refused at creation with a message -- through the C ABI (NULL handle) and through LCQProblem (SUBPROBLEM_SOLVER_ERROR from
     runSolver, the reference's return code for a subsolver that cannot take the problem, src/SubsolverQPOASES.cpp:165-168) -- never run wrongly.
     The size check precedes any device call, so this holds on a CPU-only box too."""
@@ -124,18 +124,18 @@ def test_dense_size_limit_is_reported_not_hidden():
     import lcqpow_amd as la
     from lcqpow_amd import capi
     L = la.lib()
-    assert L.lcqp_hip_batch_create(1, 2049, 0, 1, 0, 0) is None
-    assert "nV > 2048" in capi.last_error()
-    h = L.lcqp_hip_batch_create(1, 2048, 0, 1, 0, 0)          # the largest size: accepted as far as the size goes (no device here: NULL for another reason)
+    assert L.lcqp_hip_batch_create(1, 4097, 0, 1, 0, 0) is None
+    assert "nV > 4096" in capi.last_error()
+    h = L.lcqp_hip_batch_create(1, 4096, 0, 1, 0, 0)          # the largest size: accepted as far as the size goes (no device here: NULL for another reason)
     if h is None:
-        assert "nV > 2048" not in capi.last_error()
+        assert "nV > 4096" not in capi.last_error()
     else:
         L.lcqp_hip_batch_destroy.argtypes = [ctypes.c_void_p]; L.lcqp_hip_batch_destroy(ctypes.c_void_p(h))
     import lcqpow_amd.lcqpow as lcqpow
-    n = 2049
+    n = 4097
     p = lcqpow.LCQProblem(nV=n, nC=0, nComp=1)
     o = lcqpow.Options(); o.setPrintLevel(lcqpow.PrintLevel.NONE); p.setOptions(o)
     Lm = np.zeros((1, n)); Lm[0, 0] = 1.0; Rm = np.zeros((1, n)); Rm[0, 1] = 1.0
     assert p.loadLCQP(Q=np.eye(n), g=-np.ones(n), L=Lm, R=Rm, order="C") == 0
     assert int(p.runSolver()) == capi.SUBPROBLEM_SOLVER_ERROR
-    assert "nV > 2048" in capi.last_error()
+    assert "nV > 4096" in capi.last_error()

@@ -167,7 +167,7 @@ def test_subsolver_warm_start_duals(hip, oracle):
     q1.close(); q2.close()
 
 
-@pytest.mark.parametrize("n", [100, 256, 300, 512, 700, 1024, 1500, 2048])
+@pytest.mark.parametrize("n", [100, 256, 300, 512, 700, 1024, 1500, 2048, 3000, 4096])
 def test_row_list_sweep(hip, n):
     """wg_rows through a row list with row-indexed scalars (stage 1 / stage 2 of the subsolver's trials) on its own, every padded size
     np = 128 ... 1024: row products for the listed rows only (the others keep their values), the weighted row sum over the list.
@@ -687,13 +687,27 @@ def test_lcqp_option_sweep(hip, oracle, kw):
             assert so["status"] == sh["status"]
 
 
-def test_dense_problems_between_1024_and_2048_variables(hip, oracle):
+def test_dense_problems_between_1024_and_4096_variables(hip, oracle):
     """Round 4 lifts the dense limit from nV = 1024 to 2048 (an np = 2048 instantiation: 96 KiB of LDS, one workgroup per CU, one row in flight
     per wave -- meant for single large problems).  (a) a random strictly convex QP with nV = 1300 through SubsolverHIP: the oracle's solution,
     KKT residuals; (b) the circle example at N = 700 (nV = 1402, nC = 701, nComp = 700) as a batch of one: the optimum the reference prints
     (examples/OptimizeOnCircle.cpp:144), complementarity, stationarity of the returned duals."""
     rng = np.random.default_rng(2048)
     n, m = 1300, 300
+    Mx = rng.standard_normal((n, n)) / np.sqrt(n); Q = Mx.T @ Mx + np.eye(n)
+    A = rng.standard_normal((m, n)) / np.sqrt(n); xs = rng.standard_normal(n)
+    lbA = A @ xs - rng.uniform(0.05, 0.5, m); ubA = A @ xs + rng.uniform(0.05, 0.5, m); g = rng.standard_normal(n)
+    qh = hip.SubsolverHIP(n, m, Q, A)
+    ret, it, flag = qh.solve(True, g, lbA, ubA, np.zeros(n))
+    assert ret == 0 and flag == 0
+    x, y = qh.getSolution()
+    qh.close()
+    res = P.kkt_residuals(Q, g, A, lbA, ubA, np.full(n, -np.inf), np.full(n, np.inf), x, y)
+    assert max(res) < 1e-8, res
+    qo = oracle.QP(Q, A); ro = qo.solve(True, g, lbA, ubA, np.zeros(n)); xo, yo = qo.solution()
+    assert ro[0] == 0 and np.abs(x - xo).max() < X_TOL and np.abs(y - yo).max() < Y_TOL
+    # (c) nV = 2500 on the np = 4096 instantiation (128 KiB of LDS: the four waves combine their partial sums in two copies instead of four)
+    n, m = 2500, 200
     Mx = rng.standard_normal((n, n)) / np.sqrt(n); Q = Mx.T @ Mx + np.eye(n)
     A = rng.standard_normal((m, n)) / np.sqrt(n); xs = rng.standard_normal(n)
     lbA = A @ xs - rng.uniform(0.05, 0.5, m); ubA = A @ xs + rng.uniform(0.05, 0.5, m); g = rng.standard_normal(n)
