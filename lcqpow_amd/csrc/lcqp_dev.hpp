@@ -143,8 +143,8 @@ __device__ __forceinline__ void qp_admm(Ctx<NCH>& c, const double* g, int n_it)
         // rhs = sigma*xa - g + E'(rho.z - y)
         wg_rows<NCH>(c.E, nullptr, mE, nullptr, nullptr, coef, c.lds,
                      [&](int i, double s) { rhs[i] = sigma * xa[i] - g[i] + s; });
-        wg_trsv(c.FK, np, c.nblk, rhs, true, c.lds);
-        wg_trsv(c.FK, np, c.nblk, rhs, false, c.lds);       // rhs = xt
+        wg_trsv<wg_ncopy(NCH) == 2>(c.FK, np, c.nblk, rhs, true, c.lds);
+        wg_trsv<wg_ncopy(NCH) == 2>(c.FK, np, c.nblk, rhs, false, c.lds);       // rhs = xt
         wg_rows<NCH>(c.E, nullptr, mE, rhs, ex, nullptr, c.lds, [](int, double) {});   // ex = E xt
         const bool last = (it == n_it - 1);      // the change of (ya, xa) in the last iteration feeds qp_certificate
         for (int r = t; r < mE; r += WG) {
@@ -1055,7 +1055,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             }
             wg_copy(cv, r1, np);
             PROF(c, P_MISC);
-            wg_trsv(c.F1, np, c.nblk, cv, true, c.lds);
+            wg_trsv<wg_ncopy(NCH) == 2>(c.F1, np, c.nblk, cv, true, c.lds);
             PROF(c, P_CORR_L1);
             if (na > 0) {
                 // (plain loads: the same rows are read again a few microseconds later; same-box A/B 35.1 -> 33.8 ms)
@@ -1103,7 +1103,7 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             if (have_true || nlv > 0) wg_copy(du, cv, np);
             else wg_fill(du, 0.0, np);
         }
-        wg_trsv(c.F1, np, c.nblk, du, false, c.lds);
+        wg_trsv<wg_ncopy(NCH) == 2>(c.F1, np, c.nblk, du, false, c.lds);
         PROF(c, P_CORR_L1);
         for (int i = t; i < np; i += WG) x[i] += du[i];
         for (int a = t; a < nsl; a += WG) {
@@ -1355,7 +1355,7 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
 #pragma unroll
                 for (int e = 0; e < EPT; e++) { const int i = t + e * WG; if (i < np) pk[i] = vp[e]; }
                 __syncthreads();
-                wg_symv<NCH>(c.C, nullptr, n, pk, nullptr, Cp, nullptr, nullptr, nullptr, c.lds);
+                wg_symv_t<NCH, false, false, 1>(c.C, nullptr, n, pk, nullptr, Cp, nullptr, nullptr, nullptr, c.lds);      // (one row in flight: the vectors of this pass stay in registers across the sweep)
 #pragma unroll
                 for (int e = 0; e < EPT; e++) { const int i = t + e * WG; vCp[e] = (i < np) ? Cp[i] : 0.0; }
             }

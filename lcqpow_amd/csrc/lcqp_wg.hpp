@@ -291,13 +291,15 @@ __device__ __forceinline__ void wg_combine(const double (&acc)[2 * NCH], Lds lds
 #define LCQP_DEPTH 4
 #endif
 static_assert(LCQP_DEPTH == 1 || LCQP_DEPTH == 2 || LCQP_DEPTH == 4 || LCQP_DEPTH == 8, "LCQP_DEPTH: the sweeps read NWAVE * LCQP_DEPTH rows per step and rely on that dividing the padded sizes (a build with 3, 5 or 6 reads past the matrix)");
-template <int NCH, bool TWO_M, bool TWO_V>
+// DCAP: at most this many rows in flight (a call site that keeps many registers live across the sweep passes 1)
+template <int NCH, bool TWO_M, bool TWO_V, int DCAP = 8>
 __device__ __forceinline__ void wg_symv_t(const double* __restrict__ M0, const double* __restrict__ M1, int n,
                         const double* __restrict__ v0, const double* __restrict__ v1,
                         double* o00, double* o10, double* o01, double* o11, Lds lds)
 {
     constexpr int np = 128 * NCH;
-    constexpr int D = (NCH > 8) ? 1 : (TWO_M ? (LCQP_DEPTH >= 2 ? LCQP_DEPTH / 2 : 1) : LCQP_DEPTH);      // (np = 2048: a row is 8 KiB per wave already)
+    constexpr int D0 = (NCH > 8 || (TWO_M && NCH >= 4)) ? 1 : (TWO_M ? (LCQP_DEPTH >= 2 ? LCQP_DEPTH / 2 : 1) : LCQP_DEPTH);
+    constexpr int D = D0 < DCAP ? D0 : DCAP;      // (np = 2048: a row is 8 KiB per wave already; the two-matrix sweep runs once per homotopy)
     static_assert((wg_ncopy(NCH) + 2) * np <= arena_doubles(NCH), "wg_symv: the partial copies and two staged vectors must fit the LDS arena");
     double* sv0 = lds.arena + wg_ncopy(NCH) * np;
     double* sv1 = lds.arena + (wg_ncopy(NCH) + 1) * np;
@@ -432,7 +434,7 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
         acc[2 * k] = acc[2 * k + 1] = 0.0;
     }
     const int nchunk = (m + 15) >> 4;
-    constexpr int D = (NCH > 8) ? 1 : LCQP_DEPTH;     // rows a wave keeps in flight (see wg_symv_t)
+    constexpr int D = (NCH > 8) ? 1 : ((NCH == 4 && LCQP_DEPTH > 2) ? 2 : LCQP_DEPTH);     // rows a wave keeps in flight (see wg_symv_t; np = 512 at 128 VGPRs: two rows of 4 KiB, four spill)
     for (int ch = w; ch < nchunk; ch += NWAVE) {
         const int a0 = ch << 4;
         const int mya = a0 + l;
@@ -498,6 +500,8 @@ __device__ __forceinline__ void wg_rows(const double* __restrict__ Mx, const int
 // chains.   vec: global, in/out.   LDS: arena[0..nn) b, arena[nn..5nn) partials (nn <= LCQP_MAX_ACTIVE = 896).
 // Algorithmic HBM bytes: 8*N*(N+2) for forward+backward.
 // ---------------------------------------------------------------------------------------------
+// TWO: two copies of the partial sums instead of four (the np = 4096 instantiation, wg_ncopy)
+template <bool TWO = false>
 __device__ __forceinline__ void wg_trsv(const double* __restrict__ F, int ld, int nblk, double* vec, bool forward, Lds lds)
 {
     const int nn = 64 * nblk;
@@ -535,8 +539,8 @@ __device__ __forceinline__ void wg_trsv(const double* __restrict__ F, int ld, in
         __syncthreads();
         const int cb0 = forward ? I + 1 : 0, cb1 = forward ? nblk : I;
         if (cb1 > cb0) {
-            // (nn > 2048, the np = 4096 instantiation: two copies of the partial sums instead of four -- waves 0 and 1 write, waves 2 and 3 add)
-            const bool two = nn > 2048;
+            // (TWO, the np = 4096 instantiation: two copies of the partial sums instead of four -- waves 0 and 1 write, waves 2 and 3 add)
+            constexpr bool two = TWO;
             for (int pass = 0; pass < (two ? 2 : 1); pass++) {
                 if (!two || (w >> 1) == pass)
                     for (int cb = cb0; cb < cb1; cb++) {
