@@ -18,7 +18,7 @@ for name, pat in (("kernel_stats.csv", "trace/*/*kernel_stats.csv"), ("kernel_tr
     f = glob.glob(os.path.join(src, pat))
     if not f:
         print("missing:", pat); continue
-    f = f[0]
+    f = max(f, key=os.path.getmtime)      # (several runs of the profile script may have been merged into one directory: the newest)
     rows = list(csv.DictReader(open(f)))
     if "counter_collection" in f or "kernel_trace" in f:      # keep the product kernels only (the copies of the generator run are noise)
         rows = [r for r in rows if any(k in r.get("Kernel_Name", "") for k in ("k_lcqp_run", "k_backsolve", "k_build", "k_factor", "k_trsm", "k_prepare", "k_sparse"))]
