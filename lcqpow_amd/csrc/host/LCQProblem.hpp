@@ -56,14 +56,14 @@ class LCQProblem {
     // the reference's host loop over the subsolver plugin.  hostLoop = true forces the host loop for HIP_DENSE too.
     void setHostLoop(bool hostLoop_) { hostLoop = hostLoop_; }
     // which engine the last runSolver used: 0 none yet, 1 the reference's host loop over the subsolver plugin, 2 the whole homotopy on the
-    // device (dense kernels, k_lcqp_run), 3 the sparse engine (k_sparse_run)
+    // device (dense kernels, k_lcqp_run), 3 the sparse engine (k_sparse_sched)
     enum Engine { ENGINE_NONE = 0, ENGINE_HOST_LOOP = 1, ENGINE_DENSE_DEVICE = 2, ENGINE_SPARSE_DEVICE = 3 };
     int getLastEngine() const { return lastEngine; }
 
   private:
     ReturnValue initializeSolver(bool needSubsolver = true);
     ReturnValue runOnDevice();                 // HIP_DENSE: LCQProblem::runSolver as one batch-of-one launch of k_lcqp_run
-    bool runSparseOnDevice(ReturnValue& ret);  // OSQP_SPARSE with a banded pattern: k_sparse_run; false when the pattern is not banded
+    bool runSparseOnDevice(ReturnValue& ret);  // OSQP_SPARSE with a banded or bordered pattern: k_sparse_sched; false when the pattern is not banded
     void finishFromTrace(const std::vector<double>& sc, const std::vector<double>& xs, int len);
     ReturnValue solveQPSubproblem(bool initialSolve);
     void updateLinearization();
