@@ -65,6 +65,7 @@ enum { SP_PRODUCTS, SP_ASSEMBLE, SP_FACTOR, SP_FORWARD, SP_BACKWARD, SP_VECTORS,
 // the SAME phase, runs that phase for them, and pushes each to the queue of its next phase (k_sparse_sched).  A wavefront therefore only
 // ever holds instances doing the same thing; nobody waits for a neighbour's factorisation or for the slowest polish of eight.
 enum { PH_START, PH_ROUND, PH_TRIAL, PH_FACTOR, PH_CORRECT, PH_QPEND, PH_NUM };
+enum { BY_ASSEMBLE, BY_FACTOR_LDS, BY_FACTOR, BY_SOLVE, BY_BORDER_PREPARE, BY_BORDER_SOLVE, BY_EX, BY_SWEEP, BY_START, BY_E, BY_NUM };
 struct SpState {
     // LCQProblem::runSolver (src/LCQProblem.cpp:444-560)
     int initial, histLen, algoStat, totalIter, rc, qpIter;
@@ -82,8 +83,11 @@ struct SpState {
 };
 // Queues: the batch is cut into pools of `poolSize` consecutive instances (a power of two; the byte offset of an instance inside its pool fits
 // 32 bits for every per-instance array: the saddr + 32-bit offset addressing of SpCtx::arr); wavefront w serves pool w % nPools.  Per pool
-// and phase a ring of poolSize entries (an instance is in at most one queue) and three counters: tail (next slot to write), head (next slot to
-// read), count (entries published).  ctl[pool][PH_NUM] = instances of the pool not finished yet.
+// and phase a ring of poolSize entries (an instance is in at most one queue) and three counters: tail (next position to write), head (next
+// position to read), count (entries published); every ring slot carries a SEQUENCE number beside the instance id (a bounded multi-producer /
+// multi-consumer queue after Vyukov; sequence and id share one 64-bit word, written by one store): slot p & mask is free for position p when
+// its sequence is p, holds position p's entry when it is p + 1, and is handed on to position p + poolSize by its consumer -- a producer that laps the ring onto a slot whose entry has been claimed but not
+// read yet waits instead of overwriting it.  ctl[pool][PH_NUM] = instances of the pool not finished yet.
 constexpr int QCTL = 4;      // ints per (pool, phase): tail, head, count, pad
 
 struct EllMat { const int *eidx, *epos, *ptr, *cidx, *cmap; int rows, W, tails; };   // see g_ell
@@ -123,8 +127,12 @@ struct SpBatch {
     int traceCap;
     // phase machine
     SpState* state;          // [B]
-    int *qring, *qctl;       // [nPools][PH_NUM][poolSize], [nPools][PH_NUM + 1][QCTL]
+    unsigned long long* qring;  // [nPools][PH_NUM][poolSize] ring slots: (sequence number << 32) | instance id, one 64-bit word so that a slot changes hands in one store
+    int* qctl;                  // [nPools][PH_NUM + 1][QCTL]
     int poolSize, nPools;
+    // algorithmic bytes of one event of each kind (filled by the host: formed in the kernel they are loop invariants the compiler keeps in
+    // registers across every phase)
+    double by[BY_NUM];
     unsigned long long* qprof;   // [PH_NUM + 1][3] (-DLCQP_SCHED_PROFILE): clock ticks, wavefront steps, instances served per phase; row PH_NUM: ticks / polls without work
 };
 
@@ -468,7 +476,7 @@ __device__ __forceinline__ void sp_assemble(SpCtx<G>& c, double dprim, Dd ddual,
     g_sync();
     for (int b = t; b < db.kb; b += G) Kb[(size_t)(db.N - db.kb + b) * ld + w] = 1.0;      // border positions: isolated unit pivots of the band
     g_sync();
-    c.bytes += 8.0 * ((double)db.N * ld + db.nnzQ + db.nnzE) + 4.0 * (db.nnzQ + db.nnzE);
+    c.bytes += db.by[BY_ASSEMBLE];
     SPROF(c, SP_ASSEMBLE);
 }
 
@@ -521,7 +529,7 @@ __device__ __forceinline__ void sp_factor_lds(SpCtx<G>& c, GD KF, GD Kd)
             wave_sync();
         }
     }
-    c.bytes += 8.0 * (3.0 * (double)N * (c.db->w + 1));
+    c.bytes += c.db->by[BY_FACTOR_LDS];
     c.cFact++;
     SPROF(c, SP_FACTOR);
 }
@@ -614,7 +622,7 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
 #pragma unroll
         for (int k = 0; k < G; k++) { nx[k] = nn[k]; nn[k] = n3[k]; }
     }
-    c.bytes += 12.0 * (c.db->nnzQ + c.db->nnzE) + 8.0 * (double)N * (c.db->w + 2);      // matrix entries read, factor and 1/D written
+    c.bytes += c.db->by[BY_FACTOR];      // matrix entries read, factor and 1/D written
     c.cFact++;
     SPROF(c, SP_FACTOR);
 }
@@ -707,7 +715,7 @@ __device__ __forceinline__ void sp_solve_band(SpCtx<G>& c, bool admm, GD b)
     band_sweep<G, false>(c.KF(admm), c.KD(admm), b, Np, c.gl);
     g_sync();
     SPROF(c, SP_BACKWARD);
-    c.bytes += 8.0 * (2.0 * (double)c.db->N * c.db->w + 4.0 * c.db->N);
+    c.bytes += c.db->by[BY_SOLVE];
 }
 
 // ---- the border (oracle: kkt_factor / kkt_solve) ---------------------------------------------------------------------------------
@@ -782,7 +790,7 @@ __device__ __forceinline__ void sp_border_schur(SpCtx<G>& c, bool admm, double d
         }
     }
     g_sync();
-    c.bytes += 8.0 * (2.0 * (double)db.nU + (double)kb * Np);
+    c.bytes += db.by[BY_BORDER_PREPARE];
 }
 // After the band solve of b (the border positions pass through it untouched): the border unknowns from S, then the band part corrected
 template <int G>
@@ -810,7 +818,7 @@ __device__ __forceinline__ void sp_border_solve(SpCtx<G>& c, bool admm, GD b)
         b[p] -= acc;
     }
     g_sync();
-    c.bytes += 8.0 * ((double)kb * Nb + 2.0 * Nb + db.nU);
+    c.bytes += db.by[BY_BORDER_SOLVE];
 }
 // K x = b in place: the band solve, then the border
 template <int G>
@@ -931,7 +939,7 @@ __device__ __forceinline__ int sp_ph_trial(SpCtx<G>& c, SpState& S, GD g)
         have_r1 = 1;
     } else {
         sp_Ex<G>(c, x, ex);
-        c.bytes += 12.0 * db.nnzE + 8.0 * (n + m);
+        c.bytes += db.by[BY_EX];
     }
     double res_eq = 0.0, bmax = 0.0;
     int chg = 0, act = 0;
@@ -960,7 +968,7 @@ __device__ __forceinline__ int sp_ph_trial(SpCtx<G>& c, SpState& S, GD g)
     if (!have_r1 && (trial == 0 || !changed)) {
         res_stat = sp_residual<G>(c, g, x, yt, r1, qx);
         c.cSweeps++;
-        c.bytes += 12.0 * (db.nnzQ + db.nnzE) + 8.0 * (3.0 * n + m);
+        c.bytes += db.by[BY_SWEEP];
         have_r1 = 1;
     }
     if (trial > 0 && !changed && res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) return PH_QPEND;      // a verified KKT point
@@ -1163,7 +1171,7 @@ __device__ __forceinline__ int sp_ph_start(SpCtx<G>& c, SpState& S)
     g_sync();
     // Q x0 and C x0 once; from here on both follow the steps (sp_ph_qpend)
     sp_Qx2<G>(c, xk, xk, Qx, Qp); sp_Cx2<G>(c, xk, xk, Cx, Cp);
-    c.bytes += 12.0 * db.nnzQ + 2.0 * 12.0 * db.nnzE;
+    c.bytes += db.by[BY_START];
     if (o.solveZeroPenaltyFirst) { for (int i = t; i < n; i += G) gk[i] = g[i]; g_sync(); }
     else { const double rho = S.rho; for (int i = t; i < n; i += G) gk[i] = rho * Cx[i] + gtil[i]; g_sync(); }
     S.initial = 1;
@@ -1240,10 +1248,10 @@ __device__ __forceinline__ int sp_ph_qpend(SpCtx<G>& c, SpState& S)
         // vectors.  (Q xk is not: 2.2e-16 per component is below its rounding; the dense kernel does the same.)
         sp_Ex<G>(c, xk, lx);
         sp_C_from_Ex<G, true>(c, exs, lx, [](int) { return NoPre{}; }, [&](int i, double cxq, double cxk, NoPre) { Cx[i] = cxk; Cp[i] = cxq - cxk; });
-        c.bytes += 3.0 * 12.0 * db.nnzE;
+        c.bytes += 3.0 * db.by[BY_E];
     } else {
         sp_C_from_Ex<G, false>(c, exs, exs, [&](int i) { return Cx[i]; }, [&](int i, double cxq, double, double cxk) { Cp[i] = cxq - cxk; });
-        c.bytes += 12.0 * db.nnzE;
+        c.bytes += db.by[BY_E];
     }
     if (!initial) {
         double sq = 0.0, sl = 0.0;
@@ -1409,16 +1417,20 @@ __global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db)
 }
 
 // ---- the scheduler: persistent wavefronts that serve the phase queues of their pool -------------------------------------------------------
-// Queue discipline (per pool and phase): push = take a slot (atomicAdd on tail), write the instance id into it, release fence, atomicAdd on
-// count; pop = claim up to 64 / G entries of count (compare-and-swap), take as many slots (atomicAdd on head), wait for each slot's id (a
-// pusher that holds a slot writes it a few instructions later; ids are stored +1, 0 = empty), clear it, acquire fence.  An instance is in at
-// most one queue, so a ring of poolSize entries never overflows.  Everything an instance's phase wrote to memory is released by the fence in
-// front of its push and acquired by the fence behind the pop of whichever wavefront runs its next phase.
+// Queue discipline (per pool and phase): push = take a position (atomicAdd on tail), wait until its slot's sequence says "free for this
+// position" (at once, unless the ring has been lapped), store (position + 1, instance id) into it, atomicAdd on count; pop = claim entries of
+// count (compare-and-swap), take as many positions (atomicAdd on head), wait for each slot's sequence to say "holds this position" (its pusher
+// writes it a few instructions after taking the position), acquire fence, hand the slot on (store (position + poolSize, -)).  An instance is in at most one queue, so a ring of poolSize entries never overflows.
+// Everything an instance's phase wrote to memory is released by the fence in front of its push and acquired by the fence behind the pop of
+// whichever wavefront runs its next phase.
 // agent scope: a pool is served by wavefronts of several XCDs, whose L2s are not coherent with each other -- the release writes the L2 back, the
 // acquire invalidates L1 and L2 (workgroup-scope fences in their place: stale vectors, more iterates, 15 - 25 % SLOWER; profiles/round4)
 #define SP_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #define SP_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
 __device__ __forceinline__ int q_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long q_load64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void q_store64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long q_slot(int seq, int id) { return ((unsigned long long)(unsigned)seq << 32) | (unsigned)id; }
 
 // Lanes per instance depend on the phase (round 4, second step): the band phases (PH_FACTOR, PH_CORRECT, PH_ROUND with its ADMM band solves) need
 // the G lanes the folded band layout is made for and take 64 / G instances per wavefront; the STREAMING phases (PH_START, PH_TRIAL, PH_QPEND:
@@ -1428,6 +1440,19 @@ __device__ __forceinline__ int q_load(const int* p) { return __hip_atomic_load(p
 #ifndef SP_WIDE_LANES
 #define SP_WIDE_LANES 64      // (experiment switch: 0 = every phase with G lanes per instance, the first phase machine of round 4)
 #endif
+#ifndef SP_CHAIN
+#define SP_CHAIN 1            // (experiment switch: 0 = every phase change goes through the queues)
+#endif
+#ifndef SP_WIDE_BATCH
+#define SP_WIDE_BATCH 16      // passes of a streaming step: instances popped at once = SP_WIDE_BATCH * 64 / SP_WIDE_LANES
+#endif
+#ifndef SP_CHAIN_BAND
+#define SP_CHAIN_BAND 1
+#endif
+#ifndef SP_BAND_BATCH
+#define SP_BAND_BATCH 1       // passes of a band step
+#endif
+static_assert(SP_WIDE_BATCH * (SP_WIDE_LANES ? 64 / SP_WIDE_LANES : 8) <= 64 && SP_BAND_BATCH <= 8, "a step holds its instances one per lane");
 template <int G, int GP>
 __device__ __forceinline__ int sp_run_phase(const SpBatch& db, int ph, int b, int w0, int lane)
 {
@@ -1467,14 +1492,27 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_sched(SpBatch
     constexpr int IPW = 64 / G;
     constexpr int GW = (SP_WIDE_LANES > G) ? SP_WIDE_LANES : G;      // lanes per instance of the streaming phases
     constexpr int IPWW = 64 / GW;
-    const int pool = blockIdx.x % db.nPools;
-    const int w0 = pool * db.poolSize;
-    const int mask = db.poolSize - 1;
-    int* ring = db.qring + (size_t)pool * PH_NUM * db.poolSize;
-    int* ctl = db.qctl + (size_t)pool * (PH_NUM + 1) * QCTL;
-    int* remaining = ctl + PH_NUM * QCTL;
-    for (int idle = 0;;) {
+    __shared__ int s_id[WGS], s_next[WGS], s_ctl[2];      // the step's instances, where each goes next; [0] how many they are, [1] polls without work in a row
+    // the pool's queues, derived afresh in front of the pop and in front of the push: nothing of the scheduler is alive across a phase
+    struct Q { int w0, mask; unsigned long long* ring; int* ctl; int* remaining; };
+    auto queues = [&]() {
+        int pool = blockIdx.x % db.nPools;
+        asm volatile("" : "+s"(pool));
+        Q q;
+        q.w0 = pool * db.poolSize; q.mask = db.poolSize - 1;
+        q.ring = db.qring + (size_t)pool * PH_NUM * db.poolSize;
+        q.ctl = db.qctl + (size_t)pool * (PH_NUM + 1) * QCTL;
+        q.remaining = q.ctl + PH_NUM * QCTL;
+        return q;
+    };
+    if (threadIdx.x == 0) s_ctl[1] = 0;
+    for (;;) {
         const int lane = here((int)threadIdx.x);      // per step: nothing derived from the lane number is carried around the loop (it would be hoisted and spilled)
+        const Q q0 = queues();
+        const int w0 = q0.w0, mask = q0.mask;
+        unsigned long long* ring = q0.ring;
+        int* ctl = q0.ctl;
+        int* remaining = q0.remaining;
         // ---- pop: one phase for the whole wavefront (lane 0 decides).  A band phase with a full wavefront's worth of instances first (the long
         // steps run at full width), else the fullest streaming queue, else whatever a band queue holds.
         int ph = -1, take = 0, base = 0;
@@ -1487,7 +1525,7 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_sched(SpBatch
             if (ph < 0) for (int k = 0; k < PH_NUM; k++) if (isWide(k) && cnt[k] > best) { best = cnt[k]; ph = k; }
             if (ph < 0) for (int k = 0; k < PH_NUM; k++) if (cnt[k] > best) { best = cnt[k]; ph = k; }
             if (ph >= 0) {
-                take = min(best, isWide(ph) ? IPWW : IPW);
+                take = min(best, isWide(ph) ? IPWW * SP_WIDE_BATCH : IPW * SP_BAND_BATCH);
                 if (atomicCAS(&ctl[ph * QCTL + 2], best, best - take) == best) base = atomicAdd(&ctl[ph * QCTL + 1], take);
                 else { ph = -1; take = 0; }      // somebody else moved the counter: look again
             }
@@ -1498,40 +1536,74 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_sched(SpBatch
 #endif
         if (take == 0) {
             if (q_load(remaining) <= 0) break;
-            if (++idle > 4) __builtin_amdgcn_s_sleep(32);
+            const int idle = s_ctl[1] + 1;
+            if (lane == 0) s_ctl[1] = idle;
+            if (idle > 4) __builtin_amdgcn_s_sleep(32);
 #ifdef LCQP_SCHED_PROFILE
             if (lane == 0) { atomicAdd(&db.qprof[PH_NUM * 3 + 0], __builtin_amdgcn_s_memtime() - tq0); atomicAdd(&db.qprof[PH_NUM * 3 + 1], 1ull); }
 #endif
             continue;
         }
-        idle = 0;
+        if (lane == 0) { s_ctl[1] = 0; s_ctl[0] = take; }
         int myid = -1;
+        const size_t qoff = (size_t)ph * db.poolSize;
         if (lane < take) {
-            int* slot = &ring[(size_t)ph * db.poolSize + ((base + lane) & mask)];
-            int v;
-            while ((v = q_load(slot)) == 0) __builtin_amdgcn_s_sleep(1);
-            __hip_atomic_store(slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            myid = v - 1;
+            const int pos = base + lane;
+            unsigned long long e;
+            while ((int)((e = q_load64(&ring[qoff + (pos & mask)])) >> 32) != pos + 1) __builtin_amdgcn_s_sleep(1);
+            myid = (int)(unsigned)e;
         }
-        SP_ACQUIRE();
+        SP_ACQUIRE();                                                                    // (also orders the slot's read in front of handing it on)
+        if (lane < take) {
+            const int pos = base + lane;
+            q_store64(&ring[qoff + (pos & mask)], q_slot(pos + db.poolSize, -1));
+        }
         const bool wide = GW != G && (ph == PH_START || ph == PH_TRIAL || ph == PH_QPEND);
-        const int gw = wide ? GW : G;                       // lanes per instance in this step
-        const int b = __shfl(myid, lane / gw, 64);
-        // ---- run the phase for the instances popped (lane groups without one idle through it)
-        int next = -1;
-        if (b >= 0) {
-            if (wide) next = sp_run_phase<G, GW>(db, ph, b, w0, lane);
-            else next = sp_run_phase<G, G>(db, ph, b, w0, lane);
+        // ---- run the phase for the instances popped (lane groups without one idle through it).  The instances of the step and where each goes
+        // next are kept in LDS, one per lane: no register of the scheduler is alive across a phase.
+        s_id[lane] = myid;
+        __builtin_amdgcn_wave_barrier();
+        if (wide) {
+            // streaming phases: the instances popped (up to SP_WIDE_BATCH) one after the other, GW lanes each, so that the fences of the step
+            // -- the release writes back the whole XCD's L2 -- are paid once for all of them.  A streaming phase that leads to another one
+            // (an accepted trial -> the end of its QP -> the first trial of the next) stays here: same lanes, same instance, its own stores in
+            // program order -- no queue, no fences.
+            for (int j = 0; j < take; j += IPWW) {
+                const int ln = here(lane), bj = s_id[j + ln / GW];
+                int nj = -1;
+                if (bj >= 0)
+                    for (int p = ph;; p = nj) {
+                        nj = sp_run_phase<G, GW>(db, p, bj, w0, ln);
+                        if (SP_CHAIN == 0 || !(nj == PH_TRIAL || nj == PH_QPEND)) break;
+                    }
+                if ((ln & (GW - 1)) == 0) s_next[j + ln / GW] = nj;
+            }
+        } else {
+            // band phases: 64 / G instances side by side, SP_BAND_BATCH such passes per step
+            for (int j = 0; j < take; j += IPW) {
+                const int l0 = here(lane), bj = s_id[j + l0 / G];
+                int nj = -1;
+                if (bj >= 0)
+                    for (int p = ph;; p = nj) {      // (a factorisation is always followed by its correction: same lanes, same instances)
+                        nj = sp_run_phase<G, G>(db, p, here(bj), w0, here(l0));      // (re-laundered per pass: nothing of the instance's addressing is carried around the loop)
+                        if (SP_CHAIN_BAND == 0 || !(p == PH_FACTOR && nj == PH_CORRECT)) break;
+                    }
+                if ((l0 & (G - 1)) == 0) s_next[j + l0 / G] = nj;
+            }
         }
+        __builtin_amdgcn_wave_barrier();
         // ---- push: what this wavefront wrote is released, then every instance goes to the queue of its next phase
         SP_RELEASE();
-        if (b >= 0 && (lane & (gw - 1)) == 0) {
-            if (next == PH_NUM) atomicSub(remaining, 1);
+        if (here((int)threadIdx.x) < s_ctl[0]) {
+            const Q q1 = queues();
+            const int b = s_id[threadIdx.x], next = s_next[threadIdx.x];
+            if (next == PH_NUM) atomicSub(q1.remaining, 1);
             else {
-                const int s = atomicAdd(&ctl[next * QCTL + 0], 1);
-                __hip_atomic_store(&ring[(size_t)next * db.poolSize + (s & mask)], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                SP_RELEASE();
-                atomicAdd(&ctl[next * QCTL + 2], 1);
+                const int pos = atomicAdd(&q1.ctl[next * QCTL + 0], 1), sl = pos & q1.mask;
+                const size_t noff = (size_t)next * db.poolSize;
+                while ((int)(q_load64(&q1.ring[noff + sl]) >> 32) != pos) __builtin_amdgcn_s_sleep(1);      // (waits only when the ring has been lapped onto a slot that is still being read)
+                q_store64(&q1.ring[noff + sl], q_slot(pos + 1, b));
+                atomicAdd(&q1.ctl[next * QCTL + 2], 1);
             }
         }
 #ifdef LCQP_SCHED_PROFILE
@@ -1555,7 +1627,10 @@ __global__ void k_sparse_sched_init(SpBatch db)
     }
     if (b < db.nPools * db.poolSize) {
         const int pool = b / db.poolSize, i = b % db.poolSize;
-        for (int k = 0; k < PH_NUM; k++) db.qring[((size_t)pool * PH_NUM + k) * db.poolSize + i] = (k == PH_START && pool * db.poolSize + i < db.B) ? pool * db.poolSize + i + 1 : 0;
+        for (int k = 0; k < PH_NUM; k++) {
+            const bool filled = (k == PH_START && pool * db.poolSize + i < db.B);      // position i of the start queue holds instance i of the pool
+            db.qring[((size_t)pool * PH_NUM + k) * db.poolSize + i] = filled ? q_slot(i + 1, pool * db.poolSize + i) : q_slot(i, -1);
+        }
     }
 }
 
@@ -1827,6 +1902,19 @@ try {
     SpBatch& d = h->db;
     memset(&d, 0, sizeof(d));
     d.B = batch; d.n = n; d.m = m; d.nC = nC; d.nComp = nComp; d.N = N; d.Np = ((N + 63) / 64) * 64; d.w = w; d.ld = ld; d.nnzQ = nnzQ; d.nnzE = nnzA; d.G = G; d.kb = kb; d.nU = nU; d.nCb = nCb;
+    {   // algorithmic bytes per event (what each event has to read and write once: 8-byte values, 4-byte indices)
+        const double dN = N, dq = nnzQ, de = nnzA, Nb = N - kb;
+        d.by[BY_ASSEMBLE] = 8.0 * (dN * ld + dq + de) + 4.0 * (dq + de);
+        d.by[BY_FACTOR_LDS] = 8.0 * (3.0 * dN * (w + 1));
+        d.by[BY_FACTOR] = 12.0 * (dq + de) + 8.0 * dN * (w + 2);
+        d.by[BY_SOLVE] = 8.0 * (2.0 * dN * w + 4.0 * dN);
+        d.by[BY_BORDER_PREPARE] = 8.0 * (2.0 * (double)nU + (double)kb * d.Np);
+        d.by[BY_BORDER_SOLVE] = 8.0 * ((double)kb * Nb + 2.0 * Nb + nU);
+        d.by[BY_EX] = 12.0 * de + 8.0 * (n + m);
+        d.by[BY_SWEEP] = 12.0 * (dq + de) + 8.0 * (3.0 * n + m);
+        d.by[BY_START] = 12.0 * dq + 2.0 * 12.0 * de;
+        d.by[BY_E] = 12.0 * de;
+    }
     const size_t Np = d.Np;
     lcqp_hip_options_default(&d.opt);
     bool ok = hipStreamCreate(&h->stream) == hipSuccess && hipEventCreate(&h->ev0) == hipSuccess && hipEventCreate(&h->ev1) == hipSuccess &&
@@ -1891,7 +1979,7 @@ try {
         while ((size_t)(2 * pool) * perInst < ((size_t)1 << 32) && pool < batch) pool *= 2;
         if (const char* e = std::getenv("LCQP_SPARSE_POOL")) { const int v = std::atoi(e); if (v >= 1 && v < pool && (v & (v - 1)) == 0) pool = v; }      // test hook: several small pools
         d.poolSize = pool; d.nPools = (batch + pool - 1) / pool;
-        ok = ok && (d.state = sp_alloc<SpState>(h, B)) && (d.qring = sp_alloc<int>(h, (size_t)d.nPools * PH_NUM * pool)) &&
+        ok = ok && (d.state = sp_alloc<SpState>(h, B)) && (d.qring = sp_alloc<unsigned long long>(h, (size_t)d.nPools * PH_NUM * pool)) &&
              (d.qctl = sp_alloc<int>(h, (size_t)d.nPools * (PH_NUM + 1) * QCTL)) && (d.qprof = sp_alloc<unsigned long long>(h, (PH_NUM + 1) * 3));
     }
     if (!ok) { g_sp_err = "device allocation failed"; return nullptr; }      // (the guard destroys the handle)
