@@ -104,6 +104,8 @@ struct SpBatch {
     double *Kb;              // [B][N*ld] assembled band rows (input of a factorisation): Kb[i*ld + k] = K[i][i-w+k]
     double *KaF, *KaD;       // ADMM KKT factor in the folded layout of band_sweep [B][Np*G], 1/D [B][Np]
     double *KpF, *KpD;       // polish KKT factor
+    double* K0;              // [Np][G] per instance: the band rows of [Q, E'; E, .] with every row of E in, diagonal slot Q_ii (variables) -- what sp_factor_reg streams
+    int bitWords;            // 32-bit words of a working set's bit set in LDS (sp_ph_factor), 0: it does not fit, the flags are read from memory
     double *nv, *mv, *Nv;    // [B][NV_NUM][n], [B][MV_NUM][m], [B][2][Np]
     // Bordered band (round 3): the last kb positions of the ordering are border nodes -- rows or variables too dense for any band (the
     // coupling constraint and the two shared variables of examples/OptimizeOnCircle.cpp).  K = [Bd U'; U C]: the band engine factorises
@@ -162,6 +164,8 @@ typedef GP<int> GI;
 template <class X> struct val_of { typedef X type; };
 template <class T> struct val_of<GRef<T>> { typedef T type; };
 
+extern __shared__ double sp_dyn_lds[];      // G <= 16: the working sets' bit sets (sp_ph_factor); G > 16: the windows of sp_factor_lds
+
 template <int G>
 struct SpCtx {
     const SpBatch* db;
@@ -187,6 +191,7 @@ struct SpCtx {
     __device__ __forceinline__ GD Kb() const { return arr(db->Kb, (size_t)db->N * db->ld); }
     __device__ __forceinline__ GD KF(bool admm) const { return arr(admm ? db->KaF : db->KpF, (size_t)db->Np * G); }
     __device__ __forceinline__ GD KD(bool admm) const { return arr(admm ? db->KaD : db->KpD, db->Np); }
+    __device__ __forceinline__ GD K0() const { return arr(db->K0, (size_t)db->Np * G); }
     __device__ __forceinline__ GD BW(bool admm) const { return arr(db->bW, (size_t)2 * db->kb * db->Np, (unsigned)(admm ? db->kb * db->Np : 0)); }
     __device__ __forceinline__ GD BUv(bool admm) const { return arr(db->bUv, (size_t)2 * db->nU, (unsigned)(admm ? db->nU : 0)); }
     __device__ __forceinline__ GD BS(bool admm) const { return arr(db->bS, (size_t)2 * db->kb * db->kb, (unsigned)(admm ? db->kb * db->kb : 0)); }
@@ -545,34 +550,30 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
 {
     constexpr int GM = G - 1;
     const int N = c.db->N, Np = c.db->Np, l = here(c.gl);
-    const int nnzQ = c.db->nnzQ, nvar = c.db->n;
-    const int* __restrict__ bsrc = c.db->bsrc;
-    GD Qv = c.Qx(), Ev = c.Ex();
+    GD K0 = c.K0();
     const int NG = (N + GM) & ~GM;
     // band row r in band order (entry k: column r - (G-1) + k), assembled on the fly from the values of Q and E: variables carry
     // Q + dprim I; constraint row rr carries its entries of E and -ddual(rr) on the diagonal when it is in the working set, -1 alone
     // when it is not (the KKT matrix is never written to memory)
-    // Two levels of dependent loads per row (round 4; four before: code -> row of E -> status -> value, and position -> node -> Q_ii -> value):
-    // level 1, shared by the batch: where each band entry comes from (bsrc), which row of E gates it (bgate), what the diagonal is (bdiag:
-    // >= 0 the entry of Q, -1 a variable without a stored diagonal, -2 - rr the constraint row rr, INT_MIN a border position);
-    // level 2, this instance's values and working-set flags.  The factorisation was bound by this chain, not by its arithmetic.
+    // The values of a band row come from the instance's assembled rows (K0, written once by k_sparse_setup: G doubles per row, contiguous --
+    // round 4 gathered them from the values of Q and E here, 7 scattered 8-byte loads per row and lane); what depends on the working set is
+    // applied on the way: bgate (shared by the batch) names the row of E whose membership gates an entry (-1: none), bdiag what the
+    // diagonal is (>= -1 a variable: Q_ii, in K0, + dprim; -2 - rr the constraint row rr; INT_MIN a border position).
     const int* __restrict__ bgate = c.db->bgate;
     const int* __restrict__ bdiag = c.db->bdiag;
     auto load_row = [&](double* dst, int r) {
         if (r < N) {
-            int code[G], gate[G];
+            int gate[G];
 #pragma unroll
-            for (int k = 0; k < GM; k++) { code[k] = bsrc[r * G + k]; gate[k] = bgate[r * G + k]; }
+            for (int k = 0; k < G; k += 4) { const int4 g4 = *reinterpret_cast<const int4*>(bgate + (size_t)r * G + k); gate[k] = g4.x; gate[k + 1] = g4.y; gate[k + 2] = g4.z; gate[k + 3] = g4.w; }
             const int bd = bdiag[r];
+            double val[G];
 #pragma unroll
-            for (int k = 0; k < GM; k++) {
-                double v = 0.0;
-                if (code[k] >= nnzQ) { if (use(gate[k])) v = Ev[code[k] - nnzQ]; }
-                else if (code[k] >= 0) v = Qv[code[k]];
-                dst[k] = v;
-            }
+            for (int k = 0; k < G; k += 2) { const dv2 v = K0.ld2(r * G + k); val[k] = v.x; val[k + 1] = v.y; }
+#pragma unroll
+            for (int k = 0; k < GM; k++) dst[k] = (gate[k] < 0 || use(gate[k])) ? val[k] : 0.0;
             if (bd == INT_MIN) dst[GM] = 1.0;                           // a border position: an isolated unit pivot of the band
-            else if (bd >= -1) dst[GM] = (bd >= 0 ? (double)Qv[bd] : 0.0) + dprim;
+            else if (bd >= -1) dst[GM] = val[GM] + dprim;
             else { const int rr = -2 - bd; dst[GM] = use(rr) ? -ddual(rr) : -1.0; }
         } else {
 #pragma unroll
@@ -1009,11 +1010,25 @@ __device__ __forceinline__ int sp_ph_factor(SpCtx<G>& c, SpState& S)
     // by the host when every Hessian of the batch is safely definite) and is only kept when every pivot has the sign its node
     // prescribes and a safe size; a variable's pivot failing makes the safe level permanent for the instance.
     int level = (db.lightOK && !c.info->bigReg) ? 0 : 1;
+    // the working set as a bit set in LDS: the factorisation asks for the membership of the row behind every entry of E it meets (up to
+    // 2 w per band row) -- from memory these were gathers of 4-byte flags, 8 instances apart in one wavefront
+    unsigned* bits = nullptr;
+    if (G <= 16 && db.bitWords > 0) {
+        bits = reinterpret_cast<unsigned*>(sp_dyn_lds) + (size_t)((int)threadIdx.x / G) * db.bitWords;
+        for (int w = t; w < db.bitWords; w += G) {
+            unsigned word = 0u;
+#pragma unroll 8
+            for (int k = 0; k < 32; k++) { const int r = w * 32 + k; if (r < m && st[r] != ST_INACT) word |= 1u << k; }
+            bits[w] = word;
+        }
+        wave_sync();
+    }
     for (;;) {
         S.dpUsed = level ? c.info->delta : c.info->deltaS;
         S.d2Used = level ? c.info->delta2 : c.info->delta2S;
         const double d2 = S.d2Used;
-        sp_factor_band<G>(c, c.KF(false), c.KD(false), S.dpUsed, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; });
+        if (bits) sp_factor_band<G>(c, c.KF(false), c.KD(false), S.dpUsed, [=](int) { return d2; }, [=](int r) { return ((bits[r >> 5] >> (r & 31)) & 1u) != 0u; });
+        else sp_factor_band<G>(c, c.KF(false), c.KD(false), S.dpUsed, [=](int) { return d2; }, [=](int r) { return st[r] != ST_INACT; });
         if (level == 1) break;
         int badVar = 0, badRow = 0;
         GD Kd = c.KD(false);
@@ -1344,7 +1359,6 @@ __device__ __forceinline__ int sp_ph_qpend(SpCtx<G>& c, SpState& S)
     return sp_qp_begin<G>(c, S, gk);
 }
 
-extern __shared__ double sp_dyn_lds[];
 
 template <int G>
 __device__ __forceinline__ SpCtx<G> sp_ctx(const SpBatch& db, int b, int w0, int lane)
@@ -1407,6 +1421,22 @@ __global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db)
         c.info->deltaS = db.opt.proxSmall * scale; c.info->delta2S = 1e-14 / scale; c.info->bigReg = 0;
     }
     g_sync();
+    if constexpr (G <= 16) {
+        // the assembled band rows every factorisation of this instance streams (sp_factor_reg): the one gather from the values of Q and E
+        GD K0 = c.K0(), Qv = c.Qx(), Ev = c.Ex();
+        const int nnzQ = db.nnzQ;
+#pragma unroll 2
+        for (int r = t; r < db.N; r += G) {
+#pragma unroll
+            for (int k = 0; k < G - 1; k++) {
+                const int code = db.bsrc[r * G + k];
+                K0[r * G + k] = (code >= nnzQ) ? (double)Ev[code - nnzQ] : ((code >= 0) ? (double)Qv[code] : 0.0);
+            }
+            const int bd = db.bdiag[r];
+            K0[r * G + G - 1] = (bd >= 0) ? (double)Qv[bd] : 0.0;
+        }
+        g_sync();
+    }
     sp_factor_band<G>(c, c.KF(true), c.KD(true), db.opt.admmSigma * scale, [=](int r) { return 1.0 / rhov[r]; }, [](int) { return true; });
     if (db.kb > 0) {
         sp_border_prepare<G>(c, true, [](int) { return true; });
@@ -1638,7 +1668,8 @@ template <int G>
 static void sp_launch(const SpBatch& db, hipStream_t stream, hipEvent_t mid)
 {
     const int ipw = 64 / G, grid = (db.B + ipw - 1) / ipw;
-    const size_t ldsBytes = G <= 16 ? 0 : sizeof(double) * (size_t)ipw * (G * G + 16 * G);       // LDS window of sp_factor_lds: per group G x G and 16 staged rows
+    // LDS: the working sets' bit sets of sp_ph_factor (G <= 16), the window of sp_factor_lds (per group G x G and 16 staged rows) otherwise
+    const size_t ldsBytes = G <= 16 ? sizeof(unsigned) * (size_t)ipw * db.bitWords : sizeof(double) * (size_t)ipw * (G * G + 16 * G);
     hipLaunchKernelGGL(k_sparse_setup<G>, dim3(grid), dim3(WGS), ldsBytes, stream, db);
     (void)hipEventRecord(mid, stream);
     const int ninit = std::max(db.nPools * db.poolSize, db.nPools * (PH_NUM + 1) * QCTL);
@@ -1902,6 +1933,7 @@ try {
     SpBatch& d = h->db;
     memset(&d, 0, sizeof(d));
     d.B = batch; d.n = n; d.m = m; d.nC = nC; d.nComp = nComp; d.N = N; d.Np = ((N + 63) / 64) * 64; d.w = w; d.ld = ld; d.nnzQ = nnzQ; d.nnzE = nnzA; d.G = G; d.kb = kb; d.nU = nU; d.nCb = nCb;
+    d.bitWords = (G <= 16 && (size_t)(64 / G) * ((m + 31) / 32) * sizeof(unsigned) <= 16384) ? (m + 31) / 32 : 0;      // at most 16 KB of LDS per wavefront
     {   // algorithmic bytes per event (what each event has to read and write once: 8-byte values, 4-byte indices)
         const double dN = N, dq = nnzQ, de = nnzA, Nb = N - kb;
         d.by[BY_ASSEMBLE] = 8.0 * (dN * ld + dq + de) + 4.0 * (dq + de);
@@ -1965,6 +1997,7 @@ try {
          (d.Kb = sp_alloc<double>(h, G > 16 ? B * N * ld : 0)) &&      // the band array is only written by the LDS-window factorisation
          (d.KaF = sp_alloc<double>(h, B * Np * G)) && (d.KaD = sp_alloc<double>(h, B * Np)) &&
          (d.KpF = sp_alloc<double>(h, B * Np * G)) && (d.KpD = sp_alloc<double>(h, B * Np)) &&
+         (d.K0 = sp_alloc<double>(h, G <= 16 ? B * Np * G : 0)) &&
          (d.nv = sp_alloc<double>(h, B * NV_NUM * n)) && (d.mv = sp_alloc<double>(h, B * MV_NUM * m)) && (d.Nv = sp_alloc<double>(h, B * 2 * Np)) &&
          (d.lbL = sp_alloc<double>(h, B * nComp)) && (d.lbR = sp_alloc<double>(h, B * nComp)) && (d.mi = sp_alloc<int>(h, B * MI_NUM * m)) &&
          (d.info = sp_alloc<SpInfo>(h, B)) && (d.stats = sp_alloc<lcqp_stats_t>(h, B)) && (d.xout = sp_alloc<double>(h, B * n)) &&
