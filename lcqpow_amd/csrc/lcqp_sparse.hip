@@ -1934,6 +1934,7 @@ try {
     memset(&d, 0, sizeof(d));
     d.B = batch; d.n = n; d.m = m; d.nC = nC; d.nComp = nComp; d.N = N; d.Np = ((N + 63) / 64) * 64; d.w = w; d.ld = ld; d.nnzQ = nnzQ; d.nnzE = nnzA; d.G = G; d.kb = kb; d.nU = nU; d.nCb = nCb;
     d.bitWords = (G <= 16 && (size_t)(64 / G) * ((m + 31) / 32) * sizeof(unsigned) <= 16384) ? (m + 31) / 32 : 0;      // at most 16 KB of LDS per wavefront
+    if (const char* e = std::getenv("LCQP_SPARSE_NOBITS")) { if (std::atoi(e) == 1) d.bitWords = 0; }                    // test hook: the path of problems with more rows than that
     {   // algorithmic bytes per event (what each event has to read and write once: 8-byte values, 4-byte indices)
         const double dN = N, dq = nnzQ, de = nnzA, Nb = N - kb;
         d.by[BY_ASSEMBLE] = 8.0 * (dN * ld + dq + de) + 4.0 * (dq + de);

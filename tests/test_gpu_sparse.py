@@ -104,6 +104,22 @@ def test_sparse_phase_machine_pools(hip, oracle, monkeypatch, pool, B):
     sb.close()
 
 
+@pytest.mark.parametrize("span", [6, 10])
+def test_sparse_working_set_bits_in_lds_or_flags_in_memory(hip, monkeypatch, span):
+    """sp_ph_factor (lane groups of 8 and 16) asks a bit set in LDS for the working set while it assembles a band row; problems with more
+    rows of E than 16 KB of LDS per wavefront hold read the 4-byte flags from memory instead (LCQP_SPARSE_NOBITS=1 forces that path).  Same
+    matrix either way: the same bits."""
+    n, nC, nK, B = 512, 256, 64, 11
+    sb0, _, x0, y0, st0 = _run(hip, n, nC, nK, B, span=span)
+    assert sb0.lanes() in (8, 16, 32)
+    sb0.close()
+    monkeypatch.setenv("LCQP_SPARSE_NOBITS", "1")
+    sb, _, x, y, st = _run(hip, n, nC, nK, B, span=span)
+    assert np.array_equal(x, x0) and np.array_equal(y, y0)
+    assert [s["iterTotal"] for s in st] == [s["iterTotal"] for s in st0] and all(s["returnValue"] == 0 for s in st)
+    sb.close()
+
+
 @pytest.mark.parametrize("span", [10, 18])
 def test_sparse_wider_bands(hip, oracle, span):
     """constraint rows over 10 / 18 variables: half bandwidths beyond 7 select wider lane groups by themselves"""
