@@ -645,6 +645,7 @@ template <int G, bool FWD>
 __device__ __forceinline__ void band_sweep(GD K, GD Kd, GD b, int Np, int gl)
 {
     constexpr int CH = G < 16 ? G : 16, NCHUNK = 64 / CH, BPS = 64 / G, RING = (G == 8) ? SP_SWEEP_RING : 2;
+    static_assert(RING >= 2 && NCHUNK % RING == 0, "the ring slots are assigned statically per 64 positions: RING has to divide 64 / CH (6 gave wrong coefficients and a run without end)");
     gl = here(gl);
     auto at = [&](int p) -> int { return FWD ? p : Np - 1 - p; };
     double cf[RING][CH];
