@@ -65,6 +65,9 @@ __device__ __forceinline__ double ld_stream(const double* p) { return *p; }
 __device__ __forceinline__ int tid_here() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
 __device__ __forceinline__ int lane_id() { return tid_here() & 63; }
 __device__ __forceinline__ int wave_id() { return tid_here() >> 6; }
+#ifndef LCQP_SEQ_WAVE
+#define LCQP_SEQ_WAVE 1
+#endif
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -694,6 +697,17 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
     double* dl = lds.arena + 64 * TILE_LD;
     // the smallest pivot and the failure flag are kept in LDS (dl[8], dl[9]; thread 0 writes them), not in registers around the loops
     if (t == 0) { dl[8] = INFINITY; dl[9] = 0.0; }
+#if LCQP_SEQ_WAVE
+    // Which wave runs the sequential stretches (the 16x16 sub-block chains below).  With wave 0 in every workgroup, the stretches of the
+    // workgroups that share a CU queue up on ONE SIMD when the dispatcher has put every wave 0 there (k_factor: 0.40 ms with one workgroup
+    // per two CUs, 1.30 ms with four per CU).  The waves say where they are (HW_REG_HW_ID: slot [3:0], SIMD [5:4]); the workgroup in slot k
+    // of its CU takes its wave on SIMD k mod 4.  Any choice is correct; this one spreads the stretches when slots are handed out in order.
+    {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if (lane_id() == 0) dl[10 + wave_id()] = (double)(hw & 0x3fu);
+    }
+#endif
     const int nn = 64 * nblk;
     if (tau > 0.0) {
         for (int i = t; i < nn; i += WG) d0[i] = F[(size_t)i * ld + i];
@@ -721,9 +735,17 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
         const int nsub = (tau > 0.0) ? min(4, max(0, (nreal - o + 15) >> 4)) : 4;
         for (int jb = 0; jb < nsub; jb++) {
             const int c0 = 16 * jb;
-            if (t < 64) {
+#if LCQP_SEQ_WAVE
+            int sw = 0;
+            { const int want = ((int)dl[10]) & 3;
+              for (int w = 1; w < 4; w++) if (((((int)dl[10 + w]) >> 4) & 3) == want) sw = w;
+              if (((((int)dl[10]) >> 4) & 3) == want) sw = 0; }
+#else
+            const int sw = 0;
+#endif
+            if ((t >> 6) == sw) {
                 __builtin_amdgcn_s_setprio(3);   // the only sequential stretch: let it win issue slots from streaming waves
-                const int l = t;
+                const int l = t & 63;
                 double minpiv = INFINITY;
                 int fail = 0;
                 double a[16], dcol[16];
