@@ -104,6 +104,26 @@ def test_sparse_phase_machine_pools(hip, oracle, monkeypatch, pool, B):
     sb.close()
 
 
+def test_sparse_scheduler_under_contention_is_reproducible(hip, oracle):
+    """A batch large enough that every pop and push of k_sparse_sched races with others (1200 instances, 2048 persistent wavefronts; streaming
+    steps of up to 16 instances, band steps of 8, chained phases): three runs on one handle regroup the instances differently and must give
+    the same bits; all solved; a sample equals the oracle.  (tools/micro/sparse_soak.py does the same at the benchmark's size.)"""
+    n, nC, nK, B = 256, 128, 32, 1200
+    sb, inst, x, y, st = _run(hip, n, nC, nK, B)
+    assert all(s["returnValue"] == 0 for s in st)
+    for _ in range(2):
+        sb.run(); sb.synchronize()
+        x2, y2, st2 = sb.solution()
+        assert np.array_equal(x2, x) and np.array_equal(y2, y)
+        assert [s["iterTotal"] for s in st2] == [s["iterTotal"] for s in st]
+    opt = oracle.default_options(perturbStep=0)
+    for b in (0, 399, 800, B - 1):
+        d = inst[b]
+        ro = oracle.sparse_lcqp_solve(n, nC, nK, d["Q"].tocsr(), d["g"], d["E"].tocsr(), lbA=d["lbA"], ubA=d["ubA"], opt=opt)
+        assert ro["ret"] == 0 and np.abs(x[b] - ro["x"]).max() < 1e-9 and np.abs(y[b] - ro["y"]).max() < 1e-7
+    sb.close()
+
+
 @pytest.mark.parametrize("span", [6, 10])
 def test_sparse_working_set_bits_in_lds_or_flags_in_memory(hip, monkeypatch, span):
     """sp_ph_factor (lane groups of 8 and 16) asks a bit set in LDS for the working set while it assembles a band row; problems with more
