@@ -204,6 +204,7 @@ struct orc_qp {
     int k_ready;      /* LK exists (qp_build_K): the ADMM factor is built when the first ADMM iteration needs it, as on the device (lcqp_dev.hpp: qp_build_K) */
     int* boxidx;
     double *E, *Et, *l, *u, *rhov;
+    double *rn;       /* |E_r|_2 of every row: scale of the rounding floor of a computed E_r x (qp_polish, the active-row test) */
     double scale, sigma, spv, rho;
     double *L1, *LK;
     /* persistent solver state (hot start) */
@@ -258,7 +259,7 @@ orc_qp_t* orc_qp_create(int nV, int nC, const double* Q, const double* A, const 
 
 static void qp_free_setup(orc_qp_t* q)
 {
-    free(q->boxidx); free(q->E); free(q->Et); free(q->l); free(q->u); free(q->rhov);
+    free(q->boxidx); free(q->E); free(q->Et); free(q->l); free(q->u); free(q->rhov); free(q->rn); q->rn = NULL;
     free(q->L1); free(q->LK); free(q->x); free(q->y); free(q->st); free(q->xa); free(q->ya); free(q->za);
     free(q->xref); free(q->w_n1); free(q->w_n2); free(q->w_n3); free(q->w_m1); free(q->w_m2); free(q->w_a1); free(q->w_a2); free(q->w_a3); free(q->w_a4);
     free(q->Ti); free(q->slot_row); free(q->row_slot); free(q->crow);
@@ -319,6 +320,8 @@ static int qp_setup(orc_qp_t* q, const double* lbA, const double* ubA, const dou
         q->l[nC + k] = bound_or(lb, q->boxidx[k], -INFINITY);
         q->u[nC + k] = bound_or(ub, q->boxidx[k], INFINITY);
     }
+    q->rn = dalloc(mE);
+    for (int r = 0; r < mE; r++) { double s2 = 0; for (int k = 0; k < n; k++) s2 += q->E[(size_t)r * n + k] * q->E[(size_t)r * n + k]; q->rn[r] = sqrt(s2); }
     double scale = 0;
     for (int i = 0; i < n; i++) { double d = fabs(q->Q[(size_t)i * n + i]); if (d > scale) scale = d; }
     if (!(scale > 1e-300)) scale = 1.0;
@@ -755,7 +758,20 @@ static double row_violation(double e, double l, double u, double feasTol)
     return 0.0;
 }
 
-static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int* st, int reuse)
+/* Round 5, two additions (device: qp_polish in lcqp_dev.hpp, the same arithmetic):
+ *  (1) ACTIVE ROWS TO THEIR ROUNDING FLOOR.  The homotopy ends on phi < complementarityTolerance = 1e3 eps (src/LCQProblem.cpp:511-534,
+ *      src/Options.cpp:297), a sum of products (L_i x - lbL_i)(R_i x - lbR_i) in which one factor is the residual of an ACTIVE row of this QP.
+ *      An active-set solver like the reference's holds its active rows to rounding; a residual test at resTol (1 + |b|) = 1e-12 does not.
+ *      A point that passes the residual tests is therefore accepted only when every row of the factor also holds to
+ *      16 eps (|b_r| + |E_r| |x|) -- the rounding of a computed E_r x --, else one more correction (iterative refinement, at most two per
+ *      polish) is taken first.  On well-conditioned QPs the rows are at that floor after every correction and nothing changes.
+ *  (2) DAMPED TRIALS.  damp != 0 (the rounds after g_damp_round failed ones): the primal-dual update -- all wrong-signed rows out, all
+ *      violated rows in -- thrashes on LP-like QPs (singular Hessian, |g| ~ 1e7 at the end of a penalty homotopy); a damped polish
+ *      changes ONE row per trial: the row with the largest wrong-signed multiplier leaves, else the most violated row enters, and
+ *      it may take 4 n + 32 more trials. */
+static int g_damp_round = 3;
+void orc_qp_set_damp_round(int r) { g_damp_round = r; }
+static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int* st, int reuse, int damp)
 {
     const int n = q->nV, mE = q->mE, robust = q->robust;
     const orc_options_t* o = &q->opt;
@@ -774,7 +790,9 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
     int cap_on = 0;
     if (!reuse && g_enter_cap_div > 0) { cap_on = 1; for (int r = 0; r < mE; r++) if (st[r] != ST_INACT) cap_on = 0; }
 
-    for (int trial = 0; trial < o->maxTrials; trial++) {
+    const int maxTrials = damp ? o->maxTrials + 4 * n + 32 : o->maxTrials;
+    int nrefine = 0;
+    for (int trial = 0; trial < maxTrials; trial++) {
         q->c_trials++;
         int changed = 0, promoted = 0, nlv = 0, have_true = 0;
         if (trial == 0) {
@@ -803,10 +821,17 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
             }
             have_true = 1;      /* the first trial only corrects: the working set it was handed stays */
         } else {
-            /* (a) leaving rows */
+            /* (a) leaving rows (damped: the one with the largest wrong-signed multiplier, the lowest index among equals) */
+            double ylvmax = 0.0;
+            if (damp)
+                for (int r = 0; r < mE; r++) {
+                    const int s = st[r];
+                    if (((s == ST_LOWER && yfull[r] > ytol) || (s == ST_UPPER && yfull[r] < -ytol)) && fabs(yfull[r]) > ylvmax) ylvmax = fabs(yfull[r]);
+                }
             for (int r = 0; r < mE; r++) {
                 const int s = st[r];
                 if ((s == ST_LOWER && yfull[r] > ytol) || (s == ST_UPPER && yfull[r] < -ytol)) {
+                    if (damp && (nlv > 0 || fabs(yfull[r]) < ylvmax)) continue;
                     ylv[r] = yfull[r]; yfull[r] = 0.0; st[r] = ST_INACT; nlv++; changed = 1;
                 }
             }
@@ -843,12 +868,22 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
                     vcut = lo;      /* the lower end: a few more than cap rows -- with the upper end a tie of many equally violated rows would never enter */
                 }
             }
+            int nent = 0;
+            if (damp) {      /* one change per trial: the most violated row enters (the lowest index among equals), and only when no row left */
+                vcut = INFINITY;
+                if (!changed) {
+                    double vm = 0.0;
+                    for (int r = 0; r < mE; r++) if (st[r] == ST_INACT) { const double v = row_violation(Ex[r], q->l[r], q->u[r], o->feasTol); if (v > vm) vm = v; }
+                    if (vm > 0.0) vcut = vm;
+                }
+            }
             for (int r = 0; r < mE; r++) {
                 const int s = st[r];
                 const double ftol = o->feasTol * (1.0 + fabs(Ex[r]));
                 if (s == ST_INACT) {
-                    if (Ex[r] < q->l[r] - ftol) { if (q->l[r] - Ex[r] >= vcut) { st[r] = ST_LOWER; changed = 1; } }
-                    else if (Ex[r] > q->u[r] + ftol) { if (Ex[r] - q->u[r] >= vcut) { st[r] = ST_UPPER; changed = 1; } }
+                    if (damp && nent > 0) continue;
+                    if (Ex[r] < q->l[r] - ftol) { if (q->l[r] - Ex[r] >= vcut) { st[r] = ST_LOWER; changed = 1; nent++; } }
+                    else if (Ex[r] > q->u[r] + ftol) { if (Ex[r] - q->u[r] >= vcut) { st[r] = ST_UPPER; changed = 1; nent++; } }
                 } else if (robust && q->dep[r]) {
                     /* the last factor update flagged this row as dependent on the rows before it, so the correction left its
                      * multiplier alone and did not enforce its equation.  Strictly inside its bound: the row is not active.
@@ -872,7 +907,10 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
                     for (int k = 0; k < n; k++) s += qr[k] * x[k];
                     r1[i] = -g[i] - s;
                 }
-                double res_stat = 0, res_eq = 0, bmax = 0;
+                double res_stat = 0, res_eq = 0, bmax = 0, xn = 0;
+                int nloose = 0;      /* rows of the factor that are not at the rounding floor of E_r x */
+                for (int i = 0; i < n; i++) xn += x[i] * x[i];
+                xn = sqrt(xn);
                 for (int r = 0; r < mE; r++) {
                     if (st[r] == ST_INACT) continue;
                     const double* e = q->E + (size_t)r * n;
@@ -885,12 +923,16 @@ static int qp_polish(orc_qp_t* q, const double* g, double* x, double* yfull, int
                     const double b = (st[r] == ST_UPPER) ? q->u[r] : q->l[r];
                     if (fabs(b - Ex[r]) > res_eq) res_eq = fabs(b - Ex[r]);
                     if (fabs(b) > bmax) bmax = fabs(b);
+                    if (q->row_slot[r] >= 0 && fabs(b - Ex[r]) > 16.0 * ORC_EPS * (fabs(b) + q->rn[r] * xn)) nloose++;
                 }
                 for (int i = 0; i < n; i++) {
                     du[i] = r1[i];                         /* residual of the QP as given: the next hot start needs it without the proximal term */
                     r1[i] -= spv * (x[i] - q->xref[i]);
                     double a = fabs(r1[i]); if (a > res_stat) res_stat = a;
                 }
+                if (res_stat <= o->resTol * gs && res_eq <= o->resTol * (1.0 + bmax) && nloose > 0 && nrefine < 2 && trial + 1 < maxTrials) {
+                    nrefine++;      /* solved to the residual tolerance, but the active rows can be held more exactly: one more correction */
+                } else
                 if (res_stat <= o->resTol * gs && res_eq <= o->resTol * (1.0 + bmax)) {
                     /* the proximal QP is solved.  Is it the QP as given, i.e. is sigma_p |x - xref| below the tolerance too? */
                     double res_orig = 0;
@@ -1085,7 +1127,7 @@ int orc_qp_solve(orc_qp_t* q, int initialSolve, int* iterations, int* exit_flag,
         }
         memcpy(xt, q->xa, sizeof(double) * n);
         for (int r = 0; r < mE; r++) yt[r] = (stt[r] != ST_INACT) ? q->ya[r] : 0.0;
-        if (qp_polish(q, g, xt, yt, stt, round == 0 && use_stored_set)) { solved = 1; break; }
+        if (qp_polish(q, g, xt, yt, stt, round == 0 && use_stored_set, round >= g_damp_round)) { solved = 1; break; }
         if (round >= 1 && n_admm > 0) qp_adapt_rho(q, g);
         if (round >= 2) {    /* at least 20 ADMM iterations behind us: is the QP infeasible or unbounded? */
             certificate = qp_certificate(q, g);
