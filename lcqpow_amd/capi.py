@@ -79,6 +79,8 @@ def lib():
         L.lcqp_hip_batch_setup.argtypes = [C.c_void_p]
         L.lcqp_hip_batch_run.argtypes = [C.c_void_p]
         L.lcqp_hip_batch_synchronize.argtypes = [C.c_void_p]
+        L.lcqp_hip_batch_set_run_chunks.argtypes = [C.c_void_p, C.c_int]
+        L.lcqp_hip_batch_get_run_chunks.argtypes = [C.c_void_p]
         L.lcqp_hip_batch_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.lcqp_hip_batch_get_solution.argtypes = [C.c_void_p, c_double_p, c_double_p, C.POINTER(Stats)]
         L.lcqp_hip_batch_get_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, C.POINTER(C.c_int)]
@@ -272,6 +274,13 @@ class BatchLCQP:
 
     def synchronize(self):
         _check(lib().lcqp_hip_batch_synchronize(self.h), "synchronize")
+
+    def set_run_chunks(self, chunks):
+        """slices of consecutive instances a run works through (0: the library chooses); the setup of slice c + 1 runs beside the homotopy of slice c"""
+        _check(lib().lcqp_hip_batch_set_run_chunks(self.h, int(chunks)), "set_run_chunks")
+
+    def run_chunks(self):
+        return int(lib().lcqp_hip_batch_get_run_chunks(self.h))
 
     def last_timing(self):
         a = C.c_float(0); b = C.c_float(0)

@@ -725,8 +725,18 @@ __device__ __forceinline__ void ti_delete(Ctx<NCH>& c, int p, int& nT, int& ns)
 // reuse != 0 (hot start from the last verified solution): the first trial needs no sweep, because
 // r1 = r1_last + (g_last - g) and E x = ex_last hold exactly for an unchanged (x, y).
 // ---------------------------------------------------------------------------------------------
+// Round 5 (oracle: the same two additions, the same arithmetic):
+//   * ACTIVE ROWS TO THEIR ROUNDING FLOOR.  runSolver ends on phi < complementarityTolerance = 1e3 eps (src/LCQProblem.cpp:511-534,
+//     src/Options.cpp:297), a sum of products in which one factor is the residual of an active row of this QP.  A point that passes the
+//     residual tests is accepted only when every row of the factor also holds to 16 eps (|b_r| + |E_r| |x|), the rounding of a computed
+//     E_r x; else one more correction (iterative refinement, at most two per polish) comes first.  On well-conditioned QPs the rows are
+//     at that floor after every correction: nothing changes (the synthetic workload is bit-identical).
+//   * damp != 0 (the rounds after DAMP_ROUND failed ones): ONE change of the working set per trial -- the row with the largest
+//     wrong-signed multiplier leaves, else the most violated row enters -- and 4 n + 32 more trials: the full primal-dual update
+//     thrashes on LP-like QPs (singular Hessian, |g| ~ 1e7 at the end of a penalty homotopy).
+constexpr int DAMP_ROUND = 3;
 template <int NCH, bool ROBUST, bool LR>
-__device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse, double ytol, double rtolG)
+__device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse, double ytol, double rtolG, int damp)
 {
     constexpr int np = 128 * NCH;
     // every size sweeps through row lists (round 2 kept the plain sweep at np = 1024 because the list sweep returned wrong residuals in that
@@ -761,12 +771,16 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
     const int capNa = min(min(min(max(2 * c.n, 64), mE), capS), max_active(NCH));   // room for the degenerate vertices of small problems
 
     // |x - x_last sweep| for the margins; x becomes the x of the last sweep.  Returns the shrink of the margins per unit row norm.
+    double xnrm = 0.0;      // |x|_2 at the top of the current trial (scale of the rounding floor of E_r x)
     auto sweep_distance = [&]() -> double {
         double d2 = 0.0, x2 = 0.0;
         for (int i = tid_here(); i < c.n; i += WG) { const double xv = x[i], dd = xv - xs[i]; d2 += dd * dd; x2 += xv * xv; xs[i] = xv; }     // the n variables, not the padding
         // |E_r (x - x_last)| <= |E_r| |x - x_last|; the factor covers the tolerance that moves with E_r x (feasTol (1 + |E_r x|)),
         // the second term the rounding of a computed E_r x (~ eps |E_r| |x|)
-        return uniform_d(sqrt(block_sum(d2, c.lds)) * shrinkF + 1e-13 * sqrt(block_sum(x2, c.lds)));
+        double sd2, sx2;
+        block_sum2(d2, x2, sd2, sx2, c.lds);
+        xnrm = uniform_d(sqrt(sx2));
+        return uniform_d(sqrt(sd2) * shrinkF + 1e-13 * xnrm);
     };
 
     // a polish that gives up leaves no multipliers of leaving rows behind (M_YLV is zero between trials)
@@ -777,7 +791,14 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
     };
 
     int capOn = 0;      // the cap on entering rows applies to polishes that start from an empty working set (oracle: cap_on)
-    for (int trial = 0; trial < o.maxTrials; trial++) {
+    int nrefine = 0;    // refinement corrections taken for the active rows alone
+    const int maxTrials = damp ? o.maxTrials + 4 * c.n + 32 : o.maxTrials;
+    auto violation = [&](int r) -> double {
+        if (st[r] != ST_INACT) return 0.0;
+        const double e = ex[r], ftol = o.feasTol * (1.0 + fabs(e));
+        return (e < l[r] - ftol) ? l[r] - e : ((e > u[r] + ftol) ? e - u[r] : 0.0);
+    };
+    for (int trial = 0; trial < maxTrials; trial++) {
         const int t = tid_here();      // per trial: nothing derived from the thread number is carried around the loop (it would be hoisted and spilled)
         c.cTrials++;
         int changed = 0, nlv = 0, have_true = 0, need_true = 0;
@@ -809,12 +830,21 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             }
         } else {
             // (a) leaving rows; margins of the inactive rows shrink by |E_r| * |x - x_last sweep|
-            const double dl = LISTS ? sweep_distance() : 0.0;
+            const double dl = sweep_distance();
             int cntLv = 0;
+            int rLeave = -1;      // damped: the one row that may leave (largest wrong-signed multiplier, lowest index among equals)
+            if (damp) {
+                double vb = 0.0;
+                for (int r = t; r < mE; r += WG) { const int s = st[r]; const double yv = yt[r]; if ((s == ST_LOWER && yv > ytol) || (s == ST_UPPER && yv < -ytol)) vb = fmax(vb, fabs(yv)); }
+                const double ylvmax = block_max(vb, c.lds);
+                int rb = 1 << 30;
+                for (int r = t; r < mE; r += WG) { const int s = st[r]; const double yv = yt[r]; if (((s == ST_LOWER && yv > ytol) || (s == ST_UPPER && yv < -ytol)) && fabs(yv) >= ylvmax) rb = min(rb, r); }
+                rLeave = (int)(-block_max((double)(-rb), c.lds) + 0.5);
+            }
             wg_map<4>(mE, [&](int r) { return MapID3{st[r], yt[r], mg[r], rn[r]}; },
                       [&](int r, MapID3 v) {
                           int s = v.s;
-                          if ((s == ST_LOWER && v.a > ytol) || (s == ST_UPPER && v.a < -ytol)) { ylv[r] = v.a; yt[r] = 0.0; st[r] = ST_INACT; s = ST_INACT; cntLv++; }
+                          if (((s == ST_LOWER && v.a > ytol) || (s == ST_UPPER && v.a < -ytol)) && (!damp || r == rLeave)) { ylv[r] = v.a; yt[r] = 0.0; st[r] = ST_INACT; s = ST_INACT; cntLv++; }
                           if (LISTS) mg[r] = (s != ST_INACT) ? -1.0 : v.b - v.c * dl;
                       });
             nlv = block_sum_i(cntLv, c.lds);
@@ -838,12 +868,22 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             // each -- only those at or above a cut enter (twelve bisection steps on [0, largest violation]); the others stay inactive with
             // a negative margin, i.e. they are read again in the next trial.
             double vcut = 0.0;
+            int rEnter = -1;      // damped: the one row that may enter (most violated, lowest index among equals), and only when no row left
+            if (damp) {
+                vcut = INFINITY;
+                if (!changed) {
+                    double vm = 0.0;
+                    for (int a = t; a < nread; a += WG) vm = fmax(vm, violation(LISTS ? list[a] : a));
+                    vm = block_max(vm, c.lds);
+                    if (vm > 0.0) {
+                        int rb = 1 << 30;
+                        for (int a = t; a < nread; a += WG) { const int r = LISTS ? list[a] : a; if (violation(r) >= vm) rb = min(rb, r); }
+                        rEnter = (int)(-block_max((double)(-rb), c.lds) + 0.5);
+                        vcut = vm;
+                    }
+                }
+            } else
             if (capOn) {
-                auto violation = [&](int r) -> double {
-                    if (st[r] != ST_INACT) return 0.0;
-                    const double e = ex[r], ftol = o.feasTol * (1.0 + fabs(e));
-                    return (e < l[r] - ftol) ? l[r] - e : ((e > u[r] + ftol) ? e - u[r] : 0.0);
-                };
                 double vm = 0.0, cv = 0.0, vmax, nviol;
                 for (int a = t; a < nread; a += WG) { const double v = violation(LISTS ? list[a] : a); if (v > 0.0) { cv += 1.0; vm = fmax(vm, v); } }
                 block_max_sum(vm, cv, vmax, nviol, c.lds);
@@ -870,8 +910,9 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                 nDense += (hotc[r] < 0);
                 const double e = ex[r], ftol = o.feasTol * (1.0 + fabs(e));
                 if (s == ST_INACT) {
-                    if (e < l[r] - ftol && l[r] - e >= vcut) { st[r] = ST_LOWER; chg |= 1; }
-                    else if (e > u[r] + ftol && e - u[r] >= vcut) { st[r] = ST_UPPER; chg |= 1; }
+                    const bool may = !damp || r == rEnter;
+                    if (may && e < l[r] - ftol && l[r] - e >= vcut) { st[r] = ST_LOWER; chg |= 1; }
+                    else if (may && e > u[r] + ftol && e - u[r] >= vcut) { st[r] = ST_UPPER; chg |= 1; }
                     else if (LISTS) mg[r] = fmin(e - (l[r] - ftol), (u[r] + ftol) - e);      // (negative for a violated row that waits)
                 } else if (depRows && dep[r]) {
                     bool viol, inside = false;
@@ -926,13 +967,20 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                     nDense2 += (hotc[r] < 0) ? 1.0 : 0.0;
                     if (s == ST_INACT) continue;
                     const double bb = (s == ST_UPPER) ? u[r] : l[r];
-                    res_eq = fmax(res_eq, fabs(bb - ex[r]));
+                    const double rr = fabs(bb - ex[r]);
+                    res_eq = fmax(res_eq, rr);
                     bmax = fmax(bmax, fabs(bb));
+                    // a row of the factor that is not at the rounding floor of E_r x (counted in units of 2^20 beside the dense-row count: one reduction)
+                    if (rslot[r] >= 0 && rr > 16.0 * 2.221e-16 * (fabs(bb) + rn[r] * xnrm)) nDense2 += 1048576.0;
                 }
-                { double re, nd; block_max_sum(res_eq, nDense2, re, nd, c.lds); res_eq = re; if (t == 0) c.info->work[4] += nd; }
+                int nloose;
+                { double re, nd; block_max_sum(res_eq, nDense2, re, nd, c.lds); res_eq = re; nloose = (int)(nd * (1.0 / 1048576.0)); nd -= 1048576.0 * nloose; if (t == 0) c.info->work[4] += nd; }
                 bmax = block_max(bmax, c.lds);
                 // the proximal QP is solved: is it the QP as given (sigma_p |x - xref| below the tolerance too)?  Else (PSD Hessians far from
                 // xref) the next step of the proximal-point iteration is anchored here
+                if (res_stat <= rtolG && res_eq <= o.resTol * (1.0 + bmax) && nloose > 0 && nrefine < 2 && trial + 1 < maxTrials) {
+                    nrefine++;      // solved to the residual tolerance, but the active rows can be held more exactly: one more correction
+                } else
                 if (res_stat <= rtolG && res_eq <= o.resTol * (1.0 + bmax) && !(wg_maxabs(du, np, c.lds) <= rtolG)) {
                     for (int i = t; i < np; i += WG) { xref[i] = x[i]; r1[i] = du[i]; }
                     __syncthreads();
@@ -1203,7 +1251,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         }
         for (int i = t; i < np; i += WG) xt[i] = xa[i];
         __syncthreads();
-        if (qp_polish<NCH, ROBUST, LR>(c, g, round == 0 && use_stored, ytolQ, rtolQ)) { solved = 1; break; }
+        if (qp_polish<NCH, ROBUST, LR>(c, g, round == 0 && use_stored, ytolQ, rtolQ, round >= DAMP_ROUND)) { solved = 1; break; }
         if (ADAPT && round >= 1 && n_admm > 0 && qp_adapt_rho<NCH>(c, g) < 0) return 3;      // no usable ADMM factor left
         if (round >= 2) {    // at least 20 ADMM iterations behind us: is the QP infeasible or unbounded?
             certificate = qp_certificate<NCH>(c, g);
@@ -1307,7 +1355,8 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
         int initial = 1;
         wg_symv<NCH>(c.Q, c.C, n, xk, nullptr, Qx, Cx, nullptr, nullptr, c.lds);      // Q x0, C x0: the one sweep over Q and C of the homotopy
         const double *xq = c.V(V_XQ), *qxn = c.V(V_QXN), *aty = c.V(V_ATY);
-        double* sP = c.lds.arena;                     // pk for the gather through the rows of C
+        double* sP = c.lds.arena;                     // pk and (behind it) xk for the gathers through the rows of C
+        double* sX = c.lds.arena + np;
         for (;;) {
             rc = solveQP(initial);
             const int t = tid_here();      // per iterate (see qp_polish)
@@ -1338,26 +1387,30 @@ __device__ __forceinline__ void lcqp_run(Ctx<NCH>& c)
                     z = z ^ (z >> 31);
                     vx[e] += ((int)(z % 3ULL) - 1) * 2.221e-16;
                 }
-                if (in) sP[i] = vp[e];
+                if (in) { sP[i] = vp[e]; sX[i] = vx[e]; }
             }
             if (!initial && o.perturbStep) perturbCounter += (uint64_t)n;
             __syncthreads();
-            // C pk (:1217-1237 need Qk pk): from the compressed rows of C when it is sparse (one-hot L, R: 2 nComp non-zeros), else a sweep
+            // C pk (:1217-1237 need Qk pk) and C xk: from the compressed rows of C when it is sparse (one-hot L, R: 2 nComp non-zeros), else
+            // one sweep with both vectors.  C xk is formed from xk itself in every iterate (round 5; it used to follow the steps by
+            // linearity, C xk += alpha C pk): phi = phi_const + g_phi'xk + xk'C xk / 2 (getPhi :1172-1185) cancels to 1e3 eps at a solution,
+            // and forty roundings of size eps |C xk| carried along drowned that -- the reference forms the product anew each time.
             if (cnz >= 0) {
 #pragma unroll
                 for (int e = 0; e < EPT; e++) {
-                    double sdot = 0.0;
-                    for (int k = c0[e]; k < c1[e]; k++) sdot += ccv[k] * sP[ci[k]];
+                    double sdot = 0.0, sx = 0.0;
+                    for (int k = c0[e]; k < c1[e]; k++) { const double cv = ccv[k]; const int j = ci[k]; sdot += cv * sP[j]; sx += cv * sX[j]; }
                     vCp[e] = sdot;
+                    vCx[e] = sx;
                 }
                 __syncthreads();
             } else {
 #pragma unroll
-                for (int e = 0; e < EPT; e++) { const int i = t + e * WG; if (i < np) pk[i] = vp[e]; }
+                for (int e = 0; e < EPT; e++) { const int i = t + e * WG; if (i < np) { pk[i] = vp[e]; xk[i] = vx[e]; } }
                 __syncthreads();
-                wg_symv_t<NCH, false, false, 1>(c.C, nullptr, n, pk, nullptr, Cp, nullptr, nullptr, nullptr, c.lds);      // (one row in flight: the vectors of this pass stay in registers across the sweep)
+                wg_symv_t<NCH, false, true, 1>(c.C, nullptr, n, pk, xk, Cp, nullptr, Cx, nullptr, c.lds);      // (one row in flight: the vectors of this pass stay in registers across the sweep)
 #pragma unroll
-                for (int e = 0; e < EPT; e++) { const int i = t + e * WG; vCp[e] = (i < np) ? Cp[i] : 0.0; }
+                for (int e = 0; e < EPT; e++) { const int i = t + e * WG; vCp[e] = (i < np) ? Cp[i] : 0.0; vCx[e] = (i < np) ? Cx[i] : 0.0; }
             }
             if (!initial) {
                 // getOptimalStepLength :1217-1237: qk = pk'Qk pk, lk = pk'(Qk xk + g_tilde)

@@ -52,6 +52,7 @@ struct SpInfo {
     int haveSolution, stfValid, hasY0, bigReg;     // bigReg: this instance needs the safe regularisation of the polish (a Hessian that is only semidefinite)
     double scale, sigma, delta, delta2, phiConst;
     double deltaS, delta2S;                        // the light level tried first (sp_polish)
+    double e1max;                                  // largest row 1-norm of E: with |x|_inf the scale of the rounding of a computed E_r x (the active-row test of the polish)
     double hist[64];
     double bytes;        // algorithmic bytes counted by the kernel
     double prof[8];      // -DLCQP_PROFILE: clock ticks per phase (SP_* below)
@@ -75,8 +76,8 @@ struct SpState {
     // the subsolver call (oracle: sqp_solve)
     int round, n_admm, use_stored, backup_pending, admm_ready, trials0, admm0;
     // the polish (oracle: sqp_polish)
-    int trial, reuse, fact_valid, borderTodo;
-    double gs, ytol, dpUsed, d2Used;
+    int trial, reuse, fact_valid, borderTodo, nrefine;      // nrefine: refinement corrections taken for the active rows alone
+    double gs, ytol, dpUsed, d2Used, xinf;                  // xinf: |x|_inf behind the last correction
     // work counters
     int cAdmm, cTrials, cFact, cCorr, cSweeps;
     double bytes;
@@ -880,7 +881,7 @@ __device__ __forceinline__ int sp_polish_begin(SpCtx<G>& c, SpState& S, GD g, in
     S.ytol = o.feasTol * S.gs;
     S.fact_valid = 0; S.borderTodo = 0;
     S.dpUsed = c.info->delta; S.d2Used = c.info->delta2;      // regularisation of the factorisation in use
-    S.trial = 0; S.reuse = reuse;
+    S.trial = 0; S.reuse = reuse; S.nrefine = 0; S.xinf = 0.0;
     return PH_TRIAL;
 }
 
@@ -944,7 +945,10 @@ __device__ __forceinline__ int sp_ph_trial(SpCtx<G>& c, SpState& S, GD g)
         c.bytes += db.by[BY_EX];
     }
     double res_eq = 0.0, bmax = 0.0;
-    int chg = 0, act = 0;
+    int chg = 0, act = 0, loose = 0;
+    // active rows are held to the rounding floor of a computed E_r x, 16 eps (|b_r| + |E_r|_1 |x|_inf), before a point is accepted (round 5;
+    // oracle: sqp_polish; dense twin: qp_polish in lcqp_dev.hpp): runSolver ends on phi < 1e3 eps, a sum of products of such residuals
+    const double exScale = c.info->e1max * S.xinf;
     g_map<G, 4>(m, t, [&](int r) { return StRow{st[r], ex[r], l[r], u[r], yt[r]}; },
                 [&](int r, StRow v) {
                     int ns = v.s;
@@ -956,6 +960,7 @@ __device__ __forceinline__ int sp_ph_trial(SpCtx<G>& c, SpState& S, GD g)
                         const double bb = (v.s == ST_UPPER) ? v.hi : v.lo;
                         res_eq = nmax(res_eq, fabs(bb - v.e));
                         bmax = fmax(bmax, fabs(bb));
+                        loose |= (fabs(bb - v.e) > 16.0 * 2.221e-16 * (fabs(bb) + exScale));
                         if (v.s == ST_LOWER && v.y > ytol) ns = ST_INACT;
                         if (v.s == ST_UPPER && v.y < -ytol) ns = ST_INACT;
                     }
@@ -973,7 +978,10 @@ __device__ __forceinline__ int sp_ph_trial(SpCtx<G>& c, SpState& S, GD g)
         c.bytes += db.by[BY_SWEEP];
         have_r1 = 1;
     }
-    if (trial > 0 && !changed && res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) return PH_QPEND;      // a verified KKT point
+    if (trial > 0 && !changed && res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) {
+        if (!(g_any<G>(loose) && S.nrefine < 2 && trial + 1 < o.maxTrials)) return PH_QPEND;      // a verified KKT point
+        S.nrefine++;      // ... whose active rows can be held more exactly: one more correction
+    }
     if (changed && trial > 0) {
         if (trial >= 2 && nact > n && changed > max(n / 2, 32)) return sp_polish_failed<G>(c, S);       // overshooting cold start: hand over to ADMM
         // leaving rows: their multipliers leave the residual (r1 += E_r' y_r), then the new working set takes over
@@ -1081,7 +1089,9 @@ __device__ __forceinline__ int sp_ph_correct(SpCtx<G>& c, SpState& S)
     }
     S.borderTodo = 0;
     if (db.kb > 0) sp_border_solve<G>(c, false, b);
-    g_map<G, 8>(n, t, [&](int i) { return D2{b[iperm[i]], x[i]}; }, [&](int i, D2 v) { x[i] = v.b + v.a; });
+    double xm = 0.0;
+    g_map<G, 8>(n, t, [&](int i) { return D2{b[iperm[i]], x[i]}; }, [&](int i, D2 v) { const double xn = v.b + v.a; x[i] = xn; xm = fmax(xm, fabs(xn)); });
+    S.xinf = g_max<G>(xm);
     g_map<G, 8>(m, t, [&](int r) { return ID2{st[r], b[iperm[n + r]], yt[r]}; }, [&](int r, ID2 v) { if (v.s != ST_INACT) yt[r] = v.y + v.v; });
     g_sync();
     c.cCorr++;
@@ -1416,7 +1426,14 @@ __global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db)
     } else {
         for (int i = t; i < n; i += G) gphi[i] = 0.0;
     }
+    double e1 = 0.0;
+    {
+        GD Ev = c.Ex();
+        for (int r = t; r < m; r += G) { double s1 = 0.0; for (int k = db.Ep[r]; k < db.Ep[r + 1]; k++) s1 += fabs(Ev[k]); e1 = fmax(e1, s1); }
+        e1 = g_max<G>(e1);
+    }
     if (t == 0) {
+        c.info->e1max = e1;
         c.info->scale = scale; c.info->sigma = db.opt.admmSigma * scale; c.info->delta = db.opt.proxBig * scale; c.info->delta2 = 1e-9 / scale;
         c.info->phiConst = phiConst; c.info->haveSolution = 0; c.info->stfValid = 0; c.info->bytes = 0.0;
         c.info->deltaS = db.opt.proxSmall * scale; c.info->delta2S = 1e-14 / scale; c.info->bigReg = 0;

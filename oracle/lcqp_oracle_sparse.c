@@ -296,7 +296,10 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
     for (int i = 0; i < n; i++) if (fabs(g[i]) > gmax) gmax = fabs(g[i]);
     const double gs = 1.0 + gmax;
     double *r1 = q->r1, *Ex = q->ex, *b = q->wN;
-    int fact_valid = 0;
+    int fact_valid = 0, nrefine = 0;
+    double xinf = 0.0;      /* |x|_inf behind the last correction */
+    double e1max = 0.0;     /* largest row 1-norm of E: with |x|_inf the scale of the rounding of a computed E_r x */
+    for (int r = 0; r < m; r++) { double s1 = 0.0; for (int k = q->Ep[r]; k < q->Ep[r + 1]; k++) s1 += fabs(q->Ex[k]); if (s1 > e1max) e1max = s1; }
     for (int trial = 0; trial < o->maxTrials; trial++) {
         q->c_trials++;
         /* Two stages, as on the dense path (round 3).  Stage 1 is what every trial needs: E x, for the status test.  Stage 2 -- the true
@@ -312,8 +315,11 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
             sp_Ex(q, x, Ex);
         }
         double res_stat = 0, res_eq = 0, bmax = 0;
-        int changed = 0, nact = 0;
+        int changed = 0, nact = 0, nloose = 0;
         const double ytol = o->feasTol * gs;
+        /* active rows are held to the rounding floor of a computed E_r x before a point is accepted (round 5; the dense twin is qp_polish in
+         * lcqp_oracle.c, the device's sp_ph_trial): runSolver ends on phi < 1e3 eps (src/LCQProblem.cpp:511-534, src/Options.cpp:297) */
+        const double exScale = e1max * xinf;
         for (int r = 0; r < m; r++) {
             int s = st[r], ns = s;
             if (s == SP_INACT) {
@@ -324,6 +330,7 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
                 const double bb = (s == SP_UPPER) ? q->u[r] : q->l[r];
                 if (fabs(bb - Ex[r]) > res_eq || Ex[r] != Ex[r]) res_eq = fabs(bb - Ex[r]);
                 if (fabs(bb) > bmax) bmax = fabs(bb);
+                if (fabs(bb - Ex[r]) > 16.0 * 2.221e-16 * (fabs(bb) + exScale)) nloose++;
                 if (s == SP_LOWER && y[r] > ytol) ns = SP_INACT;
                 if (s == SP_UPPER && y[r] < -ytol) ns = SP_INACT;
             }
@@ -339,6 +346,9 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
             have_r1 = 1;
         }
         if (have_r1) for (int i = 0; i < n; i++) if (fabs(r1[i]) > res_stat || r1[i] != r1[i]) res_stat = fabs(r1[i]);      /* a NaN stays (and is never accepted) */
+        if (trial > 0 && !changed && res_stat <= o->resTol * gs && res_eq <= o->resTol * (1.0 + bmax) && nloose > 0 && nrefine < 2 && trial + 1 < o->maxTrials) {
+            nrefine++;      /* a verified KKT point whose active rows can be held more exactly: one more correction */
+        } else
         if (trial > 0 && !changed && res_stat <= o->resTol * gs && res_eq <= o->resTol * (1.0 + bmax)) {
             memcpy(q->r1_last, r1, sizeof(double) * n); memcpy(q->ex_last, Ex, sizeof(double) * m); memcpy(q->g_last, g, sizeof(double) * n);
             return 1;
@@ -395,7 +405,8 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
             b[q->iperm[n + r]] = v;
         }
         kkt_solve(&q->Kp, b);
-        for (int i = 0; i < n; i++) x[i] += b[q->iperm[i]];
+        xinf = 0.0;
+        for (int i = 0; i < n; i++) { x[i] += b[q->iperm[i]]; if (fabs(x[i]) > xinf) xinf = fabs(x[i]); }
         for (int r = 0; r < m; r++) if (st[r] != SP_INACT) y[r] += b[q->iperm[n + r]];
         q->c_corr++;
     }

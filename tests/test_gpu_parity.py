@@ -214,15 +214,15 @@ def test_lcqp_reference_problems(hip, oracle, name):
         # rows are duplicated by a box bound it depends on how the unique SUM is split between the duplicates -- S or W for the same point)
         _cmp(ro, rh, xtol=1e-7, ytol=np.inf, status=False)
         # Stationarity type (a parity output, row (a)13): each side reports what the reference's rule (src/LCQProblem.cpp:1412-1482) gives on ITS
-        # multipliers, and the oracle's answer is the committed one (W).  The two raw answers differ -- W on the oracle, S on the device -- and
-        # legitimately so: pair 25 has L_25 = -e_38 while variable 38 sits on its box bound lb = 0, two constraints that pin x_38 from both sides,
-        # so only -y_L25 + y_box38 = -0.0538 is defined (equal on both sides, asserted below through `comb`) and any amount can be added to both
-        # multipliers; the oracle happens to return -5e-11 on the row (W: a negative multiplier on a biactive pair), the device +0.029 (S).
-        # The stationarity types are defined by the EXISTENCE of multipliers with the right signs: applied to the most favourable admissible
-        # split (problems.stationarity_type, merge_box) the rule gives the same type, S, on both sides -- that is what is asserted.
+        # multipliers.  Pair 25 has L_25 = -e_38 while variable 38 sits on its box bound lb = 0, two constraints that pin x_38 from both sides, so
+        # only -y_L25 + y_box38 = -0.0538 is defined (equal on both sides, asserted below through `comb`) and any amount can be added to both
+        # multipliers.  Until round 4 the oracle returned -5e-11 on the row (W: a negative multiplier on a biactive pair) and the device +0.029
+        # (S); since the subsolver holds its active rows to their rounding floor (round 5) both sides return the same split and the same raw
+        # type, S, which is also the committed golden value.  The rule applied to the most favourable admissible split
+        # (problems.stationarity_type, merge_box) -- "there EXIST multipliers with these signs", the definition of the types -- gives S too.
         for r in (ro, rh):
             assert r["stats"]["status"] == P.stationarity_type(d, r["x"], r["y"], r["stats"]["rhoOpt"])
-        assert ro["stats"]["status"] == int(GOLD["example_data_stats"][3]) == 1
+        assert ro["stats"]["status"] == rh["stats"]["status"] == int(GOLD["example_data_stats"][3]) == 4
         assert P.stationarity_type(d, ro["x"], ro["y"], ro["stats"]["rhoOpt"], merge_box=True) == \
                P.stationarity_type(d, rh["x"], rh["y"], rh["stats"]["rhoOpt"], merge_box=True) == 4
         n, nC, nComp = d["nV"], d["nC"], d["nComp"]
@@ -386,6 +386,29 @@ def test_lcqp_synthetic_vs_oracle(hip, oracle, B, n, nC, nComp):
         assert abs((d["L"] @ xb) @ (d["R"] @ xb)) < 1e3 * 2.221e-16          # complementarity tolerance
     assert same_path >= (B + 1) // 2     # iterate counts agree except for tolerance-borderline instances
     bt.close()
+
+
+@pytest.mark.parametrize("chunks", [2, 3, 7])
+def test_lcqp_run_in_chunks_is_bitwise_the_same(hip, chunks):
+    """lcqp_hip_batch_set_run_chunks: a run that works through the batch in slices of consecutive instances (the setup of slice c + 1 beside
+    the homotopy of slice c, every kernel on a view of the batch) returns the bits of a run in one piece, trace and statistics included"""
+    B, n, nC, nComp = 13, 64, 96, 16
+    opt = hip.default_options(perturbStep=0, storeSteps=1)
+    res = []
+    for k in (1, chunks):
+        bt = hip.BatchLCQP(B, n, nC, nComp, opt=opt)
+        bt.generate_synthetic(0)
+        bt.set_run_chunks(k)
+        bt.run()
+        x, y, st = bt.solution()
+        assert bt.run_chunks() == k
+        res.append((x, y, st, [bt.trace(b) for b in (0, B // 2, B - 1)]))
+        bt.close()
+    (x1, y1, s1, t1), (x2, y2, s2, t2) = res
+    assert np.array_equal(x1, x2) and np.array_equal(y1, y2) and s1 == s2
+    for (a1, b1), (a2, b2) in zip(t1, t2):
+        assert np.array_equal(a1, a2) and np.array_equal(b1, b2)
+    assert all(s["returnValue"] == 0 for s in s1)
 
 
 def test_lcqp_synthetic_golden(hip):
@@ -589,28 +612,66 @@ def test_lcqp_shape_sweep(hip, oracle, n, nC, nComp):
     bt.close()
 
 
-def test_lcqp_structure_fuzz(hip, oracle):
-    """tools/gpu_fuzz.py: random small LCQPs with the irregular structure the synthetic generator never produces (singular
-    Hessians, dense / overlapping complementarity rows, equalities, duplicate and empty rows, finite upper complementarity
-    bounds, box bounds, warm-start duals; about a quarter are infeasible or unbounded by construction).  HIP and oracle must
-    end the same way: same return code and, on success, the same solution.  A few per cent may legitimately differ -- a
-    trial accepted on one side and rejected on the other at the residual tolerance sends a degenerate or nonconvex problem
-    down another path -- so the bound is 5 %."""
+def _fuzz_module():
     import importlib.util
     spec = importlib.util.spec_from_file_location("gpu_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_fuzz.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
+    return fz
+
+
+def test_lcqp_structure_fuzz(hip, oracle):
+    """tools/gpu_fuzz.py: random small LCQPs with the irregular structure the synthetic generator never produces (singular
+    Hessians, dense / overlapping complementarity rows, equalities, duplicate and empty rows, finite upper complementarity
+    bounds, box bounds, warm-start duals; about a quarter are infeasible or unbounded by construction).  HIP and oracle must
+    end the same way: the SAME RETURN CODE on every problem and, on success, the same solution.  Until round 4 a few per cent
+    differed (bound: 5 %) because the subsolver accepted active rows at 1e-12 while runSolver ends on phi < 1e3 eps
+    (src/LCQProblem.cpp:511-534, src/Options.cpp:297); since the rows of the factor are held to their rounding floor (round 5) the five
+    sets of tools/run_fuzz_sets.sh (1750 problems) show no differing return code and one other stationary point
+    (profiles/round5/fuzz_*.log).  Asserted here on seed 5: no return code differs, at most 1 % other stationary points."""
+    fz = _fuzz_module()
     count = 150
     cats, rets = fz.run(count, seed=5, verbose=False)
-    assert cats["same"] + cats["same solution, other iterate count"] >= count - count // 20, (cats, rets)
+    assert cats["return codes differ"] == 0, (cats, rets)
+    assert cats["other stationary point"] <= count // 100, (cats, rets)
     assert cats.get("branch minimiser checked", 0) >= count // 8 and cats.get("NOT a branch minimiser", 0) == 0, cats
     assert rets.get((0, 0), 0) >= count // 2, rets          # the generator is not mostly producing failures
 
 
+@pytest.mark.parametrize("seed,ids", [(1, (542, 550, 555)), (3, (12, 70)), (11, (34, 277))])
+def test_fuzz_regressions_end_the_same_way(hip, oracle, seed, ids):
+    """The fuzz problems on which HIP and the oracle used to end differently (profiles/round4/fuzz_batched_seed1_600.log, fuzz_host.log,
+    fuzz_diverge.log): seed 1 id 542 (oracle 0 / HIP 203: HIP stood at phi = 9e-13 above the 2.2e-13 tolerance and raised the penalty until a
+    QP failed), ids 550 and seed 3 id 70 (201 / 203), seed 11 ids 34 and 277 and the oracle-vs-oracle cases seed 1 id 555, seed 3 id 12 (other
+    stationary points after one side passed the termination test at its rounding floor).  Two causes, both removed in round 5: the subsolver
+    accepted active rows at resTol (1 + |b|) = 1e-12 instead of their rounding floor, and the device carried C xk along the steps by linearity,
+    forty roundings of eps |C xk| against a complementarity value that cancels to 1e3 eps (getPhi, src/LCQProblem.cpp:1172-1185).  The damped
+    polish (one change of the working set per trial after three failed rounds) settles the LP-like QPs at rho ~ 1e7 of ids 550 and 70.
+    Asserted: same return code, and on success the same solution and stationarity type (seed 1 id 542 passes the termination test two
+    penalty updates later on the device, rho 10.24 against 2.56, at the same point)."""
+    fz = _fuzz_module()
+    oracle.lcqp_set_robust(1)
+    rng = np.random.default_rng(seed)
+    for k in range(max(ids) + 1):
+        d = fz.make(rng)
+        if k not in ids:
+            continue
+        ro = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0))
+        rh = P.hip_solve(hip, d, hip.default_options(perturbStep=0))
+        assert ro["ret"] == rh["ret"], (seed, k, ro["ret"], rh["ret"])
+        if ro["ret"] == 0:
+            assert np.abs(ro["x"] - rh["x"]).max() < 1e-6 * (1.0 + np.abs(ro["x"]).max()), (seed, k)
+            assert ro["stats"]["status"] == rh["stats"]["status"], (seed, k)
 
-def test_fuzz_divergences_are_the_termination_test_at_its_rounding_floor(hip, oracle):
-    """The three problems of fuzz seed 11 (ids 34, 194, 277; profiles/round3/fuzz_batched.log) on which HIP and the oracle end at different
-    stationary points, root-caused with `python tools/gpu.py fuzz_diverge 11 34 194 277` (profiles/round4/fuzz_diverge.log): the two
+
+def test_fuzz_divergence_is_the_termination_test_at_its_rounding_floor(hip, oracle):
+    """The one problem of the five fuzz sets (1750 problems, profiles/round5/fuzz_*.log) on which HIP and the oracle still end at different
+    stationary points: seed 11 id 194 (ids 34 and 277 of that seed did too until round 4 and agree since the subsolver holds its active rows to
+    their rounding floor: test_fuzz_regressions_end_the_same_way).  Its iterates reach |x| ~ 1e2 ... 1e3 (objective -14939) along the 16-dimensional
+    null space of its Hessian, and phi = phi_const + g_phi'x + 1/2 x'Cx (getPhi :1172-1185) is evaluated by both sides to eps |x|^2 |C| ~ 1e-12:
+    the oracle reads -9.1e-13 at iterate 3 and ends, the device +9.0e-13 and goes on (profiles/round5/fuzz_diverge_11_194.log) -- the reference's
+    own test `phi < 2.2e-13` applied to a number whose rounding error is four times the tolerance.  Root-caused in round 4 with
+    `python tools/gpu.py fuzz_diverge 11 34 194 277` (profiles/round4/fuzz_diverge.log): the two
     homotopies agree iterate for iterate (to 1e-7) up to the iterate at which ONE side passes the termination test
     phi < complementarityTolerance = 2.2e-13 (src/LCQProblem.cpp:511-534) and the other does not.  At such an iterate the active side of
     every pair sits on its bound to the subsolver's residual tolerance (1e-12 relative, either sign), and with non-zero lbL / lbR -- all three
@@ -625,7 +686,7 @@ def test_fuzz_divergences_are_the_termination_test_at_its_rounding_floor(hip, or
     spec.loader.exec_module(fz)
     oracle.lcqp_set_robust(1)
     rng = np.random.default_rng(11)
-    ids = (34, 194, 277)
+    ids = (194,)
     ctol = 1e3 * 2.221e-16
     for k in range(max(ids) + 1):
         d = fz.make(rng)
