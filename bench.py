@@ -68,7 +68,7 @@ def pmc_traffic(workload, B, shape):
 def run_devices(devices, make_batch, steps, warmup, barrier):
     """warm-up, then `steps` timed steps on every device of this process (asynchronous launches on one stream per device,
     then a join); returns (elapsed s, batches, per-device list of (setup ms, solve ms) sums)"""
-    bts = [make_batch(d) for d in devices]
+    bts = [make_batch(d, k) for k, d in enumerate(devices)]      # (k: the shard of this process a device solves -- a device may appear twice, --devices 0,0)
     for bt in bts:
         bt.synchronize()
     for _ in range(warmup):
@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--no-resident", action="store_true", help="skip the 8192-resident-instances measurement")
     ap.add_argument("--no-sparse", action="store_true", help="skip the sparse_config5 object (BASELINE configs[4]) of the default line")
     ap.add_argument("--sparse-batch", type=int, default=65536, help="instances of the sparse_config5 object")
+    ap.add_argument("--devices", type=str, default=None, help="comma-separated device ids of the N shards (default 0..N-1; under torch.distributed.run: rank r takes entry r). "
+                    "A device may appear more than once: `--gpus 2 --devices 0,0` rehearses the N = 2 path -- two shards, aggregation, JSON -- on a one-GPU box")
     args = ap.parse_args()
     sparse = args.workload == "sparse"
     B = args.batch or (65536 if sparse else 1024)
@@ -130,13 +132,25 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         dist.init_process_group(backend="gloo")
-        devices, world = [local_rank], world_env
-        if local_rank >= ndev:
-            raise SystemExit(f"rank {rank}: device {local_rank} requested, {ndev} visible")
+        dev_of_rank = local_rank
+        if args.devices:
+            ids = [int(v) for v in args.devices.split(",")]
+            if len(ids) != world_env:
+                raise SystemExit(f"--devices names {len(ids)} devices for WORLD_SIZE={world_env}")
+            dev_of_rank = ids[local_rank]
+        devices, world = [dev_of_rank], world_env
+        if dev_of_rank >= ndev:
+            raise SystemExit(f"rank {rank}: device {dev_of_rank} requested, {ndev} visible")
     else:
-        if args.gpus > ndev:
-            raise SystemExit(f"--gpus {args.gpus} requested but only {ndev} device(s) visible: refusing to report a smaller run")
-        devices, world = list(range(args.gpus)), args.gpus
+        if args.devices:
+            devices = [int(v) for v in args.devices.split(",")]
+            if len(devices) != args.gpus or any(d_ < 0 or d_ >= ndev for d_ in devices):
+                raise SystemExit(f"--devices {args.devices}: need {args.gpus} ids below {ndev}")
+        else:
+            if args.gpus > ndev:
+                raise SystemExit(f"--gpus {args.gpus} requested but only {ndev} device(s) visible: refusing to report a smaller run")
+            devices = list(range(args.gpus))
+        world = args.gpus
 
     opt = la.default_options(perturbStep=0, printLevel=0)     # defaults except these two
 
@@ -155,13 +169,13 @@ def main():
         return sb
 
     if sparse:
-        def make_batch(dev):
-            gidx = devices.index(dev) if not launched else rank
+        def make_batch(dev, k=0):
+            gidx = k if not launched else rank
             first, _ = shard_range(gidx, world, B)
             return make_sparse_batch(dev, first, B, n, nC, nComp)
     else:
-        def make_batch(dev):
-            gidx = devices.index(dev) if not launched else rank
+        def make_batch(dev, k=0):
+            gidx = k if not launched else rank
             first, _ = shard_range(gidx, world, B)
             bt = la.BatchLCQP(B, n, nC, nComp, device=dev, opt=opt)
             bt.generate_synthetic(first)
@@ -225,7 +239,8 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": dict({"workload": wl, "global_batch": B * world,
-                        "parallelism": f"batch-sharded x{world}, no collective" + ("" if launched or world == 1 else " (one process drives all devices)"),
+                        "parallelism": f"batch-sharded x{world}, no collective" + ("" if launched or world == 1 else " (one process drives all devices)")
+                                       + (f"; shards on devices {args.devices} (a rehearsal of the N > 1 path, not a scaling measurement)" if args.devices and len(set(args.devices.split(","))) < world else ""),
                         "solved": n_ok, "mean_lcqp_iterates": mean("iterTotal"), "mean_outer": mean("iterOuter"),
                         "mean_qp_trials": mean("trials"), "mean_residual_sweeps": mean("reserved"), "mean_admm_iters": mean("admmIter"),
                         "setup_ms_per_step": setup_ms, "homotopy_kernel_ms_per_step": solve_ms}, **cfg_extra),
@@ -239,7 +254,17 @@ def main():
         out["roofline"]["traffic_frac"] = tr / kernel_s / 1e9 / HBM_PEAK_GBS
     main_proc = (rank == 0)
 
-    if main_proc and world == 1 and not sparse and not args.no_pipelined:
+    def extra(name, fn):
+        """an optional object of the line: whatever goes wrong in it (a device with less free memory, a host without the sysfs entries the
+        CPU placements read) is recorded in its place and never costs the headline that has been measured already"""
+        try:
+            fn()
+        except BaseException as e:      # (SystemExit of a failed load included)
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    def extra_pipelined():
         # not the headline: the same K steps as a stream of batches through the product's pipeline (lcqpow_amd.BatchPipeline, the twin of
         # LCQPow::BatchPipeline in lcqpow_amd/csrc/host/BatchLCQProblem.hpp): two batch objects, each with its own buffers and HIP stream, so
         # that the launch tail of one step -- its slowest instances, most workgroup slots already idle -- overlaps with the setup kernels and
@@ -264,7 +289,10 @@ def main():
                             "note": "product call: lcqpow_amd.BatchPipeline / LCQPow::BatchPipeline, two batch objects in flight on two streams; every step still does setup + homotopy"}
         pipe.close(); bt2.close()
 
-    if main_proc and world == 1 and not sparse and not args.no_resident and shape == (256, 512, 64) and B == 1024:
+    if main_proc and world == 1 and not sparse and not args.no_pipelined:
+        extra("pipelined", extra_pipelined)
+
+    def extra_resident():
         # the node-sized job of BASELINE configs[3] (8192 instances) resident on ONE GPU: shows what the tail of a launch that is
         # exactly one residency wave (B = 1024 = 256 CUs x 4) costs
         btR = la.BatchLCQP(8192, n, nC, nComp, device=devices[0], opt=opt)
@@ -278,29 +306,95 @@ def main():
                                 "roofline_frac": btR.algorithmic_bytes() / (kR * 1e-3) / 1e9 / HBM_PEAK_GBS}
         btR.close()
 
-    if main_proc and world == 1 and not sparse and not args.no_sparse and shape == (256, 512, 64) and B == 1024:
-        # BASELINE configs[4] in the default line: the sparse arm (OSQP-style ADMM KKT + polish on the banded KKT matrix) on a batch of four times
-        # what the resident wavefronts hold (8 instances per wavefront, 2 wavefronts per SIMD: 16 384) -- the persistent wavefronts of
-        # k_sparse_sched regroup instances by phase, which needs filled queues; 150 GB of the 288 GB -- one warm-up and one timed step;
-        # `python bench.py --workload sparse` runs the same workload as the headline with steps / warmup / cpu_baseline
-        Bs, ns, nCs, nKs = args.sparse_batch, 4096, 2048, 512
-        sb = make_sparse_batch(devices[0], 0, Bs, ns, nCs, nKs)
-        sb.run(); sb.synchronize()
-        ts = time.perf_counter(); sb.run(); sb.synchronize(); dts = time.perf_counter() - ts
-        _, _, sts = sb.solution()
-        s_ms, k_ms = sb.last_timing()
-        sbytes = sb.algorithmic_bytes()
-        ach = sbytes / ((s_ms + k_ms) * 1e-3) / 1e9
-        out["sparse_config5"] = {"metric": f"LCQPs/sec (batched sparse n={ns},nC={nCs},nComp={nKs}, OSQP-style ADMM KKT + polish)", "value": Bs / dts, "unit": "LCQPs/s",
-                                 "batch": Bs, "steps": 1, "ms_per_step": 1e3 * dts, "solved": sum(1 for s_ in sts if s_["returnValue"] == 0),
-                                 "kkt_half_bandwidth": sb.bandwidth(), "lanes_per_instance": sb.lanes(),
-                                 "mean_lcqp_iterates": float(np.mean([s_["iterTotal"] for s_ in sts])),
-                                 "roofline": {"bound": "hbm", "kernel": "k_sparse_setup + k_sparse_sched", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                              "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("sparse", Bs, (ns, nCs, nKs)), "algorithmic_bytes_per_launch": sbytes},
-                                 "data": "synthetic (lcqpow_amd/synth_sparse.py: banded pattern, numpy PCG64 seed0=0x4C43515000000005 ^ instance id)"}
-        sb.close()
+    if main_proc and world == 1 and not sparse and not args.no_resident and shape == (256, 512, 64) and B == 1024:
+        extra("resident_8192", extra_resident)
 
-    if main_proc and not sparse and not args.no_backsolve:
+    def sparse_object(Bs, ns=4096, nCs=2048, nKs=512):
+        """one warm-up and one timed step of the sparse arm (OSQP-style ADMM KKT + polish on the banded KKT matrix) on Bs instances"""
+        sb = make_sparse_batch(devices[0], 0, Bs, ns, nCs, nKs)
+        try:
+            sb.run(); sb.synchronize()
+            ts = time.perf_counter(); sb.run(); sb.synchronize(); dts = time.perf_counter() - ts
+            xs_, _, sts = sb.solution()
+            s_ms, k_ms = sb.last_timing()
+            sbytes = sb.algorithmic_bytes()
+            ach = sbytes / ((s_ms + k_ms) * 1e-3) / 1e9
+            obj = {"metric": f"LCQPs/sec (batched sparse n={ns},nC={nCs},nComp={nKs}, OSQP-style ADMM KKT + polish)", "value": Bs / dts, "unit": "LCQPs/s",
+                   "batch": Bs, "steps": 1, "ms_per_step": 1e3 * dts, "solved": sum(1 for s_ in sts if s_["returnValue"] == 0),
+                   "kkt_half_bandwidth": sb.bandwidth(), "lanes_per_instance": sb.lanes(),
+                   "mean_lcqp_iterates": float(np.mean([s_["iterTotal"] for s_ in sts])),
+                   "roofline": {"bound": "hbm", "kernel": "k_sparse_setup + k_sparse_sched", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("sparse", Bs, (ns, nCs, nKs)), "algorithmic_bytes_per_launch": sbytes},
+                   "data": "synthetic (lcqpow_amd/synth_sparse.py: banded pattern, numpy PCG64 seed0=0x4C43515000000005 ^ instance id)"}
+            return obj, xs_
+        finally:
+            sb.close()
+
+    def sparse_cpu_baseline(xgpu, cnt, ns=4096, nCs=2048, nKs=512):
+        """the sparse CPU oracle (oracle/lcqp_oracle_sparse.c) on instances 0 .. cnt-1 of the same workload, one LCQP per thread"""
+        import threading
+        import scipy.sparse as sp
+        import oracle_py as O
+        from lcqpow_amd import synth_sparse as S
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        oopt = O.default_options(perturbStep=0, printLevel=0)
+        Qpat, Apat, qo, eo = S.sparse_pattern_arrays(ns, nCs, nKs)
+        inst = [S.sparse_values(i, ns, nCs, nKs, orders=(qo, eo)) for i in range(cnt)]
+        csr = [(sp.csc_matrix((d["Qx"], Qpat.indices, Qpat.indptr), shape=Qpat.shape).tocsr(),
+                sp.csc_matrix((d["Ex"], Apat.indices, Apat.indptr), shape=Apat.shape).tocsr()) for d in inst]
+        perm, w, kb = O.kkt_ordering(ns, csr[0][0].indptr, csr[0][0].indices, csr[0][1].indptr, csr[0][1].indices,
+                                      rows_follow=all(O.hessian_is_definite_by_diagonal(c[0]) for c in csr))
+        res = [None] * cnt
+
+        def work(lo, hi):
+            for i in range(lo, hi):
+                d = inst[i]
+                res[i] = O.sparse_lcqp_solve(ns, nCs, nKs, csr[i][0], d["g"], csr[i][1], lbA=d["lbA"], ubA=d["ubA"], opt=oopt, perm=perm, w=w)
+        nth = min(threads, cnt)
+        chunks = [(k * cnt // nth, (k + 1) * cnt // nth) for k in range(nth)]
+        O.lib()
+        tc = time.perf_counter()
+        th = [threading.Thread(target=work, args=c_) for c_ in chunks]      # ctypes releases the GIL inside the C solver
+        [t_.start() for t_ in th]; [t_.join() for t_ in th]
+        dtc = time.perf_counter() - tc
+        t1 = time.perf_counter(); work(0, 2); single = 2 / (time.perf_counter() - t1)
+        ok = sum(1 for r_ in res if r_ is not None and r_["ret"] == 0)
+        dx = float(max(np.abs(res[i]["x"] - xgpu[i]).max() for i in range(cnt)))
+        return {"value": cnt / dtc, "unit": "LCQPs/s", "cores": len(O.host_cpu_topology()[0]), "threads": nth, "kind": "port",
+                "sample": f"instances 0..{cnt - 1} of the same sparse workload, CPU oracle (oracle/lcqp_oracle_sparse.c, the "
+                          f"same ADMM-KKT + polish algorithm with band LDL' in scalar C; the reference's OSQP path cannot be "
+                          f"built: external/osqp is empty), one LCQP per thread, {ok}/{cnt} solved in {dtc:.2f} s",
+                "single_core_value": single, "max_abs_dx_vs_gpu": dx}
+
+    def extra_sparse():
+        # BASELINE configs[4] in the default line, at two batch sizes: 65 536 instances -- four times what the resident wavefronts hold (8 per
+        # wavefront, 2 wavefronts per SIMD: 16 384); the persistent wavefronts of k_sparse_sched regroup instances by phase, which needs filled
+        # queues; 150 GB of the 288 GB (16 384 when that does not fit) -- and 4 096, the size a caller with a moderate batch sees.  One warm-up and
+        # one timed step each; `python bench.py --workload sparse` runs the same workload as the headline with steps / warmup.
+        small, xs_small = sparse_object(4096)
+        try:
+            big, _ = sparse_object(args.sparse_batch)
+        except BaseException as e:
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            big, _ = sparse_object(16384)
+            big["note"] = f"batch {args.sparse_batch} failed ({type(e).__name__}: {e}); 16384 instead"
+        big["batch_4096"] = {k_: small[k_] for k_ in ("value", "unit", "batch", "ms_per_step", "solved", "mean_lcqp_iterates", "roofline")}
+        out["sparse_config5"] = big
+        if args.cpu_sample > 0:
+            try:
+                cb = sparse_cpu_baseline(xs_small, min(4096, max(args.cpu_sample, 32)))
+                cb["gpu_over_cpu"] = big["value"] / cb["value"]
+                big["cpu_baseline"] = cb
+            except BaseException as e:
+                if isinstance(e, KeyboardInterrupt):
+                    raise
+                big["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+
+    if main_proc and world == 1 and not sparse and not args.no_sparse and shape == (256, 512, 64) and B == 1024:
+        extra("sparse_config5", extra_sparse)
+
+    def extra_backsolve():
         # the factor-once / back-solve-many kernel pair on its own (SURVEY.md §8d: bytes_bs(N) = 8 N (N+2)), cache-cold: 4096
         # factors of order n = 2 GiB at n = 256, far beyond the 256 MiB Infinity Cache, one right-hand side each; the in-situ
         # rate of the same routine inside k_lcqp_run is in profiles/round2 (tools/gpu.py phase_profile)
@@ -320,84 +414,65 @@ def main():
                                    "note": "algorithmic bytes 8 N (N+2) per pair; of the diagonal 64x64 blocks only the triangle each pass needs is fetched"}
         del K, rhs
 
-    if main_proc and world == 1 and args.cpu_sample > 0:
+    if main_proc and not sparse and not args.no_backsolve:
+        extra("backsolve_kernel", extra_backsolve)
+
+    def extra_cpu_baseline():
         import oracle_py as O
         threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         oopt = O.default_options(perturbStep=0, printLevel=0)
         if sparse:
-            import threading
-            import scipy.sparse as sp
-            from lcqpow_amd import synth_sparse as S
-            cnt = min(B, max(args.cpu_sample, threads))
-            Qpat, Apat, qo, eo = S.sparse_pattern_arrays(n, nC, nComp)
-            inst = [S.sparse_values(i, n, nC, nComp, orders=(qo, eo)) for i in range(cnt)]
-            csr = [(sp.csc_matrix((d["Qx"], Qpat.indices, Qpat.indptr), shape=Qpat.shape).tocsr(),
-                    sp.csc_matrix((d["Ex"], Apat.indices, Apat.indptr), shape=Apat.shape).tocsr()) for d in inst]
-            perm, w, kb = O.kkt_ordering(n, csr[0][0].indptr, csr[0][0].indices, csr[0][1].indptr, csr[0][1].indices,
-                                          rows_follow=all(O.hessian_is_definite_by_diagonal(c[0]) for c in csr))
-            res = [None] * cnt
+            out["cpu_baseline"] = sparse_cpu_baseline(x, min(B, max(args.cpu_sample, threads)), n, nC, nComp)
+            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            return
+        # steady state (oracle/lcqp_oracle.c::orc_synth_bench): pinned workers, `per` instances each, generated and one warm-up solve
+        # done before the clock starts, the allocator keeps the workers' buffers; one run with a worker per physical core, one with a
+        # worker per hardware thread; the reference itself is single-threaded (one LCQProblem = one thread), so "all cores" means
+        # independent instances side by side, as on the GPU
+        phys, allc = O.host_cpu_topology()
+        per = max(1, args.cpu_sample // 8)                       # default 8 instances per worker
+        doms = O.l3_domains(phys)
+        # worker placements: one and two workers per L3 domain (an instance's working set, ~15 MB, then stays in its L3), one per physical
+        # core, one per hardware thread -- the baseline is the best of them
+        plans = [("one worker per L3 domain", [d[0] for d in doms], per), ("two workers per L3 domain", [c for d in doms for c in d[:2]], per),
+                 ("one worker per physical core", phys, per), ("one worker per hardware thread", allc, max(1, per // 2))]
+        runs, seen = [], set()
+        xo = None
+        for tag, cpus, k_ in plans:
+            if len(cpus) in seen:
+                continue
+            seen.add(len(cpus))
+            want = (len(cpus) * k_ >= min(len(phys) * per, B) or tag == plans[-1][0]) and xo is None      # the first run that covers the compared instances returns its solutions (by size, not by identity of the cpu list)
+            ok_, sec_, xr, _, _ = O.synth_bench(0, len(cpus), k_, cpus=cpus, n=n, nC=nC, nComp=nComp, opt=oopt, want_xy=want)
+            if want:
+                xo = xr
+            runs.append({"placement": tag, "workers": len(cpus), "instances_per_worker": k_, "solved": ok_, "seconds": sec_, "value": len(cpus) * k_ / sec_})
+        ok1, sec1, x1_, _, _ = O.synth_bench(0, 1, 8, cpus=phys[:1], n=n, nC=nC, nComp=nComp, opt=oopt, want_xy=True)
+        if xo is None:
+            xo = x1_          # (every placement that would have returned solutions was a duplicate: compare the eight instances of the single worker)
+        single = 8 / sec1
+        best = max(runs, key=lambda r_: r_["value"])
+        v_cores = ([r_["value"] for r_ in runs if r_["workers"] == len(phys)] or [best["value"]])[0]
+        stream = O.host_stream_gbps(phys, 256, 2)
+        ncmp = min(len(phys) * per, B, len(xo))
+        dx = float(np.abs(xo[:ncmp] - x[:ncmp]).max())
+        out["cpu_baseline"] = {"value": best["value"], "unit": "LCQPs/s", "cores": len(phys), "threads": len(allc), "kind": "port",
+                               "best_placement": best["placement"], "workers_at_best": best["workers"], "runs": runs,
+                               "value_one_worker_per_core": v_cores, "single_core_value": single,
+                               "single_core_times_cores": single * len(phys), "parallel_efficiency_vs_single_core": best["value"] / (single * len(phys)),
+                               "host_stream_read_GBps_all_cores": stream, "gpu_over_cpu": value / best["value"],
+                               "sample": f"steady state: CPU oracle (oracle/lcqp_oracle.c, same algorithm in scalar C; the reference's qpOASES path "
+                                         f"cannot be built: external/qpOASES is empty) on the same synthetic workload; workers pinned, their instances "
+                                         f"generated and one warm-up solve done before the clock starts, buffers reused (no mmap per solve); "
+                                         f"{per} instances per worker ({max(1, per // 2)} with a worker per hardware thread); best of "
+                                         f"{len(runs)} placements = {best['placement']} ({best['workers']} workers, {best['seconds']:.2f} s). One worker alone: "
+                                         f"{single:.1f} LCQPs/s; beyond one or two workers per L3 domain the oracle is bound by host memory "
+                                         f"(an instance's working set exceeds a core's L3 share; stream read rate of all cores in this run: {stream:.0f} GB/s)",
+                               "max_abs_dx_vs_gpu": dx}
 
-            def work(lo, hi):
-                for i in range(lo, hi):
-                    d = inst[i]
-                    res[i] = O.sparse_lcqp_solve(n, nC, nComp, csr[i][0], d["g"], csr[i][1], lbA=d["lbA"], ubA=d["ubA"], opt=oopt, perm=perm, w=w)
-            nth = min(threads, cnt)
-            chunks = [(k * cnt // nth, (k + 1) * cnt // nth) for k in range(nth)]
-            O.lib()
-            tc = time.perf_counter()
-            th = [threading.Thread(target=work, args=c_) for c_ in chunks]      # ctypes releases the GIL inside the C solver
-            [t_.start() for t_ in th]; [t_.join() for t_ in th]
-            dtc = time.perf_counter() - tc
-            t1 = time.perf_counter(); work(0, 2); single = 2 / (time.perf_counter() - t1)
-            ok = sum(1 for r_ in res if r_ is not None and r_["ret"] == 0)
-            dx = float(max(np.abs(res[i]["x"] - x[i]).max() for i in range(min(cnt, B))))
-            out["cpu_baseline"] = {"value": cnt / dtc, "unit": "LCQPs/s", "cores": len(O.host_cpu_topology()[0]), "threads": nth, "kind": "port",
-                                   "sample": f"instances 0..{cnt - 1} of the same sparse workload, CPU oracle (oracle/lcqp_oracle_sparse.c, the "
-                                             f"same ADMM-KKT + polish algorithm with band LDL' in scalar C; the reference's OSQP path cannot be "
-                                             f"built: external/osqp is empty), one LCQP per thread, {ok}/{cnt} solved in {dtc:.2f} s",
-                                   "single_core_value": single, "max_abs_dx_vs_gpu": dx}
-        else:
-            # steady state (oracle/lcqp_oracle.c::orc_synth_bench): pinned workers, `per` instances each, generated and one warm-up solve
-            # done before the clock starts, the allocator keeps the workers' buffers; one run with a worker per physical core, one with a
-            # worker per hardware thread; the reference itself is single-threaded (one LCQProblem = one thread), so "all cores" means
-            # independent instances side by side, as on the GPU
-            phys, allc = O.host_cpu_topology()
-            per = max(1, args.cpu_sample // 8)                       # default 8 instances per worker
-            doms = O.l3_domains(phys)
-            # worker placements: one and two workers per L3 domain (an instance's working set, ~15 MB, then stays in its L3), one per physical
-            # core, one per hardware thread -- the baseline is the best of them
-            plans = [("one worker per L3 domain", [d[0] for d in doms], per), ("two workers per L3 domain", [c for d in doms for c in d[:2]], per),
-                     ("one worker per physical core", phys, per), ("one worker per hardware thread", allc, max(1, per // 2))]
-            runs, seen = [], set()
-            xo = None
-            for tag, cpus, k_ in plans:
-                if len(cpus) in seen:
-                    continue
-                seen.add(len(cpus))
-                ok_, sec_, xr, _, _ = O.synth_bench(0, len(cpus), k_, cpus=cpus, n=n, nC=nC, nComp=nComp, opt=oopt, want_xy=(cpus is phys))
-                if cpus is phys:
-                    xo = xr
-                runs.append({"placement": tag, "workers": len(cpus), "instances_per_worker": k_, "solved": ok_, "seconds": sec_, "value": len(cpus) * k_ / sec_})
-            ok1, sec1, _, _, _ = O.synth_bench(0, 1, 8, cpus=phys[:1], n=n, nC=nC, nComp=nComp, opt=oopt, want_xy=False)
-            single = 8 / sec1
-            best = max(runs, key=lambda r_: r_["value"])
-            v_cores = [r_["value"] for r_ in runs if r_["workers"] == len(phys)][0]
-            stream = O.host_stream_gbps(phys, 256, 2)
-            ncmp = min(len(phys) * per, B)
-            dx = float(np.abs(xo[:ncmp] - x[:ncmp]).max())
-            out["cpu_baseline"] = {"value": best["value"], "unit": "LCQPs/s", "cores": len(phys), "threads": len(allc), "kind": "port",
-                                   "best_placement": best["placement"], "workers_at_best": best["workers"], "runs": runs,
-                                   "value_one_worker_per_core": v_cores, "single_core_value": single,
-                                   "single_core_times_cores": single * len(phys), "parallel_efficiency_vs_single_core": best["value"] / (single * len(phys)),
-                                   "host_stream_read_GBps_all_cores": stream, "gpu_over_cpu": value / best["value"],
-                                   "sample": f"steady state: CPU oracle (oracle/lcqp_oracle.c, same algorithm in scalar C; the reference's qpOASES path "
-                                             f"cannot be built: external/qpOASES is empty) on the same synthetic workload; workers pinned, their instances "
-                                             f"generated and one warm-up solve done before the clock starts, buffers reused (no mmap per solve); "
-                                             f"{per} instances per worker ({max(1, per // 2)} with a worker per hardware thread); best of "
-                                             f"{len(runs)} placements = {best['placement']} ({best['workers']} workers, {best['seconds']:.2f} s). One worker alone: "
-                                             f"{single:.1f} LCQPs/s; beyond one or two workers per L3 domain the oracle is bound by host memory "
-                                             f"(an instance's working set exceeds a core's L3 share; stream read rate of all cores in this run: {stream:.0f} GB/s)",
-                                   "max_abs_dx_vs_gpu": dx}
+    if main_proc and world == 1 and args.cpu_sample > 0:
+        extra("cpu_baseline", extra_cpu_baseline)
+
     for b_ in bts:
         b_.close()
     if dist is not None:

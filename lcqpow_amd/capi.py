@@ -58,6 +58,10 @@ def lib():
         if not os.path.exists(_SO):
             raise RuntimeError(f"{_SO} is missing: the HIP extension must be built (see __graft_entry__.build); "
                                "there is no CPU fallback for the product path")
+        if "LCQPOW_KEEP_HW_QUEUES" not in os.environ:
+            # every batch object has two HIP streams and the runtime maps the streams of a process onto 4 hardware queues by default: two
+            # objects of a BatchPipeline can land on one queue and run one after the other (lcqp_hip.hip: lcqp_more_hw_queues)
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         L = C.CDLL(_SO)
         L.lcqp_hip_last_error.restype = C.c_char_p
         L.lcqp_hip_options_default.argtypes = [C.POINTER(Options)]
@@ -200,6 +204,10 @@ class BatchPipeline:
         self.order = []
 
     def acquire(self):
+        # (a slot that was handed out with results and not launched again is free again; with nothing in flight every slot is)
+        self.state = [0 if s == 2 else s for s in self.state]
+        if not self.order:
+            self.state = [0] * len(self.slots)
         for k, s in enumerate(self.state):
             if s == 0:
                 return self.slots[k], False

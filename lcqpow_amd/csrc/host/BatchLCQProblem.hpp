@@ -97,9 +97,12 @@ class BatchPipeline {
     int depth() const { return (int)slots.size(); }
     BatchLCQProblem& slot(int k) { return *slots[k]; }
     // the batch object to fill next: a free one, else the oldest one in flight (waited for; its results are then in the object: resultsOf())
+    // (a slot that was handed out with results and not launched again -- a failed launch, or acquire() twice in a row -- is free again)
     BatchLCQProblem& acquire()
     {
+        if (cur >= 0 && state[cur] == 2) state[cur] = 0;
         for (size_t k = 0; k < slots.size(); ++k) if (state[k] == 0) { cur = (int)k; return *slots[k]; }
+        if (order.empty()) { for (size_t k = 0; k < slots.size(); ++k) state[k] = 0; cur = 0; return *slots[0]; }      // nothing in flight: every slot is free
         const int k = order.front(); order.erase(order.begin());
         lastRc = slots[k]->collect(); state[k] = 2; cur = k;
         return *slots[k];
@@ -118,6 +121,7 @@ class BatchPipeline {
         if (order.empty()) return 0;
         const int k = order.front(); order.erase(order.begin());
         lastRc = slots[k]->collect(); state[k] = 0;
+        if (order.empty()) for (size_t q = 0; q < slots.size(); ++q) state[q] = 0;      // drained: a pipeline that is used again starts with every slot free
         return slots[k];
     }
 

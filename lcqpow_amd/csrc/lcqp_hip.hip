@@ -46,6 +46,17 @@ __global__ __launch_bounds__(WG, 4) void k_backsolve(int np, int nblk, const dou
 // =================================================================================================
 // host side
 // =================================================================================================
+// HIP maps the streams of a process onto a few hardware queues -- 4 unless GPU_MAX_HW_QUEUES says otherwise -- and every batch object has
+// two streams: a process that keeps three batch objects alive can find both slots of a BatchPipeline on ONE queue, and its batches then
+// run one after the other (tools/micro/pipeline_check.py: 35 200 LCQPs/s with two objects alive, 30 750 with an idle third one, 34 800
+// again with eight queues).  The library therefore asks for eight queues when it is loaded, unless the variable is set already or
+// LCQPOW_KEEP_HW_QUEUES is; the HIP runtime reads the variable when it initialises, i.e. at the first HIP call of the process, so this
+// takes effect whenever the library is loaded before that (the Python binding sets it too, before it loads the library).
+__attribute__((constructor)) static void lcqp_more_hw_queues()
+{
+    if (!getenv("LCQPOW_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
+}
+
 static thread_local std::string g_err;
 static int set_err(const char* what, hipError_t e)
 {

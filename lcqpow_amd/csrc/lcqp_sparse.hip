@@ -1505,6 +1505,14 @@ template <int G, int GP>
 __device__ __forceinline__ int sp_run_phase(const SpBatch& db, int ph, int b, int w0, int lane)
 {
     SpCtx<GP> c = sp_ctx<GP>(db, b, w0, lane);
+    // INVARIANT (lock step): the record lives in global memory and EVERY lane of the instance's group reads and writes it -- the same
+    // values, in the same instruction (S.trial++, S.round++, S.nrefine++ ...: a load and a store the group issues together).  That is
+    // well defined only because (1) every branch that leads to an access of S is uniform inside the group (conditions are group
+    // reductions or values read from S itself), (2) the group's lanes are lanes of ONE wavefront (G <= 64), so a load and the store
+    // behind it are not separated by another lane's store, and (3) no other group touches this record while the instance is in a phase
+    // (an instance is in at most one queue; the hand-over is ordered by the queue's fences).  A phase routine that accesses S under a
+    // condition that differs between the lanes of a group breaks this.  (A private copy in registers, written back by lane 0, would
+    // cost 50 VGPRs of the 249 the kernel has: the band factorisation's register window takes the rest.)
     SpState& S = db.state[b];
     c.cAdmm = S.cAdmm; c.cTrials = S.cTrials; c.cFact = S.cFact; c.cCorr = S.cCorr; c.cSweeps = S.cSweeps; c.bytes = S.bytes;
     GD gk = c.V(NV_GK);

@@ -77,6 +77,40 @@ def test_bench_under_the_drivers_launcher():
     assert "no collective" in d["config"]["parallelism"] and d["scaling"] == "weak" and d["roofline"]["achieved"] > 0
 
 
+def _one_json_line(r):
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_shards_rehearsed_on_one_device():
+    """The N = 2 path of bench.py on a one-GPU box, so that an 8-GPU lease is not spent on a plumbing bug:
+    `--gpus 2 --devices 0,0` runs two shards through the same run_devices / aggregation / JSON code as `--gpus 2` on two devices -- shard r
+    solves instance ids [r B, (r + 1) B), max-over-devices time, summed solved counts.  Once from one process, once under the driver's
+    launcher with two ranks that both take device 0 (gloo control plane: barrier, max of the step time, sum of the solved counts).
+    The shards are different instances: the mean iterate count of rank 0's shard in the two-shard run equals the one-shard run's."""
+    common = ["--steps", "2", "--warmup", "1", "--batch", "16", "--cpu-sample", "0", "--no-backsolve", "--no-pipelined", "--no-resident", "--no-sparse"]
+    env = dict(os.environ); env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    one = _one_json_line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900, env=env))
+    two = _one_json_line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0"] + common,
+                                        capture_output=True, text=True, timeout=900, env=env))
+    port = 29700 + (os.getpid() % 200)
+    launched = _one_json_line(subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                              "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0"] + common,
+                                             capture_output=True, text=True, timeout=900, env=env))
+    for d in (two, launched):
+        assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+        assert d["config"]["global_batch"] == 32 and d["config"]["solved"] == 32
+        assert "no collective" in d["config"]["parallelism"] and "rehearsal" in d["config"]["parallelism"]
+        assert abs(d["value"] - 32 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
+        assert d["config"]["mean_lcqp_iterates"] == one["config"]["mean_lcqp_iterates"]      # (the per-instance means are those of shard 0 = the one-shard run's instances)
+    assert one["n_gpus"] == 1 and one["config"]["solved"] == 16
+
+
 @pytest.mark.gpu
 def test_cpp_shards_on_one_device_equal_one_batch():
     """examples/multi_gpu_batch (the sharding of SURVEY.md §8e from C++: one host thread, batch object and stream per shard): two shards of
