@@ -540,12 +540,22 @@ __device__ __forceinline__ void sp_factor_lds(SpCtx<G>& c, GD KF, GD Kd)
     SPROF(c, SP_FACTOR);
 }
 
-// ---- band LDL' with the window in registers (G <= 16) -----------------------------------------------------------------------------
-// Row r of the window lives in lane r % G, its entry of column c in register slot c % G, so that at step j (unrolled G times: u =
-// j % G is static) every lane finds the entry of column j in slot u and the entries it updates, columns j + bb, in slot (u + bb) % G:
-// no indexed register access, no LDS.  The pivot and the multipliers L[j+bb][j] travel inside the lane group by DPP; lane u, whose
-// row is finished at step u, takes over row j + G (gathered three blocks ahead from the values of Q and E).
-// Rows >= N are identity rows.  Same arithmetic, in the same order, as the LDS version and the oracle.
+// ---- band LDL' with the rows in registers and the pivot row through LDS (G <= 16) ---------------------------------------------------
+// Round 5.  Lane l of the group holds ONE row r (r % G == l) of the part of the band that is still to be eliminated, in UPPER form
+// relative to its own diagonal: wr[k] = K[r][r + k], k = 0 .. G-1 (by symmetry the entries of column r below the diagonal).  At step j
+// the lane of row j puts its row into the group's LDS buffer; every other lane -- row i = j + a, a = 1 .. G-1 -- reads the part of the
+// pivot row that reaches its own columns, p[k] = K[j][i + k] = buf[a + k] (one LDS read per entry at a lane-dependent address; behind the
+// G entries of the buffer lie G zeros, so what is outside the band needs no predicate), forms its multiplier L[i][j] = p[0] / d_j as
+// p[0] * (1 / d_j) and subtracts L[i][j] * p[k] from its row.  The lane whose row is finished takes over row j + G (gathered three
+// blocks ahead from the instance's assembled rows).  Per step: 4 LDS writes, G + 1 LDS reads, one division, G fused multiply-adds.
+// (Round 4 kept row r in LOWER form with the entry of column c in register slot c % G, so that every access had a static index, and
+// moved the pivot and the G-1 multipliers of a step through the lane group by DPP: six moves and selects per double, two divisions,
+// about a hundred instructions and 780 clocks per step for G = 8 -- the factorisation was the longest chain of an instance,
+// profiles/round5/sparse_sched_profile_small_batches.log.)  The oracle's band_factor does the same arithmetic in the same order.
+// Rows >= N are identity rows.  What depends on the working set is applied while a row is loaded: bgate (shared by the batch) names the
+// row of E whose membership gates an entry (-1: none), bdiag what the diagonal is (>= -1 a variable: Q_ii, in K0, + dprim; -2 - rr the
+// constraint row rr; INT_MIN a border position).  K0 / bgate are in the same upper form: entry k of row r is K[r + k][r].
+__shared__ double sp_piv_lds[2 * WGS];      // per lane group: the pivot row (G doubles) and G zeros behind it
 template <int G, class Dd, class Use>
 __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double dprim, Dd ddual, Use use)
 {
@@ -553,68 +563,66 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
     const int N = c.db->N, Np = c.db->Np, l = here(c.gl);
     GD K0 = c.K0();
     const int NG = (N + GM) & ~GM;
-    // band row r in band order (entry k: column r - (G-1) + k), assembled on the fly from the values of Q and E: variables carry
-    // Q + dprim I; constraint row rr carries its entries of E and -ddual(rr) on the diagonal when it is in the working set, -1 alone
-    // when it is not (the KKT matrix is never written to memory)
-    // The values of a band row come from the instance's assembled rows (K0, written once by k_sparse_setup: G doubles per row, contiguous --
-    // round 4 gathered them from the values of Q and E here, 7 scattered 8-byte loads per row and lane); what depends on the working set is
-    // applied on the way: bgate (shared by the batch) names the row of E whose membership gates an entry (-1: none), bdiag what the
-    // diagonal is (>= -1 a variable: Q_ii, in K0, + dprim; -2 - rr the constraint row rr; INT_MIN a border position).
     const int* __restrict__ bgate = c.db->bgate;
     const int* __restrict__ bdiag = c.db->bdiag;
-    auto load_row = [&](double* dst, int r) {
+    double* buf = sp_piv_lds + (size_t)(here((int)threadIdx.x) / G) * (2 * G);
+    // A row is fetched in two halves: row_issue starts the loads (the instance's assembled row, the gates and the diagonal code: 9 x 16
+    // bytes) and row_finish, one block of G steps later, applies what depends on the working set.  (Until round 5 both sat at the top of a
+    // block: the gating consumed the loads it had just issued, one memory round trip per block of G steps -- most of a factorisation's
+    // time.)
+    struct RawRow { double val[G]; int gate[G]; int bd; };
+    auto row_issue = [&](RawRow& rw, int r) {
+        const int rr = (r < N) ? r : 0;      // (rows >= N are identity rows: the loads are harmless, row_finish ignores them)
+#pragma unroll
+        for (int k = 0; k < G; k += 4) { const int4 g4 = *reinterpret_cast<const int4*>(bgate + (size_t)rr * G + k); rw.gate[k] = g4.x; rw.gate[k + 1] = g4.y; rw.gate[k + 2] = g4.z; rw.gate[k + 3] = g4.w; }
+        rw.bd = bdiag[rr];
+#pragma unroll
+        for (int k = 0; k < G; k += 2) { const dv2 v = K0.ld2(rr * G + k); rw.val[k] = v.x; rw.val[k + 1] = v.y; }
+    };
+    auto row_finish = [&](double* dst, const RawRow& rw, int r) {
         if (r < N) {
-            int gate[G];
 #pragma unroll
-            for (int k = 0; k < G; k += 4) { const int4 g4 = *reinterpret_cast<const int4*>(bgate + (size_t)r * G + k); gate[k] = g4.x; gate[k + 1] = g4.y; gate[k + 2] = g4.z; gate[k + 3] = g4.w; }
-            const int bd = bdiag[r];
-            double val[G];
-#pragma unroll
-            for (int k = 0; k < G; k += 2) { const dv2 v = K0.ld2(r * G + k); val[k] = v.x; val[k + 1] = v.y; }
-#pragma unroll
-            for (int k = 0; k < GM; k++) dst[k] = (gate[k] < 0 || use(gate[k])) ? val[k] : 0.0;
-            if (bd == INT_MIN) dst[GM] = 1.0;                           // a border position: an isolated unit pivot of the band
-            else if (bd >= -1) dst[GM] = val[GM] + dprim;
-            else { const int rr = -2 - bd; dst[GM] = use(rr) ? -ddual(rr) : -1.0; }
+            for (int k = 1; k < G; k++) dst[k] = (rw.gate[k] < 0 || use(rw.gate[k])) ? rw.val[k] : 0.0;
+            const int bd = rw.bd;
+            if (bd == INT_MIN) dst[0] = 1.0;                           // a border position: an isolated unit pivot of the band
+            else if (bd >= -1) dst[0] = rw.val[0] + dprim;
+            else { const int rr = -2 - bd; dst[0] = use(rr) ? -ddual(rr) : -1.0; }
         } else {
 #pragma unroll
-            for (int k = 0; k < G; k++) dst[k] = (k == GM) ? 1.0 : 0.0;
+            for (int k = 0; k < G; k++) dst[k] = (k == 0) ? 1.0 : 0.0;
         }
     };
-    double wr[G], nx[G], nn[G], n3[G], kf[G];       // current row; the rows of this lane one, two and three blocks ahead
-    {
-        double tmp[G];
-        load_row(tmp, l);
-#pragma unroll
-        for (int k = 0; k < G; k++) wr[(k + 1) & GM] = 0.0;
-        // row l: entry k is column l - (G-1) + k, slot (l + 1 + k) % G -- lane-dependent here (once): rotate through a select chain
-#pragma unroll
-        for (int k = 0; k < G; k++)
-#pragma unroll
-            for (int sl = 0; sl < G; sl++) if (((l + 1 + k) & GM) == sl) wr[sl] = tmp[k];
-    }
-    load_row(nx, G + l);
-    load_row(nn, 2 * G + l);
+    double wr[G], nx[G], nn[G], kf[G];       // current row; the rows of this lane one and two blocks ahead (the third is in flight: raw)
+    RawRow raw;
+    row_issue(raw, l); row_finish(wr, raw, l);
+    row_issue(raw, G + l); row_finish(nx, raw, G + l);
+    row_issue(raw, 2 * G + l); row_finish(nn, raw, 2 * G + l);
+    row_issue(raw, 3 * G + l);
+    buf[G + l] = 0.0;                                // the zeros behind the pivot row
     double rinv = 1.0;
     for (int j0 = 0; j0 < NG; j0 += G) {
-        load_row(n3, j0 + 3 * G + l);
 #pragma unroll
         for (int u = 0; u < G; u++) {
-            const int j = j0 + u;
-            const int ag = (l - u) & GM;                               // this lane holds row j + ag (ag == 0: the pivot row)
-            const double d = g_bcast<G>(wr[u], u);
-            const double la = (ag != 0) ? wr[u] / d : 0.0;               // L[j + ag][j]; zero outside the band
-            kf[u] = la;
-            if (ag == 0) rinv = 1.0 / d;
-            const double lad = la * d;
+            const int ag = (l - u) & GM;                               // this lane holds row j + ag, j = j0 + u (ag == 0: the pivot row)
+            if (ag == 0) {
 #pragma unroll
-            for (int bb = 1; bb < G; bb++) {
-                const double lb = g_bcast<G>(la, (u + bb) & GM);        // L[j + bb][j]
-                if (ag >= bb) wr[(u + bb) & GM] -= lad * lb;
+                for (int k = 0; k < G; k += 2) { dv2 v; v.x = wr[k]; v.y = wr[k + 1]; *reinterpret_cast<dv2*>(buf + k) = v; }
             }
-            if (l == u) {                                                // row j is finished: row j + G enters this lane
+            asm volatile("" ::: "memory");      // (LDS traffic of one wavefront is in order: the reads below see the pivot lane's stores)
+            const double ri = 1.0 / buf[0];
+            double p[G];
 #pragma unroll
-                for (int k = 0; k < G; k++) wr[(u + 1 + k) & GM] = nx[k];
+            for (int k = 0; k < G; k++) p[k] = buf[ag + k];              // K[j][j + ag + k]: zero beyond the band (the padding)
+            asm volatile("" ::: "memory");
+            const double la = (ag != 0) ? p[0] * ri : 0.0;                // L[j + ag][j]
+            kf[u] = la;
+            if (ag == 0) {                                               // row j is finished: row j + G enters this lane
+                rinv = ri;
+#pragma unroll
+                for (int k = 0; k < G; k++) wr[k] = nx[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < G; k++) wr[k] -= la * p[k];
             }
         }
         // forward layout: row (j0 + l) of the block holds L[.][j0 + u] in column u (zero on and above this lane's own step)
@@ -622,7 +630,9 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
         for (int k = 0; k < G; k += 2) { dv2 v; v.x = kf[k]; v.y = kf[k + 1]; *reinterpret_cast<dv2*>(reinterpret_cast<char*>(KF.base) + (size_t)(KF.off + (unsigned)((j0 + l) * G + k) * 8u)) = v; }
         if (j0 + l < Np) Kd[j0 + l] = rinv;
 #pragma unroll
-        for (int k = 0; k < G; k++) { nx[k] = nn[k]; nn[k] = n3[k]; }
+        for (int k = 0; k < G; k++) nx[k] = nn[k];
+        row_finish(nn, raw, j0 + 3 * G + l);          // issued one block ago
+        row_issue(raw, j0 + 4 * G + l);
     }
     c.bytes += c.db->by[BY_FACTOR];      // matrix entries read, factor and 1/D written
     c.cFact++;
@@ -1444,14 +1454,14 @@ __global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db)
         GD K0 = c.K0(), Qv = c.Qx(), Ev = c.Ex();
         const int nnzQ = db.nnzQ;
 #pragma unroll 2
-        for (int r = t; r < db.N; r += G) {
+        for (int r = t; r < db.N; r += G) {      // upper form: entry k of row r is K[r + k][r] (sp_factor_reg), the diagonal in entry 0
 #pragma unroll
-            for (int k = 0; k < G - 1; k++) {
+            for (int k = 1; k < G; k++) {
                 const int code = db.bsrc[r * G + k];
                 K0[r * G + k] = (code >= nnzQ) ? (double)Ev[code - nnzQ] : ((code >= 0) ? (double)Qv[code] : 0.0);
             }
             const int bd = db.bdiag[r];
-            K0[r * G + G - 1] = (bd >= 0) ? (double)Qv[bd] : 0.0;
+            K0[r * G] = (bd >= 0) ? (double)Qv[bd] : 0.0;
         }
         g_sync();
     }
@@ -1594,7 +1604,13 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_sched(SpBatch
             if (q_load(remaining) <= 0) break;
             const int idle = s_ctl[1] + 1;
             if (lane == 0) s_ctl[1] = idle;
-            if (idle > 4) __builtin_amdgcn_s_sleep(32);
+            // back off: a wavefront that finds nothing polls again later and later (each poll reads the pool's counters through the L2 all
+            // wavefronts of the pool share; with s_sleep(32) per poll a quarter of idle wavefronts halved the rate of the working ones:
+            // profiles/round5/sparse_waves.log) -- 2^min(idle, SP_BACKOFF_MAX) / 8 sleeps of 127 x 64 clocks, at most ~ 60 us
+#ifndef SP_BACKOFF_MAX
+#define SP_BACKOFF_MAX 7
+#endif
+            if (idle > 2) { const int reps = (1 << min(idle, SP_BACKOFF_MAX)) >> 3; for (int k = 0; k < max(reps, 1); k++) __builtin_amdgcn_s_sleep(127); }
 #ifdef LCQP_SCHED_PROFILE
             if (lane == 0) { atomicAdd(&db.qprof[PH_NUM * 3 + 0], __builtin_amdgcn_s_memtime() - tq0); atomicAdd(&db.qprof[PH_NUM * 3 + 1], 1ull); }
 #endif
@@ -1706,6 +1722,7 @@ static void sp_launch(const SpBatch& db, hipStream_t stream, hipEvent_t mid)
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int waves = std::min(grid, cus * 4 * SP_WAVES_PER_SIMD);
+    if (const char* e = std::getenv("LCQP_SPARSE_WAVES")) { const int v = std::atoi(e); if (v >= 1) waves = std::min(v, cus * 4 * SP_WAVES_PER_SIMD); }      // experiment switch
     waves = ((waves + db.nPools - 1) / db.nPools) * db.nPools;
     hipLaunchKernelGGL(k_sparse_sched<G>, dim3(waves), dim3(WGS), ldsBytes, stream, db);
 }
@@ -1938,6 +1955,14 @@ try {
         // the same information one level of indirection shorter (sp_factor_reg: load_row): the gating row of every band entry, the diagonal of every position
         M.bgate.assign((size_t)N * ld, -1);
         for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) if (M.bandE[k] >= 0) M.bgate[M.bandE[k]] = r;
+        if (G <= 16) {
+            // sp_factor_reg keeps a row in UPPER form relative to its diagonal: entry k of row r is K[r + k][r] = the lower-form entry
+            // (r + k, ld - 1 - k); the diagonal slot (k = 0) is described by bdiag
+            std::vector<int> su((size_t)N * ld, -1), gu((size_t)N * ld, -1);
+            for (int r = 0; r < N; r++)
+                for (int k = 1; k < ld && r + k < N; k++) { su[(size_t)r * ld + k] = M.bsrc[(size_t)(r + k) * ld + (ld - 1 - k)]; gu[(size_t)r * ld + k] = M.bgate[(size_t)(r + k) * ld + (ld - 1 - k)]; }
+            M.bsrc.swap(su); M.bgate.swap(gu);
+        }
         M.bdiag.assign(N, -1);
         for (int p_ = 0; p_ < N; p_++) {
             const int node = pm[p_];

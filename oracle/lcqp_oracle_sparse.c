@@ -74,21 +74,27 @@ static void sp_ETy_sub(const sqp_t* q, const double* y, double* out)   /* out -=
 /* ---- band LDL' (quasi-definite matrix, no pivoting) ---------------------------------------------------------------------- */
 static void band_factor(band_t* f)
 {
+    /* Right-looking, every row in UPPER form relative to its diagonal, U[r][k] = K[r][r + k] (by symmetry the entries of column r below the
+     * diagonal) -- the arithmetic of the device's sp_factor_reg (round 5) in the same order: at step j the row i = j + a forms its
+     * multiplier L[i][j] = U[j][a] * (1 / d_j) and loses L[i][j] * U[j][a + k], k = 0 .. w - a.  (Until round 4: left-looking, L[i][j] =
+     * s / d_j with the products (L[i][k] d_k) L[j][k] -- the same sums in another association.)  Result in f->B as before: L below the
+     * diagonal (unit diagonal implied), D on it. */
     const int N = f->N, w = f->w, ld = w + 1;
-    for (int i = 0; i < N; i++) {
-        double* ri = f->B + (size_t)i * ld;
-        const int j0 = i - w > 0 ? i - w : 0;
-        for (int j = j0; j < i; j++) {
-            const double* rj = f->B + (size_t)j * ld;
-            const int k0 = j - w > j0 ? j - w : j0;
-            double s = ri[w - (i - j)];
-            for (int k = k0; k < j; k++) s -= ri[w - (i - k)] * f->B[(size_t)k * ld + w] * rj[w - (j - k)];
-            ri[w - (i - j)] = s / rj[w];
+    double* U = (double*)malloc(sizeof(double) * (size_t)(N ? N : 1) * ld);
+    for (int r = 0; r < N; r++)
+        for (int k = 0; k <= w; k++) U[(size_t)r * ld + k] = (r + k < N) ? f->B[(size_t)(r + k) * ld + (w - k)] : 0.0;
+    for (int j = 0; j < N; j++) {
+        const double* uj = U + (size_t)j * ld;
+        const double d = uj[0], rinv = 1.0 / d;
+        for (int a = 1; a <= w && j + a < N; a++) {
+            double* ui = U + (size_t)(j + a) * ld;
+            const double la = uj[a] * rinv;
+            for (int k = 0; k + a <= w; k++) ui[k] -= la * uj[a + k];
+            f->B[(size_t)(j + a) * ld + (w - a)] = la;
         }
-        double d = ri[w];
-        for (int k = j0; k < i; k++) { const double lik = ri[w - (i - k)]; d -= lik * lik * f->B[(size_t)k * ld + w]; }
-        ri[w] = d;
+        f->B[(size_t)j * ld + w] = d;
     }
+    free(U);
 }
 static void band_solve(const band_t* f, double* b)
 {
