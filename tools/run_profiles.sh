@@ -19,6 +19,7 @@ rocprofv3 --kernel-trace --stats -d $O/trace_sparse --output-format csv -- pytho
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch_sparse --output-format csv -- python3 $R/bench.py $S > /dev/null 2>> $O/rocprof.err
 rocprofv3 --pmc WRITE_SIZE -d $O/write_sparse --output-format csv -- python3 $R/bench.py $S > /dev/null 2>> $O/rocprof.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/sq_sparse --output-format csv -- python3 $R/bench.py $S > /dev/null 2>> $O/rocprof.err
+$R/tools/run_profiles_sizes.sh ${1:-r3} > /dev/null 2>&1
 python3 $R/tools/prof_trim.py $O
 find $O -name "*.csv" | head -80 > $O/files.txt
 tail -5 $O/rocprof.err
