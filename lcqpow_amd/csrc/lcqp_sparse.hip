@@ -592,12 +592,15 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
             for (int k = 0; k < G; k++) dst[k] = (k == 0) ? 1.0 : 0.0;
         }
     };
-    double wr[G], nx[G], nn[G], kf[G];       // current row; the rows of this lane one and two blocks ahead (the third is in flight: raw)
+    // G = 8: the rows of this lane one and two blocks ahead are held gated (nx, nn), the third is in flight (raw); G = 16 has registers for
+    // one gated row ahead and the one in flight only (DEEP: with the third row 296 B of scratch, without it less)
+    constexpr bool DEEP = (G == 8);
+    double wr[G], nx[G], nn[DEEP ? G : 1], kf[G];
     RawRow raw;
     row_issue(raw, l); row_finish(wr, raw, l);
     row_issue(raw, G + l); row_finish(nx, raw, G + l);
-    row_issue(raw, 2 * G + l); row_finish(nn, raw, 2 * G + l);
-    row_issue(raw, 3 * G + l);
+    if (DEEP) { row_issue(raw, 2 * G + l); row_finish(nn, raw, 2 * G + l); }
+    row_issue(raw, (DEEP ? 3 : 2) * G + l);
     buf[G + l] = 0.0;                                // the zeros behind the pivot row
     double rinv = 1.0;
     for (int j0 = 0; j0 < NG; j0 += G) {
@@ -629,10 +632,15 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
 #pragma unroll
         for (int k = 0; k < G; k += 2) { dv2 v; v.x = kf[k]; v.y = kf[k + 1]; *reinterpret_cast<dv2*>(reinterpret_cast<char*>(KF.base) + (size_t)(KF.off + (unsigned)((j0 + l) * G + k) * 8u)) = v; }
         if (j0 + l < Np) Kd[j0 + l] = rinv;
+        if (DEEP) {
 #pragma unroll
-        for (int k = 0; k < G; k++) nx[k] = nn[k];
-        row_finish(nn, raw, j0 + 3 * G + l);          // issued one block ago
-        row_issue(raw, j0 + 4 * G + l);
+            for (int k = 0; k < G; k++) nx[k] = nn[k];
+            row_finish(nn, raw, j0 + 3 * G + l);          // issued one block ago
+            row_issue(raw, j0 + 4 * G + l);
+        } else {
+            row_finish(nx, raw, j0 + 2 * G + l);
+            row_issue(raw, j0 + 3 * G + l);
+        }
     }
     c.bytes += c.db->by[BY_FACTOR];      // matrix entries read, factor and 1/D written
     c.cFact++;

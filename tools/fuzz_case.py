@@ -22,6 +22,9 @@ for k in range(max(ids) + 1):
             print(f"       stat {row[0]:.2e} phi {row[1]:.2e} rho {row[2]:g} alpha {row[3]:.4g} |p| {row[6]:.2e} qpit {row[7]:g}")
     so, sh, xo, xh = ro["trace_scalars"], rh["trace_scalars"], ro["trace_x"], rh["trace_x"]
     kk = min(len(so), len(sh))
+    if kk == 0:
+        print('  (one side recorded no iterate: the first QP failed there)')
+        continue
     dxs = np.array([np.abs(xo[i] - xh[i]).max() for i in range(kk)])
     big = dxs > 1e-6 * (1 + np.abs(xo[:kk]).max())
     first = int(np.argmax(big)) if big.any() else kk
