@@ -269,6 +269,40 @@ static void test_batch()
     }
 }
 
+static void test_pipeline()
+{   // LCQPow::BatchPipeline: two batch objects in flight; the slots' bookkeeping (ADVICE, round 4): acquire() twice without a launch in between
+    // must not dereference an empty launch order, a slot handed out with results and not launched again is free again, a drained pipeline
+    // starts over with every slot free; a run in chunks gives the bits of a run in one piece
+    const int B = 6, n = 64, nC = 96, nComp = 16;
+    Options options; options.setPrintLevel(NONE); options.setPerturbStep(false);
+    BatchPipeline pipe(2, B, n, nC, nComp);
+    CHECK(pipe.ok());
+    for (int k = 0; k < pipe.depth(); k++) { CHECK(pipe.slot(k).setOptions(options) == SUCCESSFUL_RETURN); CHECK(pipe.slot(k).generateSynthetic(0x4C43515000000001ULL, 0) == SUCCESSFUL_RETURN); }
+    BatchLCQProblem& a0 = pipe.acquire();
+    BatchLCQProblem& a1 = pipe.acquire();          // nothing launched: the same free slot again, no crash
+    CHECK(&a0 == &a1 && !pipe.hasResults());
+    std::vector<double> xref(n), x(n);
+    int launched = 0, collected = 0;
+    for (int step = 0; step < 5; step++) {
+        BatchLCQProblem& b = pipe.acquire();
+        if (pipe.hasResults()) { collected++; CHECK(b.getReturnValue(0) == SUCCESSFUL_RETURN); }
+        if (step == 3) CHECK(b.setRunChunks(3) == SUCCESSFUL_RETURN);      // one of the runs in three slices
+        CHECK(pipe.launch(b) == SUCCESSFUL_RETURN); launched++;
+    }
+    while (BatchLCQProblem* b = pipe.drain()) {
+        collected++;
+        for (int i = 0; i < B; i++) CHECK(b->getReturnValue(i) == SUCCESSFUL_RETURN);
+        b->getPrimalSolution(B - 1, x.data());
+        if (collected == launched - 1) xref = x;
+        if (collected == launched) for (int k = 0; k < n; k++) CHECK(x[k] == xref[k]);      // same instances, one run in chunks: the same bits
+    }
+    CHECK(collected == launched);
+    BatchLCQProblem& again = pipe.acquire();        // drained: every slot is free, nothing to wait for
+    CHECK(!pipe.hasResults());
+    CHECK(pipe.launch(again) == SUCCESSFUL_RETURN);
+    CHECK(pipe.drain() == &again && pipe.drain() == 0);
+}
+
 static int run_from_files(const char* dir, int nV, int nC, int nComp)
 {   // examples/solve_lcqp_from_file.cpp: loadLCQP(file names) + runSolver, then print the solution
     auto f = [&](const char* name) { static std::vector<std::string> keep; keep.push_back(std::string(dir) + "/" + name + ".txt"); return keep.back().c_str(); };
@@ -303,6 +337,7 @@ int main(int argc, char** argv)
         test_circle(argc > 2);
         test_loops_agree();
         test_batch();
+        test_pipeline();
     }
     std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED%.0d\n", failures);
     return failures ? 1 : 0;
