@@ -1491,8 +1491,19 @@ __global__ __launch_bounds__(WGS) void k_sparse_setup(SpBatch db)
 // whichever wavefront runs its next phase.
 // agent scope: a pool is served by wavefronts of several XCDs, whose L2s are not coherent with each other -- the release writes the L2 back, the
 // acquire invalidates L1 and L2 (workgroup-scope fences in their place: stale vectors, more iterates, 15 - 25 % SLOWER; profiles/round4)
+#ifdef SP_XCD_POOLS
+// EXPERIMENT (round 5, -DSP_XCD_POOLS; needs a pool count that is a multiple of 8, LCQP_SPARSE_POOL): a pool is served only by wavefronts of
+// ONE XCD (chosen by the XCC id the wavefront reads from its hardware register: wavefronts do not migrate), so everything an instance's
+// phases read and write goes through one L2 and the hand-over needs no L2 write-back and no L2 invalidation: the release waits for the
+// stores to reach L2 (the vector L1 is write-through), the acquire invalidates the vector L1 only.  Measured (profiles/round5/
+// sparse_xcd_pools_light_fences_dropped.log): same results, 10 400 - 10 800 against 12 700 LCQPs/s at B = 65 536, 73 against 11 000 at
+// B = 16 384 (one pool per XCD: the wavefronts of an XCD all wait on one pool's queues).  The L2 invalidations are not where the traffic is.
+#define SP_ACQUIRE() do { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); asm volatile("buffer_inv sc0" ::: "memory"); } while (0)
+#define SP_RELEASE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); } while (0)
+#else
 #define SP_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #define SP_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#endif
 __device__ __forceinline__ int q_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long q_load64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void q_store64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1570,7 +1581,13 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_sched(SpBatch
     // the pool's queues, derived afresh in front of the pop and in front of the push: nothing of the scheduler is alive across a phase
     struct Q { int w0, mask; unsigned long long* ring; int* ctl; int* remaining; };
     auto queues = [&]() {
+#ifdef SP_XCD_POOLS
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        int pool = (int)(xcc & 7u) + 8 * (int)((blockIdx.x >> 3) % (unsigned)(db.nPools >> 3));
+#else
         int pool = blockIdx.x % db.nPools;
+#endif
         asm volatile("" : "+s"(pool));
         Q q;
         q.w0 = pool * db.poolSize; q.mask = db.poolSize - 1;
