@@ -1218,6 +1218,19 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
     __syncthreads();
     int n_admm = initial ? o.admmFirst : o.admmHot;
     const int use_stored = (!initial && uniform_i(c.info->haveSolution) && n_admm == 0);
+    // Rows flagged dependent keep their multiplier while a solve runs (their equations are not in the factor).  ACROSS the solves of a
+    // homotopy that let the multipliers of two parallel rows -- duplicated or redundant equalities -- drift apart without bound (1e11
+    // against -1e11 after eight penalty updates: only their sum is determined), until the cancellation error of A'y exceeded the
+    // stationarity tolerance at a point that IS stationary (fuzz seed 22 id 283: MAX_ITERATIONS_REACHED).  A hot start therefore hands a
+    // flagged row's multiplier back: it starts at zero, the stored residual no longer belongs to the stored point, and the polish takes its
+    // cold entry (the true residual, every row) on the stored working set.  (round 5; oracle: orc_qp_solve)
+    int reuse_stored = use_stored;
+    if (ROBUST && use_stored && uniform_i(c.info->ndep) > 0) {
+        const int* dep = c.I(I_DEP);
+        int z = 0;
+        for (int r = t; r < mE; r += WG) if (dep[r] && st[r] != ST_INACT && yq[r] != 0.0) { yq[r] = 0.0; ya[r] = 0.0; z = 1; }
+        if (block_or(z, c.lds)) reuse_stored = 0;
+    }
     int solved = 0, admm_ready = 0, certificate = 0;   // za = clip(E xa) is only needed once ADMM runs
     for (int round = 0; round < o.maxRounds && !solved; round++) {
         const int t = tid_here();      // per round (see qp_admm)
@@ -1251,7 +1264,7 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         }
         for (int i = t; i < np; i += WG) xt[i] = xa[i];
         __syncthreads();
-        if (qp_polish<NCH, ROBUST, LR>(c, g, round == 0 && use_stored, ytolQ, rtolQ, round >= DAMP_ROUND)) { solved = 1; break; }
+        if (qp_polish<NCH, ROBUST, LR>(c, g, round == 0 && reuse_stored, ytolQ, rtolQ, round >= DAMP_ROUND)) { solved = 1; break; }
         if (ADAPT && round >= 1 && n_admm > 0 && qp_adapt_rho<NCH>(c, g) < 0) return 3;      // no usable ADMM factor left
         if (round >= 2) {    // at least 20 ADMM iterations behind us: is the QP infeasible or unbounded?
             certificate = qp_certificate<NCH>(c, g);

@@ -1099,6 +1099,17 @@ int orc_qp_solve(orc_qp_t* q, int initialSolve, int* iterations, int* exit_flag,
     memcpy(q->ya, q->y, sizeof(double) * mE);
     int n_admm = initialSolve ? o->admmFirst : o->admmHot;
     int use_stored_set = (!initialSolve && q->have_solution && n_admm == 0);
+    /* Rows flagged dependent keep their multiplier while a solve runs (their equations are not in the factor).  ACROSS the solves of a
+     * homotopy that let the multipliers of two parallel rows -- duplicated or redundant equalities -- drift apart without bound (1e11 against
+     * -1e11 after eight penalty updates: their sum is what the QP determines), until the cancellation error of A'y alone exceeded the
+     * stationarity tolerance and the homotopy ran into maxIterations at a point that IS stationary (fuzz seed 22 id 283).  A hot start
+     * therefore hands a flagged row's multiplier back: it starts at zero, the stored residual no longer belongs to the stored point, and the
+     * polish takes its cold entry (the true residual, every row), on the stored working set.  (round 5; device: qp_solve) */
+    int reuse_stored = use_stored_set;
+    if (use_stored_set && q->robust)
+        for (int r = 0; r < q->mE; r++)
+            if (q->dep[r] && q->st[r] != ST_INACT && q->y[r] != 0.0) { q->y[r] = 0.0; reuse_stored = 0; }
+    if (!reuse_stored) memcpy(q->ya, q->y, sizeof(double) * q->mE);
     int admm_ready = 0; /* za = clip(E xa) is only needed once ADMM runs */
     double* xt = (double*)malloc(sizeof(double) * (n ? n : 1));
     double* yt = (double*)malloc(sizeof(double) * (mE ? mE : 1));
@@ -1127,7 +1138,7 @@ int orc_qp_solve(orc_qp_t* q, int initialSolve, int* iterations, int* exit_flag,
         }
         memcpy(xt, q->xa, sizeof(double) * n);
         for (int r = 0; r < mE; r++) yt[r] = (stt[r] != ST_INACT) ? q->ya[r] : 0.0;
-        if (qp_polish(q, g, xt, yt, stt, round == 0 && use_stored_set, round >= g_damp_round)) { solved = 1; break; }
+        if (qp_polish(q, g, xt, yt, stt, round == 0 && reuse_stored, round >= g_damp_round)) { solved = 1; break; }
         if (round >= 1 && n_admm > 0) qp_adapt_rho(q, g);
         if (round >= 2) {    /* at least 20 ADMM iterations behind us: is the QP infeasible or unbounded? */
             certificate = qp_certificate(q, g);

@@ -638,7 +638,7 @@ def test_lcqp_structure_fuzz(hip, oracle):
     assert rets.get((0, 0), 0) >= count // 2, rets          # the generator is not mostly producing failures
 
 
-@pytest.mark.parametrize("seed,ids", [(1, (542, 550, 555)), (3, (12, 70)), (11, (34, 277))])
+@pytest.mark.parametrize("seed,ids", [(1, (542, 550, 555)), (3, (12, 70)), (11, (34, 277)), (15, (200,)), (22, (283,))])
 def test_fuzz_regressions_end_the_same_way(hip, oracle, seed, ids):
     """The fuzz problems on which HIP and the oracle used to end differently (profiles/round4/fuzz_batched_seed1_600.log, fuzz_host.log,
     fuzz_diverge.log): seed 1 id 542 (oracle 0 / HIP 203: HIP stood at phi = 9e-13 above the 2.2e-13 tolerance and raised the penalty until a
@@ -647,6 +647,10 @@ def test_fuzz_regressions_end_the_same_way(hip, oracle, seed, ids):
     accepted active rows at resTol (1 + |b|) = 1e-12 instead of their rounding floor, and the device carried C xk along the steps by linearity,
     forty roundings of eps |C xk| against a complementarity value that cancels to 1e3 eps (getPhi, src/LCQProblem.cpp:1172-1185).  The damped
     polish (one change of the working set per trial after three failed rounds) settles the LP-like QPs at rho ~ 1e7 of ids 550 and 70.
+    Seed 15 id 200 and seed 22 id 283 (oracle MAX_ITERATIONS_REACHED, HIP 0; profiles/round5/fuzz_campaign_before_dependent_row_reset.log): two parallel
+    equality rows whose multipliers drifted to 5e11 and -6e10 over the hot starts -- only their sum is determined -- until the cancellation error
+    of A'y alone, 1.1e-7, kept the stationarity test from ever passing at a stationary point; a hot start now resets the multiplier of a row that
+    is flagged dependent (qp_solve / orc_qp_solve).
     Asserted: same return code, and on success the same solution and stationarity type (seed 1 id 542 passes the termination test two
     penalty updates later on the device, rho 10.24 against 2.56, at the same point)."""
     fz = _fuzz_module()
