@@ -26,5 +26,5 @@ print(f"B = {B}: {B / dt:.0f} LCQPs/s, {dt * 1e3:.0f} ms; lanes per instance {sb
 tot = p[:, 0].sum()
 for k, nm in enumerate(("start", "round (ADMM preamble)", "trial head", "factorisation", "correction", "QP end + LCQP iterate", "polls without work")):
     ticks, steps, served = p[k]
-    print(f"  {nm:24s} {100 * ticks / tot:5.1f} % of the wavefront time; {steps:10.0f} steps, {served / max(steps, 1):4.2f} instances per step, {ticks / max(steps, 1) / 100:8.1f} us per step")
+    print(f"  {nm:24s} {100 * ticks / tot:5.1f} % of the wavefront time; {steps:10.0f} steps, {served / max(steps, 1):4.2f} instances per step, {ticks / max(steps, 1) / 100:8.1f} x 100 clocks per step")
 sb.close()
