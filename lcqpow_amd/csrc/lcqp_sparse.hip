@@ -1746,7 +1746,12 @@ static void sp_launch(const SpBatch& db, hipStream_t stream, hipEvent_t mid)
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    int waves = std::min(grid, cus * 4 * SP_WAVES_PER_SIMD);
+    // More wavefronts than one per 64 / G instances for batches that do not fill the machine (round 5, profiles/round5/sparse_waves_small_batches.log):
+    // a streaming phase runs ONE instance on a wavefront's 64 lanes, so a wavefront that holds eight instances serialises their trial heads and
+    // QP ends; with a wavefront per instance (up to 256) or per four instances B = 64 gains 52 %, 256: 44 %, 512: 39 %, 1024: 23 %, 2048: 12 %,
+    // 8192: 4 % (4096: +-0); idle wavefronts back off exponentially, so the surplus costs nothing.
+    int waves = std::max(grid, std::max(std::min(db.B, 256), db.B / 4));
+    waves = std::min(waves, cus * 4 * SP_WAVES_PER_SIMD);
     if (const char* e = std::getenv("LCQP_SPARSE_WAVES")) { const int v = std::atoi(e); if (v >= 1) waves = std::min(v, cus * 4 * SP_WAVES_PER_SIMD); }      // experiment switch
     waves = ((waves + db.nPools - 1) / db.nPools) * db.nPools;
     hipLaunchKernelGGL(k_sparse_sched<G>, dim3(waves), dim3(WGS), ldsBytes, stream, db);
