@@ -595,7 +595,7 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
     // G = 8: the rows of this lane one and two blocks ahead are held gated (nx, nn), the third is in flight (raw); G = 16 has registers for
     // one gated row ahead and the one in flight only (DEEP: with the third row 296 B of scratch, without it less)
     constexpr bool DEEP = (G == 8);
-    double wr[G], nx[G], nn[DEEP ? G : 1], kf[G];
+    double wr[G], nx[G], nn[DEEP ? G : 1], kf[DEEP ? G : 1];
     RawRow raw;
     row_issue(raw, l); row_finish(wr, raw, l);
     row_issue(raw, G + l); row_finish(nx, raw, G + l);
@@ -618,7 +618,8 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
             for (int k = 0; k < G; k++) p[k] = buf[ag + k];              // K[j][j + ag + k]: zero beyond the band (the padding)
             asm volatile("" ::: "memory");
             const double la = (ag != 0) ? p[0] * ri : 0.0;                // L[j + ag][j]
-            kf[u] = la;
+            if (DEEP) kf[u] = la;
+            else KF[(j0 + l) * G + u] = la;                                 // (G = 16: no registers for a block of the factor; one 8-byte store per step)
             if (ag == 0) {                                               // row j is finished: row j + G enters this lane
                 rinv = ri;
 #pragma unroll
@@ -629,8 +630,10 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
             }
         }
         // forward layout: row (j0 + l) of the block holds L[.][j0 + u] in column u (zero on and above this lane's own step)
+        if (DEEP) {
 #pragma unroll
-        for (int k = 0; k < G; k += 2) { dv2 v; v.x = kf[k]; v.y = kf[k + 1]; *reinterpret_cast<dv2*>(reinterpret_cast<char*>(KF.base) + (size_t)(KF.off + (unsigned)((j0 + l) * G + k) * 8u)) = v; }
+            for (int k = 0; k < G; k += 2) { dv2 v; v.x = kf[k]; v.y = kf[k + 1]; *reinterpret_cast<dv2*>(reinterpret_cast<char*>(KF.base) + (size_t)(KF.off + (unsigned)((j0 + l) * G + k) * 8u)) = v; }
+        }
         if (j0 + l < Np) Kd[j0 + l] = rinv;
         if (DEEP) {
 #pragma unroll
