@@ -325,21 +325,37 @@ struct ID { int i; double a; };
 // the tile and the indices of the NEXT tile are in flight together.  xv(j) returns a D2 (two vectors share one pass over the
 // matrix); pre(i) loads what the consumer needs beside the sums; out(i, s0, s1, pre) consumes.
 
-template <int G, int U, int W, class Xv, class Pre, class Out>
+template <int G, int U, int W, bool MAP, class Xv, class Pre, class Out>
 __device__ __forceinline__ void g_ell(const EllMat& E, int gl, GD vals, Xv xv, Pre pre, Out out)
 {
     const int rows = E.rows;
     gl = here(gl);
+    // indices of a tile: the column slab and either the position slab (a value map: E^T over E's values) or the row's two pointers --
+    // without a map the values of a row lie in row order, position of entry q = ptr[i] + q: two loads per row instead of W (round 5)
+    constexpr int PW = MAP ? W : 2;
+    constexpr bool mapped = MAP;
+    constexpr bool PREF = !MAP;   // with a map the next tile's 2 W indices per row do not fit the register budget of the G = 8 scheduler kernel
+    int ci[U][W], pa[U][PW];      // pa: positions (map) / pa[u][0], pa[u][1] = ptr[i], ptr[i + 1] (no map)
+    auto load_idx = [&](int t0, int (&c)[U][W], int (&p)[U][PW]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = t0 + u * G; const bool ok = i < rows;
+#pragma unroll
+            for (int q = 0; q < W; q++) {
+                c[u][q] = ok ? E.eidx[q * rows + i] : 0;
+                if (mapped) p[u][q % PW] = ok ? E.epos[q * rows + i] : -1;
+            }
+            if (!mapped) { p[u][0] = ok ? E.ptr[i] : 0; p[u][1] = ok ? E.ptr[i + 1] : 0; }
+        }
+    };
+    if (gl < rows) load_idx(gl, ci, pa);
     for (int i0 = gl; i0 < rows; i0 += U * G) {
-        int ci[U][W], ps[U][W];
+        int ps[U][W];
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
-            for (int q = 0; q < W; q++) {
-                const int i = i0 + u * G; const bool ok = i < rows;
-                ci[u][q] = ok ? E.eidx[q * rows + i] : 0;
-                ps[u][q] = ok ? E.epos[q * rows + i] : -1;
-            }
+            for (int q = 0; q < W; q++)
+                ps[u][q] = mapped ? pa[u][q % PW] : ((pa[u][0] + q < pa[u][1]) ? pa[u][0] + q : -1);
         double a[U][W]; D2 xs[U][W];
         typename val_of<decltype(pre(0))>::type pv[U];
 #pragma unroll
@@ -354,6 +370,10 @@ __device__ __forceinline__ void g_ell(const EllMat& E, int gl, GD vals, Xv xv, P
             const int i = i0 + u * G;
             pv[u] = pre(i < rows ? i : 0);
         }
+        // the indices of the NEXT tile go out behind this tile's values: one round trip per tile instead of two
+        int cn[U][W], pn[U][PW];
+        const bool more = i0 + U * G < rows;
+        if (PREF && more) load_idx(i0 + U * G, cn, pn);
 #pragma unroll
         for (int u = 0; u < U; u++) {
             double s0 = 0.0, s1 = 0.0;
@@ -369,21 +389,29 @@ __device__ __forceinline__ void g_ell(const EllMat& E, int gl, GD vals, Xv xv, P
                 out(i, s0, s1, pv[u]);
             }
         }
+        if (PREF) {
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int q = 0; q < W; q++) { ci[u][q] = cn[u][q]; pa[u][q % PW] = pn[u][q % PW]; }
+            }
+        } else if (more) load_idx(i0 + U * G, ci, pa);
     }
 }
 // dispatch on the slab width of the pattern (4 or 8)
-template <int G, class Xv, class Pre, class Out>
+template <int G, bool MAP, class Xv, class Pre, class Out>
 __device__ __forceinline__ void sp_ell(const EllMat& E, int gl, GD vals, Xv xv, Pre pre, Out out)
 {
-    if (E.W == 4) g_ell<G, 4, 4>(E, gl, vals, xv, pre, out);
-    else g_ell<G, 2, 8>(E, gl, vals, xv, pre, out);
+    if (E.W == 4) g_ell<G, 4, 4, MAP>(E, gl, vals, xv, pre, out);
+    else g_ell<G, 2, 8, MAP>(E, gl, vals, xv, pre, out);
 }
 struct NoPre { };
 
 template <int G> __device__ __forceinline__ void sp_Ex(SpCtx<G>& c, GD x, GD out)
 {
     SPROF(c, SP_VECTORS);
-    sp_ell<G>(c.db->ellE, c.gl, c.Ex(), [&](int j) { return D2{x[j], 0.0}; }, [](int) { return NoPre{}; }, [&](int r, double s, double, NoPre) { out[r] = s; });
+    sp_ell<G, false>(c.db->ellE, c.gl, c.Ex(), [&](int j) { return D2{x[j], 0.0}; }, [](int) { return NoPre{}; }, [&](int r, double s, double, NoPre) { out[r] = s; });
     g_sync();
     SPROF(c, SP_PRODUCTS);
 }
@@ -391,7 +419,7 @@ template <int G> __device__ __forceinline__ void sp_Ex(SpCtx<G>& c, GD x, GD out
 template <int G> __device__ __forceinline__ void sp_Qx2(SpCtx<G>& c, GD x0, GD x1, GD o0, GD o1)
 {
     SPROF(c, SP_VECTORS);
-    sp_ell<G>(c.db->ellQ, c.gl, c.Qx(), [&](int j) { return D2{x0[j], x1[j]}; }, [](int) { return NoPre{}; },
+    sp_ell<G, false>(c.db->ellQ, c.gl, c.Qx(), [&](int j) { return D2{x0[j], x1[j]}; }, [](int) { return NoPre{}; },
               [&](int i, double s0, double s1, NoPre) { o0[i] = s0; o1[i] = s1; });
     g_sync();
     SPROF(c, SP_PRODUCTS);
@@ -401,7 +429,7 @@ template <int G, class Pre, class Base> __device__ __forceinline__ double sp_ETy
 {
     SPROF(c, SP_VECTORS);
     double mx = 0.0;
-    sp_ell<G>(c.db->ellT, c.gl, c.Ex(), [&](int r) { return D2{y[r], 0.0}; }, pre,
+    sp_ell<G, true>(c.db->ellT, c.gl, c.Ex(), [&](int r) { return D2{y[r], 0.0}; }, pre,
               [&](int i, double s, double, typename val_of<decltype(pre(0))>::type pv) { const double v = base(pv) - s; out[i] = v; mx = nmax(mx, fabs(v)); });
     g_sync();
     SPROF(c, SP_PRODUCTS);
@@ -412,10 +440,10 @@ template <int G, class Pre, class Base> __device__ __forceinline__ double sp_ETy
 template <int G> __device__ __forceinline__ double sp_residual(SpCtx<G>& c, GD g, GD x, GD y, GD r1, GD qx)
 {
     SPROF(c, SP_VECTORS);
-    sp_ell<G>(c.db->ellQ, c.gl, c.Qx(), [&](int j) { return D2{x[j], 0.0}; }, [](int) { return NoPre{}; }, [&](int i, double s, double, NoPre) { qx[i] = s; });
+    sp_ell<G, false>(c.db->ellQ, c.gl, c.Qx(), [&](int j) { return D2{x[j], 0.0}; }, [](int) { return NoPre{}; }, [&](int i, double s, double, NoPre) { qx[i] = s; });
     g_sync();
     double mx = 0.0;
-    sp_ell<G>(c.db->ellT, c.gl, c.Ex(), [&](int r) { return D2{y[r], 0.0}; }, [&](int i) { return D2{g[i], qx[i]}; },
+    sp_ell<G, true>(c.db->ellT, c.gl, c.Ex(), [&](int r) { return D2{y[r], 0.0}; }, [&](int i) { return D2{g[i], qx[i]}; },
               [&](int i, double s, double, D2 pv) { const double v = (-pv.a - pv.b) - s; r1[i] = v; mx = nmax(mx, fabs(v)); });
     g_sync();
     SPROF(c, SP_PRODUCTS);
@@ -427,11 +455,11 @@ template <int G> __device__ __forceinline__ void sp_Cx2(SpCtx<G>& c, GD v0, GD v
 {
     SPROF(c, SP_VECTORS);
     GD lx0 = c.M(MV_LX), lx1 = c.M(MV_LX2);
-    sp_ell<G>(c.db->ellE, c.gl, c.Ex(), [&](int j) { return D2{v0[j], v1[j]}; }, [](int) { return NoPre{}; },
+    sp_ell<G, false>(c.db->ellE, c.gl, c.Ex(), [&](int j) { return D2{v0[j], v1[j]}; }, [](int) { return NoPre{}; },
               [&](int r, double s0, double s1, NoPre) { lx0[r] = s0; lx1[r] = s1; });
     g_sync();
     const int nC = c.db->nC, nK = c.db->nComp;
-    sp_ell<G>(c.db->ellT, c.gl, c.Ex(),
+    sp_ell<G, true>(c.db->ellT, c.gl, c.Ex(),
               [&](int r) { const int rr = r >= nC + nK ? r - nK : (r >= nC ? r + nK : -1);      // R'(L v) + L'(R v)
                            return rr >= 0 ? D2{lx0[rr], lx1[rr]} : D2{0.0, 0.0}; },
               [](int) { return NoPre{}; }, [&](int i, double s0, double s1, NoPre) { o0[i] = s0; o1[i] = s1; });
@@ -444,7 +472,7 @@ template <int G, bool TWO, class Pre, class Out> __device__ __forceinline__ void
 {
     SPROF(c, SP_VECTORS);
     const int nC = c.db->nC, nK = c.db->nComp;
-    sp_ell<G>(c.db->ellT, c.gl, c.Ex(),
+    sp_ell<G, true>(c.db->ellT, c.gl, c.Ex(),
               [&](int r) { const int rr = r >= nC + nK ? r - nK : (r >= nC ? r + nK : -1);
                            return rr >= 0 ? D2{lx0[rr], TWO ? (double)lx1[rr] : 0.0} : D2{0.0, 0.0}; },
               pre, [&](int i, double s0, double s1, typename val_of<decltype(pre(0))>::type pv) { out(i, s0, s1, pv); });
@@ -957,38 +985,45 @@ __device__ __forceinline__ int sp_ph_trial(SpCtx<G>& c, SpState& S, GD g)
     // multipliers of the leaving rows, below); the trial that accepts always has the true residual.
     double res_stat = 0.0;
     int have_r1 = 0;
-    if (trial == 0 && S.reuse) {
-        // hot start with an unchanged (x, y): r1 = r1_last + (g_last - g) and E x are in place -- the residual and E x of the accepted
-        // trial stay where they are, and the LCQP level adds (g_last - g) to r1 in the pass that forms the new g (sp_ph_qpend)
-        have_r1 = 1;
-    } else {
-        sp_Ex<G>(c, x, ex);
-        c.bytes += db.by[BY_EX];
-    }
     double res_eq = 0.0, bmax = 0.0;
     int chg = 0, act = 0, loose = 0;
     // active rows are held to the rounding floor of a computed E_r x, 16 eps (|b_r| + |E_r|_1 |x|_inf), before a point is accepted (round 5;
     // oracle: sqp_polish; dense twin: qp_polish in lcqp_dev.hpp): runSolver ends on phi < 1e3 eps, a sum of products of such residuals
     const double exScale = c.info->e1max * S.xinf;
-    g_map<G, 4>(m, t, [&](int r) { return StRow{st[r], ex[r], l[r], u[r], yt[r]}; },
-                [&](int r, StRow v) {
-                    int ns = v.s;
-                    if (v.s == ST_INACT) {
-                        const double ftol = o.feasTol * (1.0 + fabs(v.e));
-                        if (v.e < v.lo - ftol) ns = ST_LOWER;
-                        else if (v.e > v.hi + ftol) ns = ST_UPPER;
-                    } else {
-                        const double bb = (v.s == ST_UPPER) ? v.hi : v.lo;
-                        res_eq = nmax(res_eq, fabs(bb - v.e));
-                        bmax = fmax(bmax, fabs(bb));
-                        loose |= (fabs(bb - v.e) > 16.0 * 2.221e-16 * (fabs(bb) + exScale));
-                        if (v.s == ST_LOWER && v.y > ytol) ns = ST_INACT;
-                        if (v.s == ST_UPPER && v.y < -ytol) ns = ST_INACT;
-                    }
-                    newst[r] = ns;
-                    chg += (ns != v.s);
-                    act += (ns != ST_INACT);
-                });
+    auto status = [&](int r, StRow v) {
+        int ns = v.s;
+        if (v.s == ST_INACT) {
+            const double ftol = o.feasTol * (1.0 + fabs(v.e));
+            if (v.e < v.lo - ftol) ns = ST_LOWER;
+            else if (v.e > v.hi + ftol) ns = ST_UPPER;
+        } else {
+            const double bb = (v.s == ST_UPPER) ? v.hi : v.lo;
+            res_eq = nmax(res_eq, fabs(bb - v.e));
+            bmax = fmax(bmax, fabs(bb));
+            loose |= (fabs(bb - v.e) > 16.0 * 2.221e-16 * (fabs(bb) + exScale));
+            if (v.s == ST_LOWER && v.y > ytol) ns = ST_INACT;
+            if (v.s == ST_UPPER && v.y < -ytol) ns = ST_INACT;
+        }
+        newst[r] = ns;
+        chg += (ns != v.s);
+        act += (ns != ST_INACT);
+    };
+    if (trial == 0 && S.reuse) {
+        // hot start with an unchanged (x, y): r1 = r1_last + (g_last - g) and E x are in place -- the residual and E x of the accepted
+        // trial stay where they are, and the LCQP level adds (g_last - g) to r1 in the pass that forms the new g (sp_ph_qpend)
+        have_r1 = 1;
+        g_map<G, 4>(m, t, [&](int r) { return StRow{st[r], ex[r], l[r], u[r], yt[r]}; }, status);
+    } else {
+        // E x and the status test in ONE pass (round 5): the row's state rides along as the product's `pre`, the sum goes straight into the
+        // test and into ex (the right-hand side of the correction needs it) -- no second pass over st, ex, l, u, y
+        SPROF(c, SP_VECTORS);
+        sp_ell<G, false>(db.ellE, c.gl, c.Ex(), [&](int j) { return D2{x[j], 0.0}; },
+                  [&](int r) { return StRow{st[r], 0.0, l[r], u[r], yt[r]}; },
+                  [&](int r, double s0, double, StRow v) { ex[r] = s0; v.e = s0; status(r, v); });
+        g_sync();
+        SPROF(c, SP_PRODUCTS);
+        c.bytes += db.by[BY_EX];
+    }
     const int changed = g_sum_i<G>(chg), nact = g_sum_i<G>(act);
     res_eq = g_max<G>(res_eq);
     bmax = g_max<G>(bmax);
@@ -2074,7 +2109,8 @@ try {
         for (int i = 0; i < rows; i++)
             for (int q = 0; q < W && ptr[i] + q < ptr[i + 1]; q++) { const int k = ptr[i] + q; ei[(size_t)q * rows + i] = idx[k]; ep[(size_t)q * rows + i] = map ? map[k] : k; }
         e.rows = rows; e.W = W; e.tails = mx > W ? 1 : 0; e.ptr = dptr; e.cidx = didx; e.cmap = dmap;
-        return (e.eidx = sp_alloc<int>(h, ei.size(), ei.data())) && (e.epos = sp_alloc<int>(h, ep.size(), ep.data()));
+        e.epos = nullptr;      // without a map the position of entry q of row i is ptr[i] + q (g_ell): no position slab
+        return (e.eidx = sp_alloc<int>(h, ei.size(), ei.data())) && (!map || (e.epos = sp_alloc<int>(h, ep.size(), ep.data())));
     };
     ok = ok && make_ell(d.ellQ, n, std::vector<int>(Qp, Qp + n + 1), std::vector<int>(Qi, Qi + nnzQ), nullptr, d.Qp, d.Qi, nullptr) &&
          make_ell(d.ellE, m, Ep, Ei, nullptr, d.Ep, d.Ei, nullptr) && make_ell(d.ellT, n, ETp, ETi, ETmap.data(), d.ETp, d.ETi, d.ETmap);
