@@ -15,7 +15,7 @@ for line in sys.stdin:
         if m and cur: rows[cur][s]=m.group(1)
     if 'error' in line: print(line.rstrip())
 for k,v in rows.items():
-    name=subprocess.run(['c++filt',k],capture_output=True,text=True).stdout.strip().split('(')[0]
+    name=subprocess.run(['c++filt',k],capture_output=True,text=True).stdout.strip().replace('(anonymous namespace)::','').split('(')[0]
     print(f'{name:40s}', ' '.join(f'{a}={b}' for a,b in v.items()))
 "
 done
