@@ -133,6 +133,7 @@ struct SpBatch {
     unsigned long long* qring;  // [nPools][PH_NUM][poolSize] ring slots: (sequence number << 32) | instance id, one 64-bit word so that a slot changes hands in one store
     int* qctl;                  // [nPools][PH_NUM + 1][QCTL]
     int poolSize, nPools;
+    int wideDiv;                // SIMDs of the device per pool (sp_launch): unfinished instances of the pool / wideDiv = instances of a streaming step
     // algorithmic bytes of one event of each kind (filled by the host: formed in the kernel they are loop invariants the compiler keeps in
     // registers across every phase)
     double by[BY_NUM];
@@ -1654,7 +1655,14 @@ __global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_sched(SpBatch
             if (ph < 0) for (int k = 0; k < PH_NUM; k++) if (isWide(k) && cnt[k] > best) { best = cnt[k]; ph = k; }
             if (ph < 0) for (int k = 0; k < PH_NUM; k++) if (cnt[k] > best) { best = cnt[k]; ph = k; }
             if (ph >= 0) {
-                take = min(best, isWide(ph) ? IPWW * SP_WIDE_BATCH : IPW * SP_BAND_BATCH);
+                // instances of a streaming step: they run one after the other on this wavefront, so a long step makes the last of them wait
+                // for the others while wavefronts elsewhere poll -- P = unfinished instances per SIMD of the machine up to 4, P / 2 beyond,
+                // at most SP_WIDE_BATCH (the fences of a step are paid once for all of them: full steps for batches that fill the
+                // machine).  profiles/round5/sparse_wide_batch_rule.log: against 16 per step +20 % at B = 1024, +15 % at 2048, +11 % at
+                // 4096, +7 % at 8192, the same from 16 384 on
+                int wb = SP_WIDE_BATCH;
+                if (isWide(ph)) { const int P = q_load(remaining) / db.wideDiv; wb = max(1, min(SP_WIDE_BATCH, P <= 4 ? P : max(4, P >> 1))); }
+                take = min(best, isWide(ph) ? IPWW * wb : IPW * SP_BAND_BATCH);
                 if (atomicCAS(&ctl[ph * QCTL + 2], best, best - take) == best) base = atomicAdd(&ctl[ph * QCTL + 1], take);
                 else { ph = -1; take = 0; }      // somebody else moved the counter: look again
             }
@@ -1792,7 +1800,10 @@ static void sp_launch(const SpBatch& db, hipStream_t stream, hipEvent_t mid)
     waves = std::min(waves, cus * 4 * SP_WAVES_PER_SIMD);
     if (const char* e = std::getenv("LCQP_SPARSE_WAVES")) { const int v = std::atoi(e); if (v >= 1) waves = std::min(v, cus * 4 * SP_WAVES_PER_SIMD); }      // experiment switch
     waves = ((waves + db.nPools - 1) / db.nPools) * db.nPools;
-    hipLaunchKernelGGL(k_sparse_sched<G>, dim3(waves), dim3(WGS), ldsBytes, stream, db);
+    SpBatch dbs = db;
+    dbs.wideDiv = std::max(1, cus * 4 / std::max(1, db.nPools));
+    if (const char* e = std::getenv("LCQP_SPARSE_WIDE_DIV")) { const int v = std::atoi(e); if (v >= 1) dbs.wideDiv = v; }      // experiment switch
+    hipLaunchKernelGGL(k_sparse_sched<G>, dim3(waves), dim3(WGS), ldsBytes, stream, dbs);
 }
 
 }  // namespace
