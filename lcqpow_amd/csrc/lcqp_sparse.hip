@@ -1191,7 +1191,8 @@ __device__ __forceinline__ int sp_qp_begin(SpCtx<G>& c, SpState& S, GD g)
     if (!S.use_stored) return PH_ROUND;
     g_map<G, 4>(m, t, [&](int r) { return ID3{st[r], l[r], u[r], 0.0, yq[r]}; },
                 [&](int r, ID3 v) { const int s = (v.lo == v.hi) ? ST_EQ : v.s; stt[r] = s; yt[r] = (s != ST_INACT) ? v.y : 0.0; });
-    g_map<G, 8>(n, t, [&](int i) { return xq[i]; }, [&](int i, double v) { xt[i] = v; });
+    // (xt is xq already: the stored solution is the accepted trial vector of the QP before, copied from xt in sp_ph_qpend, and nothing has
+    // written xt since -- use_stored is only set behind that copy)
     g_sync();
     return sp_polish_begin<G>(c, S, g, 1);
 }
@@ -1279,7 +1280,7 @@ __device__ __forceinline__ int sp_ph_qpend(SpCtx<G>& c, SpState& S)
         GD xq = c.V(NV_XQ), xt = c.V(NV_XT), yq = c.M(MV_YQ), yt = c.M(MV_YT);
         GI st = c.I(MI_ST), stt = c.I(MI_STT);
         S.qpIter = (c.cTrials - S.trials0) + (c.cAdmm - S.admm0);
-        g_map<G, 8>(n, t, [&](int i) { return xt[i]; }, [&](int i, double v) { xq[i] = v; });
+        // (x: in the pass below that forms pk)
         g_map<G, 8>(m, t, [&](int r) { return ID{stt[r], yt[r]}; }, [&](int r, ID v) { yq[r] = v.a; st[r] = v.i; });
         if (t == 0) c.info->haveSolution = 1;
         g_sync();
@@ -1287,12 +1288,6 @@ __device__ __forceinline__ int sp_ph_qpend(SpCtx<G>& c, SpState& S)
     SPROF(c, SP_VECTORS);
     S.st.subproblemIter += S.qpIter; S.st.qpSolverExitFlag = 0; S.st.qpSolves++;
     double rho = S.rho, alphak = S.alphak;
-    auto getPhi = [&]() -> double {
-        double s = 0.0;
-#pragma unroll 8
-        for (int i = t; i < n; i += G) s += (hasPhi ? gphi[i] * xk[i] : 0.0) + 0.5 * xk[i] * Cx[i];
-        return phiConst + g_sum<G>(s);
-    };
     auto updatePenalty = [&]() {
         if (o.nDynamicPenalty > 0) S.histLen = 0;
         rho *= o.penaltyUpdateFactor;
@@ -1306,8 +1301,8 @@ __device__ __forceinline__ int sp_ph_qpend(SpCtx<G>& c, SpState& S)
     // (round 2: one pass over Q, one over E, two over E' per iterate.)
     GD qxs = c.V(NV_TMP), exs = c.M(MV_EX), r1s = c.V(NV_R1), gs0 = gk;
     {
-        GD xq = c.V(NV_XQ), yq = c.M(MV_YQ);
-        g_map<G, 4>(n, t, [&](int i) { return D4{xq[i], xk[i], qxs[i], Qx[i]}; }, [&](int i, D4 v) { xnew[i] = v.a; pk[i] = v.a - v.b; Qp[i] = v.c - v.d; });
+        GD xq = c.V(NV_XQ), xt = c.V(NV_XT), yq = c.M(MV_YQ);
+        g_map<G, 4>(n, t, [&](int i) { return D4{xt[i], xk[i], qxs[i], Qx[i]}; }, [&](int i, D4 v) { xq[i] = v.a; xnew[i] = v.a; pk[i] = v.a - v.b; Qp[i] = v.c - v.d; });
         g_map<G, 8>(m, t, [&](int r) { return yq[r]; }, [&](int r, double v) { yk[r] = -v; });     // src/SubsolverOSQP.cpp:196-199
         g_sync();
     }
@@ -1325,6 +1320,7 @@ __device__ __forceinline__ int sp_ph_qpend(SpCtx<G>& c, SpState& S)
         S.perturbCounter += (uint64_t)n;
         g_sync();
     }
+    double sq = 0.0, sl = 0.0;      // pk'(Q + rho C) pk and pk'((Q + rho C) xk + g~)
     if (perturbed) {
         // the perturbation has to reach the penalty gradient rho C xk -- it is there to break the symmetry of problems like warm_up
         // (perturbStep :1353-1362) -- so C xk is taken from the perturbed xk: one more pass over E, the column gather carries two
@@ -1333,13 +1329,21 @@ __device__ __forceinline__ int sp_ph_qpend(SpCtx<G>& c, SpState& S)
         sp_C_from_Ex<G, true>(c, exs, lx, [](int) { return NoPre{}; }, [&](int i, double cxq, double cxk, NoPre) { Cx[i] = cxk; Cp[i] = cxq - cxk; });
         c.bytes += 3.0 * db.by[BY_E];
     } else {
-        sp_C_from_Ex<G, false>(c, exs, exs, [&](int i) { return Cx[i]; }, [&](int i, double cxq, double, double cxk) { Cp[i] = cxq - cxk; });
+        // C pk and, in the same pass, the two sums of the step length (round 5: they were a pass of their own over pk, Qp, Cp, Qx, Cx, gtil)
+        struct D5 { double cx, pk, qp, qx, gt; };
+        sp_C_from_Ex<G, false>(c, exs, exs, [&](int i) { return D5{Cx[i], pk[i], Qp[i], Qx[i], gtil[i]}; },
+                               [&](int i, double cxq, double, D5 v) {
+                                   const double cp = cxq - v.cx;
+                                   Cp[i] = cp;
+                                   sq += v.pk * (v.qp + rho * cp); sl += v.pk * ((v.qx + rho * v.cx) + v.gt);
+                               });
         c.bytes += db.by[BY_E];
     }
     if (!initial) {
-        double sq = 0.0, sl = 0.0;
+        if (perturbed) {
 #pragma unroll 4
-        for (int i = t; i < n; i += G) { sq += pk[i] * (Qp[i] + rho * Cp[i]); sl += pk[i] * ((Qx[i] + rho * Cx[i]) + gtil[i]); }
+            for (int i = t; i < n; i += G) { sq += pk[i] * (Qp[i] + rho * Cp[i]); sl += pk[i] * ((Qx[i] + rho * Cx[i]) + gtil[i]); }
+        }
         const double qk = g_sum<G>(sq), lk = g_sum<G>(sl);
         alphak = 1.0;
         if (qk > 0 && lk < 0) alphak = fmin(-lk / qk, 1.0);
@@ -1347,19 +1351,21 @@ __device__ __forceinline__ int sp_ph_qpend(SpCtx<G>& c, SpState& S)
     S.initial = 0;
     // the step, the products that follow it, and updateStationarity without a box term: statk = Qk xk + g_tilde - E'yk with
     // E'yk = -E'yq = gs0 + Q xq + r1s
-    double statMax = 0.0;
-    { struct D10 { double a, b, c, d, e, f, g0, q, r, gt; };
-      g_map<G, 2>(n, t, [&](int i) { return D10{xk[i], pk[i], Qx[i], Qp[i], Cx[i], Cp[i], gs0[i], qxs[i], r1s[i], gtil[i]}; },
+    double statMax = 0.0, phiSum = 0.0;
+    { struct D10 { double a, b, c, d, e, f, g0, q, r, gt, gp; };
+      g_map<G, 2>(n, t, [&](int i) { return D10{xk[i], pk[i], Qx[i], Qp[i], Cx[i], Cp[i], gs0[i], qxs[i], r1s[i], gtil[i], hasPhi ? (double)gphi[i] : 0.0}; },
                   [&](int i, D10 v) {
-                      const double qn = v.c + alphak * v.d, cn = v.e + alphak * v.f;
-                      xk[i] = v.a + alphak * v.b; Qx[i] = qn; Cx[i] = cn;
+                      const double qn = v.c + alphak * v.d, cn = v.e + alphak * v.f, xn = v.a + alphak * v.b;
+                      xk[i] = xn; Qx[i] = qn; Cx[i] = cn;
                       statMax = nmax(statMax, fabs(((qn + rho * cn) + v.gt) - ((v.g0 + v.q) + v.r)));
+                      phiSum += (hasPhi ? v.gp * xn : 0.0) + 0.5 * xn * cn;      // getPhi of the new iterate, in its order of summation
                   }); }
     g_sync();
     const double statInf = g_max<G>(statMax);
+    const double phiStep = phiConst + g_sum<G>(phiSum);      // (xk and C xk do not change again in this iterate: every getPhi below is this value)
     int totalIter = S.totalIter;
     if (db.traceCap > 0 && totalIter < db.traceCap) {   // storeSteps :488-490, printIteration :1528-1576 (the host rebuilds both from this)
-        const double phiNow = getPhi();
+        const double phiNow = phiStep;
         double so = 0.0, sm = 0.0, pm = 0.0;
         for (int i = t; i < n; i += G) { const double xv = xk[i]; so += g[i] * xv + 0.5 * xv * Qx[i]; sm += 0.5 * rho * xv * Cx[i]; pm = fmax(pm, fabs(pk[i])); }
         const double objNow = g_sum<G>(so), meritNow = objNow + g_sum<G>(sm), stepNow = g_max<G>(pm);
@@ -1375,7 +1381,7 @@ __device__ __forceinline__ int sp_ph_qpend(SpCtx<G>& c, SpState& S)
     bool leyffer = false;
     const int nd = o.nDynamicPenalty;
     if (nd > 0) {
-        const double cur = getPhi();
+        const double cur = phiStep;
         if (S.histLen < nd) { if (t == 0) hist[S.histLen] = cur; S.histLen++; g_sync(); }
         else {
             if (!(cur < o.complementarityTolerance)) {
@@ -1390,7 +1396,7 @@ __device__ __forceinline__ int sp_ph_qpend(SpCtx<G>& c, SpState& S)
     if (leyffer) { updatePenalty(); S.st.iterOuter++; }
     bool done = false;
     if (statInf < o.stationarityTolerance) {
-        if (getPhi() < o.complementarityTolerance) {
+        if (phiStep < o.complementarityTolerance) {
             sp_Ex<G>(c, xk, lx);
             int sflag = 1, mflag = 1, wflag = 0;
             const double ctol = o.complementarityTolerance;
@@ -1611,7 +1617,7 @@ __device__ __forceinline__ int sp_run_phase(const SpBatch& db, int ph, int b, in
 }
 
 template <int G>
-__global__ __launch_bounds__(WGS, SP_WAVES_PER_SIMD) void k_sparse_sched(SpBatch db)
+__global__ __launch_bounds__(WGS, (G <= 8 ? SP_WAVES_PER_SIMD : 1)) void k_sparse_sched(SpBatch db)
 {
     constexpr int IPW = 64 / G;
     constexpr int GW = (SP_WIDE_LANES > G) ? SP_WIDE_LANES : G;      // lanes per instance of the streaming phases
@@ -1797,8 +1803,9 @@ static void sp_launch(const SpBatch& db, hipStream_t stream, hipEvent_t mid)
     // QP ends; with a wavefront per instance (up to 256) or per four instances B = 64 gains 52 %, 256: 44 %, 512: 39 %, 1024: 23 %, 2048: 12 %,
     // 8192: 4 % (4096: +-0); idle wavefronts back off exponentially, so the surplus costs nothing.
     int waves = std::max(grid, std::max(std::min(db.B, 256), db.B / 4));
-    waves = std::min(waves, cus * 4 * SP_WAVES_PER_SIMD);
-    if (const char* e = std::getenv("LCQP_SPARSE_WAVES")) { const int v = std::atoi(e); if (v >= 1) waves = std::min(v, cus * 4 * SP_WAVES_PER_SIMD); }      // experiment switch
+    const int resident = cus * 4 * (G <= 8 ? SP_WAVES_PER_SIMD : 1);      // (k_sparse_sched's launch bounds)
+    waves = std::min(waves, resident);
+    if (const char* e = std::getenv("LCQP_SPARSE_WAVES")) { const int v = std::atoi(e); if (v >= 1) waves = std::min(v, resident); }      // experiment switch
     waves = ((waves + db.nPools - 1) / db.nPools) * db.nPools;
     SpBatch dbs = db;
     dbs.wideDiv = std::max(1, cus * 4 / std::max(1, db.nPools));
