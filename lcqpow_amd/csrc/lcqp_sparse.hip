@@ -1131,8 +1131,9 @@ __device__ __forceinline__ int sp_ph_correct(SpCtx<G>& c, SpState& S)
     GI st = c.I(MI_STT);
     const int* iperm = db.iperm;
     SPROF(c, SP_VECTORS);
-    g_map<G, 8>(n, t, [&](int i) { return ID{iperm[i], r1[i]}; }, [&](int, ID v) { b[v.i] = v.a; });
-    g_map<G, 4>(m, t, [&](int r) { return ID4{iperm[n + r], st[r], l[r], u[r], ex[r]}; },
+    // (deep tiles: the band's lane groups are 8 lanes wide, a pass over n is n / (8 U) round trips)
+    g_map<G, 16>(n, t, [&](int i) { return ID{iperm[i], r1[i]}; }, [&](int, ID v) { b[v.i] = v.a; });
+    g_map<G, 6>(m, t, [&](int r) { return ID4{iperm[n + r], st[r], l[r], u[r], ex[r]}; },
                 [&](int, ID4 v) { b[v.p] = (v.s != ST_INACT) ? ((v.s == ST_UPPER) ? v.hi : v.lo) - v.e : 0.0; });
     g_sync();
     SPROF(c, SP_RHS);
@@ -1147,9 +1148,9 @@ __device__ __forceinline__ int sp_ph_correct(SpCtx<G>& c, SpState& S)
     S.borderTodo = 0;
     if (db.kb > 0) sp_border_solve<G>(c, false, b);
     double xm = 0.0;
-    g_map<G, 8>(n, t, [&](int i) { return D2{b[iperm[i]], x[i]}; }, [&](int i, D2 v) { const double xn = v.b + v.a; x[i] = xn; xm = fmax(xm, fabs(xn)); });
+    g_map<G, 12>(n, t, [&](int i) { return D2{b[iperm[i]], x[i]}; }, [&](int i, D2 v) { const double xn = v.b + v.a; x[i] = xn; xm = fmax(xm, fabs(xn)); });
     S.xinf = g_max<G>(xm);
-    g_map<G, 8>(m, t, [&](int r) { return ID2{st[r], b[iperm[n + r]], yt[r]}; }, [&](int r, ID2 v) { if (v.s != ST_INACT) yt[r] = v.y + v.v; });
+    g_map<G, 10>(m, t, [&](int r) { return ID2{st[r], b[iperm[n + r]], yt[r]}; }, [&](int r, ID2 v) { if (v.s != ST_INACT) yt[r] = v.y + v.v; });
     g_sync();
     c.cCorr++;
     S.trial++;
@@ -1302,7 +1303,7 @@ __device__ __forceinline__ int sp_ph_qpend(SpCtx<G>& c, SpState& S)
     GD qxs = c.V(NV_TMP), exs = c.M(MV_EX), r1s = c.V(NV_R1), gs0 = gk;
     {
         GD xq = c.V(NV_XQ), xt = c.V(NV_XT), yq = c.M(MV_YQ);
-        g_map<G, 4>(n, t, [&](int i) { return D4{xt[i], xk[i], qxs[i], Qx[i]}; }, [&](int i, D4 v) { xq[i] = v.a; xnew[i] = v.a; pk[i] = v.a - v.b; Qp[i] = v.c - v.d; });
+        g_map<G, 8>(n, t, [&](int i) { return D4{xt[i], xk[i], qxs[i], Qx[i]}; }, [&](int i, D4 v) { xq[i] = v.a; xnew[i] = v.a; pk[i] = v.a - v.b; Qp[i] = v.c - v.d; });
         g_map<G, 8>(m, t, [&](int r) { return yq[r]; }, [&](int r, double v) { yk[r] = -v; });     // src/SubsolverOSQP.cpp:196-199
         g_sync();
     }
@@ -1353,7 +1354,7 @@ __device__ __forceinline__ int sp_ph_qpend(SpCtx<G>& c, SpState& S)
     // E'yk = -E'yq = gs0 + Q xq + r1s
     double statMax = 0.0, phiSum = 0.0;
     { struct D10 { double a, b, c, d, e, f, g0, q, r, gt, gp; };
-      g_map<G, 2>(n, t, [&](int i) { return D10{xk[i], pk[i], Qx[i], Qp[i], Cx[i], Cp[i], gs0[i], qxs[i], r1s[i], gtil[i], hasPhi ? (double)gphi[i] : 0.0}; },
+      g_map<G, 3>(n, t, [&](int i) { return D10{xk[i], pk[i], Qx[i], Qp[i], Cx[i], Cp[i], gs0[i], qxs[i], r1s[i], gtil[i], hasPhi ? (double)gphi[i] : 0.0}; },
                   [&](int i, D10 v) {
                       const double qn = v.c + alphak * v.d, cn = v.e + alphak * v.f, xn = v.a + alphak * v.b;
                       xk[i] = xn; Qx[i] = qn; Cx[i] = cn;
