@@ -241,7 +241,8 @@ def main():
         "config": dict({"workload": wl, "global_batch": B * world,
                         "parallelism": f"batch-sharded x{world}, no collective" + ("" if launched or world == 1 else " (one process drives all devices)")
                                        + (f"; shards on devices {args.devices} (a rehearsal of the N > 1 path, not a scaling measurement)" if args.devices and len(set(args.devices.split(","))) < world else ""),
-                        "solved": n_ok, "mean_lcqp_iterates": mean("iterTotal"), "mean_outer": mean("iterOuter"),
+                        "solved": n_ok, "mean_lcqp_iterates": mean("iterTotal"), "max_lcqp_iterates": int(max(s_["iterTotal"] for s_ in st)),
+                        "mean_outer": mean("iterOuter"),
                         "mean_qp_trials": mean("trials"), "mean_residual_sweeps": mean("reserved"), "mean_admm_iters": mean("admmIter"),
                         "setup_ms_per_step": setup_ms, "homotopy_kernel_ms_per_step": solve_ms}, **cfg_extra),
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
