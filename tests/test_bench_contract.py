@@ -23,6 +23,7 @@ def test_bench_json_contract():
     assert d["unit"] == "LCQPs/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["solved"] == 16
+    assert d["config"]["max_lcqp_iterates"] >= d["config"]["mean_lcqp_iterates"] >= 1      # (a batch is as fast as its slowest instance: both are reported)
     assert abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -53,6 +54,7 @@ def test_bench_sparse_workload_line():
     assert r.returncode == 0, r.stdout + r.stderr
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["unit"] == "LCQPs/s" and d["config"]["solved"] == 8 and "sparse" in d["config"]["workload"]
+    assert d["config"]["max_lcqp_iterates"] >= d["config"]["mean_lcqp_iterates"] >= 1
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0 and d["roofline"]["traffic"] is None
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["max_abs_dx_vs_gpu"] < 1e-8
 
