@@ -41,7 +41,10 @@ constexpr int WGS = 64;      // one wavefront per workgroup; 64 / G instances in
 #define SP_WAVES_PER_SIMD 2  // register budget of k_sparse_sched: 512 / SP_WAVES_PER_SIMD per lane
 #endif
 #ifndef SP_SWEEP_RING
-#define SP_SWEEP_RING 4      // coefficient chunks (8 steps each) of a band sweep in flight at G = 8
+#define SP_SWEEP_RING 8      // coefficient chunks (8 steps each) of a band sweep in flight at G = 8: seven chunks = 56 steps ahead of use, 8 800 / 5 600 clocks of
+                             // the forward / backward sweep (with 4: 3 800 / 2 400, less than a round trip to memory on a busy machine -- the sweeps of a full
+                             // machine took 1.7 x the time of a lone instance's; profiles/round5/sparse_sweep_ring8_ab.log: +5.5 % at B = 1024, +3.6 % at 4096,
+                             // -1.6 % at 16 384, +-0 at 65 536; round 4 had measured it at 65 536 only)
 #endif
 enum { NV_G, NV_GTIL, NV_GPHI, NV_XK, NV_PK, NV_XNEW, NV_GK, NV_QX, NV_CX, NV_QP, NV_CP, NV_TMP, NV_XQ, NV_XA, NV_XT, NV_R1,
        NV_X0, NV_NUM };
@@ -621,18 +624,22 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
             for (int k = 0; k < G; k++) dst[k] = (k == 0) ? 1.0 : 0.0;
         }
     };
-    // G = 8: the rows of this lane one and two blocks ahead are held gated (nx, nn), the third is in flight (raw); G = 16 has registers for
-    // one gated row ahead and the one in flight only (DEEP: with the third row 296 B of scratch, without it less)
+    // G = 8: the lane's row of the next block is held gated (nx) and the rows of the two blocks behind it are in flight (ra, rb): a row is
+    // requested FOUR blocks before it is the pivot row's neighbour and gated two blocks after the request -- under load a round trip to
+    // memory is longer than the ~2.3 us a block of eight steps takes, and with one block between request and use the chain waited for it at every
+    // block (the factorisation steps of a full machine took 1.7 x the time of a lone instance).  The block loop is unrolled by two so that
+    // each buffer is named statically (a copy from one to the other would wait for the load).  G = 16 has registers for one gated row
+    // ahead and one in flight only (DEEP: with a second one in flight scratch).
     constexpr bool DEEP = (G == 8);
-    double wr[G], nx[G], nn[DEEP ? G : 1], kf[DEEP ? G : 1];
-    RawRow raw;
-    row_issue(raw, l); row_finish(wr, raw, l);
-    row_issue(raw, G + l); row_finish(nx, raw, G + l);
-    if (DEEP) { row_issue(raw, 2 * G + l); row_finish(nn, raw, 2 * G + l); }
-    row_issue(raw, (DEEP ? 3 : 2) * G + l);
+    double wr[G], nx[G], kf[DEEP ? G : 1];
+    RawRow ra, rb;
+    row_issue(ra, l); row_finish(wr, ra, l);
+    row_issue(ra, G + l); row_finish(nx, ra, G + l);
+    row_issue(ra, 2 * G + l);
+    if (DEEP) row_issue(rb, 3 * G + l);
     buf[G + l] = 0.0;                                // the zeros behind the pivot row
     double rinv = 1.0;
-    for (int j0 = 0; j0 < NG; j0 += G) {
+    auto block = [&](int j0, RawRow& raw) {
 #pragma unroll
         for (int u = 0; u < G; u++) {
             const int ag = (l - u) & GM;                               // this lane holds row j + ag, j = j0 + u (ag == 0: the pivot row)
@@ -664,15 +671,16 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
             for (int k = 0; k < G; k += 2) { dv2 v; v.x = kf[k]; v.y = kf[k + 1]; *reinterpret_cast<dv2*>(reinterpret_cast<char*>(KF.base) + (size_t)(KF.off + (unsigned)((j0 + l) * G + k) * 8u)) = v; }
         }
         if (j0 + l < Np) Kd[j0 + l] = rinv;
-        if (DEEP) {
-#pragma unroll
-            for (int k = 0; k < G; k++) nx[k] = nn[k];
-            row_finish(nn, raw, j0 + 3 * G + l);          // issued one block ago
-            row_issue(raw, j0 + 4 * G + l);
-        } else {
-            row_finish(nx, raw, j0 + 2 * G + l);
-            row_issue(raw, j0 + 3 * G + l);
+        row_finish(nx, raw, j0 + 2 * G + l);          // requested two blocks ago (G = 16: one)
+        row_issue(raw, j0 + (DEEP ? 4 : 3) * G + l);
+    };
+    if (DEEP) {
+        for (int j0 = 0; j0 < NG; j0 += 2 * G) {
+            block(j0, ra);
+            if (j0 + G < NG) block(j0 + G, rb);
         }
+    } else {
+        for (int j0 = 0; j0 < NG; j0 += G) block(j0, ra);
     }
     c.bytes += c.db->by[BY_FACTOR];      // matrix entries read, factor and 1/D written
     c.cFact++;
