@@ -121,6 +121,7 @@ def main():
 
     import numpy as np
     import lcqpow_amd as la
+    la.request_hw_queues(8)      # this program runs a BatchPipeline beside other batch objects: ask before the first HIP call (the library never sets it itself)
 
     ndev = la.device_count()
     if ndev < 1:

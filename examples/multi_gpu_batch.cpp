@@ -17,6 +17,7 @@ struct ShardResult { int solved = 0; long iterates = 0; double checksum = 0.0; b
 
 int main(int argc, char** argv)
 {
+    lcqp_hip_request_hw_queues(8);      // before the first HIP call: one queue per shard stream (the library never sets it by itself)
     const int ndev = lcqp_hip_device_count();
     if (ndev < 1) { std::printf("no GPU visible\n"); return 1; }
     const int total = argc > 1 ? std::atoi(argv[1]) : 2048, shards = argc > 2 ? std::atoi(argv[2]) : ndev;

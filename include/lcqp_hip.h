@@ -73,6 +73,11 @@ typedef struct {
 void lcqp_hip_options_default(lcqp_options_t* opt);               /* Options::setToDefault, src/Options.cpp:296 */
 const char* lcqp_hip_last_error(void);
 int  lcqp_hip_device_count(void);
+/* Ask the HIP runtime for n hardware queues (sets GPU_MAX_HW_QUEUES unless the environment already holds a value).  Opt-in, for the
+ * PROGRAM to call before the first HIP call of the process -- the runtime reads the variable once; the library never changes the
+ * environment by itself.  A BatchPipeline with more batch objects alive than its own wants this.
+ * Returns 0 (set), 1 (already set by the caller's environment: left alone) or LCQP_HIP_ERROR (n outside 1..64). */
+int  lcqp_hip_request_hw_queues(int n);
 
 /* ------------------------------------------------------------------------------------------------
  * QP object == SubsolverBase implementation state.
@@ -135,15 +140,7 @@ int  lcqp_hip_batch_setup(lcqp_hip_batch_t* b);
  * stream; includes setup if it has not run since the last load. */
 int  lcqp_hip_batch_run(lcqp_hip_batch_t* b);
 int  lcqp_hip_batch_synchronize(lcqp_hip_batch_t* b);
-/* A run may work through the batch in `chunks` slices of consecutive instances (1 ... 8; 0 = the library's choice, which is 1; the environment
- * variable LCQP_RUN_CHUNKS overrides that choice): the setup kernels of slice c + 1 -- bound by the matrix cores -- then run beside the homotopy
- * launch of slice c -- bound by HBM -- on a stream of their own.  Results do not depend on the number of slices.  An experiment switch: on
- * the BASELINE batch every split is slower than one slice (profiles/round5/run_chunks_ab.log).  lcqp_hip_batch_get_run_chunks: the number
- * the last run used. */
-int  lcqp_hip_batch_set_run_chunks(lcqp_hip_batch_t* b, int chunks);
-int  lcqp_hip_batch_get_run_chunks(lcqp_hip_batch_t* b);
-/* time of the last run measured with HIP events on the batch stream, ms: setup_ms = the setup kernels no homotopy launch runs beside (all of
- * them in a run of one slice, those of the first slice otherwise), solve_ms = from the start of the first homotopy launch to the end of the last */
+/* time of the last run measured with HIP events on the batch stream, ms: setup_ms = the setup kernels, solve_ms = the homotopy launch */
 int  lcqp_hip_batch_last_timing(lcqp_hip_batch_t* b, float* setup_ms, float* solve_ms);
 /* getPrimalSolution / getDualSolution / getOutputStatistics, src/LCQProblem.cpp:1485-1504,1519:
  * x[B][nV], y[B][nV+nC+2nComp], stats[B]; returnValue of runSolver is stats[i].returnValue. */

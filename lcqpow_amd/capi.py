@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# LCQPOW_HIP_LIBRARY: another build of the same HIP library (experiment variants under ab_tmp/); there is no CPU fallback either way
+# LCQPOW_HIP_LIBRARY: another build of the same HIP library (experiment variants under build/ab/); there is no CPU fallback either way
 _SO = os.environ.get("LCQPOW_HIP_LIBRARY") or os.path.join(_HERE, "liblcqpow_hip.so")
 c_double_p = C.POINTER(C.c_double)
 
@@ -51,6 +51,17 @@ def library_path():
     return _SO
 
 
+def request_hw_queues(n=8):
+    """Ask the HIP runtime for n hardware queues (GPU_MAX_HW_QUEUES) -- an explicit call of the PROGRAM (bench.py, the examples), before
+    the first HIP call of the process; the library never changes the environment by itself.  Every batch object has two HIP streams and
+    the runtime maps the streams of a process onto 4 queues by default: the two slots of a BatchPipeline can land on one queue and run one
+    after the other.  Returns True when the variable was set, False when the environment already holds a value (left alone)."""
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        return False
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(n))
+    return True
+
+
 def lib():
     """Load liblcqpow_hip.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
     global _lib
@@ -58,10 +69,6 @@ def lib():
         if not os.path.exists(_SO):
             raise RuntimeError(f"{_SO} is missing: the HIP extension must be built (see __graft_entry__.build); "
                                "there is no CPU fallback for the product path")
-        if "LCQPOW_KEEP_HW_QUEUES" not in os.environ:
-            # every batch object has two HIP streams and the runtime maps the streams of a process onto 4 hardware queues by default: two
-            # objects of a BatchPipeline can land on one queue and run one after the other (lcqp_hip.hip: lcqp_more_hw_queues)
-            os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         L = C.CDLL(_SO)
         L.lcqp_hip_last_error.restype = C.c_char_p
         L.lcqp_hip_options_default.argtypes = [C.POINTER(Options)]
@@ -83,8 +90,6 @@ def lib():
         L.lcqp_hip_batch_setup.argtypes = [C.c_void_p]
         L.lcqp_hip_batch_run.argtypes = [C.c_void_p]
         L.lcqp_hip_batch_synchronize.argtypes = [C.c_void_p]
-        L.lcqp_hip_batch_set_run_chunks.argtypes = [C.c_void_p, C.c_int]
-        L.lcqp_hip_batch_get_run_chunks.argtypes = [C.c_void_p]
         L.lcqp_hip_batch_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.lcqp_hip_batch_get_solution.argtypes = [C.c_void_p, c_double_p, c_double_p, C.POINTER(Stats)]
         L.lcqp_hip_batch_get_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p, C.POINTER(C.c_int)]
@@ -198,6 +203,11 @@ class BatchPipeline:
         # hardware queues (4 by default, GPU_MAX_HW_QUEUES); every batch object has two streams, so a process that keeps more than two batch
         # objects alive can find both slots of a pipeline on one queue -- and its batches run one after the other (tools/micro/pipeline_check.py:
         # 35 200 LCQPs/s with two objects alive, 30 750 with an idle third one, 34 800 again with GPU_MAX_HW_QUEUES=8)
+        if "GPU_MAX_HW_QUEUES" not in os.environ:
+            import warnings
+            warnings.warn("BatchPipeline with the HIP runtime's default of 4 hardware queues: with more batch objects alive than the pipeline's, "
+                          "two slots can share a queue and run one after the other; call lcqpow_amd.request_hw_queues() before the first HIP "
+                          "call of the process, or set GPU_MAX_HW_QUEUES", RuntimeWarning, stacklevel=2)
         self.owned = over is None
         self.slots = list(over) if over is not None else [BatchLCQP(batch, nV, nC, nComp, with_box=with_box, device=device, opt=opt) for _ in range(depth)]
         self.state = [0] * len(self.slots)          # 0 free, 1 in flight, 2 finished
@@ -282,13 +292,6 @@ class BatchLCQP:
 
     def synchronize(self):
         _check(lib().lcqp_hip_batch_synchronize(self.h), "synchronize")
-
-    def set_run_chunks(self, chunks):
-        """slices of consecutive instances a run works through (0: the library chooses); the setup of slice c + 1 runs beside the homotopy of slice c"""
-        _check(lib().lcqp_hip_batch_set_run_chunks(self.h, int(chunks)), "set_run_chunks")
-
-    def run_chunks(self):
-        return int(lib().lcqp_hip_batch_get_run_chunks(self.h))
 
     def last_timing(self):
         a = C.c_float(0); b = C.c_float(0)

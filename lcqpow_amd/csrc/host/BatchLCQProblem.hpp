@@ -64,8 +64,6 @@ class BatchLCQProblem {
     const lcqp_stats_t& getStats(int i) const { return st[i]; }
     int getNumberOfPrimals() const { return nV_; }
     int getNumberOfDuals() const { return nV_ + nC_ + 2 * nComp_; }
-    // slices a run works through (lcqp_hip_batch_set_run_chunks; 0: the library's choice, which is one)
-    ReturnValue setRunChunks(int chunks) { return (ReturnValue)lcqp_hip_batch_set_run_chunks(h, chunks); }
     lcqp_hip_batch_t* handle() { return h; }
 
   private:

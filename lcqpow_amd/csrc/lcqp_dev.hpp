@@ -943,9 +943,9 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             if (LISTS) {
                 nact = wg_compact(mE, [&](int r) { return cold || st[r] != ST_INACT; }, lact, c.lds);
                 // du: the residual of the QP as given (the next hot start and A'y need it without the proximal term); r1: with it
-                wg_rows<NCH, true>(c.E, lact, nact, x, ex, yt, c.lds, [&](int i, double s) { const double ro = -g[i] - qx[i] - s; du[i] = ro; r1[i] = ro - spv * (x[i] - xref[i]); }, hotc, hotv);
+                wg_rows<NCH, true>(c.E, lact, nact, x, ex, yt, c.lds, [&](int i, double s) { const double ro = -g[i] - qx[i] - s; du[i] = ro; r1[i] = ro - spv * (x[i] - xref[i]); cv[i] = fabs(g[i]) + fabs(qx[i]) + fabs(s); }, hotc, hotv);
             } else {
-                wg_rows<NCH>(c.E, nullptr, mE, x, ex, yt, c.lds, [&](int i, double s) { const double ro = -g[i] - qx[i] - s; du[i] = ro; r1[i] = ro - spv * (x[i] - xref[i]); }, hotc, hotv);
+                wg_rows<NCH>(c.E, nullptr, mE, x, ex, yt, c.lds, [&](int i, double s) { const double ro = -g[i] - qx[i] - s; du[i] = ro; r1[i] = ro - spv * (x[i] - xref[i]); cv[i] = fabs(g[i]) + fabs(qx[i]) + fabs(s); }, hotc, hotv);
             }
             c.cSweeps++;
             if (cold) {
@@ -959,7 +959,14 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                     __syncthreads();
                 }
             } else {
-                const double res_stat = wg_maxabs(r1, np, c.lds);
+                // (round 6; oracle: the same) THE RESIDUAL'S OWN ROUNDING FLOOR.  r1 is a sum of three vectors, g, Qx and E'y: it cannot be evaluated,
+                // let alone reduced by a correction, below a few dozen roundings of the largest.  On a QP whose solution lies far out along a flat
+                // direction of Q (fuzz seed 8 id 370: |g| = 2, |Qx| = |E'y| = 1e3) resTol (1 + |g|) asked for 3e-15 relative to the terms and the
+                // refinement stagnated at 7e-12 with the RIGHT working set, for forty rounds.  The tolerance is at least 64 eps max_i(|g_i| + |Qx|_i + |E'y|_i);
+                // well-scaled QPs never see it.
+                double res_stat, rscale;
+                wg_maxabs2(r1, cv, np, c.n, res_stat, rscale, c.lds);
+                const double rtolS = uniform_d(fmax(rtolG, 64.0 * 2.221e-16 * rscale));
                 double res_eq = 0.0, bmax = 0.0, nDense2 = 0.0;
                 for (int a = t; a < nact; a += WG) {
                     const int r = LISTS ? lact[a] : a;
@@ -968,24 +975,29 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
                     if (s == ST_INACT) continue;
                     const double bb = (s == ST_UPPER) ? u[r] : l[r];
                     const double rr = fabs(bb - ex[r]);
-                    res_eq = fmax(res_eq, rr);
+                    // (round 6) a row at the rounding floor of its computed E_r x cannot be held more exactly: it does not count as a residual
+                    const bool above = rr > 16.0 * 2.221e-16 * (fabs(bb) + rn[r] * xnrm);
+                    if (above) res_eq = fmax(res_eq, rr);
                     bmax = fmax(bmax, fabs(bb));
-                    // a row of the factor that is not at the rounding floor of E_r x (counted in units of 2^20 beside the dense-row count: one reduction)
-                    if (rslot[r] >= 0 && rr > 16.0 * 2.221e-16 * (fabs(bb) + rn[r] * xnrm)) nDense2 += 1048576.0;
+                    // a row of the factor that is not at that floor (counted in units of 2^20 beside the dense-row count: one reduction)
+                    if (rslot[r] >= 0 && above) nDense2 += 1048576.0;
                 }
                 int nloose;
                 { double re, nd; block_max_sum(res_eq, nDense2, re, nd, c.lds); res_eq = re; nloose = (int)(nd * (1.0 / 1048576.0)); nd -= 1048576.0 * nloose; if (t == 0) c.info->work[4] += nd; }
                 bmax = block_max(bmax, c.lds);
                 // the proximal QP is solved: is it the QP as given (sigma_p |x - xref| below the tolerance too)?  Else (PSD Hessians far from
                 // xref) the next step of the proximal-point iteration is anchored here
-                if (res_stat <= rtolG && res_eq <= o.resTol * (1.0 + bmax) && nloose > 0 && nrefine < 2 && trial + 1 < maxTrials) {
+#ifdef LCQP_TRACE_QP
+                if (tid_here() == 0) printf("  hip trial %d stage 2: res_stat %.3e (tol %.3e) res_eq %.3e (tol %.3e) loose %d scale %.2e |x| %.2e\n", trial, res_stat, rtolS, res_eq, o.resTol * (1.0 + bmax), nloose, rscale, xnrm);
+#endif
+                if (res_stat <= rtolS && res_eq <= o.resTol * (1.0 + bmax) && nloose > 0 && nrefine < 2 && trial + 1 < maxTrials) {
                     nrefine++;      // solved to the residual tolerance, but the active rows can be held more exactly: one more correction
                 } else
-                if (res_stat <= rtolG && res_eq <= o.resTol * (1.0 + bmax) && !(wg_maxabs(du, np, c.lds) <= rtolG)) {
+                if (res_stat <= rtolS && res_eq <= o.resTol * (1.0 + bmax) && !(wg_maxabs(du, np, c.lds) <= rtolS)) {
                     for (int i = t; i < np; i += WG) { xref[i] = x[i]; r1[i] = du[i]; }
                     __syncthreads();
                 } else
-                if (res_stat <= rtolG && res_eq <= o.resTol * (1.0 + bmax)) {
+                if (res_stat <= rtolS && res_eq <= o.resTol * (1.0 + bmax)) {
                     double *r1s = c.V(V_R1S), *gs0 = c.V(V_GS), *exs = c.M(M_EXS), *aty = c.V(V_ATY);
                     // A'y_A + y_box = -E'y = g + Qx + r1 at the verified point (all three are direct sums of this trial)
                     double* qxn = c.V(V_QXN);
@@ -1093,6 +1105,9 @@ __device__ __forceinline__ int qp_polish(Ctx<NCH>& c, const double* g, int reuse
             fact_valid = 1;
         }
         const int nsp = 64 * ((nsl + 63) >> 6);
+#ifdef LCQP_TRACE_QP      // diagnostic build (tools/fuzz_case.py --trace): one line per trial, the oracle prints the same lines when its trace switch is on
+        if (tid_here() == 0) printf("  hip trial %d damp %d: left %d changed %d true %d na %d ns %d dep %d\n", trial, damp, nlv, changed, have_true, na, nsl, ROBUST ? c.info->ndep : 0);
+#endif
         if (have_true) {
             // full correction:  c = L1^-1 r1 ;  S dy = T c - r2 ;  dx = L1^-T (c - T' dy)      (T: the rows of Et in the slots of the factor)
             for (int a = t; a < nsp; a += WG) {
@@ -1264,6 +1279,9 @@ __device__ __forceinline__ int qp_solve(Ctx<NCH>& c, int initial, const double* 
         }
         for (int i = t; i < np; i += WG) xt[i] = xa[i];
         __syncthreads();
+#ifdef LCQP_TRACE_QP
+        if (tid_here() == 0) printf(" hip round %d: admm %d stored %d reuse %d trials so far %d\n", round, n_admm, use_stored, round == 0 && reuse_stored, c.cTrials - trials0);
+#endif
         if (qp_polish<NCH, ROBUST, LR>(c, g, round == 0 && reuse_stored, ytolQ, rtolQ, round >= DAMP_ROUND)) { solved = 1; break; }
         if (ADAPT && round >= 1 && n_admm > 0 && qp_adapt_rho<NCH>(c, g) < 0) return 3;      // no usable ADMM factor left
         if (round >= 2) {    // at least 20 ADMM iterations behind us: is the QP infeasible or unbounded?

@@ -49,12 +49,17 @@ __global__ __launch_bounds__(WG, 4) void k_backsolve(int np, int nblk, const dou
 // HIP maps the streams of a process onto a few hardware queues -- 4 unless GPU_MAX_HW_QUEUES says otherwise -- and every batch object has
 // two streams: a process that keeps three batch objects alive can find both slots of a BatchPipeline on ONE queue, and its batches then
 // run one after the other (tools/micro/pipeline_check.py: 35 200 LCQPs/s with two objects alive, 30 750 with an idle third one, 34 800
-// again with eight queues).  The library therefore asks for eight queues when it is loaded, unless the variable is set already or
-// LCQPOW_KEEP_HW_QUEUES is; the HIP runtime reads the variable when it initialises, i.e. at the first HIP call of the process, so this
-// takes effect whenever the library is loaded before that (the Python binding sets it too, before it loads the library).
-__attribute__((constructor)) static void lcqp_more_hw_queues()
+// again with eight queues).  The library does NOT touch the environment by itself (round 6; it used to, from a constructor: that changed
+// the queue count of every GPU user of the host process).  A program that wants the queues asks for them explicitly, before the first
+// HIP call of the process -- the runtime reads the variable once, when it initialises: bench.py and the examples do.
+// Returns 0 when the variable was set, 1 when the caller's environment already holds a value (left alone), LCQP_HIP_ERROR on a bad count.
+extern "C" int lcqp_hip_request_hw_queues(int n)
 {
-    if (!getenv("LCQPOW_KEEP_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
+    if (n < 1 || n > 64) return LCQP_HIP_ERROR;
+    if (getenv("GPU_MAX_HW_QUEUES")) return 1;
+    char buf[16];
+    snprintf(buf, sizeof buf, "%d", n);
+    return setenv("GPU_MAX_HW_QUEUES", buf, /*overwrite=*/0) == 0 ? 0 : LCQP_HIP_ERROR;
 }
 
 static thread_local std::string g_err;
@@ -122,37 +127,7 @@ struct lcqp_hip_batch {
     bool setupDone, ran, anyLoaded;
     int nch;
     size_t bytesTotal;
-    // lcqp_hip_batch_run in chunks (round 5): chunk c runs its setup kernels and its homotopy launch on chunkStream[c] (chunk 0: `stream`),
-    // the setup of chunk c + 1 waits for the setup of chunk c, so that the matrix-core-bound setup of the next chunk runs beside the
-    // HBM-bound homotopy of the last one
-    int runChunks;                        // 0: chosen by the library (lcqp_hip_batch_set_run_chunks)
-    int chunksUsed;                       // chunks of the last run
-    std::vector<hipStream_t> chunkStream; // [c - 1] for chunk c >= 1
-    std::vector<hipEvent_t> chunkEv;      // per chunk: setup done, run done, fork, join
 };
-constexpr int MAX_RUN_CHUNKS = 8;
-
-// the instances [first, first + count) of a batch as a batch of their own: every per-instance array starts `first` instances later
-static DevBatch batch_view(const DevBatch& d, int first, int count)
-{
-    DevBatch v = d;
-    const size_t f = (size_t)first, np = d.np, mE = d.mEcap, cs = d.capS;
-    v.B = count;
-    v.Q += f * np * np; v.C += f * np * np; v.E += f * mE * np; v.Et += f * mE * np; v.F1 += f * np * np; v.FK += f * np * np;
-    v.S += f * cs * cs; v.S2 += f * cs * cs; v.DS += f * (cs / 64) * 4096; v.D1 += f * (size_t)d.nblk * 4096; v.dscr += f * 4096;
-    v.MM += f * (size_t)d.mMld * d.mMld; v.crow += f * cs;
-    v.Cp += f * (np + 1); v.Ci += f * (size_t)d.capC; v.Cv += f * (size_t)d.capC;
-    v.nv += f * V_NUM * np; v.mv += f * M_NUM * mE; v.sv += f * S_NUM * cs;
-    v.mi += f * I_NUM * mE; v.idx += f * cs; v.boxidx += f * np;
-    v.lbL += f * (size_t)(d.nComp ? d.nComp : 1); v.lbR += f * (size_t)(d.nComp ? d.nComp : 1);
-    v.yk += f * (size_t)d.nd; v.y0 += f * (size_t)d.nd; v.xout += f * (size_t)d.n; v.yout += f * (size_t)d.nd;
-    v.stats += f; v.info += f; v.prof += f * 16;
-    const int tc = d.traceCap < 0 ? -d.traceCap : d.traceCap;
-    if (v.traceS) v.traceS += f * (size_t)tc * 8;
-    if (v.traceX) v.traceX += f * (size_t)tc * d.n;
-    if (v.traceLen) v.traceLen += f;
-    return v;
-}
 
 // -DLCQP_ONLY_NCH=k (experiment builds, tools/gpu_ab.py): link only the kernels of one padded size
 // padded size of a problem with n variables in units of 128: 1, 2, 3, 4, then 8 (np = 1024), 16 (np = 2048) and 32 (np = 4096)
@@ -177,11 +152,10 @@ static void lcqp_dispatch(int nch, int kid, int grid, hipStream_t s, const Launc
     }
 #endif
 }
-static void dispatch_db(lcqp_hip_batch* h, int kid, int grid, const int* list = nullptr, int initial = 0, uint64_t seed0 = 0, uint64_t first = 0, hipStream_t on = nullptr,
-                        const DevBatch* view = nullptr)
+static void dispatch_db(lcqp_hip_batch* h, int kid, int grid, const int* list = nullptr, int initial = 0, uint64_t seed0 = 0, uint64_t first = 0, hipStream_t on = nullptr)
 {
     LaunchArgs a;
-    a.db = view ? *view : h->db; a.list = list; a.initial = initial; a.seed0 = seed0; a.first = first;
+    a.db = h->db; a.list = list; a.initial = initial; a.seed0 = seed0; a.first = first;
     lcqp_dispatch(h->nch, kid, grid, on ? on : h->stream, a);
 }
 
@@ -206,7 +180,6 @@ try {
     lcqp_hip_batch* h = new (std::nothrow) lcqp_hip_batch();
     if (!h) { g_err = "out of host memory"; return nullptr; }
     h->device = device; h->setupDone = false; h->ran = false; h->anyLoaded = false; h->bytesTotal = 0;
-    h->runChunks = 0; h->chunksUsed = 1;
     h->stage[0] = h->stage[1] = nullptr; h->stageBytes = 0;
     h->stream = nullptr; h->ev0 = h->ev1 = h->ev2 = nullptr; h->side = nullptr; h->evFork = h->evJoin = nullptr;
     DevBatch& d = h->db;
@@ -285,8 +258,6 @@ try {
     if (h->ev2) (void)hipEventDestroy(h->ev2);
     if (h->evFork) (void)hipEventDestroy(h->evFork);
     if (h->evJoin) (void)hipEventDestroy(h->evJoin);
-    for (hipEvent_t e : h->chunkEv) (void)hipEventDestroy(e);
-    for (hipStream_t st : h->chunkStream) (void)hipStreamDestroy(st);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -500,30 +471,29 @@ try {
 }
 catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
-// the setup kernels of the instances of `v` (the whole batch, or one chunk of it) on stream `on`, the C branch on the side stream
-static int launch_setup(lcqp_hip_batch* h, const DevBatch* view = nullptr, hipStream_t on = nullptr, hipEvent_t evFork = nullptr, hipEvent_t evJoin = nullptr)
+// the setup kernels of the batch on its stream, the C branch on the side stream
+static int launch_setup(lcqp_hip_batch* h)
 {
-    const DevBatch& d = view ? *view : h->db;
-    if (!on) on = h->stream;
-    if (!evFork) { evFork = h->evFork; evJoin = h->evJoin; }
+    const DevBatch& d = h->db;
+    hipStream_t on = h->stream;
     const int ntile = d.nblk * (d.nblk + 1) / 2;
-    dispatch_db(h, ID_k_prepare, d.B, nullptr, 0, 0, 0, on, &d);
+    dispatch_db(h, ID_k_prepare, d.B);
     // C and its compressed rows depend on L and R only, the chain L1 -> Et -> M on Q and E: two branches.  The short one goes to the side
     // stream and fills the machine while k_factor (one workgroup per instance, chains of 64-step diagonal blocks) leaves most of it idle.
     const bool fork = d.nComp > 0;
     if (fork) {
-        HIPCHK(hipEventRecord(evFork, on));
-        HIPCHK(hipStreamWaitEvent(h->side, evFork, 0));
-        dispatch_db(h, ID_k_build_C, d.B * ntile, nullptr, 0, 0, 0, h->side, &d);
-        dispatch_db(h, ID_k_compress_C, d.B, nullptr, 0, 0, 0, h->side, &d);
-        HIPCHK(hipEventRecord(evJoin, h->side));
+        HIPCHK(hipEventRecord(h->evFork, on));
+        HIPCHK(hipStreamWaitEvent(h->side, h->evFork, 0));
+        dispatch_db(h, ID_k_build_C, d.B * ntile, nullptr, 0, 0, 0, h->side);
+        dispatch_db(h, ID_k_compress_C, d.B, nullptr, 0, 0, 0, h->side);
+        HIPCHK(hipEventRecord(h->evJoin, h->side));
     }
-    dispatch_db(h, ID_k_factor, d.B, nullptr, 0, 0, 0, on, &d);
-    dispatch_db(h, ID_k_trsm, d.B * ((d.mEcap + 63) / 64), nullptr, 0, 0, 0, on, &d);
+    dispatch_db(h, ID_k_factor, d.B);
+    dispatch_db(h, ID_k_trsm, d.B * ((d.mEcap + 63) / 64));
     // the join sits in front of the last setup kernel, not behind it: an event recorded right after a stream wait carried a late time stamp
     // (the homotopy kernel appeared 2 ms shorter than rocprofv3 and the wall clock say), and the side branch has long finished by then
-    if (fork) HIPCHK(hipStreamWaitEvent(on, evJoin, 0));
-    { const int nb = (d.mMld + 127) / 128; dispatch_db(h, ID_k_build_M, d.B * (nb * (nb + 1) / 2), nullptr, 0, 0, 0, on, &d); }      // 128 x 128 tiles of the lower triangle
+    if (fork) HIPCHK(hipStreamWaitEvent(on, h->evJoin, 0));
+    { const int nb = (d.mMld + 127) / 128; dispatch_db(h, ID_k_build_M, d.B * (nb * (nb + 1) / 2)); }      // 128 x 128 tiles of the lower triangle
     HIPCHK(hipGetLastError());
     h->setupDone = true;
     return 0;
@@ -537,70 +507,20 @@ try {
 }
 catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
 
-// Chunks of one run (round 5; an experiment switch, off by default: see default_run_chunks for the measurement).  The setup of a batch is bound
-// by the matrix cores and by latency (k_build_M, k_trsm, k_factor), the homotopy by HBM: one after the other, the setup is 17 % of a step
-// during which the memory system idles.  With K chunks of consecutive instances the setup of chunk c + 1 runs beside the homotopy of chunk c
-// (its own stream, started when the setup of chunk c is done).  Results do not depend on K (instances are independent; every kernel
-// addresses its instances through a view of the batch, batch_view).
-extern "C" int lcqp_hip_batch_set_run_chunks(lcqp_hip_batch_t* h, int chunks)
-try {
-    if (!h || chunks < 0 || chunks > MAX_RUN_CHUNKS) return LCQP_INVALID_ARGUMENT;
-    h->runChunks = chunks;
-    return 0;
-}
-catch (...) { g_err = "out of host memory"; return LCQP_HIP_ERROR; }   // nothing throws across the C boundary
-
-extern "C" int lcqp_hip_batch_get_run_chunks(lcqp_hip_batch_t* h) { return h ? h->chunksUsed : 0; }
-
-static int default_run_chunks(const lcqp_hip_batch* h)
-{
-    if (const char* e = getenv("LCQP_RUN_CHUNKS")) { const int k = atoi(e); if (k >= 1 && k <= MAX_RUN_CHUNKS) return k; }
-    // One chunk.  Measured on the BASELINE batch (profiles/round5/run_chunks_ab.log, run_chunks_timeline_*.txt): 30 200 LCQPs/s in one chunk,
-    // 26 800 in two, 27 100 in three, 23 100 in four -- the setup kernels of chunk c + 1 crawl beside a homotopy launch that saturates HBM
-    // (k_build_M of 512 instances: 12.8 ms instead of 1.3 ms; they keep few loads in flight and every one of them queues behind the
-    // streams), so the second homotopy launch starts late and the two end one after the other.
-    (void)h;
-    return 1;
-}
-
+// One launch for the whole batch.  (Round 5 measured the setup of one slice of the batch beside the homotopy of the slice before, as a
+// switch of this call: slower at every split -- profiles/round5/run_chunks_ab.log: 30 200 LCQPs/s in one piece, 26 800 / 27 100 / 23 100 in
+// two / three / four slices, the setup kernels crawl beside a homotopy launch that saturates HBM.  The switch is gone; overlap across
+// BATCHES is the product's BatchPipeline.)
 extern "C" int lcqp_hip_batch_run(lcqp_hip_batch_t* h)
 try {
     if (!h) return LCQP_LCQPOBJECT_NOT_SETUP;
     HIPCHK(hipSetDevice(h->device));
-    int K = h->runChunks > 0 ? h->runChunks : default_run_chunks(h);
-    if (K > h->db.B) K = h->db.B;
-    h->chunksUsed = K;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    if (K <= 1) {
-        int rc = launch_setup(h);   // the factorisations are part of runSolver's cost (initializeSolver :885)
-        if (rc) return rc;
-        HIPCHK(hipEventRecord(h->ev1, h->stream));
-        dispatch_db(h, ID_k_lcqp_run, h->db.B);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(h->ev2, h->stream));
-        h->ran = true;
-        return 0;
-    }
-    while ((int)h->chunkStream.size() < K - 1) { hipStream_t st; HIPCHK(hipStreamCreate(&st)); h->chunkStream.push_back(st); }
-    while ((int)h->chunkEv.size() < 4 * K) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->chunkEv.push_back(e); }
-    const int B = h->db.B;
-    for (int c = 0; c < K; c++) {
-        const int first = (int)((long long)B * c / K), count = (int)((long long)B * (c + 1) / K) - first;
-        const DevBatch v = batch_view(h->db, first, count);
-        hipStream_t on = c == 0 ? h->stream : h->chunkStream[c - 1];
-        hipEvent_t evSetup = h->chunkEv[4 * c], evRun = h->chunkEv[4 * c + 1], evFork = h->chunkEv[4 * c + 2], evJoin = h->chunkEv[4 * c + 3];
-        if (c > 0) {
-            HIPCHK(hipStreamWaitEvent(on, h->chunkEv[4 * (c - 1)], 0));      // behind the setup of the chunk before (and, through it, behind ev0 and everything queued on the batch's stream before this run)
-        }
-        int rc = launch_setup(h, &v, on, evFork, evJoin);
-        if (rc) return rc;
-        HIPCHK(hipEventRecord(evSetup, on));
-        if (c == 0) HIPCHK(hipEventRecord(h->ev1, h->stream));      // the part of the setup no homotopy runs beside
-        dispatch_db(h, ID_k_lcqp_run, count, nullptr, 0, 0, 0, on, &v);
-        HIPCHK(hipGetLastError());
-        if (c > 0) HIPCHK(hipEventRecord(evRun, on));
-    }
-    for (int c = 1; c < K; c++) HIPCHK(hipStreamWaitEvent(h->stream, h->chunkEv[4 * c + 1], 0));      // the batch's stream ends behind every chunk
+    int rc = launch_setup(h);   // the factorisations are part of runSolver's cost (initializeSolver :885)
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    dispatch_db(h, ID_k_lcqp_run, h->db.B);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev2, h->stream));
     h->ran = true;
     return 0;

@@ -246,6 +246,20 @@ __device__ __forceinline__ double wg_maxabs(const double* a, int n, Lds lds)
     return block_max(s, lds);
 }
 
+// max|a[0..na)| and max b[0..nb) (b >= 0) with one barrier pair
+__device__ __forceinline__ void wg_maxabs2(const double* a, const double* b, int na, int nb, double& ma, double& mb, Lds lds)
+{
+    double s = 0, u = 0;
+    for (int i = tid_here(); i < na; i += WG) { s = fmax(s, fabs(a[i])); if (i < nb) u = fmax(u, b[i]); }
+    s = wave_max(s); u = wave_max(u);
+    if (lane_id() == 0) { lds.red[wave_id()] = s; lds.red[4 + wave_id()] = u; }
+    __syncthreads();
+    const double ra = fmax(fmax(lds.red[0], lds.red[1]), fmax(lds.red[2], lds.red[3]));
+    const double rb = fmax(fmax(lds.red[4], lds.red[5]), fmax(lds.red[6], lds.red[7]));
+    __syncthreads();
+    ma = uniform_d(ra); mb = uniform_d(rb);
+}
+
 // cross-wave combine of per-lane accumulators acc[2*NCH] (lane l holds columns 128k+2l, +1):
 // out[c] = post(c, sum over waves).  Uses arena[0 .. 4*np).
 template <int NCH, class Post>

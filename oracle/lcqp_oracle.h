@@ -129,6 +129,7 @@ int orc_lcqp_solve(int nV, int nC, int nComp,
 void orc_lcqp_set_robust(int on);
 /* 1 (default): the QP solver sums E x in the device's order (64 lanes + butterfly); 0: left to right.  See dot_lanes in lcqp_oracle.c. */
 void orc_qp_set_sum_order(int device_order);
+void orc_qp_set_trace(int on);          /* diagnostic: one stderr line per round / trial of orc_qp_solve (the device prints the same in a -DLCQP_TRACE_QP build) */
 void orc_qp_set_enter_cap(int div);      /* cap on entering rows of a cold polish: max(n / div, 16) per trial; 0: off (test hook) */
 
 /* ---- synthetic instances (include/lcqp_synth.h) and a threaded batch driver for the CPU baseline ---- */

@@ -272,7 +272,7 @@ static void test_batch()
 static void test_pipeline()
 {   // LCQPow::BatchPipeline: two batch objects in flight; the slots' bookkeeping (ADVICE, round 4): acquire() twice without a launch in between
     // must not dereference an empty launch order, a slot handed out with results and not launched again is free again, a drained pipeline
-    // starts over with every slot free; a run in chunks gives the bits of a run in one piece
+    // starts over with every slot free; every run of the same instances gives the same bits
     const int B = 6, n = 64, nC = 96, nComp = 16;
     Options options; options.setPrintLevel(NONE); options.setPerturbStep(false);
     BatchPipeline pipe(2, B, n, nC, nComp);
@@ -286,7 +286,6 @@ static void test_pipeline()
     for (int step = 0; step < 5; step++) {
         BatchLCQProblem& b = pipe.acquire();
         if (pipe.hasResults()) { collected++; CHECK(b.getReturnValue(0) == SUCCESSFUL_RETURN); }
-        if (step == 3) CHECK(b.setRunChunks(3) == SUCCESSFUL_RETURN);      // one of the runs in three slices
         CHECK(pipe.launch(b) == SUCCESSFUL_RETURN); launched++;
     }
     while (BatchLCQProblem* b = pipe.drain()) {
@@ -294,7 +293,7 @@ static void test_pipeline()
         for (int i = 0; i < B; i++) CHECK(b->getReturnValue(i) == SUCCESSFUL_RETURN);
         b->getPrimalSolution(B - 1, x.data());
         if (collected == launched - 1) xref = x;
-        if (collected == launched) for (int k = 0; k < n; k++) CHECK(x[k] == xref[k]);      // same instances, one run in chunks: the same bits
+        if (collected == launched) for (int k = 0; k < n; k++) CHECK(x[k] == xref[k]);      // same instances, another slot: the same bits
     }
     CHECK(collected == launched);
     BatchLCQProblem& again = pipe.acquire();        // drained: every slot is free, nothing to wait for

@@ -138,6 +138,11 @@ def qp_set_sum_order(device_order):
     lib().orc_qp_set_sum_order(int(device_order))
 
 
+def qp_set_trace(on):
+    """one stderr line per round / trial of the oracle's QP solver (tools/fuzz_case.py --trace)"""
+    lib().orc_qp_set_trace(int(on))
+
+
 def qp_set_enter_cap(div):
     """cap on entering rows of a cold polish: max(n / div, 16) rows per trial (default 8, the device's value); 0 switches it off"""
     lib().orc_qp_set_enter_cap(int(div))

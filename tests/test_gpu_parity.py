@@ -388,29 +388,6 @@ def test_lcqp_synthetic_vs_oracle(hip, oracle, B, n, nC, nComp):
     bt.close()
 
 
-@pytest.mark.parametrize("chunks", [2, 3, 7])
-def test_lcqp_run_in_chunks_is_bitwise_the_same(hip, chunks):
-    """lcqp_hip_batch_set_run_chunks: a run that works through the batch in slices of consecutive instances (the setup of slice c + 1 beside
-    the homotopy of slice c, every kernel on a view of the batch) returns the bits of a run in one piece, trace and statistics included"""
-    B, n, nC, nComp = 13, 64, 96, 16
-    opt = hip.default_options(perturbStep=0, storeSteps=1)
-    res = []
-    for k in (1, chunks):
-        bt = hip.BatchLCQP(B, n, nC, nComp, opt=opt)
-        bt.generate_synthetic(0)
-        bt.set_run_chunks(k)
-        bt.run()
-        x, y, st = bt.solution()
-        assert bt.run_chunks() == k
-        res.append((x, y, st, [bt.trace(b) for b in (0, B // 2, B - 1)]))
-        bt.close()
-    (x1, y1, s1, t1), (x2, y2, s2, t2) = res
-    assert np.array_equal(x1, x2) and np.array_equal(y1, y2) and s1 == s2
-    for (a1, b1), (a2, b2) in zip(t1, t2):
-        assert np.array_equal(a1, a2) and np.array_equal(b1, b2)
-    assert all(s["returnValue"] == 0 for s in s1)
-
-
 def test_lcqp_synthetic_golden(hip):
     bt = hip.BatchLCQP(4, 256, 512, 64, opt=hip.default_options(perturbStep=0))
     bt.generate_synthetic(0)

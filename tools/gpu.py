@@ -514,7 +514,7 @@ def cmd_phase_profile():
     so = os.path.join(ROOT, "gpurun_out", "liblcqpow_hip_prof.so")
     os.makedirs(os.path.dirname(so), exist_ok=True)
     extra = [a for a in sys.argv[1:] if a.startswith("-D")]
-    pre = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--so=")]      # a prebuilt -DLCQP_PROFILE library (e.g. under ab_tmp/)
+    pre = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--so=")]      # a prebuilt -DLCQP_PROFILE library (e.g. under build/ab/)
     if pre:
         so = os.path.abspath(pre[0])
     elif not os.path.exists(so) or "--rebuild" in sys.argv:
@@ -704,8 +704,8 @@ def cmd_sparse_check():
 def cmd_sparse_profile():
     """Diagnostic: where does k_sparse_sched spend its time?  Runs a -DLCQP_PROFILE build of the library (s_memtime stamps between phases,
     per instance) on the sparse BASELINE workload and prints the share of each phase.  Shares only -- the stamped build is not the
-    measured build.   usage: python tools/gpu.py sparse_profile --so=ab_tmp/libprof.so [B]
-    (build the library first, here or on the box:  python -c "import __graft_entry__ as g; g.build_hip(True, 'ab_tmp/libprof.so', ['-DLCQP_PROFILE'], 2)")"""
+    measured build.   usage: python tools/gpu.py sparse_profile --so=build/ab/libprof.so [B]
+    (build the library first, here or on the box:  python -c "import __graft_entry__ as g; g.build_hip(True, 'build/ab/libprof.so', ['-DLCQP_PROFILE'], 2)")"""
     import ctypes as C, os, sys
     import numpy as np
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

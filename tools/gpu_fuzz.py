@@ -157,7 +157,19 @@ def run(count, seed, verbose=True, host=False):
     return cats, rets
 
 
+def source_stamp():
+    """first line of every fuzz log: the sources both sides were built from (kernel hash as in bench.py, sha256 of the oracle's C files)"""
+    import hashlib
+    import bench
+    h = hashlib.sha256()
+    for f in ("lcqp_oracle.c", "lcqp_oracle_sparse.c", "lcqp_oracle.h"):
+        with open(os.path.join(ROOT, "oracle", f), "rb") as fh:
+            h.update(fh.read())
+    return f"sources: kernels {bench.kernel_source_hash()} oracle {h.hexdigest()[:16]}"
+
+
 def main():
+    print(source_stamp(), flush=True)
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     mode = sys.argv[3] if len(sys.argv) > 3 else ""

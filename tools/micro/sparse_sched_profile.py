@@ -1,5 +1,5 @@
 """Where do the wavefronts of k_sparse_sched spend their time?  Needs a -DLCQP_SCHED_PROFILE build of the library:
-   python tools/build_variants.py schedprof:-DLCQP_SCHED_PROFILE ; python tools/micro/sparse_sched_profile.py ab_tmp/schedprof.so [B]"""
+   python tools/build_variants.py schedprof:-DLCQP_SCHED_PROFILE ; python tools/micro/sparse_sched_profile.py build/ab/schedprof.so [B]"""
 import ctypes as C, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
