@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--nC", type=int, default=None)
     ap.add_argument("--nComp", type=int, default=None)
-    ap.add_argument("--cpu-sample", type=int, default=64, help="CPU baseline: 8 x instances per worker of the steady-state run (64 = 8 per physical core; 0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=128, help="CPU baseline: 8 x instances per worker of the steady-state run (128 = 16 per worker; 0 = skip)")
     ap.add_argument("--no-backsolve", action="store_true", help="skip the standalone back-solve kernel measurement")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-batches-in-flight measurement")
     ap.add_argument("--no-resident", action="store_true", help="skip the 8192-resident-instances measurement")
@@ -256,15 +256,18 @@ def main():
         out["roofline"]["traffic_frac"] = tr / kernel_s / 1e9 / HBM_PEAK_GBS
     main_proc = (rank == 0)
 
+    errors = []      # objects of the line that failed: the line is still printed (the headline has been measured), the exit code is 1
+
     def extra(name, fn):
-        """an optional object of the line: whatever goes wrong in it (a device with less free memory, a host without the sysfs entries the
-        CPU placements read) is recorded in its place and never costs the headline that has been measured already"""
+        """an optional object of the line: a failure in it is recorded in its place AND in out["errors"], and the process exits non-zero
+        after printing the line -- a regression that breaks the pipeline, the sparse arm or the back-solve kernel must not look like a pass"""
         try:
             fn()
         except BaseException as e:      # (SystemExit of a failed load included)
             if isinstance(e, KeyboardInterrupt):
                 raise
             out[name] = {"error": f"{type(e).__name__}: {e}"}
+            errors.append(f"{name}: {type(e).__name__}: {e}")
 
     def extra_pipelined():
         # not the headline: the same K steps as a stream of batches through the product's pipeline (lcqpow_amd.BatchPipeline, the twin of
@@ -377,21 +380,23 @@ def main():
         try:
             big, _ = sparse_object(args.sparse_batch)
         except BaseException as e:
-            if isinstance(e, KeyboardInterrupt):
+            # only a device that cannot hold the 150 GB of the large batch gets the smaller one; anything else is a failure of this object
+            if isinstance(e, KeyboardInterrupt) or not any(w_ in str(e).lower() for w_ in ("out of memory", "outofmemory", "hipmalloc")):
                 raise
             big, _ = sparse_object(16384)
-            big["note"] = f"batch {args.sparse_batch} failed ({type(e).__name__}: {e}); 16384 instead"
+            big["note"] = f"batch {args.sparse_batch} does not fit ({type(e).__name__}: {e}); 16384 instead"
         big["batch_4096"] = {k_: small[k_] for k_ in ("value", "unit", "batch", "ms_per_step", "solved", "mean_lcqp_iterates", "roofline")}
         out["sparse_config5"] = big
         if args.cpu_sample > 0:
             try:
-                cb = sparse_cpu_baseline(xs_small, min(4096, max(args.cpu_sample, 32)))
+                cb = sparse_cpu_baseline(xs_small, min(4096, max(4 * args.cpu_sample, 32)))      # (512 instances: about a second on all cores)
                 cb["gpu_over_cpu"] = big["value"] / cb["value"]
                 big["cpu_baseline"] = cb
             except BaseException as e:
                 if isinstance(e, KeyboardInterrupt):
                     raise
                 big["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+                errors.append(f"sparse_config5.cpu_baseline: {type(e).__name__}: {e}")
 
     if main_proc and world == 1 and not sparse and not args.no_sparse and shape == (256, 512, 64) and B == 1024:
         extra("sparse_config5", extra_sparse)
@@ -419,6 +424,53 @@ def main():
     if main_proc and not sparse and not args.no_backsolve:
         extra("backsolve_kernel", extra_backsolve)
 
+    def extra_backsolve_in_situ():
+        # The back-solves of the PRODUCT path: wg_trsv with the constant factor L1 inside k_lcqp_run (the stand-alone k_backsolve above is a
+        # micro-benchmark the product never launches).  Bytes: the kernel's own count of triangular solves (work_sums[5]) x bytes_bs(N) / 2.
+        # Time: a -DLCQP_PROFILE build of the same sources (lcqpow_amd/liblcqpow_hip_prof.so, __graft_entry__.build_hip_profile) stamps the
+        # shader clock between the phases of every instance; the solves' share of all instance cycles, applied to the mean busy time of an
+        # instance in THIS (un-stamped) run, is the time the B concurrent instances spend in them.
+        import ctypes as C
+        import importlib.util
+        prof_so = os.path.join(ROOT, "lcqpow_amd", "liblcqpow_hip_prof.so")
+        if not os.path.exists(prof_so):
+            raise RuntimeError(f"{prof_so} is missing (python -c 'import __graft_entry__ as g; g.build()')")
+        spec = importlib.util.spec_from_file_location("capi_prof", os.path.join(ROOT, "lcqpow_amd", "capi.py"))
+        cp = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(cp)
+        cp._SO = prof_so
+        bp = cp.BatchLCQP(B, n, nC, nComp, device=devices[0], opt=cp.default_options(perturbStep=0, printLevel=0))
+        try:
+            bp.generate_synthetic(0)
+            bp.run(); bp.run(); bp.synchronize()
+            _, kms = bp.last_timing()
+            xp, _, _ = bp.solution()
+            prof = np.zeros((B, 16), dtype=np.uint64)
+            cp.lib().lcqp_hip_batch_read_profile.argtypes = [C.c_void_p, C.c_void_p]
+            cp._check(cp.lib().lcqp_hip_batch_read_profile(bp.h, prof.ctypes.data_as(C.c_void_p)), "read_profile")
+            wsp = bp.work_sums()
+        finally:
+            bp.close()
+        cyc = prof[:, :11].astype(float)
+        tot = cyc.sum(axis=1)
+        if not tot.all():
+            raise RuntimeError("the profile build returned empty counters")
+        share = float(cyc[:, 4].sum() / tot.sum())                      # bucket 4 = "corr: L1 trsv" (lcqp_dev.hpp: P_CORR_L1)
+        busy = float(tot.mean() / tot.max())                            # share of the launch an average instance is running
+        t_l1 = share * busy * solve_ms * 1e-3                           # seconds all B instances spend in the solves, side by side
+        bytes_l1 = float(wsp[5]) * 8.0 * n * (n + 2) / 2.0
+        gbs = bytes_l1 / t_l1 / 1e9
+        out["backsolve_in_situ"] = {"kernel": "wg_trsv(L1) inside k_lcqp_run", "triangular_solves_per_lcqp": float(wsp[5] / B),
+                                    "algorithmic_bytes_per_launch": bytes_l1, "share_of_instance_cycles": share, "mean_busy_share_of_launch": busy,
+                                    "ms_attributed": 1e3 * t_l1, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                    "profile_build_kernel_ms": kms, "bitwise_equal_to_product": bool(np.array_equal(xp, x)),
+                                    "note": "time = (share of the instances' stamped cycles spent in the L1 solves) x (mean busy share of the launch) x (this run's "
+                                            "k_lcqp_run time); the factor of an instance (0.5 MB) is re-read 118 times per LCQP, partly from the Infinity "
+                                            "Cache, so the figure is algorithmic bytes over time, not HBM traffic"}
+
+    if main_proc and world == 1 and not sparse and not args.no_backsolve and shape == (256, 512, 64):
+        extra("backsolve_in_situ", extra_backsolve_in_situ)
+
     def extra_cpu_baseline():
         import oracle_py as O
         threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -432,7 +484,7 @@ def main():
         # worker per hardware thread; the reference itself is single-threaded (one LCQProblem = one thread), so "all cores" means
         # independent instances side by side, as on the GPU
         phys, allc = O.host_cpu_topology()
-        per = max(1, args.cpu_sample // 8)                       # default 8 instances per worker
+        per = max(1, args.cpu_sample // 8)                       # default 16 instances per worker
         doms = O.l3_domains(phys)
         # worker placements: one and two workers per L3 domain (an instance's working set, ~15 MB, then stays in its L3), one per physical
         # core, one per hardware thread -- the baseline is the best of them
@@ -481,7 +533,11 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if main_proc:
+        if errors:
+            out["errors"] = errors
         print(json.dumps(out))
+        if errors:
+            sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -33,6 +33,7 @@ typedef struct {
      * matrix is quasi-definite). */
     int kb;
     double *U, *W, *S;   /* kb x N (U, then W), kb x kb */
+    double* Uf;          /* N x (w+1): the rows in upper form while band_factor runs (allocated once at setup, beside B) */
 } band_t;
 
 typedef struct {
@@ -80,7 +81,7 @@ static void band_factor(band_t* f)
      * s / d_j with the products (L[i][k] d_k) L[j][k] -- the same sums in another association.)  Result in f->B as before: L below the
      * diagonal (unit diagonal implied), D on it. */
     const int N = f->N, w = f->w, ld = w + 1;
-    double* U = (double*)malloc(sizeof(double) * (size_t)(N ? N : 1) * ld);
+    double* U = f->Uf;      /* workspace of the object: no allocation inside the timed CPU path (ADVICE, round 5) */
     for (int r = 0; r < N; r++)
         for (int k = 0; k <= w; k++) U[(size_t)r * ld + k] = (r + k < N) ? f->B[(size_t)(r + k) * ld + (w - k)] : 0.0;
     for (int j = 0; j < N; j++) {
@@ -94,7 +95,6 @@ static void band_factor(band_t* f)
         }
         f->B[(size_t)j * ld + w] = d;
     }
-    free(U);
 }
 static void band_solve(const band_t* f, double* b)
 {
@@ -198,7 +198,7 @@ static void kkt_solve(const band_t* f, double* b)
 /* ---- subsolver ---------------------------------------------------------------------------------------------------------- */
 static void sqp_free(sqp_t* q)
 {
-    free(q->iperm); free(q->l); free(q->u); free(q->rhov); free(q->Ka.B); free(q->Kp.B); free(q->Ka.U); free(q->Ka.W); free(q->Ka.S); free(q->Kp.U); free(q->Kp.W); free(q->Kp.S); free(q->stf); free(q->x); free(q->y);
+    free(q->iperm); free(q->l); free(q->u); free(q->rhov); free(q->Ka.B); free(q->Kp.B); free(q->Ka.Uf); free(q->Kp.Uf); free(q->Ka.U); free(q->Ka.W); free(q->Ka.S); free(q->Kp.U); free(q->Kp.W); free(q->Kp.S); free(q->stf); free(q->x); free(q->y);
     free(q->st); free(q->xa); free(q->ya); free(q->za); free(q->r1); free(q->ex); free(q->wN); free(q->r1_last); free(q->ex_last);
     free(q->g_last); free(q->newst);
 }
@@ -256,8 +256,10 @@ static int sqp_setup(sqp_t* q, const double* lbE, const double* ubE)
     const int kb = q->kb, Nb = N - kb;
     q->Ka.N = q->Kp.N = Nb; q->Ka.w = q->Kp.w = q->w; q->Ka.kb = q->Kp.kb = kb;
     q->Ka.B = dal((size_t)Nb * (q->w + 1)); q->Kp.B = dal((size_t)Nb * (q->w + 1));
+    q->Ka.Uf = dal((size_t)Nb * (q->w + 1)); q->Kp.Uf = dal((size_t)Nb * (q->w + 1));
     q->Ka.U = dal((size_t)kb * Nb); q->Ka.W = dal((size_t)kb * Nb); q->Ka.S = dal((size_t)kb * kb);
     q->Kp.U = dal((size_t)kb * Nb); q->Kp.W = dal((size_t)kb * Nb); q->Kp.S = dal((size_t)kb * kb);
+    if (!q->Ka.B || !q->Kp.B || !q->Ka.Uf || !q->Kp.Uf || !q->Ka.U || !q->Ka.W || !q->Ka.S || !q->Kp.U || !q->Kp.W || !q->Kp.S) { free(dd); return 3; }   /* out of memory: a setup failure, not a NULL dereference */
     kkt_assemble(q, &q->Ka, q->sigma, dd, NULL);
     kkt_factor(&q->Ka);
     free(dd);
@@ -489,7 +491,7 @@ int orc_sparse_lcqp_solve(int nV, int nC, int nComp,
         lE[nC + i] = lbL ? lbL[i] : 0.0; uE[nC + i] = ubL ? ubL[i] : INFINITY;
         lE[nC + nComp + i] = lbR ? lbR[i] : 0.0; uE[nC + nComp + i] = ubR ? ubR[i] : INFINITY;
     }
-    sqp_setup(q, lE, uE);
+    if (sqp_setup(q, lE, uE) != 0) { free(lE); free(uE); sqp_free(q); stats->qpSolverExitFlag = 3; stats->returnValue = ORC_SUBPROBLEM_SOLVER_ERROR; return ORC_SUBPROBLEM_SOLVER_ERROR; }   /* out of memory */
     double *xk = dal(n), *yk = dal(m), *pk = dal(n), *xnew = dal(n), *gk = dal(n), *gtil = dal(n), *gphi = dal(n), *statk = dal(n);
     double *Qxv = dal(n), *Cxv = dal(n), *Qpv = dal(n), *Cpv = dal(n), *lx = dal(m), *tmp = dal(n);
     const int hasPhi = (lbL != NULL) || (lbR != NULL);

@@ -268,3 +268,35 @@ def sparse_instance(inst, n=4096, nC=2048, nComp=512, seed0=SPARSE_SEED0, span=6
     Q = sp.csc_matrix((v["Qx"], Qp.indices, Qp.indptr), shape=Qp.shape)
     E = sp.csc_matrix((v["Ex"], Ep.indices, Ep.indptr), shape=Ep.shape)
     return dict(Q=Q, E=E, g=v["g"], lbA=v["lbA"], ubA=v["ubA"], nV=n, nC=nC, nComp=nComp)
+
+
+def lcqp_kkt_residuals(d, x, y, rho):
+    """Independent of every solver in this repository: the first-order conditions of the LCQP itself, evaluated with numpy from the
+    problem data, at a returned point (x, y) with y in the reference's layout [box (nV), A (nC), L (nComp), R (nComp)] AFTER transformDuals
+    (src/LCQProblem.cpp:1381-1409: y_L -= rho R x, y_R -= rho L x -- without the shift by lbR / lbL, which is added back here).
+    Returns (stationarity, primal infeasibility, complementarity |sum (Lx - lbL)(Rx - lbR)|, largest wrong-signed multiplier of an
+    inequality row of A or a box bound)."""
+    n, nC, nComp = d["nV"], d["nC"], d["nComp"]
+    Q, g, L, R = d["Q"], d["g"], d["L"], d["R"]
+    A = d.get("A") if d.get("A") is not None else np.zeros((0, n))
+    lbL = d.get("lbL") if d.get("lbL") is not None else np.zeros(nComp)
+    lbR = d.get("lbR") if d.get("lbR") is not None else np.zeros(nComp)
+    ubL = d.get("ubL") if d.get("ubL") is not None else np.full(nComp, INF)
+    ubR = d.get("ubR") if d.get("ubR") is not None else np.full(nComp, INF)
+    lbA = d.get("lbA") if d.get("lbA") is not None else np.full(nC, -INF)
+    ubA = d.get("ubA") if d.get("ubA") is not None else np.full(nC, INF)
+    lb = d.get("lb") if d.get("lb") is not None else np.full(n, -INF)
+    ub = d.get("ub") if d.get("ub") is not None else np.full(n, INF)
+    yB, yA, yL, yR = y[:n], y[n:n + nC], y[n + nC:n + nC + nComp], y[n + nC + nComp:]
+    stat = np.abs(Q @ x + g - A.T @ yA - L.T @ (yL + rho * lbR) - R.T @ (yR + rho * lbL) - yB).max()
+    Ax, Lx, Rx = A @ x, L @ x, R @ x
+    feas = max(np.maximum(lbA - Ax, Ax - ubA).max(initial=0.0), np.maximum(lb - x, x - ub).max(initial=0.0),
+               np.maximum(lbL - Lx, Lx - ubL).max(initial=0.0), np.maximum(lbR - Rx, Rx - ubR).max(initial=0.0), 0.0)
+    compl = abs(float((Lx - lbL) @ (Rx - lbR)))
+    sign = 0.0
+    for yy, v, lo, hi in ((yA, Ax, lbA, ubA), (yB, x, lb, ub)):
+        tol = 1e-7 * (1.0 + np.abs(v))
+        with np.errstate(invalid="ignore"):
+            at_lo = np.isfinite(lo) & (v - lo <= tol); at_hi = np.isfinite(hi) & (hi - v <= tol)
+        sign = max(sign, np.where(~at_lo, np.maximum(yy, 0.0), 0.0).max(initial=0.0), np.where(~at_hi, np.maximum(-yy, 0.0), 0.0).max(initial=0.0))
+    return float(stat), float(feas), compl, float(sign)

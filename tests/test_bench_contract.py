@@ -21,6 +21,11 @@ def test_bench_json_contract():
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["unit"] == "LCQPs/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    # no object of the line may hide a failure (bench.py exits non-zero and lists them under "errors" when one does)
+    assert "errors" not in d, d["errors"]
+    for k in ("pipelined", "backsolve_kernel", "cpu_baseline"):
+        assert k in d and "error" not in d[k], (k, d.get(k))
+    assert d["pipelined"]["bitwise_equal_to_sequential"] and d["backsolve_kernel"]["frac"] > 0
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["solved"] == 16
     assert d["config"]["max_lcqp_iterates"] >= d["config"]["mean_lcqp_iterates"] >= 1      # (a batch is as fast as its slowest instance: both are reported)
@@ -56,6 +61,7 @@ def test_bench_sparse_workload_line():
     assert d["unit"] == "LCQPs/s" and d["config"]["solved"] == 8 and "sparse" in d["config"]["workload"]
     assert d["config"]["max_lcqp_iterates"] >= d["config"]["mean_lcqp_iterates"] >= 1
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0 and d["roofline"]["traffic"] is None
+    assert "errors" not in d and "error" not in d["cpu_baseline"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["max_abs_dx_vs_gpu"] < 1e-8
 
 
@@ -130,3 +136,19 @@ def test_cpp_shards_on_one_device_equal_one_batch():
         assert "2048/2048 LCQPs solved" in line, line
         out[shards] = float(line.split("checksum")[1].split(",")[0].strip())
     assert abs(out[1] - out[2]) <= 1e-10 * abs(out[1]), out      # (the sum of 2048 x 256 solution entries, associated per shard)
+
+
+@pytest.mark.gpu
+def test_bench_in_situ_backsolve_object():
+    """the default workload's line carries the back-solves of the PRODUCT path (wg_trsv inside k_lcqp_run) beside the stand-alone kernel: bytes
+    counted by the kernel, time from the stamped build of the same sources, results of the stamped build bit-identical to the product's"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--no-pipelined",
+                        "--no-resident", "--no-sparse"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert "errors" not in d
+    b = d["backsolve_in_situ"]
+    assert "error" not in b and b["bitwise_equal_to_product"]
+    assert 50 < b["triangular_solves_per_lcqp"] < 400 and 0.02 < b["share_of_instance_cycles"] < 0.6 and 0.5 < b["mean_busy_share_of_launch"] <= 1.0
+    assert abs(b["algorithmic_bytes_per_launch"] - b["triangular_solves_per_lcqp"] * 1024 * 8 * 256 * 258 / 2) < 1e-6 * b["algorithmic_bytes_per_launch"]
+    assert b["frac"] > 0.1

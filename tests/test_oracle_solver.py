@@ -87,6 +87,41 @@ def test_golden_regression(oracle, name):
     assert np.abs(r["trace_scalars"][:, 2] - GOLD[name + "_trace"][:, 2]).max() == 0     # rho sequence
 
 
+GOLD_R4 = np.load(os.path.join(P.GOLDEN, "oracle_golden_round4.npz"))
+
+
+@pytest.mark.parametrize("name", ["warm_up", "warm_up_x0", "warm_up_w_A", "warm_up_binary", "circle", "example_data"])
+def test_golden_solutions_hold_independently(name):
+    """A drift shared by the oracle and the device cannot hide behind a regenerated fixture (ADVICE, round 5): (i) the committed golden
+    solutions satisfy the first-order conditions of the LCQP ITSELF, evaluated with numpy from the problem data -- stationarity of the
+    returned duals, feasibility, complementarity at the reference's tolerance, multiplier signs; (ii) they agree with the solutions
+    committed BEFORE the subsolver changes of rounds 5 and 6 (tests/golden/oracle_golden_round4.npz, from commit fe45f58): only statuses
+    and iterate counts may move, and on example_data the split of a multiplier among its duplicated rows (the sums are held)."""
+    d = getattr(P, name)()
+    x, y, st = GOLD[name + "_x"], GOLD[name + "_y"], GOLD[name + "_stats"]
+    stat, feas, compl, sign = P.lcqp_kkt_residuals(d, x, y, st[4])
+    assert stat < 1e-9 and feas < 1e-9 and compl < 1e3 * 2.221e-16 and sign < 1e-8, (stat, feas, compl, sign)
+    x4, y4, st4 = GOLD_R4[name + "_x"], GOLD_R4[name + "_y"], GOLD_R4[name + "_stats"]
+    assert st4[0] == st[0] == 0 and st4[4] == st[4]                   # return value and final penalty
+    assert np.abs(x - x4).max() < 1e-9
+    if name != "example_data":
+        assert np.abs(y - y4).max() < 1e-7
+    else:
+        n, nC, nComp = d["nV"], d["nC"], d["nComp"]
+        E = np.vstack([np.eye(n), d["A"], d["L"], d["R"]])              # the multipliers act through E'y: that product is what the QPs determine
+        assert np.abs(E.T @ (y - y4)).max() < 1e-7
+
+
+@pytest.mark.parametrize("inst,shape", [(i, s) for i in range(4) for s in ((64, 96, 16), (256, 512, 64))])
+def test_golden_synthetic_solutions_hold_independently(oracle, inst, shape):
+    n, nC, nComp = shape
+    d = oracle.synth_generate(inst, n, nC, nComp)
+    key = f"synth_{n}_{inst}"
+    stat, feas, compl, sign = P.lcqp_kkt_residuals(d, GOLD[key + "_x"], GOLD[key + "_y"], GOLD[key + "_stats"][4])
+    assert stat < 1e-9 and feas < 1e-9 and compl < 1e3 * 2.221e-16 and sign < 1e-8, (stat, feas, compl, sign)
+    assert np.array_equal(GOLD[key + "_x"], GOLD_R4[key + "_x"]) and np.array_equal(GOLD[key + "_y"], GOLD_R4[key + "_y"])      # bit for bit since round 4
+
+
 @pytest.mark.parametrize("n,m,seed", [(2, 2, 1), (20, 30, 2), (64, 100, 3), (128, 200, 7)])
 def test_qp_subsolver_kkt(oracle, n, m, seed):
     """The QP subsolver returns a KKT point (=> the unique minimiser of a strictly convex QP) in the
