@@ -8,5 +8,5 @@ package is only ctypes plumbing: :mod:`lcqpow_amd.capi` binds ``include/lcqp_hip
 ``OutputStatistics``, ``cscWrapper``, enums) over ``include/lcqp_host.h``.  Neither falls back to a CPU path:
 using them without the built libraries raises.
 """
-from .capi import (Options, Stats, BatchLCQP, BatchPipeline, SubsolverHIP, default_options, lib, library_path, request_hw_queues,  # noqa: F401
+from .capi import (Options, Stats, BatchLCQP, BatchPipeline, SubsolverHIP, default_options, lib, library_path, request_hw_queues, solve_mixed,  # noqa: F401
                    util_symv, util_gemv, util_gemv_t, util_symm_product, util_rows_list, chol_solve, device_count, CSCMatrix, SparseBatchLCQP)

@@ -193,6 +193,50 @@ class SubsolverHIP:
             pass
 
 
+def solve_mixed(problems, opt=None, device=0):
+    """A list of LCQPs of DIFFERENT shapes in one call: the Python twin of LCQPow::MixedBatchLCQProblem (lcqpow_amd/csrc/host/BatchLCQProblem.hpp).
+    problems: dicts with nV, nC, nComp, Q, g, L, R and optionally lbL, ubL, lbR, ubR, A, lbA, ubA, lb, ub, x0, y0 (the argument list of
+    LCQProblem::loadLCQP).  They are sorted into buckets of equal (nV, nC, nComp, box bounds or not), one BatchLCQP per bucket created for
+    exactly that shape -- every instance gets the bits of its solo run -- and bucket k + 1 is created, loaded and launched while bucket k
+    runs.  Within a bucket instances may differ in which optional arguments they carry.  Returns one dict per problem, in input order:
+    ret (the reference's ReturnValue), x, y, stats."""
+    keys = ("lbL", "ubL", "lbR", "ubR", "A", "lbA", "ubA", "lb", "ub", "x0", "y0")
+    buckets = {}
+    for i, d in enumerate(problems):
+        box = d.get("lb") is not None or d.get("ub") is not None
+        buckets.setdefault((d["nV"], d["nC"], d["nComp"], box), []).append(i)
+    out = [None] * len(problems)
+
+    def collect(bt, members):
+        x, y, st = bt.solution()
+        for s_, i in enumerate(members):
+            out[i] = dict(ret=st[s_]["returnValue"], x=x[s_], y=y[s_], stats=st[s_])
+        bt.close()
+
+    flying = None
+    for (nV, nC, nComp, box), members in buckets.items():
+        bt = BatchLCQP(len(members), nV, nC, nComp, with_box=box, device=device, opt=opt)
+        failed = False
+        for s_, i in enumerate(members):
+            d = problems[i]
+            rc = bt.load(s_, 1, d["Q"], d["g"], d["L"], d["R"], **{k: d.get(k) for k in keys})
+            if rc != 0:      # as LCQProblem::loadLCQP: the code is the problem's result, the others of the bucket are not run with a hole among them
+                for j in members:
+                    out[j] = dict(ret=int(rc) if j == i else 300, x=None, y=None, stats=None)
+                failed = True
+                break
+        if failed:
+            bt.close()
+            continue
+        bt.run()                       # asynchronous on the bucket's own stream
+        if flying is not None:
+            collect(*flying)           # the bucket before ran while this one was created and loaded
+        flying = (bt, members)
+    if flying is not None:
+        collect(*flying)
+    return out
+
+
 class BatchPipeline:
     """A stream of batches over `depth` BatchLCQP objects (each has its own HIP stream; run() only launches): the host-side twin of
     LCQPow::BatchPipeline (lcqpow_amd/csrc/host/BatchLCQProblem.hpp, DESIGN.md section 8a).  acquire() hands out the object to fill next --

@@ -133,5 +133,93 @@ class BatchPipeline {
     ReturnValue lastRc = SUCCESSFUL_RETURN;
 };
 
+// A list of LCQPs of DIFFERENT shapes solved in one call (round 6).  The reference is one object per problem, any mix of sizes
+// (include/LCQProblem.hpp:56-60, 87-144); the device kernels take one shape per batch object, so the problems are sorted into buckets of equal
+// (nV, nC, nComp, box bounds or not) -- one BatchLCQProblem per bucket, created for exactly that shape, so that every instance gets the bits of
+// its solo run -- and the buckets go through the device two at a time: bucket k + 1 is created, loaded and launched while bucket k runs
+// (each batch object has its own HIP stream).  Within a bucket instances may differ in everything the reference lets differ per problem:
+// lbL / lbR / ubL / ubR, lbA / ubA, lb / ub, x0, y0 given or not.
+// Usage:   MixedBatchLCQProblem mixed;  mixed.setOptions(opt);
+//          int i = mixed.addProblem(nV, nC, nComp, Q, g, L, R, ...);      // argument list of LCQProblem::loadLCQP; pointers are borrowed until runSolver returns
+//          mixed.runSolver();  mixed.getPrimalSolution(i, x);  mixed.getReturnValue(i);
+class MixedBatchLCQProblem {
+  public:
+    explicit MixedBatchLCQProblem(int device = 0) : device_(device), haveOptions(false) {}
+    ReturnValue setOptions(const Options& o) { options = o; haveOptions = true; return SUCCESSFUL_RETURN; }
+    int addProblem(int nV, int nC, int nComp, const double* Q, const double* g, const double* L, const double* R,
+                   const double* lbL = 0, const double* ubL = 0, const double* lbR = 0, const double* ubR = 0,
+                   const double* A = 0, const double* lbA = 0, const double* ubA = 0, const double* lb = 0,
+                   const double* ub = 0, const double* x0 = 0, const double* y0 = 0)
+    {
+        Problem p = {nV, nC, nComp, Q, g, L, R, lbL, ubL, lbR, ubR, A, lbA, ubA, lb, ub, x0, y0, -1, -1};
+        problems.push_back(p);
+        return (int)problems.size() - 1;
+    }
+    int size() const { return (int)problems.size(); }
+    int numberOfBuckets() const { return (int)buckets.size(); }
+    // runSolver for every problem; the return value is that of the first call that failed to LOAD or LAUNCH (per-problem results: getReturnValue)
+    ReturnValue runSolver()
+    {
+        for (size_t k = 0; k < buckets.size(); ++k) delete buckets[k].batch;
+        buckets.clear();
+        for (size_t i = 0; i < problems.size(); ++i) {
+            Problem& p = problems[i];
+            const bool box = p.lb || p.ub;
+            size_t k = 0;
+            for (; k < buckets.size(); ++k) if (buckets[k].nV == p.nV && buckets[k].nC == p.nC && buckets[k].nComp == p.nComp && buckets[k].box == box) break;
+            if (k == buckets.size()) { Bucket b = {p.nV, p.nC, p.nComp, box, std::vector<int>(), 0}; buckets.push_back(b); }
+            p.bucket = (int)k; p.slot = (int)buckets[k].members.size();
+            buckets[k].members.push_back((int)i);
+        }
+        ReturnValue first = SUCCESSFUL_RETURN;
+        int inFlight = -1;
+        for (size_t k = 0; k < buckets.size(); ++k) {
+            Bucket& b = buckets[k];
+            b.batch = new BatchLCQProblem((int)b.members.size(), b.nV, b.nC, b.nComp, b.box, device_);
+            ReturnValue rc = b.batch->ok() ? SUCCESSFUL_RETURN : LCQPOBJECT_NOT_SETUP;
+            if (rc == SUCCESSFUL_RETURN && haveOptions) rc = b.batch->setOptions(options);
+            for (size_t s = 0; s < b.members.size() && rc == SUCCESSFUL_RETURN; ++s) {
+                const Problem& p = problems[b.members[s]];
+                rc = b.batch->loadLCQP((int)s, p.Q, p.g, p.L, p.R, p.lbL, p.ubL, p.lbR, p.ubR, p.A, p.lbA, p.ubA, p.lb, p.ub, p.x0, p.y0);
+            }
+            if (rc == SUCCESSFUL_RETURN) rc = b.batch->runSolverAsync();
+            if (rc != SUCCESSFUL_RETURN) { if (first == SUCCESSFUL_RETURN) first = rc; delete b.batch; b.batch = 0; }
+            // the bucket launched before this one is collected now: its kernels ran while this one was created and loaded
+            if (inFlight >= 0) { const ReturnValue rcC = buckets[inFlight].batch->collect(); if (rcC != SUCCESSFUL_RETURN && first == SUCCESSFUL_RETURN) first = rcC; }
+            inFlight = b.batch ? (int)k : -1;
+        }
+        if (inFlight >= 0) { const ReturnValue rcC = buckets[inFlight].batch->collect(); if (rcC != SUCCESSFUL_RETURN && first == SUCCESSFUL_RETURN) first = rcC; }
+        return first;
+    }
+    ~MixedBatchLCQProblem() { for (size_t k = 0; k < buckets.size(); ++k) delete buckets[k].batch; }
+    MixedBatchLCQProblem(const MixedBatchLCQProblem&) = delete;
+    MixedBatchLCQProblem& operator=(const MixedBatchLCQProblem&) = delete;
+
+    ReturnValue getReturnValue(int i) const { const BatchLCQProblem* b = batchOf(i); return b ? b->getReturnValue(problems[i].slot) : LCQPOBJECT_NOT_SETUP; }
+    AlgorithmStatus getPrimalSolution(int i, double* xOpt) const { return batchOf(i)->getPrimalSolution(problems[i].slot, xOpt); }
+    AlgorithmStatus getDualSolution(int i, double* yOpt) const { return batchOf(i)->getDualSolution(problems[i].slot, yOpt); }
+    const lcqp_stats_t& getStats(int i) const { return batchOf(i)->getStats(problems[i].slot); }
+    int getNumberOfPrimals(int i) const { return problems[i].nV; }
+    int getNumberOfDuals(int i) const { return problems[i].nV + problems[i].nC + 2 * problems[i].nComp; }
+
+  private:
+    struct Problem {
+        int nV, nC, nComp;
+        const double *Q, *g, *L, *R, *lbL, *ubL, *lbR, *ubR, *A, *lbA, *ubA, *lb, *ub, *x0, *y0;
+        int bucket, slot;
+    };
+    struct Bucket { int nV, nC, nComp; bool box; std::vector<int> members; BatchLCQProblem* batch; };
+    const BatchLCQProblem* batchOf(int i) const
+    {
+        if (i < 0 || i >= (int)problems.size() || problems[i].bucket < 0 || problems[i].bucket >= (int)buckets.size()) return 0;
+        return buckets[problems[i].bucket].batch;
+    }
+    int device_;
+    bool haveOptions;
+    Options options;
+    std::vector<Problem> problems;
+    std::vector<Bucket> buckets;
+};
+
 }  // namespace LCQPow
 #endif

@@ -341,10 +341,13 @@ try {
     if (!L || !R) return LCQP_INVALID_COMPLEMENTARITY_MATRIX;        // :611-612
     if ((lb || ub) && d.boxcap == 0) { g_err = "batch was created without box-bound capacity"; return LCQP_INVALID_ARGUMENT; }
     HIPCHK(hipSetDevice(h->device));
-    // a batch mixes instances: keep one setting of "lbL/lbR given" per batch (phi expressions :969-996)
+    // A batch may mix instances with and without lbL / lbR (round 6): an absent bound vector is the zero vector (setComplementarityBounds
+    // :726-785), and the phi expressions of :969-996 with zeros -- phi_const = 0, g_phi = 0, g_tilde = g + rho 0 -- are the arithmetic of an
+    // instance loaded without them, bit for bit.  The batch-wide flag only says whether ANY instance carries bounds, i.e. whether the
+    // kernels read the (zero-filled) arrays at all; a (re)load starting at instance 0, or the first load of the object, starts it over.
     const int hasL = lbL ? 1 : 0, hasR = lbR ? 1 : 0;
-    if (!h->anyLoaded || first == 0) { d.hasLbL = hasL; d.hasLbR = hasR; h->anyLoaded = true; }   // a (re)load starting at instance 0 or the first load of the object decides
-    else if (d.hasLbL != hasL || d.hasLbR != hasR) { g_err = "lbL/lbR must be given for all instances of a batch or for none"; return LCQP_INVALID_ARGUMENT; }
+    if (!h->anyLoaded || first == 0) { d.hasLbL = hasL; d.hasLbR = hasR; h->anyLoaded = true; }
+    else { d.hasLbL |= hasL; d.hasLbR |= hasR; }
     // pinned staging: [Qp | Ep | nvb | mvb | ybuf | lbuf | rbuf | info | bidx]
     const size_t nQ = (size_t)np * np, nE = (size_t)mE * np, nNV = (size_t)V_NUM * np, nMV = (size_t)M_NUM * mE;
     const size_t nY = (size_t)d.nd, nLR = (size_t)(nComp ? nComp : 1);

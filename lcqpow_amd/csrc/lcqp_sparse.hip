@@ -2252,8 +2252,9 @@ try {
     if (!g) return LCQP_INVALID_OBJECTIVE_LINEAR_TERM;
     SPCHK(hipSetDevice(h->device));
     const int hasL = lbL ? 1 : 0, hasR = lbR ? 1 : 0;
+    // instances with and without lbL / lbR may share a batch: an absent vector is the zero vector, the same arithmetic (lcqp_hip_batch_load)
     if (!h->loaded || first == 0) { d.hasLbL = hasL; d.hasLbR = hasR; }
-    else if (d.hasLbL != hasL || d.hasLbR != hasR) { g_sp_err = "lbL/lbR must be given for all instances of a batch or for none"; return LCQP_INVALID_ARGUMENT; }
+    else { d.hasLbL |= hasL; d.hasLbR |= hasR; }
     std::vector<double> ex(d.nnzE), nvb((size_t)NV_NUM * n), mvb((size_t)MV_NUM * m), lb(nK), rb(nK);
     for (int k = 0; k < count; k++) {
         const size_t b = (size_t)first + k;

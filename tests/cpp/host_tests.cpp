@@ -269,6 +269,60 @@ static void test_batch()
     }
 }
 
+static void test_mixed_batch()
+{   // LCQPow::MixedBatchLCQProblem: problems of three shapes, some with shifted complementarity bounds, in one call; every instance equals its solo
+    // run through a batch of one (the bits: same kernels, same shape)
+    const int shapes[3][3] = {{10, 4, 3}, {33, 12, 6}, {64, 0, 16}};
+    std::vector<std::vector<double> > store;
+    struct Ref { int nV, nC, nComp; const double *Q, *g, *L, *R, *lbL, *lbR, *A, *lbA, *ubA; };
+    std::vector<Ref> refs;
+    unsigned long long state = 0x1234567ULL;
+    auto rnd = [&]() { state = state * 6364136223846793005ULL + 1442695040888963407ULL; return (double)((state >> 11) & ((1ULL << 53) - 1)) / (double)(1ULL << 53); };
+    for (int rep = 0; rep < 2; rep++)
+        for (int s = 0; s < 3; s++) {
+            const int n = shapes[s][0], nC = shapes[s][1], nK = shapes[s][2];
+            std::vector<double> Q((size_t)n * n, 0.0), g(n), L((size_t)nK * n, 0.0), R((size_t)nK * n, 0.0), A((size_t)nC * n), lbA(nC), ubA(nC), lbL(nK), lbR(nK);
+            for (int i = 0; i < n; i++) { Q[(size_t)i * n + i] = 1.0 + rnd(); g[i] = 2.0 * rnd() - 1.0; }
+            for (int i = 0; i + 1 < n; i++) { const double v = 0.2 * rnd(); Q[(size_t)i * n + i + 1] = v; Q[(size_t)(i + 1) * n + i] = v; }
+            for (int i = 0; i < nK; i++) { L[(size_t)i * n + i] = 1.0; R[(size_t)i * n + nK + i] = 1.0; lbL[i] = -0.1 * rnd(); lbR[i] = -0.1 * rnd(); }
+            for (int r = 0; r < nC; r++) { for (int k = 0; k < n; k++) A[(size_t)r * n + k] = (2.0 * rnd() - 1.0) / 4.0; lbA[r] = -1.0 - rnd(); ubA[r] = 1.0 + rnd(); }
+            const size_t b0 = store.size();
+            store.push_back(Q); store.push_back(g); store.push_back(L); store.push_back(R); store.push_back(lbL); store.push_back(lbR); store.push_back(A); store.push_back(lbA); store.push_back(ubA);
+            (void)b0;
+        }
+    for (size_t p = 0; p < store.size() / 9; p++) {
+        const int s = (int)(p % 3);
+        const std::vector<double>* v = &store[9 * p];
+        const bool shifted = (p >= 3);      // the second repetition carries lbL / lbR, the first does not: mixed within every bucket
+        Ref r = {shapes[s][0], shapes[s][1], shapes[s][2], v[0].data(), v[1].data(), v[2].data(), v[3].data(), shifted ? v[4].data() : 0, shifted ? v[5].data() : 0,
+                 shapes[s][1] ? v[6].data() : 0, shapes[s][1] ? v[7].data() : 0, shapes[s][1] ? v[8].data() : 0};
+        refs.push_back(r);
+    }
+    Options options; options.setPrintLevel(NONE); options.setPerturbStep(false);
+    MixedBatchLCQProblem mixed;
+    CHECK(mixed.setOptions(options) == SUCCESSFUL_RETURN);
+    for (size_t p = 0; p < refs.size(); p++) {
+        const Ref& r = refs[p];
+        CHECK(mixed.addProblem(r.nV, r.nC, r.nComp, r.Q, r.g, r.L, r.R, r.lbL, 0, r.lbR, 0, r.A, r.lbA, r.ubA) == (int)p);
+    }
+    CHECK(mixed.runSolver() == SUCCESSFUL_RETURN);
+    CHECK(mixed.numberOfBuckets() == 3 && mixed.size() == 6);
+    for (size_t p = 0; p < refs.size(); p++) {
+        const Ref& r = refs[p];
+        BatchLCQProblem solo(1, r.nV, r.nC, r.nComp);
+        CHECK(solo.ok() && solo.setOptions(options) == SUCCESSFUL_RETURN);
+        CHECK(solo.loadLCQP(0, r.Q, r.g, r.L, r.R, r.lbL, 0, r.lbR, 0, r.A, r.lbA, r.ubA) == SUCCESSFUL_RETURN);
+        CHECK(solo.runSolver() == SUCCESSFUL_RETURN);
+        CHECK(mixed.getReturnValue((int)p) == SUCCESSFUL_RETURN && solo.getReturnValue(0) == SUCCESSFUL_RETURN);
+        std::vector<double> xm(r.nV), xs(r.nV), ym(mixed.getNumberOfDuals((int)p)), ys(ym.size());
+        CHECK(mixed.getPrimalSolution((int)p, xm.data()) == solo.getPrimalSolution(0, xs.data()));
+        mixed.getDualSolution((int)p, ym.data()); solo.getDualSolution(0, ys.data());
+        for (int k = 0; k < r.nV; k++) CHECK(xm[k] == xs[k]);
+        for (size_t k = 0; k < ym.size(); k++) CHECK(ym[k] == ys[k]);
+        CHECK(mixed.getStats((int)p).iterTotal == solo.getStats(0).iterTotal);
+    }
+}
+
 static void test_pipeline()
 {   // LCQPow::BatchPipeline: two batch objects in flight; the slots' bookkeeping (ADVICE, round 4): acquire() twice without a launch in between
     // must not dereference an empty launch order, a slot handed out with results and not launched again is free again, a drained pipeline
@@ -337,6 +391,7 @@ int main(int argc, char** argv)
         test_loops_agree();
         test_batch();
         test_pipeline();
+        test_mixed_batch();
     }
     std::printf(failures ? "FAILED (%d)\n" : "ALL PASSED%.0d\n", failures);
     return failures ? 1 : 0;

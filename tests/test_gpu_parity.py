@@ -589,6 +589,47 @@ def test_lcqp_shape_sweep(hip, oracle, n, nC, nComp):
     bt.close()
 
 
+def test_mixed_shapes_and_bounds_in_one_call(hip):
+    """The reference is one object per problem, any mix of sizes and of optional arguments (include/LCQProblem.hpp:56-60, 87-144).  One call of
+    lcqpow_amd.solve_mixed (C++: LCQPow::MixedBatchLCQProblem) takes problems of three shapes, with and without lbL / lbR, box bounds, A and
+    x0, in shuffled order: every instance returns the bits of its solo run.  (Until round 6 a batch refused to mix instances with and without
+    lbL / lbR; an absent vector is the zero vector -- setComplementarityBounds :726-785 -- and the same arithmetic.)"""
+    rng = np.random.default_rng(7)
+    probs = []
+    for n, nC, nComp in ((12, 5, 3), (40, 20, 8), (70, 0, 16)):
+        for variant in range(4):
+            M = rng.uniform(-1, 1, (n, n)); Q = M.T @ M / n + np.eye(n)
+            g = rng.uniform(-1, 1, n)
+            L = np.zeros((nComp, n)); R = np.zeros((nComp, n))
+            for i in range(nComp):
+                L[i, i] = 1.0; R[i, nComp + i] = 1.0
+            xs = rng.uniform(0.2, 1, n); xs[nComp:2 * nComp] = 0.0
+            d = dict(Q=Q, g=g, L=L, R=R, nV=n, nC=nC, nComp=nComp)
+            if nC:
+                A = rng.uniform(-1, 1, (nC, n)) / np.sqrt(n)
+                d.update(A=A, lbA=A @ xs - rng.uniform(0.1, 1, nC), ubA=A @ xs + rng.uniform(0.1, 1, nC))
+            if variant & 1:      # shifted complementarity bounds on some instances of a bucket only
+                d.update(lbL=rng.uniform(-0.2, 0.0, nComp), lbR=rng.uniform(-0.2, 0.0, nComp))
+            if variant & 2:      # box bounds: another bucket of the same (nV, nC, nComp)
+                d.update(lb=xs - 2.0, ub=np.where(rng.random(n) < 0.5, xs + 2.0, np.inf))
+            if variant == 3:
+                d.update(x0=rng.uniform(-0.1, 0.1, n))
+            probs.append(d)
+    order = rng.permutation(len(probs))
+    mixed = [probs[i] for i in order]
+    opt = hip.default_options(perturbStep=0)
+    res = hip.solve_mixed(mixed, opt=opt)
+    assert len(res) == len(mixed)
+    nbuckets = len({(d["nV"], d["nC"], d["nComp"], "lb" in d) for d in mixed})
+    assert nbuckets == 6
+    for d, r in zip(mixed, res):
+        solo = P.hip_solve(hip, d, opt)
+        assert r["ret"] == solo["ret"] == 0, (d["nV"], r["ret"], solo["ret"])
+        assert np.array_equal(r["x"], solo["x"]) and np.array_equal(r["y"], solo["y"]) and r["stats"] == solo["stats"]
+        stat, feas, compl, sign = P.lcqp_kkt_residuals(d, r["x"], r["y"], r["stats"]["rhoOpt"])
+        assert stat < 1e-8 and feas < 1e-8 and compl < 1e-9, (stat, feas, compl)
+
+
 def _fuzz_module():
     import importlib.util
     spec = importlib.util.spec_from_file_location("gpu_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_fuzz.py"))
