@@ -219,6 +219,7 @@ const char* lcqp_hip_sparse_last_error(void);
 int  lcqp_hip_sparse_sched_profile(lcqp_hip_sparse_t* s, unsigned long long* out21);
 int  lcqp_hip_sparse_bandwidth(const lcqp_hip_sparse_t* s);              /* half bandwidth of the KKT band */
 int  lcqp_hip_sparse_lanes(const lcqp_hip_sparse_t* s);                  /* lanes of a wavefront per instance: 8, 16, 32 or 64 */
+int  lcqp_hip_sparse_fronts(const lcqp_hip_sparse_t* s);                 /* fronts of the general sparse LDL' (a pattern that is neither banded nor bordered: nested dissection, dense fronts, a wavefront per instance); 0: a band engine */
 int  lcqp_hip_sparse_border(const lcqp_hip_sparse_t* s);                 /* border nodes of the bordered band: the last positions of the ordering (0: plain band) */
 /* perm[nV + nC + 2 nComp]: position -> node.  Two orderings of the band are prepared (the second, for Hessians that are safely definite by
  * their diagonals, puts every row behind one of its variables); this is the one the instances loaded so far select (before any load: the first) */

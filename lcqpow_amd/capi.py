@@ -476,6 +476,7 @@ class SparseBatchLCQP:
         L.lcqp_hip_sparse_bandwidth.argtypes = [C.c_void_p]
         L.lcqp_hip_sparse_lanes.argtypes = [C.c_void_p]
         L.lcqp_hip_sparse_border.argtypes = [C.c_void_p]
+        L.lcqp_hip_sparse_fronts.argtypes = [C.c_void_p]
         L.lcqp_hip_sparse_get_ordering.argtypes = [C.c_void_p, ip]
         L.lcqp_hip_sparse_set_options.argtypes = [C.c_void_p, C.POINTER(Options)]
         L.lcqp_hip_sparse_load.argtypes = [C.c_void_p, C.c_int, C.c_int] + [c_double_p] * 11
@@ -513,6 +514,10 @@ class SparseBatchLCQP:
     def border(self):
         """border nodes of the bordered band: the last positions of ordering() (0: plain band)"""
         return lib().lcqp_hip_sparse_border(self.h)
+
+    def fronts(self):
+        """fronts of the general sparse LDL' (0: one of the band engines runs this pattern)"""
+        return lib().lcqp_hip_sparse_fronts(self.h)
 
     def ordering(self):
         perm = np.zeros(self.nV + self.m, dtype=np.int32)

@@ -19,6 +19,7 @@
 // dense kernels behind the same OSQP_SPARSE surface.
 #include "lcqp_wg.hpp"
 #include "../../include/lcqp_hip.h"
+#include "lcqp_sparse_general.hpp"
 
 #include <algorithm>
 #include <climits>
@@ -137,6 +138,15 @@ struct SpBatch {
     int* qctl;                  // [nPools][PH_NUM + 1][QCTL]
     int poolSize, nPools;
     int wideDiv;                // SIMDs of the device per pool (sp_launch): unfinished instances of the pool / wideDiv = instances of a streaming step
+    // General sparse LDL' (round 6; lcqp_sparse_general.hpp): patterns that are neither banded nor bordered -- multifrontal over a nested-
+    // dissection tree with dense fronts, one wavefront per instance (G = 64).  general != 0: KaF / KpF hold the panels of the fronts
+    // (gLsize doubles per instance instead of Np * G), KaD / KpD 1 / D per position as for the band; kb = 0, lightOK = 0.
+    int general, gnF, gMaxFront;
+    unsigned gLsize, gStackSize;
+    const int *gPiv0, *gNp, *gNb, *gRowPtr, *gRows, *gChildPtr, *gChild, *gRel, *gAsmPtr, *gAsmSrc, *gAsmGate, *gAsmPos;
+    const unsigned *gLoff, *gCBoff;
+    double *gStack, *gFront;     // [B][gStackSize] update blocks of the fronts, [B][gMaxFront^2] a front too large for LDS
+    size_t kfStride;             // doubles per instance of KaF / KpF
     // algorithmic bytes of one event of each kind (filled by the host: formed in the kernel they are loop invariants the compiler keeps in
     // registers across every phase)
     double by[BY_NUM];
@@ -194,7 +204,9 @@ struct SpCtx {
     __device__ __forceinline__ GD Ex() const { return arr(db->Ex, db->nnzE); }
     __device__ __forceinline__ GD Nv() const { return arr(db->Nv, (size_t)2 * db->Np); }
     __device__ __forceinline__ GD Kb() const { return arr(db->Kb, (size_t)db->N * db->ld); }
-    __device__ __forceinline__ GD KF(bool admm) const { return arr(admm ? db->KaF : db->KpF, (size_t)db->Np * G); }
+    __device__ __forceinline__ GD KF(bool admm) const { return arr(admm ? db->KaF : db->KpF, db->kfStride); }
+    __device__ __forceinline__ GD GStack() const { return arr(db->gStack, db->gStackSize); }
+    __device__ __forceinline__ GD GFront() const { return arr(db->gFront, (size_t)db->gMaxFront * db->gMaxFront); }
     __device__ __forceinline__ GD KD(bool admm) const { return arr(admm ? db->KaD : db->KpD, db->Np); }
     __device__ __forceinline__ GD K0() const { return arr(db->K0, (size_t)db->Np * G); }
     __device__ __forceinline__ GD BW(bool admm) const { return arr(db->bW, (size_t)2 * db->kb * db->Np, (unsigned)(admm ? db->kb * db->Np : 0)); }
@@ -687,9 +699,188 @@ __device__ __forceinline__ void sp_factor_reg(SpCtx<G>& c, GD KF, GD Kd, double 
     SPROF(c, SP_FACTOR);
 }
 // the band part of the KKT matrix [Q + dprim I, E_use'; E_use, -diag(ddual)] factorised: assembled on the fly (G <= 16) or through the band array
+// ---- general sparse LDL' (round 6): multifrontal over the dissection tree, one wavefront per instance ------------------------------------
+// Symbolic side: lcqp_sparse_general.hpp (fronts in postorder: pivots = a leaf region or a separator, update rows = the boundary of the
+// region the front closes; assembly lists; positions of a child's update rows in its parent's front; storage offsets).  CPU restatement of
+// the loops below, checked against a dense solve: tests/cpp/general_ldl_test.cpp.  The reference's OSQP arm factorises the same matrix
+// with QDLDL whatever the pattern (src/SubsolverOSQP.cpp:136-152).
+// A front F (ff x ff, column-major, lower triangle used) lives in LDS when ff <= 64, else in the instance's front buffer; its pivots go
+// in blocks of GEN_JB: the block's columns (the panel, rows below included) are staged in LDS, eliminated there, stored scaled into the
+// factor's panel storage, and applied to the rest of the front as ONE rank-GEN_JB update -- GEN_JB fused multiply-adds per entry read and
+// written.  No pivoting: K is quasi-definite for delta, delta2 > 0, and every symmetric permutation of a quasi-definite matrix factorises.
+constexpr int GEN_JB = 8;
+constexpr int GEN_LDS_FRONT = 64;        // fronts up to this size are factorised inside LDS
+constexpr int GEN_MAX_FRONT = 576;       // panel of the largest front: 576 x 8 doubles beside nothing else in the 40 KB of a wavefront
+
+template <bool LDSF, class FA, class Dd, class Use>
+__device__ __forceinline__ void sp_general_front(SpCtx<64>& c, int f, FA F, double* P, GD Lst, GD Kd, GD stack, double dprim, Dd ddual, Use use)
+{
+    const SpBatch& db = *c.db;
+    const int t = here(c.gl), n = db.n, nnzQ = db.nnzQ;
+    const int np = db.gNp[f], nb = db.gNb[f], ff = np + nb, piv0 = db.gPiv0[f];
+    auto sync = [&]() { if (LDSF) wave_sync(); else g_sync(); };
+    for (int e = t; e < ff * ff; e += 64) F[e] = 0.0;
+    sync();
+    {   // the entries of K whose column is a pivot of this front (one entry of Q or E each: distinct positions); rows of E gated by value
+        GD Qv = c.Qx(), Ev = c.Ex();
+        const int e1 = db.gAsmPtr[f + 1];
+        for (int e = db.gAsmPtr[f] + t; e < e1; e += 64) {
+            const int src = db.gAsmSrc[e], gate = db.gAsmGate[e];
+            const double v = (gate >= 0 && !use(gate)) ? 0.0 : (src >= nnzQ ? (double)Ev[src - nnzQ] : (double)Qv[src]);
+            F[db.gAsmPos[e]] = v;
+        }
+    }
+    sync();
+    for (int j = t; j < np; j += 64) {      // diagonals: Q_ii + dprim; -ddual for an active row, -1 for a decoupled one
+        const int node = db.pnode[piv0 + j];
+        if (node < n) F[j + ff * j] += dprim;
+        else F[j + ff * j] = use(node - n) ? -ddual(node - n) : -1.0;
+    }
+    sync();
+    for (int ci = db.gChildPtr[f]; ci < db.gChildPtr[f + 1]; ci++) {      // extend-add: the children's update blocks, one child after the other
+        const int ch = db.gChild[ci], nbc = db.gNb[ch];
+        GD CB = stack + (int)db.gCBoff[ch];
+        const int* rel = db.gRel + db.gRowPtr[ch];
+        for (int e = t; e < nbc * nbc; e += 64) {
+            const int b = e / nbc, a = e - b * nbc;
+            if (a >= b) F[rel[a] + ff * rel[b]] += (double)CB[a + nbc * b];
+        }
+        sync();
+    }
+    double* dv = c.win + GEN_MAX_FRONT * GEN_JB;      // 1 / D of the block's pivots (behind the largest panel either variant uses)
+    GD Lp = Lst + (int)db.gLoff[f];
+    for (int j0 = 0; j0 < np; j0 += GEN_JB) {
+        const int jb = min(GEN_JB, np - j0), h = ff - j0;
+        // the panel of the block: rows j0 .. ff-1, columns j0 .. j0+jb-1 -> P[(i - j0) * JB + c]
+        for (int e = t; e < h * jb; e += 64) { const int cc = e / h, i = e - cc * h; P[i * GEN_JB + cc] = F[(j0 + i) + ff * (j0 + cc)]; }
+        wave_sync();
+        for (int cc = 0; cc < jb; cc++) {      // eliminate inside the panel (columns unscaled: column c holds l_ic d_c)
+            const double dinv = 1.0 / P[cc * GEN_JB + cc];
+            if (t == 0) { dv[cc] = dinv; Kd[piv0 + j0 + cc] = dinv; }
+            for (int i = cc + 1 + t; i < h; i += 64) {
+                const double li = P[i * GEN_JB + cc] * dinv;
+                for (int c2 = cc + 1; c2 < jb; c2++) if (c2 <= i) P[i * GEN_JB + c2] -= li * P[c2 * GEN_JB + cc];
+            }
+            wave_sync();
+        }
+        // the scaled columns are the factor's panel (column-major, ld = ff)
+        for (int e = t; e < h * jb; e += 64) { const int cc = e / h, i = e - cc * h; if (i > cc) Lp[(j0 + i) + ff * (j0 + cc)] = P[i * GEN_JB + cc] * dv[cc]; }
+        // rank-jb update of what lies behind the block: row i of a lane, columns k = j0+jb .. i, four entries of F in flight
+        const int k0 = j0 + jb;
+        for (int i = k0 + t; i < ff; i += 64) {
+            double pi[GEN_JB];
+#pragma unroll
+            for (int cc = 0; cc < GEN_JB; cc++) pi[cc] = (cc < jb) ? P[(i - j0) * GEN_JB + cc] * dv[cc] : 0.0;
+            for (int k = k0; k <= i; k += 4) {
+                double fv[4], sv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) fv[u] = (k + u <= i) ? (double)F[i + ff * (k + u)] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    double acc = 0.0;
+                    if (k + u <= i) {
+                        const double* pk = P + (k + u - j0) * GEN_JB;
+#pragma unroll
+                        for (int cc = 0; cc < GEN_JB; cc++) if (cc < jb) acc += pi[cc] * pk[cc];
+                    }
+                    sv[u] = acc;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (k + u <= i) F[i + ff * (k + u)] = fv[u] - sv[u];
+            }
+        }
+        sync();
+    }
+    {   // the update block goes onto the stack (its place was fixed by the host: where its children's blocks lay)
+        GD CB = stack + (int)db.gCBoff[f];
+        for (int e = t; e < nb * nb; e += 64) { const int b = e / nb, a = e - b * nb; if (a >= b) CB[a + nb * b] = (double)F[(np + a) + ff * (np + b)]; }
+    }
+    g_sync();
+}
+
+template <class Dd, class Use>
+__device__ __forceinline__ void sp_general_factor(SpCtx<64>& c, GD Lst, GD Kd, double dprim, Dd ddual, Use use)
+{
+    const SpBatch& db = *c.db;
+    double* Fl = c.win;                                       // 64 x 64 front in LDS
+    double* P = c.win + GEN_LDS_FRONT * GEN_LDS_FRONT;        // panel of a front in LDS (64 x 8) ...
+    GD stack = c.GStack(), Fg = c.GFront();
+    SPROF(c, SP_VECTORS);
+    for (int f = 0; f < db.gnF; f++) {
+        const int ff = db.gNp[f] + db.gNb[f];
+        if (ff <= GEN_LDS_FRONT) sp_general_front<true>(c, f, Fl, P, Lst, Kd, stack, dprim, ddual, use);
+        else sp_general_front<false>(c, f, Fg, c.win, Lst, Kd, stack, dprim, ddual, use);      // ... or of a front in memory (up to GEN_MAX_FRONT x 8: the whole window)
+    }
+    c.bytes += db.by[BY_FACTOR];
+    SPROF(c, SP_FACTOR);
+}
+
+// K z = b in place (b in the ordering of the fronts): forward over the fronts in postorder, 1 / D, backward in reverse.  Per front the
+// right-hand side's entries (pivots and update rows) are gathered into LDS, the panel is staged in LDS in chunks of columns (all lanes load,
+// many loads in flight) and the columns are applied one after the other: an axpy per column forward, a dot product per column backward.
+template <bool FWD>
+__device__ __forceinline__ void sp_general_sweep(SpCtx<64>& c, GD Lst, GD b)
+{
+    const SpBatch& db = *c.db;
+    const int t = here(c.gl);
+    double* bl = c.win;                         // ff entries
+    double* Pc = c.win + GEN_MAX_FRONT;         // a chunk of columns: (ff) x cw, column-major
+    constexpr int CHUNK = GEN_LDS_FRONT * GEN_LDS_FRONT + 16 * 64 - GEN_MAX_FRONT;      // doubles left in the window
+    for (int q = 0; q < db.gnF; q++) {
+        const int f = FWD ? q : db.gnF - 1 - q;
+        const int np = db.gNp[f], nb = db.gNb[f], ff = np + nb, piv0 = db.gPiv0[f];
+        const int* rows = db.gRows + db.gRowPtr[f];
+        GD Lp = Lst + (int)db.gLoff[f];
+        for (int i = t; i < ff; i += 64) bl[i] = (double)b[i < np ? piv0 + i : rows[i - np]];
+        const int cw = max(1, min(np, CHUNK / ff));
+        for (int c0 = FWD ? 0 : ((np - 1) / cw) * cw; FWD ? c0 < np : c0 >= 0; c0 += FWD ? cw : -cw) {
+            const int c1 = min(np, c0 + cw), h = ff - c0;      // rows c0 .. ff-1 of the columns c0 .. c1-1
+            wave_sync();
+            for (int e = t; e < h * (c1 - c0); e += 64) { const int cc = e / h, i = e - cc * h; Pc[i + h * cc] = (i > cc) ? (double)Lp[(c0 + i) + ff * (c0 + cc)] : 0.0; }
+            wave_sync();
+            if (FWD) {
+                for (int cc = 0; cc < c1 - c0; cc++) {
+                    const double yj = bl[c0 + cc];
+                    for (int i = cc + 1 + t; i < h; i += 64) bl[c0 + i] -= Pc[i + h * cc] * yj;
+                    wave_sync();
+                }
+            } else {
+                for (int cc = c1 - c0 - 1; cc >= 0; cc--) {
+                    double sacc = 0.0;
+                    for (int i = cc + 1 + t; i < h; i += 64) sacc += Pc[i + h * cc] * bl[c0 + i];
+                    sacc = g_sum<64>(sacc);
+                    if (t == 0) bl[c0 + cc] -= sacc;
+                    wave_sync();
+                }
+            }
+        }
+        wave_sync();
+        if (FWD) { for (int i = t; i < ff; i += 64) b[i < np ? piv0 + i : rows[i - np]] = bl[i]; }
+        else { for (int i = t; i < np; i += 64) b[piv0 + i] = bl[i]; }
+        g_sync();
+    }
+}
+
+__device__ __forceinline__ void sp_general_solve(SpCtx<64>& c, bool admm, GD b)
+{
+    const SpBatch& db = *c.db;
+    SPROF(c, SP_VECTORS);
+    sp_general_sweep<true>(c, c.KF(admm), b);
+    {
+        GD Kd = c.KD(admm);
+        g_map<64, 8>(db.N, c.gl, [&](int p) { return D2{b[p], Kd[p]}; }, [&](int p, D2 v) { b[p] = v.a * v.b; });
+        g_sync();
+    }
+    SPROF(c, SP_FORWARD);
+    sp_general_sweep<false>(c, c.KF(admm), b);
+    SPROF(c, SP_BACKWARD);
+    c.bytes += db.by[BY_SOLVE];
+}
+
 template <int G, class Dd, class Use>
 __device__ __forceinline__ void sp_factor_band(SpCtx<G>& c, GD KF, GD Kd, double dprim, Dd ddual, Use use)
 {
+    if constexpr (G == 64) { if (c.db->general) { sp_general_factor(c, KF, Kd, dprim, ddual, use); return; } }
     if constexpr (G <= 16) sp_factor_reg<G>(c, KF, Kd, dprim, ddual, use);
     else { sp_assemble<G>(c, dprim, ddual, use); sp_factor_lds<G>(c, KF, Kd); }
 }
@@ -768,6 +959,7 @@ __device__ __forceinline__ void band_sweep(GD K, GD Kd, GD b, int Np, int gl)
 template <int G>
 __device__ __forceinline__ void sp_solve_band(SpCtx<G>& c, bool admm, GD b)
 {
+    if constexpr (G == 64) { if (c.db->general) { sp_general_solve(c, admm, b); return; } }
     const int Np = c.db->Np;
     SPROF(c, SP_VECTORS);
     band_sweep<G, true>(c.KF(admm), c.KD(admm), b, Np, c.gl);
@@ -1946,6 +2138,9 @@ try {
     // border (at most SP_KBMAX nodes), the positions behind the band.  Arrow-shaped KKT matrices (a coupling row, a shared variable:
     // examples/OptimizeOnCircle.cpp:44) become a narrow band plus a few border nodes.
     std::vector<int> permA, border;
+    bool general = false;
+    if (const char* e = std::getenv("LCQP_SPARSE_GENERAL")) general = std::atoi(e) == 1;      // test hook: the general LDL' on a pattern the band engine would take
+    lcqp_general::Symbolic sym;
     std::vector<char> isBorder(N, 0);
     std::vector<std::vector<int>> sub(N);
     auto bandwidth = [&](const std::vector<int>& pm) {
@@ -1956,7 +2151,7 @@ try {
         return wv;
     };
     int wA = 0;
-    for (;;) {
+    for (; !general;) {
         for (int v = 0; v < N; v++) { sub[v].clear(); if (!isBorder[v]) for (int u : adj[v]) if (!isBorder[u]) sub[v].push_back(u); }
         std::vector<int> full;
         rcm_order(N, sub, full);
@@ -1966,14 +2161,25 @@ try {
         wA = bandwidth(permA);
         if (wA <= SP_WMAX) break;
         if ((int)border.size() >= SP_KBMAX) {
-            g_sp_err = "KKT band of this pattern has half bandwidth " + std::to_string(wA) + " > " + std::to_string(SP_WMAX) + " after reverse Cuthill-McKee with " +
-                       std::to_string(SP_KBMAX) + " border nodes: neither a banded nor a bordered problem (use the dense kernels)";
-            return nullptr;
+            // neither a banded nor a bordered problem: the general sparse LDL' (round 6; until then such a pattern was refused here and ran densified)
+            general = true;
+            break;
         }
         int best = -1; size_t deg = 0;
         for (int v = 0; v < N; v++) if (!isBorder[v] && sub[v].size() > deg) { deg = sub[v].size(); best = v; }
         if (best < 0) { g_sp_err = "ordering failed"; return nullptr; }
         isBorder[best] = 1; border.push_back(best);
+    }
+    if (general) {
+        sym = lcqp_general::analyze(n, m, adj, Qp, Qi, Ep.data(), Ei.data(), 32);
+        if (sym.maxFront > GEN_MAX_FRONT || sym.Lsize >= (1LL << 28) || sym.stackSize >= (1LL << 28)) {
+            g_sp_err = "general sparse LDL' of this pattern: largest front " + std::to_string(sym.maxFront) + " (limit " + std::to_string(GEN_MAX_FRONT) + "), " +
+                       std::to_string((long long)sym.Lsize) + " factor entries: too dense for the sparse engine (use the dense kernels)";
+            return nullptr;
+        }
+        border.clear(); std::fill(isBorder.begin(), isBorder.end(), 0);
+        permA = sym.perm; wA = 0;
+        for (int v = 0; v < N; v++) sub[v] = adj[v];
     }
     const int kb = (int)border.size(), Nband = N - kb;
     // A second ordering of the same band nodes for batches whose Hessians are safely definite (chosen at run time, sp_choose_ordering): a
@@ -2004,11 +2210,11 @@ try {
     }
     const int wB = bandwidth(permB);
     auto lanes_for = [](int wv) { return wv < 8 ? 8 : (wv < 16 ? 16 : (wv < 32 ? 32 : 64)); };
-    const bool hasB = wB <= SP_WMAX && lanes_for(wB) == lanes_for(wA);      // not at the price of a wider lane group
+    const bool hasB = !general && wB <= SP_WMAX && lanes_for(wB) == lanes_for(wA);      // not at the price of a wider lane group
     int w = hasB ? std::max(wA, wB) : wA;
     if (w < 1) w = 1;
-    // lanes per instance: the smallest of 8, 16, 32, 64 above the half bandwidth (LCQP_SPARSE_LANES raises it: test hook)
-    int G = lanes_for(w);
+    // lanes per instance: the smallest of 8, 16, 32, 64 above the half bandwidth (LCQP_SPARSE_LANES raises it: test hook); the general LDL' takes a wavefront
+    int G = general ? 64 : lanes_for(w);
     if (const char* e = std::getenv("LCQP_SPARSE_LANES")) { const int v = std::atoi(e); if ((v == 16 || v == 32 || v == 64) && v > G) G = v; }
     const int ld = G, wS = G - 1;          // band rows are stored G wide: entry k of row i is K[i][i - (G-1) + k] (zero outside the true band)
     // what depends on the ordering: inverse permutation, band slot of every entry of Q and E (-1: not in the band -- an upper-triangle entry
@@ -2042,6 +2248,10 @@ try {
         OrdMaps M;
         M.perm = pm; M.iperm.assign(N, 0);
         for (int p = 0; p < N; p++) M.iperm[pm[p]] = p;
+        if (general) {      // no band: the maps of the band engines stay empty (sp_assemble / sp_factor_reg are never entered)
+            M.bandQ.assign(nnzQ, -1); M.bandE.assign(nnzA, -1); M.bsrc.assign(1, -1); M.bgate.assign(1, -1); M.bdiag.assign(N, -1); M.Upos.assign(1, 0);
+            return M;
+        }
         M.bandQ.assign(nnzQ, -1); M.bandE.assign(nnzA, -1); M.bsrc.assign((size_t)N * ld, -1);
         for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) { const int pi = M.iperm[i], pj = M.iperm[Qi[k]]; if (pj <= pi && pi < Nband) M.bandQ[k] = pi * ld + wS - (pi - pj); }
         for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { const int pr = M.iperm[n + r], pc = M.iperm[Ei[k]]; const int hi = std::max(pr, pc), lo = std::min(pr, pc); if (hi < Nband) M.bandE[k] = hi * ld + wS - (hi - lo); }
@@ -2079,6 +2289,9 @@ try {
     SpBatch& d = h->db;
     memset(&d, 0, sizeof(d));
     d.B = batch; d.n = n; d.m = m; d.nC = nC; d.nComp = nComp; d.N = N; d.Np = ((N + 63) / 64) * 64; d.w = w; d.ld = ld; d.nnzQ = nnzQ; d.nnzE = nnzA; d.G = G; d.kb = kb; d.nU = nU; d.nCb = nCb;
+    d.general = general ? 1 : 0;
+    d.kfStride = general ? (size_t)sym.Lsize : (size_t)d.Np * G;
+    if (general) { d.gnF = sym.nF; d.gMaxFront = sym.maxFront; d.gLsize = (unsigned)sym.Lsize; d.gStackSize = (unsigned)std::max<long long>(sym.stackSize, 1); d.w = 0; }
     d.bitWords = (G <= 16 && (size_t)(64 / G) * ((m + 31) / 32) * sizeof(unsigned) <= 16384) ? (m + 31) / 32 : 0;      // at most 16 KB of LDS per wavefront
     if (const char* e = std::getenv("LCQP_SPARSE_NOBITS")) { if (std::atoi(e) == 1) d.bitWords = 0; }                    // test hook: the path of problems with more rows than that
     {   // algorithmic bytes per event (what each event has to read and write once: 8-byte values, 4-byte indices)
@@ -2093,6 +2306,10 @@ try {
         d.by[BY_SWEEP] = 12.0 * (dq + de) + 8.0 * (3.0 * n + m);
         d.by[BY_START] = 12.0 * dq + 2.0 * 12.0 * de;
         d.by[BY_E] = 12.0 * de;
+        if (general) {      // a factorisation reads every value of Q and E once and writes the panels and 1 / D; a solve reads the panels twice
+            d.by[BY_FACTOR] = 12.0 * (dq + de) + 8.0 * ((double)sym.Lsize + dN);
+            d.by[BY_SOLVE] = 8.0 * (2.0 * (double)sym.Lsize + 4.0 * dN);
+        }
     }
     const size_t Np = d.Np;
     lcqp_hip_options_default(&d.opt);
@@ -2142,18 +2359,32 @@ try {
     ok = ok && make_ell(d.ellQ, n, std::vector<int>(Qp, Qp + n + 1), std::vector<int>(Qi, Qi + nnzQ), nullptr, d.Qp, d.Qi, nullptr) &&
          make_ell(d.ellE, m, Ep, Ei, nullptr, d.Ep, d.Ei, nullptr) && make_ell(d.ellT, n, ETp, ETi, ETmap.data(), d.ETp, d.ETi, d.ETmap);
     ok = ok && (d.Qx = sp_alloc<double>(h, B * nnzQ)) && (d.Ex = sp_alloc<double>(h, B * nnzA)) &&
-         (d.Kb = sp_alloc<double>(h, G > 16 ? B * N * ld : 0)) &&      // the band array is only written by the LDS-window factorisation
-         (d.KaF = sp_alloc<double>(h, B * Np * G)) && (d.KaD = sp_alloc<double>(h, B * Np)) &&
-         (d.KpF = sp_alloc<double>(h, B * Np * G)) && (d.KpD = sp_alloc<double>(h, B * Np)) &&
+         (d.Kb = sp_alloc<double>(h, (G > 16 && !general) ? B * N * ld : 0)) &&      // the band array is only written by the LDS-window factorisation
+         (d.KaF = sp_alloc<double>(h, B * d.kfStride)) && (d.KaD = sp_alloc<double>(h, B * Np)) &&
+         (d.KpF = sp_alloc<double>(h, B * d.kfStride)) && (d.KpD = sp_alloc<double>(h, B * Np)) &&
          (d.K0 = sp_alloc<double>(h, G <= 16 ? B * Np * G : 0)) &&
          (d.nv = sp_alloc<double>(h, B * NV_NUM * n)) && (d.mv = sp_alloc<double>(h, B * MV_NUM * m)) && (d.Nv = sp_alloc<double>(h, B * 2 * Np)) &&
          (d.lbL = sp_alloc<double>(h, B * nComp)) && (d.lbR = sp_alloc<double>(h, B * nComp)) && (d.mi = sp_alloc<int>(h, B * MI_NUM * m)) &&
          (d.info = sp_alloc<SpInfo>(h, B)) && (d.stats = sp_alloc<lcqp_stats_t>(h, B)) && (d.xout = sp_alloc<double>(h, B * n)) &&
          (d.yout = sp_alloc<double>(h, B * m));
+    if (general) {
+        std::vector<unsigned> lo(sym.Loff.begin(), sym.Loff.end()), co(sym.CBoff.begin(), sym.CBoff.end());
+        ok = ok && (d.gPiv0 = sp_alloc<int>(h, sym.piv0.size(), sym.piv0.data())) && (d.gNp = sp_alloc<int>(h, sym.np.size(), sym.np.data())) &&
+             (d.gNb = sp_alloc<int>(h, sym.nb.size(), sym.nb.data())) && (d.gRowPtr = sp_alloc<int>(h, sym.rowPtr.size(), sym.rowPtr.data())) &&
+             (d.gRows = sp_alloc<int>(h, std::max<size_t>(sym.rows.size(), 1), sym.rows.empty() ? nullptr : sym.rows.data())) &&
+             (d.gChildPtr = sp_alloc<int>(h, sym.childPtr.size(), sym.childPtr.data())) &&
+             (d.gChild = sp_alloc<int>(h, std::max<size_t>(sym.child.size(), 1), sym.child.empty() ? nullptr : sym.child.data())) &&
+             (d.gRel = sp_alloc<int>(h, std::max<size_t>(sym.rel.size(), 1), sym.rel.empty() ? nullptr : sym.rel.data())) &&
+             (d.gAsmPtr = sp_alloc<int>(h, sym.asmPtr.size(), sym.asmPtr.data())) && (d.gAsmSrc = sp_alloc<int>(h, sym.asmSrc.size(), sym.asmSrc.data())) &&
+             (d.gAsmGate = sp_alloc<int>(h, sym.asmGate.size(), sym.asmGate.data())) && (d.gAsmPos = sp_alloc<int>(h, sym.asmPos.size(), sym.asmPos.data())) &&
+             (d.gLoff = sp_alloc<unsigned>(h, lo.size(), lo.data())) && (d.gCBoff = sp_alloc<unsigned>(h, co.size(), co.data())) &&
+             (d.gStack = sp_alloc<double>(h, B * d.gStackSize)) && (d.gFront = sp_alloc<double>(h, B * (size_t)d.gMaxFront * d.gMaxFront));
+    }
     {
         // pools of the phase machine (k_sparse_sched): the largest power of two of instances whose per-instance arrays all stay below 4 GiB
         // (the 32-bit lane offsets of SpCtx::arr), at most the batch rounded up to a power of two
-        size_t perInst = sizeof(double) * std::max<size_t>({(size_t)nnzQ, (size_t)nnzA, 2 * Np, (size_t)(G > 16 ? (size_t)N * ld : 0), Np * (size_t)G,
+        size_t perInst = sizeof(double) * std::max<size_t>({(size_t)nnzQ, (size_t)nnzA, 2 * Np, (size_t)((G > 16 && !general) ? (size_t)N * ld : 0), d.kfStride,
+                                                            general ? (size_t)d.gStackSize : 0, general ? (size_t)d.gMaxFront * d.gMaxFront : 0,
                                                             2 * (size_t)kb * Np, 2 * (size_t)nU, (size_t)NV_NUM * n, (size_t)MV_NUM * m, (size_t)nComp});
         perInst = std::max(perInst, sizeof(int) * (size_t)MI_NUM * m);
         int pool = 1;
@@ -2186,6 +2417,7 @@ catch (...) { }
 extern "C" int lcqp_hip_sparse_bandwidth(const lcqp_hip_sparse_t* h) { return h ? h->db.w : -1; }
 extern "C" int lcqp_hip_sparse_lanes(const lcqp_hip_sparse_t* h) { return h ? h->db.G : -1; }
 extern "C" int lcqp_hip_sparse_border(const lcqp_hip_sparse_t* h) { return h ? h->db.kb : -1; }
+extern "C" int lcqp_hip_sparse_fronts(const lcqp_hip_sparse_t* h) { return h ? (h->db.general ? h->db.gnF : 0) : -1; }
 extern "C" int lcqp_hip_sparse_get_ordering(const lcqp_hip_sparse_t* h, int* perm)
 {
     if (!h || !perm) return LCQP_INVALID_ARGUMENT;

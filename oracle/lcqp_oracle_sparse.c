@@ -34,7 +34,22 @@ typedef struct {
     int kb;
     double *U, *W, *S;   /* kb x N (U, then W), kb x kb */
     double* Uf;          /* N x (w+1): the rows in upper form while band_factor runs (allocated once at setup, beside B) */
+    struct gen_s* G;     /* general sparse LDL' (round 6; selected by a negative half bandwidth): patterns that are neither banded nor bordered */
 } band_t;
+
+/* General sparse LDL' of the permuted KKT matrix, K = L D L' without pivoting (quasi-definite for delta, delta2 > 0: any symmetric
+ * permutation factorises).  The up-looking algorithm of T. A. Davis, "Algorithm 849: a concise sparse Cholesky factorization package",
+ * ACM TOMS 31 (2005) -- the one OSQP's QDLDL restates (the reference's OSQP arm factorises its KKT matrix with it: src/SubsolverOSQP.cpp:152,
+ * osqp_setup; OSQP itself is an absent submodule) -- elimination tree and column counts once per pattern, numeric factorisation per working set.
+ * A: upper triangle of K in the ordering perm, compressed columns (row index <= column), pattern fixed (every row of E in), values
+ * re-assembled per factorisation: an inactive row keeps explicit zeros and the diagonal -1. */
+typedef struct gen_s {
+    int N, nnzA, nnzL;
+    int *Ap, *Ai; double* Ax;
+    int *posQ, *posE, *posD;        /* A-position of every non-zero of Q (-1: strictly lower in this ordering, its mirror is taken) and of E; of the diagonals */
+    int *parent, *Lp, *Li, *Lnz, *flag, *pattern;
+    double *Lx, *D, *Y;
+} gen_t;
 
 typedef struct {
     int n, m, nC, nComp, N, w, kb;      /* kb: border nodes, the last kb positions of perm */
@@ -114,6 +129,110 @@ static void band_solve(const band_t* f, double* b)
         for (int j = j0; j < i; j++) b[j] -= ri[w - (i - j)] * xi;
     }
 }
+/* ---- general sparse LDL' (see gen_t) ------------------------------------------------------------------------------------------------------ */
+static void gen_free(gen_t* G)
+{
+    if (!G) return;
+    free(G->Ap); free(G->Ai); free(G->Ax); free(G->posQ); free(G->posE); free(G->posD); free(G->parent); free(G->Lp); free(G->Li); free(G->Lnz);
+    free(G->flag); free(G->pattern); free(G->Lx); free(G->D); free(G->Y); free(G);
+}
+static int gen_cmp_int(const void* a, const void* b) { return *(const int*)a - *(const int*)b; }
+/* pattern of the upper triangle of the permuted K, the maps from the non-zeros of Q and E into it, elimination tree, column counts */
+static gen_t* gen_setup(int n, int m, const int* Qp, const int* Qi, const int* Ep, const int* Ei, const int* iperm)
+{
+    const int N = n + m;
+    gen_t* G = (gen_t*)calloc(1, sizeof(gen_t));
+    if (!G) return NULL;
+    G->N = N;
+    int* cnt = (int*)calloc((size_t)N + 1, sizeof(int));
+    /* column counts: one diagonal entry per node, one entry per Q pair (taken once: from the non-zero whose first index comes later), one per E non-zero */
+    for (int p = 0; p < N; p++) cnt[p + 1] = 1;
+    for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) { const int pi = iperm[i], pj = iperm[Qi[k]]; if (pj < pi) cnt[pi + 1]++; }
+    for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { const int pr = iperm[n + r], pj = iperm[Ei[k]]; cnt[(pr > pj ? pr : pj) + 1]++; }
+    G->Ap = (int*)malloc(sizeof(int) * ((size_t)N + 1));
+    G->Ap[0] = 0;
+    for (int p = 0; p < N; p++) G->Ap[p + 1] = G->Ap[p] + cnt[p + 1];
+    G->nnzA = G->Ap[N];
+    G->Ai = (int*)malloc(sizeof(int) * (size_t)(G->nnzA ? G->nnzA : 1));
+    G->Ax = dal((size_t)G->nnzA);
+    int* fill = (int*)calloc((size_t)N, sizeof(int));
+    for (int p = 0; p < N; p++) G->Ai[G->Ap[p] + fill[p]++] = p;
+    for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) { const int pi = iperm[i], pj = iperm[Qi[k]]; if (pj < pi) G->Ai[G->Ap[pi] + fill[pi]++] = pj; }
+    for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) {
+        const int pr = iperm[n + r], pj = iperm[Ei[k]], hi = pr > pj ? pr : pj, lo = pr > pj ? pj : pr;
+        G->Ai[G->Ap[hi] + fill[hi]++] = lo;
+    }
+    for (int p = 0; p < N; p++) qsort(G->Ai + G->Ap[p], (size_t)(G->Ap[p + 1] - G->Ap[p]), sizeof(int), gen_cmp_int);
+    /* maps (binary search in the sorted columns) */
+    G->posQ = (int*)malloc(sizeof(int) * (size_t)(Qp[n] ? Qp[n] : 1)); G->posE = (int*)malloc(sizeof(int) * (size_t)(Ep[m] ? Ep[m] : 1)); G->posD = (int*)malloc(sizeof(int) * (size_t)N);
+#define GEN_FIND(col, row, out) do { int lo_ = G->Ap[col], hi_ = G->Ap[(col) + 1] - 1; (out) = -1; while (lo_ <= hi_) { const int md_ = (lo_ + hi_) / 2; \
+        if (G->Ai[md_] == (row)) { (out) = md_; break; } if (G->Ai[md_] < (row)) lo_ = md_ + 1; else hi_ = md_ - 1; } } while (0)
+    for (int p = 0; p < N; p++) GEN_FIND(p, p, G->posD[p]);
+    for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) {
+        const int pi = iperm[i], pj = iperm[Qi[k]];
+        if (pj < pi) GEN_FIND(pi, pj, G->posQ[k]); else if (pj == pi) G->posQ[k] = G->posD[pi]; else G->posQ[k] = -1;      /* the mirror entry carries the pair */
+    }
+    for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) {
+        const int pr = iperm[n + r], pj = iperm[Ei[k]], hi = pr > pj ? pr : pj, lo = pr > pj ? pj : pr;
+        GEN_FIND(hi, lo, G->posE[k]);
+    }
+#undef GEN_FIND
+    free(cnt); free(fill);
+    /* elimination tree and column counts of L */
+    G->parent = (int*)malloc(sizeof(int) * (size_t)N); G->Lnz = (int*)calloc((size_t)N, sizeof(int)); G->flag = (int*)malloc(sizeof(int) * (size_t)N);
+    G->pattern = (int*)malloc(sizeof(int) * (size_t)N); G->Lp = (int*)malloc(sizeof(int) * ((size_t)N + 1));
+    for (int k = 0; k < N; k++) {
+        G->parent[k] = -1; G->flag[k] = k;
+        for (int p = G->Ap[k]; p < G->Ap[k + 1]; p++) {
+            int i = G->Ai[p];
+            for (; i < k && G->flag[i] != k; i = G->parent[i]) {
+                if (G->parent[i] == -1) G->parent[i] = k;
+                G->Lnz[i]++;
+                G->flag[i] = k;
+            }
+        }
+    }
+    G->Lp[0] = 0;
+    for (int k = 0; k < N; k++) G->Lp[k + 1] = G->Lp[k] + G->Lnz[k];
+    G->nnzL = G->Lp[N];
+    G->Li = (int*)malloc(sizeof(int) * (size_t)(G->nnzL ? G->nnzL : 1)); G->Lx = dal((size_t)G->nnzL); G->D = dal((size_t)N); G->Y = dal((size_t)N);
+    if (!G->Li || !G->Lx || !G->D || !G->Y) { gen_free(G); return NULL; }
+    return G;
+}
+static void gen_factor(gen_t* G)
+{
+    const int N = G->N;
+    for (int k = 0; k < N; k++) {
+        int top = N;
+        G->Y[k] = 0.0; G->flag[k] = k; G->Lnz[k] = 0;
+        for (int p = G->Ap[k]; p < G->Ap[k + 1]; p++) {
+            int i = G->Ai[p];
+            G->Y[i] += G->Ax[p];
+            int len = 0;
+            for (; G->flag[i] != k; i = G->parent[i]) { G->pattern[len++] = i; G->flag[i] = k; }
+            while (len > 0) G->pattern[--top] = G->pattern[--len];
+        }
+        G->D[k] = G->Y[k]; G->Y[k] = 0.0;
+        for (; top < N; top++) {
+            const int i = G->pattern[top];
+            const double yi = G->Y[i];
+            G->Y[i] = 0.0;
+            const int p2 = G->Lp[i] + G->Lnz[i];
+            for (int p = G->Lp[i]; p < p2; p++) G->Y[G->Li[p]] -= G->Lx[p] * yi;
+            const double lki = yi / G->D[i];
+            G->D[k] -= lki * yi;
+            G->Li[p2] = k; G->Lx[p2] = lki; G->Lnz[i]++;
+        }
+    }
+}
+static void gen_solve(const gen_t* G, double* b)
+{
+    const int N = G->N;
+    for (int j = 0; j < N; j++) { const double bj = b[j]; for (int p = G->Lp[j]; p < G->Lp[j + 1]; p++) b[G->Li[p]] -= G->Lx[p] * bj; }
+    for (int j = 0; j < N; j++) b[j] /= G->D[j];
+    for (int j = N - 1; j >= 0; j--) { double s = b[j]; for (int p = G->Lp[j]; p < G->Lp[j + 1]; p++) s -= G->Lx[p] * b[G->Li[p]]; b[j] = s; }
+}
+
 /* K = [Q + dprim I, Ea'; Ea, -diag(ddual)] in the ordering perm; rows with use[r] == 0 are decoupled (diagonal -1).  Positions >= f->N
  * are border nodes: their couplings go to U (with band nodes) and S (among themselves). */
 static void kkt_put(band_t* f, int pa, int pb, double v)
@@ -126,6 +245,22 @@ static void kkt_put(band_t* f, int pa, int pb, double v)
 }
 static void kkt_assemble(const sqp_t* q, band_t* f, double dprim, const double* ddual, const int* use)
 {
+    if (f->G) {
+        gen_t* G = f->G;
+        const int n = q->n, m = q->m;
+        memset(G->Ax, 0, sizeof(double) * (size_t)G->nnzA);
+        for (int i = 0; i < n; i++) {
+            for (int k = q->Qp[i]; k < q->Qp[i + 1]; k++) if (G->posQ[k] >= 0) G->Ax[G->posQ[k]] += q->Qx[k];
+            G->Ax[G->posD[q->iperm[i]]] += dprim;
+        }
+        for (int r = 0; r < m; r++) {
+            const int pd = G->posD[q->iperm[n + r]];
+            if (use && !use[r]) { G->Ax[pd] = -1.0; continue; }
+            G->Ax[pd] = -ddual[r];
+            for (int k = q->Ep[r]; k < q->Ep[r + 1]; k++) G->Ax[G->posE[k]] += q->Ex[k];
+        }
+        return;
+    }
     const int n = q->n, m = q->m, w = q->w, ld = w + 1, kb = f->kb;
     memset(f->B, 0, sizeof(double) * (size_t)f->N * ld);
     if (kb > 0) { memset(f->U, 0, sizeof(double) * (size_t)kb * f->N); memset(f->S, 0, sizeof(double) * (size_t)kb * kb); }
@@ -147,6 +282,7 @@ static void kkt_assemble(const sqp_t* q, band_t* f, double dprim, const double* 
 /* the factorisation of the bordered matrix: band LDL' of B, W = U inv(B) row by row, S = C - W U', dense LDL' of S in place */
 static void kkt_factor(band_t* f)
 {
+    if (f->G) { gen_factor(f->G); return; }
     const int Nb = f->N, kb = f->kb;
     band_factor(f);
     for (int b = 0; b < kb; b++) {
@@ -175,6 +311,7 @@ static void kkt_factor(band_t* f)
 /* K x = b in place (b in the ordering perm: band nodes first, then the border) */
 static void kkt_solve(const band_t* f, double* b)
 {
+    if (f->G) { gen_solve(f->G, b); return; }
     const int Nb = f->N, kb = f->kb;
     band_solve(f, b);
     if (kb == 0) return;
@@ -198,7 +335,7 @@ static void kkt_solve(const band_t* f, double* b)
 /* ---- subsolver ---------------------------------------------------------------------------------------------------------- */
 static void sqp_free(sqp_t* q)
 {
-    free(q->iperm); free(q->l); free(q->u); free(q->rhov); free(q->Ka.B); free(q->Kp.B); free(q->Ka.Uf); free(q->Kp.Uf); free(q->Ka.U); free(q->Ka.W); free(q->Ka.S); free(q->Kp.U); free(q->Kp.W); free(q->Kp.S); free(q->stf); free(q->x); free(q->y);
+    free(q->iperm); free(q->l); free(q->u); free(q->rhov); free(q->Ka.B); free(q->Kp.B); free(q->Ka.Uf); free(q->Kp.Uf); gen_free(q->Ka.G); gen_free(q->Kp.G); free(q->Ka.U); free(q->Ka.W); free(q->Ka.S); free(q->Kp.U); free(q->Kp.W); free(q->Kp.S); free(q->stf); free(q->x); free(q->y);
     free(q->st); free(q->xa); free(q->ya); free(q->za); free(q->r1); free(q->ex); free(q->wN); free(q->r1_last); free(q->ex_last);
     free(q->g_last); free(q->newst);
 }
@@ -255,8 +392,15 @@ static int sqp_setup(sqp_t* q, const double* lbE, const double* ubE)
     }
     const int kb = q->kb, Nb = N - kb;
     q->Ka.N = q->Kp.N = Nb; q->Ka.w = q->Kp.w = q->w; q->Ka.kb = q->Kp.kb = kb;
-    q->Ka.B = dal((size_t)Nb * (q->w + 1)); q->Kp.B = dal((size_t)Nb * (q->w + 1));
-    q->Ka.Uf = dal((size_t)Nb * (q->w + 1)); q->Kp.Uf = dal((size_t)Nb * (q->w + 1));
+    if (q->w < 0) {      /* general sparse LDL' (no band, no border): one symbolic analysis per factor object */
+        q->Ka.G = gen_setup(n, m, q->Qp, q->Qi, q->Ep, q->Ei, q->iperm);
+        q->Kp.G = gen_setup(n, m, q->Qp, q->Qi, q->Ep, q->Ei, q->iperm);
+        if (!q->Ka.G || !q->Kp.G) { free(dd); return 3; }
+        q->Ka.w = q->Kp.w = 0;
+    }
+    const int wst = q->w < 0 ? 0 : q->w;
+    q->Ka.B = dal((size_t)Nb * (wst + 1)); q->Kp.B = dal((size_t)Nb * (wst + 1));
+    q->Ka.Uf = dal((size_t)Nb * (wst + 1)); q->Kp.Uf = dal((size_t)Nb * (wst + 1));
     q->Ka.U = dal((size_t)kb * Nb); q->Ka.W = dal((size_t)kb * Nb); q->Ka.S = dal((size_t)kb * kb);
     q->Kp.U = dal((size_t)kb * Nb); q->Kp.W = dal((size_t)kb * Nb); q->Kp.S = dal((size_t)kb * kb);
     if (!q->Ka.B || !q->Kp.B || !q->Ka.Uf || !q->Kp.Uf || !q->Ka.U || !q->Ka.W || !q->Ka.S || !q->Kp.U || !q->Kp.W || !q->Kp.S) { free(dd); return 3; }   /* out of memory: a setup failure, not a NULL dereference */
@@ -391,7 +535,7 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
                     int badVar = 0, badRow = 0;
                     const int Nb = q->Kp.N, ld = q->w + 1;
                     for (int pp = 0; pp < Nb; pp++) {
-                        const double D = q->Kp.B[(size_t)pp * ld + q->w];
+                        const double D = q->Kp.G ? q->Kp.G->D[pp] : q->Kp.B[(size_t)pp * ld + q->w];
                         const int node = q->perm[pp];
                         if (node < n) badVar |= !(D > 1e-8 * q->scale);
                         else if (use[node - n]) badRow |= !(D < -1e-8 / q->scale);

@@ -435,6 +435,59 @@ def kkt_ordering(nV, Qp, Qi, Ep, Ei, wmax=63, kbmax=16, rows_follow=False):
     return perm, w, len(border)
 
 
+def kkt_ordering_general(nV, Qp, Qi, Ep, Ei, leaf=48):
+    """Fill-reducing ordering of the KKT graph for the oracle's general sparse LDL' (w = -1), written here with scipy -- independent of the
+    product's own analysis: nested dissection by breadth-first level structures (George 1973: a pseudo-peripheral start, the middle level
+    is the separator; parts of at most `leaf` nodes are numbered in their breadth-first order), sub-regions first, separators last.
+    Returns perm[position] = node (node < nV: variable, else row node - nV)."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import breadth_first_order, connected_components
+    m = len(Ep) - 1
+    N = nV + m
+    Qs = sp.csr_matrix((np.ones(len(Qi)), np.asarray(Qi), np.asarray(Qp)), shape=(nV, nV))
+    Es = sp.csr_matrix((np.ones(len(Ei)), np.asarray(Ei), np.asarray(Ep)), shape=(m, nV))
+    K = sp.csr_matrix(sp.bmat([[Qs, Es.T], [Es, None]], format="csr"))
+    K = sp.csr_matrix(K + K.T)
+    out = []
+
+    def levels(sub, start):
+        order, pred = breadth_first_order(sub, start, directed=False, return_predecessors=True)
+        lev = np.full(sub.shape[0], -1)
+        lev[start] = 0
+        for v in order[1:]:
+            lev[v] = lev[pred[v]] + 1
+        return order, lev
+
+    stack = [np.arange(N)]
+    pieces = []          # (nodes, is_separator) in REVERSE elimination order
+    while stack:
+        nodes = stack.pop()
+        if len(nodes) == 0:
+            continue
+        sub = sp.csr_matrix(K[nodes][:, nodes])
+        ncomp, lab = connected_components(sub, directed=False)
+        if ncomp > 1:
+            for c in range(ncomp):
+                stack.append(nodes[lab == c])
+            continue
+        if len(nodes) <= leaf:
+            order, _ = levels(sub, 0)
+            pieces.append(nodes[order])
+            continue
+        order, lev = levels(sub, 0)
+        order, lev = levels(sub, int(order[-1]))          # restart from the far end: a pseudo-peripheral node
+        mid = int(lev.max()) // 2
+        if lev.max() < 2:                                   # a clique-like piece: no separator to be had
+            pieces.append(nodes[order])
+            continue
+        sep = nodes[lev == mid]
+        pieces.append(sep)                                  # eliminated after both sides
+        stack.append(nodes[lev < mid]); stack.append(nodes[lev > mid])
+    perm = np.concatenate(pieces[::-1]).astype(np.int32)
+    assert len(perm) == N and len(np.unique(perm)) == N
+    return perm
+
+
 def sparse_lcqp_solve(nV, nC, nComp, Qcsr, g, Ecsr, lbA=None, ubA=None, lbL=None, ubL=None, lbR=None, ubR=None, x0=None, y0=None,
                       perm=None, w=None, kb=0, opt=None):
     """OSQP_SPARSE arm on the oracle (oracle/lcqp_oracle_sparse.c).  Qcsr / Ecsr: scipy CSR matrices (Q full symmetric,

@@ -265,18 +265,91 @@ def test_sparse_bordered_band_circle(hip, oracle):
     sb.close()
 
 
-def test_sparse_pattern_that_is_neither_banded_nor_bordered_is_refused(hip):
-    """a pattern with more dense nodes than the border takes (here forty dense rows over two hundred variables): the engine says so, it
-    does not run past its window (the host layer runs such a problem on the dense kernels behind the OSQP_SPARSE surface)"""
+def _solve_general(hip, oracle, d, B=1, leaf=48):
+    """one problem given as scipy matrices (Q, E = [A; L; R]) on the sparse engine and on the sparse oracle's general LDL' (w = -1) with an
+    ordering computed in Python (tests/oracle_py.py::kkt_ordering_general): independent of the product's own analysis"""
+    n, nC, nK = d["nV"], d["nC"], d["nComp"]
+    Qc, Ec = d["Q"].tocsc(), d["E"].tocsc()
+    Qc.sort_indices(); Ec.sort_indices()
+    sb = hip.SparseBatchLCQP(B, n, nC, nK, Qc, Ec, opt=hip.default_options(perturbStep=0, printLevel=0))
+    for b in range(B):
+        assert sb.load(b, 1, Qc.data[None, :], d["g"][None, :], Ec.data[None, :], lbA=d["lbA"][None, :], ubA=d["ubA"][None, :]) == 0
+    sb.run()
+    x, y, st = sb.solution()
+    Qr, Er = d["Q"].tocsr(), d["E"].tocsr()
+    perm = oracle.kkt_ordering_general(n, Qr.indptr, Qr.indices, Er.indptr, Er.indices, leaf=leaf)
+    ro = oracle.sparse_lcqp_solve(n, nC, nK, Qr, d["g"], Er, lbA=d["lbA"], ubA=d["ubA"], perm=perm, w=-1, kb=0, opt=oracle.default_options(perturbStep=0))
+    return sb, x, y, st, ro
+
+
+def test_sparse_pattern_with_dense_rows_runs_on_the_general_ldl(hip, oracle):
+    """a pattern with more dense nodes than the border of the band engine takes (forty dense rows over two hundred variables: refused until
+    round 6) is one dense front for the general sparse LDL' (lcqp_sparse_general.hpp): the engine takes it and matches the oracle"""
     import scipy.sparse as sp
     n, nC, nK = 200, 40, 8
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((nC, n)) / np.sqrt(n)
+    L = np.zeros((nK, n)); R = np.zeros((nK, n))
+    L[np.arange(nK), np.arange(nK)] = 1; R[np.arange(nK), nK + np.arange(nK)] = 1
+    xs = rng.uniform(0.2, 1.0, n); xs[nK:2 * nK] = 0.0
+    d = dict(nV=n, nC=nC, nComp=nK, Q=sp.csc_matrix(np.diag(rng.uniform(1, 2, n))), E=sp.csc_matrix(np.vstack([A, L, R])), g=rng.uniform(-1, 1, n),
+             lbA=A @ xs - rng.uniform(0.1, 1, nC), ubA=A @ xs + rng.uniform(0.1, 1, nC))
+    sb, x, y, st, ro = _solve_general(hip, oracle, d)
+    assert sb.fronts() >= 1 and sb.lanes() == 64 and sb.border() == 0
+    assert st[0]["returnValue"] == ro["ret"] == 0
+    assert np.abs(x[0] - ro["x"]).max() < 1e-9 and np.abs(y[0] - ro["y"]).max() < 1e-7
+    sb.close()
+
+
+def test_sparse_pattern_too_dense_for_the_sparse_engine_is_refused(hip):
+    """what the general LDL' cannot hold in a wavefront's LDS panel -- a front of more than 576 rows, here sixty dense rows over seven hundred
+    variables, one clique -- is refused with a message (the host layer runs such a problem on the dense kernels behind the OSQP_SPARSE surface)"""
+    import scipy.sparse as sp
+    n, nC, nK = 700, 60, 8
     rng = np.random.default_rng(0)
     A = rng.standard_normal((nC, n))
     L = np.zeros((nK, n)); R = np.zeros((nK, n))
     L[np.arange(nK), np.arange(nK)] = 1; R[np.arange(nK), nK + np.arange(nK)] = 1
     Q = sp.csc_matrix(np.eye(n)); E = sp.csc_matrix(np.vstack([A, L, R]))
-    with pytest.raises(RuntimeError, match="neither a banded nor a bordered"):
+    with pytest.raises(RuntimeError, match="too dense for the sparse engine"):
         hip.SparseBatchLCQP(1, n, nC, nK, Q, E)
+
+
+@pytest.mark.parametrize("g,nK,nC", [(20, 60, 40), (44, 300, 200)])
+def test_sparse_grid_pattern_on_the_general_ldl(hip, oracle, g, nK, nC):
+    """A KKT graph that is a 2-D grid (5-point stencil Hessian, complementarity and constraint rows between neighbouring cells): half bandwidth
+    ~ 2 g after reverse Cuthill-McKee, no small border -- the pattern that is "neither banded nor bordered".  The sparse engine runs it on the
+    general LDL' (nested dissection, dense fronts, one wavefront per instance): same solution as the oracle's general LDL' (up-looking, another
+    ordering) to 1e-9 / 1e-7, same return code and status, iterate counts equal up to one inner cycle; a batch of three copies gives three
+    times the same bits, and a second run reproduces the first."""
+    d = P.grid_lcqp(g, nK, nC)
+    sb, x, y, st, ro = _solve_general(hip, oracle, d, B=3)
+    assert sb.fronts() > 4 and sb.lanes() == 64
+    for b in range(3):
+        assert st[b]["returnValue"] == ro["ret"] == 0
+        assert np.abs(x[b] - ro["x"]).max() < 1e-9 and np.abs(y[b] - ro["y"]).max() < 1e-7
+        assert st[b]["status"] == ro["stats"]["status"] and abs(st[b]["iterTotal"] - ro["stats"]["iterTotal"]) <= 4
+        assert np.array_equal(x[b], x[0]) and np.array_equal(y[b], y[0])
+    sb.run()
+    x2, y2, _ = sb.solution()
+    assert np.array_equal(x, x2) and np.array_equal(y, y2)
+    sb.close()
+
+
+def test_sparse_general_ldl_on_a_banded_pattern_matches_the_band_engine(hip, oracle, monkeypatch):
+    """LCQP_SPARSE_GENERAL=1 (test hook) sends a pattern the band engine takes through the general LDL': the banded synthetic workload, four
+    instances with different data -- each matches the oracle (band LDL', its own ordering) like the band engine does"""
+    monkeypatch.setenv("LCQP_SPARSE_GENERAL", "1")
+    n, nC, nK, B = 512, 256, 64, 4
+    sb, inst, x, y, st = _run(hip, n, nC, nK, B)
+    assert sb.fronts() > 4 and sb.lanes() == 64
+    opt = oracle.default_options(perturbStep=0)
+    for b in range(B):
+        d = inst[b]
+        ro = oracle.sparse_lcqp_solve(n, nC, nK, d["Q"].tocsr(), d["g"], d["E"].tocsr(), lbA=d["lbA"], ubA=d["ubA"], opt=opt)
+        assert st[b]["returnValue"] == ro["ret"] == 0
+        assert np.abs(x[b] - ro["x"]).max() < 1e-9 and np.abs(y[b] - ro["y"]).max() < 1e-7
+    sb.close()
 
 
 @pytest.mark.parametrize("n,nC,nK,extra", [(512, 256, 64, 1), (512, 256, 64, 3)])
