@@ -43,6 +43,19 @@ ReturnValue LCQProblem::loadLCQP(const double* const _Q, const double* const _g,
     if (nC > 0) std::copy(_A, _A + (size_t)nC * nV, A.begin());
     std::copy(L.begin(), L.end(), A.begin() + (size_t)nC * nV);
     std::copy(R.begin(), R.end(), A.begin() + (size_t)(nC + nComp) * nV);
+    C.assign((size_t)nV * nV, 0.0);
+    Utilities::MatrixSymmetrizationProduct(L.data(), R.data(), C.data(), nComp, nV);
+    return loadVectors(_g, _lbL, _ubL, _lbR, _ubR, _lbA, _ubA, _lb, _ub, _x0, _y0);
+}
+
+// the vectors of a problem: bounds of the stacked rows (setConstraints / setComplementarityBounds, src/LCQProblem.cpp:585-608, 726-785), box
+// bounds, initial guess -- shared by the dense and the CSC loader
+ReturnValue LCQProblem::loadVectors(const double* _g, const double* _lbL, const double* _ubL, const double* _lbR, const double* _ubR,
+                                    const double* _lbA, const double* _ubA, const double* _lb, const double* _ub, const double* _x0, const double* _y0)
+{
+    const int m = nC + 2 * nComp;
+    const double inf = INFINITY;
+    g.assign(_g, _g + nV);
     lbA.assign(m, -inf); ubA.assign(m, inf);
     for (int i = 0; i < nC; ++i) { if (_lbA) lbA[i] = _lbA[i]; if (_ubA) ubA[i] = _ubA[i]; }
     haveLbL = (_lbL != 0); haveLbR = (_lbR != 0);
@@ -55,8 +68,6 @@ ReturnValue LCQProblem::loadLCQP(const double* const _Q, const double* const _g,
         lbA[nC + nComp + i] = lbR[i];
         ubA[nC + nComp + i] = _ubR ? _ubR[i] : inf;
     }
-    C.assign((size_t)nV * nV, 0.0);
-    Utilities::MatrixSymmetrizationProduct(L.data(), R.data(), C.data(), nComp, nV);
     lb.assign(nV, -inf); ub.assign(nV, inf);
     for (int i = 0; i < nV; ++i) { if (_lb) lb[i] = _lb[i]; if (_ub) ub[i] = _ub[i]; }
     haveBox = (_lb != 0) || (_ub != 0);          // lb_tmp / ub_tmp of the reference (src/LCQProblem.cpp:113-121)
@@ -132,13 +143,39 @@ ReturnValue LCQProblem::loadLCQP(const csc* const _Q, const double* const _g, co
     if (!_Q) return INVALID_ARGUMENT;
     if (!_L || !_R) return INVALID_COMPLEMENTARITY_MATRIX;
     if (!_A && nC > 0) return INVALID_CONSTRAINT_MATRIX;
-    double *dQ = Utilities::csc_to_dns(_Q), *dL = Utilities::csc_to_dns(_L), *dR = Utilities::csc_to_dns(_R);
-    double* dA = (_A && nC > 0) ? Utilities::csc_to_dns(_A) : 0;
-    ReturnValue rc = (dQ && dL && dR && (dA || nC == 0)) ? loadLCQP(dQ, _g, dL, dR, _lbL, _ubL, _lbR, _ubR, dA, _lbA, _ubA, _lb, _ub, _x0, _y0)
-                                                         : INDEX_OUT_OF_BOUNDS;
-    delete[] dQ; delete[] dL; delete[] dR; delete[] dA;
-    if (rc != SUCCESSFUL_RETURN) return rc;
-    return switchToSparseMode();
+    if (!_g) return INVALID_OBJECTIVE_LINEAR_TERM;
+    if (_Q->m != nV || _Q->n != nV || _L->m != nComp || _L->n != nV || _R->m != nComp || _R->n != nV || (_A && nC > 0 && (_A->m != nC || _A->n != nV))) return INDEX_OUT_OF_BOUNDS;
+    // Round 6: the data stay in compressed columns from the first line on, as in the reference (src/LCQProblem.cpp:390-441, 629-723).  Until then this
+    // loader went through the dense one -- dense copies of Q, L, R, A and the dense C = L'R + R'L, nComp nV^2 operations: twenty minutes and
+    // 2 GB for the 128 x 128 grid of tests/test_python_api.py before the sparse engine saw the problem.
+    clearSparse();
+    std::vector<double>().swap(Q); std::vector<double>().swap(A); std::vector<double>().swap(L); std::vector<double>().swap(R); std::vector<double>().swap(C);
+    sparseSolver = false; loaded = false;
+    const ReturnValue rv = loadVectors(_g, _lbL, _ubL, _lbR, _ubR, _lbA, _ubA, _lb, _ub, _x0, _y0);
+    if (rv != SUCCESSFUL_RETURN) return rv;
+    loaded = false;
+    Q_sparse = Utilities::copyCSC(_Q); L_sparse = Utilities::copyCSC(_L); R_sparse = Utilities::copyCSC(_R);
+    {   // A_sparse = [A; L; R] column by column (setConstraints, :629-723)
+        const int m = nC + 2 * nComp;
+        const bool hasA = (_A && nC > 0);
+        const int nnz = (hasA ? _A->p[nV] : 0) + _L->p[nV] + _R->p[nV];
+        std::vector<int> ai, ap(nV + 1, 0);
+        std::vector<double> ax;
+        ai.reserve(nnz); ax.reserve(nnz);
+        for (int j = 0; j < nV; ++j) {
+            if (hasA) for (int k = _A->p[j]; k < _A->p[j + 1]; ++k) { ai.push_back(_A->i[k]); ax.push_back(_A->x[k]); }
+            for (int k = _L->p[j]; k < _L->p[j + 1]; ++k) { ai.push_back(nC + _L->i[k]); ax.push_back(_L->x[k]); }
+            for (int k = _R->p[j]; k < _R->p[j + 1]; ++k) { ai.push_back(nC + nComp + _R->i[k]); ax.push_back(_R->x[k]); }
+            ap[j + 1] = (int)ai.size();
+        }
+        A_sparse = Utilities::copyCSC(m, nV, (int)ai.size(), ax.data(), ai.data(), ap.data());
+    }
+    C_sparse = (L_sparse && R_sparse) ? Utilities::MatrixSymmetrizationProduct(L_sparse, R_sparse) : 0;
+    if (!C_sparse) { int* p0 = new int[nV + 1](); C_sparse = Utilities::createCSC(nV, nV, 0, new double[1](), new int[1](), p0); }      // L'R + R'L = 0: an empty matrix, not a failure
+    if (!Q_sparse || !A_sparse || !L_sparse || !R_sparse || !C_sparse) { clearSparse(); return FAILED_SWITCH_TO_SPARSE; }
+    sparseSolver = true;
+    loaded = true;
+    return SUCCESSFUL_RETURN;
 }
 
 ReturnValue LCQProblem::switchToSparseMode()

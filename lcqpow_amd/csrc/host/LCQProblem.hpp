@@ -62,6 +62,8 @@ class LCQProblem {
 
   private:
     ReturnValue initializeSolver(bool needSubsolver = true);
+    ReturnValue loadVectors(const double* g, const double* lbL, const double* ubL, const double* lbR, const double* ubR, const double* lbA,
+                            const double* ubA, const double* lb, const double* ub, const double* x0, const double* y0);      // bounds, guess: shared by the dense and the CSC loader
     ReturnValue runOnDevice();                 // HIP_DENSE: LCQProblem::runSolver as one batch-of-one launch of k_lcqp_run
     bool runSparseOnDevice(ReturnValue& ret);  // OSQP_SPARSE with a banded or bordered pattern: k_sparse_sched; false when the pattern is not banded
     void finishFromTrace(const std::vector<double>& sc, const std::vector<double>& xs, int len);

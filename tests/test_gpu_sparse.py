@@ -315,7 +315,7 @@ def test_sparse_pattern_too_dense_for_the_sparse_engine_is_refused(hip):
         hip.SparseBatchLCQP(1, n, nC, nK, Q, E)
 
 
-@pytest.mark.parametrize("g,nK,nC", [(20, 60, 40), (44, 300, 200)])
+@pytest.mark.parametrize("g,nK,nC", [(44, 300, 200), (64, 300, 200)])
 def test_sparse_grid_pattern_on_the_general_ldl(hip, oracle, g, nK, nC):
     """A KKT graph that is a 2-D grid (5-point stencil Hessian, complementarity and constraint rows between neighbouring cells): half bandwidth
     ~ 2 g after reverse Cuthill-McKee, no small border -- the pattern that is "neither banded nor bordered".  The sparse engine runs it on the

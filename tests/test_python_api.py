@@ -417,22 +417,22 @@ def test_python_osqp_sparse_runs_on_the_sparse_engine(hip, oracle, capfd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("g", [44, 64])
-def test_python_sparse_pattern_that_is_neither_banded_nor_bordered_runs_on_the_gpu(hip, oracle, g):
-    """VERDICT round 3, "what's missing" 1: a sparse problem whose KKT graph is a 2-D grid (44 x 44 = 1936 and 64 x 64 = 4096 variables -- the
-    size of BASELINE config 5 --, half bandwidth 129 / 189 after reverse Cuthill-McKee, no small border) given in CSC form to LCQProblem with
-    the reference's OSQP_SPARSE arm.  The sparse engine refuses the pattern; since round 4 the dense kernels take nV <= 4096 (np = 2048 and
-    np = 4096 instantiations), so the problem still runs on the GPU behind the same surface (engine 1: the reference's host loop over the
-    SubsolverHIP plugin) -- and matches the sparse oracle, which factorises the same KKT matrices as a band of whatever width the ordering
-    gives.  (A sparse LDL' for such patterns, and anything above nV = 4096, is DESIGN.md section 9-3d.)"""
+@pytest.mark.parametrize("g,nK,nC", [(44, 300, 200), (64, 300, 200), (128, 1200, 800)])
+def test_python_sparse_pattern_that_is_neither_banded_nor_bordered_runs_on_the_gpu(hip, oracle, g, nK, nC):
+    """VERDICT rounds 3 - 5, "what's missing" 1: a sparse problem whose KKT graph is a 2-D grid (44 x 44 = 1936, 64 x 64 = 4096 -- the size of
+    BASELINE config 5 -- and 128 x 128 = 16 384 variables; half bandwidth 129 / 189 / ~ 380 after reverse Cuthill-McKee, no small border) given in
+    CSC form to LCQProblem with the reference's OSQP_SPARSE arm (src/SubsolverOSQP.cpp:136-152 takes any pattern).  Until round 5 the sparse engine
+    refused the pattern and the problem ran densified on the dense kernels (nV <= 4096 only).  Since round 6 it runs on the sparse engine
+    (getLastEngine() == 3) with the general sparse LDL' -- nested dissection, dense fronts, one wavefront per instance (lcqp_sparse_general.hpp,
+    sp_general_factor / sp_general_solve) -- and matches the sparse oracle, which factorises the same KKT matrices with its own general LDL'
+    (up-looking, an ordering computed in Python) to 1e-9 / 1e-7."""
     lcqpow = _lcqpow()
-    d = P.grid_lcqp(g)
+    d = P.grid_lcqp(g, nK, nC)
     n, nC, nK = d["nV"], d["nC"], d["nComp"]
     assert n == g * g
     Qc, Ec = d["Q"].tocsr(), d["E"].tocsr()
-    perm, w, kb = oracle.kkt_ordering(n, Qc.indptr, Qc.indices, Ec.indptr, Ec.indices, wmax=10 ** 6, kbmax=0)
-    assert w > 63 and kb == 0
-    ro = oracle.sparse_lcqp_solve(n, nC, nK, Qc, d["g"], Ec, lbA=d["lbA"], ubA=d["ubA"], perm=perm, w=w, kb=0, opt=oracle.default_options(perturbStep=0))
+    perm = oracle.kkt_ordering_general(n, Qc.indptr, Qc.indices, Ec.indptr, Ec.indices)
+    ro = oracle.sparse_lcqp_solve(n, nC, nK, Qc, d["g"], Ec, lbA=d["lbA"], ubA=d["ubA"], perm=perm, w=-1, kb=0, opt=oracle.default_options(perturbStep=0))
     assert ro["ret"] == 0
     wrap = lambda M: lcqpow.cscWrapper(M.shape[0], M.shape[1], M.nnz, np.asarray(M.data, dtype=float), M.indices, M.indptr)
     lcqp = lcqpow.LCQProblem(nV=n, nC=nC, nComp=nK)
@@ -446,9 +446,9 @@ def test_python_sparse_pattern_that_is_neither_banded_nor_bordered_runs_on_the_g
         M.sort_indices()
     assert lcqp.loadLCQP(Q=wrap(Q), g=d["g"], L=wrap(L), R=wrap(R), A=wrap(A), lbA=d["lbA"], ubA=d["ubA"]) == 0
     assert lcqp.runSolver() == 0
-    assert lcqp.getLastEngine() == 1                  # not the sparse engine (3): the pattern is refused there
+    assert lcqp.getLastEngine() == 3                  # the sparse engine (until round 5: 1, the densified host loop)
     x, y = lcqp.getPrimalSolution(), lcqp.getDualSolution()
-    assert np.abs(x - ro["x"]).max() < 1e-7 and np.abs(y - ro["y"]).max() < 1e-5
+    assert np.abs(x - ro["x"]).max() < 1e-9 and np.abs(y - ro["y"]).max() < 1e-7
     Lx, Rx = d["L"] @ x, d["R"] @ x
     assert abs(Lx @ Rx) < 1e3 * 2.221e-16 and Lx.min() > -1e-9 and Rx.min() > -1e-9
     assert np.abs(d["Q"] @ x + d["g"] - d["E"].T @ y).max() < 1e-7
