@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--no-resident", action="store_true", help="skip the 8192-resident-instances measurement")
     ap.add_argument("--no-sparse", action="store_true", help="skip the sparse_config5 object (BASELINE configs[4]) of the default line")
     ap.add_argument("--sparse-batch", type=int, default=65536, help="instances of the sparse_config5 object")
+    ap.add_argument("--grid-batch", type=int, default=256, help="instances of the grid_128 object inside sparse_config5 (the general sparse LDL'; 0 = skip)")
     ap.add_argument("--devices", type=str, default=None, help="comma-separated device ids of the N shards (default 0..N-1; under torch.distributed.run: rank r takes entry r). "
                     "A device may appear more than once: `--gpus 2 --devices 0,0` rehearses the N = 2 path -- two shards, aggregation, JSON -- on a one-GPU box")
     args = ap.parse_args()
@@ -398,8 +399,70 @@ def main():
                 big["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
                 errors.append(f"sparse_config5.cpu_baseline: {type(e).__name__}: {e}")
 
+    def extra_grid():
+        # A pattern that is neither banded nor bordered (round 6): B LCQPs whose KKT graph is a 128 x 128 grid (n = 16 384, nC = 800, nComp = 1200;
+        # lcqpow_amd/synth_sparse.py::grid_pattern_arrays) on the general sparse LDL' of the sparse engine -- nested dissection, dense fronts, one
+        # wavefront per instance (lcqp_sparse_general.hpp, sp_general_factor / sp_general_solve).  One warm-up and one timed step; CPU beside it:
+        # the sparse oracle with its own general LDL' (up-looking, an ordering computed in Python), one LCQP per thread.
+        import threading
+        import scipy.sparse as sp
+        import oracle_py as O
+        from lcqpow_amd import synth_sparse as S
+        gB = args.grid_batch
+        Qpat, Epat, qo, eo, info = S.grid_pattern_arrays(128, 800, 1200)
+        ng, nCg, nKg = info["n"], info["nC"], info["nComp"]
+        inst = [S.grid_values(i, info, (qo, eo)) for i in range(gB)]
+        sb = la.SparseBatchLCQP(gB, ng, nCg, nKg, Qpat, Epat, device=devices[0], opt=opt)
+        try:
+            rc = sb.load(0, gB, np.stack([d_["Qx"] for d_ in inst]), np.stack([d_["g"] for d_ in inst]), np.stack([d_["Ex"] for d_ in inst]),
+                         lbA=np.stack([d_["lbA"] for d_ in inst]), ubA=np.stack([d_["ubA"] for d_ in inst]))
+            if rc != 0:
+                raise RuntimeError(f"grid load failed: {rc}")
+            sb.run(); sb.synchronize()
+            tg = time.perf_counter(); sb.run(); sb.synchronize(); dtg = time.perf_counter() - tg
+            xg, _, stg = sb.solution()
+            s_ms, k_ms = sb.last_timing()
+            gbytes = sb.algorithmic_bytes()
+            ach = gbytes / ((s_ms + k_ms) * 1e-3) / 1e9
+            obj = {"metric": f"LCQPs/sec (batched sparse, KKT graph a 128 x 128 grid: n={ng},nC={nCg},nComp={nKg}; general sparse LDL')", "value": gB / dtg, "unit": "LCQPs/s",
+                   "batch": gB, "steps": 1, "ms_per_step": 1e3 * dtg, "solved": sum(1 for s_ in stg if s_["returnValue"] == 0), "fronts": sb.fronts(),
+                   "lanes_per_instance": sb.lanes(), "mean_lcqp_iterates": float(np.mean([s_["iterTotal"] for s_ in stg])),
+                   "max_lcqp_iterates": int(max(s_["iterTotal"] for s_ in stg)),
+                   "roofline": {"bound": "hbm", "kernel": "k_sparse_setup + k_sparse_sched (general LDL')", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": gbytes},
+                   "data": "synthetic (lcqpow_amd/synth_sparse.py::grid_pattern_arrays / grid_values, numpy PCG64 seed0=0x4C43515000000006 ^ (instance id + 1))"}
+        finally:
+            sb.close()
+        if args.cpu_sample > 0:
+            cnt = min(gB, max(8, args.cpu_sample // 4))
+            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            csr = [(sp.csc_matrix((d_["Qx"], Qpat.indices, Qpat.indptr), shape=Qpat.shape).tocsr(), sp.csc_matrix((d_["Ex"], Epat.indices, Epat.indptr), shape=Epat.shape).tocsr()) for d_ in inst[:cnt]]
+            perm = O.kkt_ordering_general(ng, csr[0][0].indptr, csr[0][0].indices, csr[0][1].indptr, csr[0][1].indices)
+            oopt = O.default_options(perturbStep=0, printLevel=0)
+            res = [None] * cnt
+
+            def work(lo, hi):
+                for i in range(lo, hi):
+                    res[i] = O.sparse_lcqp_solve(ng, nCg, nKg, csr[i][0], inst[i]["g"], csr[i][1], lbA=inst[i]["lbA"], ubA=inst[i]["ubA"], opt=oopt, perm=perm, w=-1, kb=0)
+            nth = min(threads, cnt)
+            O.lib()
+            tc = time.perf_counter()
+            th = [threading.Thread(target=work, args=(k_ * cnt // nth, (k_ + 1) * cnt // nth)) for k_ in range(nth)]
+            [t_.start() for t_ in th]; [t_.join() for t_ in th]
+            dtc = time.perf_counter() - tc
+            t1 = time.perf_counter(); work(0, 1); single = 1.0 / (time.perf_counter() - t1)
+            dx = float(max(np.abs(res[i]["x"] - xg[i]).max() for i in range(cnt)))
+            obj["cpu_baseline"] = {"value": cnt / dtc, "unit": "LCQPs/s", "cores": len(O.host_cpu_topology()[0]), "threads": nth, "kind": "port",
+                                   "sample": f"instances 0..{cnt - 1} of the same grid workload, sparse CPU oracle with its general LDL' (oracle/lcqp_oracle_sparse.c: the up-looking "
+                                             f"factorisation OSQP's QDLDL restates; the reference's OSQP path cannot be built), one LCQP per thread, "
+                                             f"{sum(1 for r_ in res if r_ and r_['ret'] == 0)}/{cnt} solved in {dtc:.2f} s",
+                                   "single_core_value": single, "gpu_over_cpu": obj["value"] / (cnt / dtc), "max_abs_dx_vs_gpu": dx}
+        out["sparse_config5"]["grid_128"] = obj
+
     if main_proc and world == 1 and not sparse and not args.no_sparse and shape == (256, 512, 64) and B == 1024:
         extra("sparse_config5", extra_sparse)
+        if "error" not in out.get("sparse_config5", {"error": 1}) and args.grid_batch > 0:
+            extra("sparse_config5.grid_128", extra_grid)
 
     def extra_backsolve():
         # the factor-once / back-solve-many kernel pair on its own (bytes_bs(N) = 8 N (N+2)), cache-cold: 4096

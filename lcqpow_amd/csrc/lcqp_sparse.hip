@@ -145,6 +145,7 @@ struct SpBatch {
     unsigned gLsize, gStackSize;
     const int *gPiv0, *gNp, *gNb, *gRowPtr, *gRows, *gChildPtr, *gChild, *gRel, *gAsmPtr, *gAsmSrc, *gAsmGate, *gAsmPos;
     const unsigned *gLoff, *gCBoff;
+    const int *gMeta, *gChildInfo;   // [gnF][GEN_META] np, nb, piv0, rowPtr, asmPtr, asmEnd, childPtr, childEnd, Loff, CBoff: one load per front; [children][4] nb, CBoff, rowPtr of the child
     double *gStack, *gFront;     // [B][gStackSize] update blocks of the fronts, [B][gMaxFront^2] a front too large for LDS
     size_t kfStride;             // doubles per instance of KaF / KpF
     // algorithmic bytes of one event of each kind (filled by the host: formed in the kernel they are loop invariants the compiler keeps in
@@ -712,43 +713,63 @@ constexpr int GEN_JB = 8;
 constexpr int GEN_LDS_FRONT = 64;        // fronts up to this size are factorised inside LDS
 constexpr int GEN_MAX_FRONT = 576;       // panel of the largest front: 576 x 8 doubles beside nothing else in the 40 KB of a wavefront
 
-template <bool LDSF, class FA, class Dd, class Use>
-__device__ __forceinline__ void sp_general_front(SpCtx<64>& c, int f, FA F, double* P, GD Lst, GD Kd, GD stack, double dprim, Dd ddual, Use use)
+constexpr int GEN_META = 12;
+constexpr int GEN_BITS_OFF = GEN_MAX_FRONT * GEN_JB + 16;        // doubles: the working set as a bit set behind the panel and 1 / D of a block
+constexpr int GEN_BITS_WORDS = (GEN_LDS_FRONT * GEN_LDS_FRONT + 16 * 64 - GEN_BITS_OFF) * 2;      // 32-bit words that fit the rest of the window
+
+// `in(r)`: is row r of E in the working set -- a bit in LDS (sp_general_factor builds the set once per factorisation: the gate of an entry and
+// the diagonal of a row node are then no round trip to memory)
+template <bool LDSF, class FA, class Dd, class In>
+__device__ __forceinline__ void sp_general_front(SpCtx<64>& c, int f, FA F, double* P, GD Lst, GD Kd, GD stack, double dprim, Dd ddual, In in)
 {
     const SpBatch& db = *c.db;
     const int t = here(c.gl), n = db.n, nnzQ = db.nnzQ;
-    const int np = db.gNp[f], nb = db.gNb[f], ff = np + nb, piv0 = db.gPiv0[f];
+    // everything the front needs to know about itself in ONE load (the dependent chain of a front is what a factorisation costs: about
+    // 33 us per front with a load per field, sixteen round trips; profiles/round6/general_ldl_timing.log)
+    const int* mt = db.gMeta + (size_t)f * GEN_META;
+    const int np = mt[0], nb = mt[1], piv0 = mt[2], asm0 = mt[4], asm1 = mt[5], ch0 = mt[6], ch1 = mt[7];
+    const unsigned Loff = (unsigned)mt[8], CBoff = (unsigned)mt[9];
+    const int ff = np + nb;
     auto sync = [&]() { if (LDSF) wave_sync(); else g_sync(); };
+#ifdef GEN_PROFILE      // (diagnostic: the parts of a front on the profile slots the rest of the engine hardly uses: zero -> products, assembly -> status test, children -> vectors, elimination -> factorisation, stores -> rhs)
+#define GPROF(c, P) SPROF(c, P)
+#else
+#define GPROF(c, P) do { } while (0)
+#endif
+    GPROF(c, SP_LCQP);
     for (int e = t; e < ff * ff; e += 64) F[e] = 0.0;
     sync();
+    GPROF(c, SP_PRODUCTS);
     {   // the entries of K whose column is a pivot of this front (one entry of Q or E each: distinct positions); rows of E gated by value
         GD Qv = c.Qx(), Ev = c.Ex();
-        const int e1 = db.gAsmPtr[f + 1];
-        for (int e = db.gAsmPtr[f] + t; e < e1; e += 64) {
-            const int src = db.gAsmSrc[e], gate = db.gAsmGate[e];
-            const double v = (gate >= 0 && !use(gate)) ? 0.0 : (src >= nnzQ ? (double)Ev[src - nnzQ] : (double)Qv[src]);
-            F[db.gAsmPos[e]] = v;
+        for (int e = asm0 + t; e < asm1; e += 64) {
+            const int src = db.gAsmSrc[e], gate = db.gAsmGate[e], pos = db.gAsmPos[e];
+            const double v = (src >= nnzQ ? (double)Ev[src - nnzQ] : (double)Qv[src]);
+            F[pos] = (gate >= 0 && !in(gate)) ? 0.0 : v;
         }
     }
     sync();
     for (int j = t; j < np; j += 64) {      // diagonals: Q_ii + dprim; -ddual for an active row, -1 for a decoupled one
         const int node = db.pnode[piv0 + j];
         if (node < n) F[j + ff * j] += dprim;
-        else F[j + ff * j] = use(node - n) ? -ddual(node - n) : -1.0;
+        else F[j + ff * j] = in(node - n) ? -ddual(node - n) : -1.0;
     }
     sync();
-    for (int ci = db.gChildPtr[f]; ci < db.gChildPtr[f + 1]; ci++) {      // extend-add: the children's update blocks, one child after the other
-        const int ch = db.gChild[ci], nbc = db.gNb[ch];
-        GD CB = stack + (int)db.gCBoff[ch];
-        const int* rel = db.gRel + db.gRowPtr[ch];
+    GPROF(c, SP_ASSEMBLE);
+    for (int ci = ch0; ci < ch1; ci++) {      // extend-add: the children's update blocks, one child after the other
+        const int* cm = db.gChildInfo + (size_t)ci * 4;
+        const int nbc = cm[0];
+        GD CB = stack + cm[1];
+        const int* rel = db.gRel + cm[2];
         for (int e = t; e < nbc * nbc; e += 64) {
             const int b = e / nbc, a = e - b * nbc;
             if (a >= b) F[rel[a] + ff * rel[b]] += (double)CB[a + nbc * b];
         }
         sync();
     }
+    GPROF(c, SP_VECTORS);
     double* dv = c.win + GEN_MAX_FRONT * GEN_JB;      // 1 / D of the block's pivots (behind the largest panel either variant uses)
-    GD Lp = Lst + (int)db.gLoff[f];
+    GD Lp = Lst + (int)Loff;
     for (int j0 = 0; j0 < np; j0 += GEN_JB) {
         const int jb = min(GEN_JB, np - j0), h = ff - j0;
         // the panel of the block: rows j0 .. ff-1, columns j0 .. j0+jb-1 -> P[(i - j0) * JB + c]
@@ -771,12 +792,13 @@ __device__ __forceinline__ void sp_general_front(SpCtx<64>& c, int f, FA F, doub
             double pi[GEN_JB];
 #pragma unroll
             for (int cc = 0; cc < GEN_JB; cc++) pi[cc] = (cc < jb) ? P[(i - j0) * GEN_JB + cc] * dv[cc] : 0.0;
-            for (int k = k0; k <= i; k += 4) {
-                double fv[4], sv[4];
+            constexpr int UF = LDSF ? 4 : 16;      // entries of F in flight per lane: a front in memory pays a round trip per group
+            for (int k = k0; k <= i; k += UF) {
+                double fv[UF], sv[UF];
 #pragma unroll
-                for (int u = 0; u < 4; u++) fv[u] = (k + u <= i) ? (double)F[i + ff * (k + u)] : 0.0;
+                for (int u = 0; u < UF; u++) fv[u] = (k + u <= i) ? (double)F[i + ff * (k + u)] : 0.0;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < UF; u++) {
                     double acc = 0.0;
                     if (k + u <= i) {
                         const double* pk = P + (k + u - j0) * GEN_JB;
@@ -786,16 +808,18 @@ __device__ __forceinline__ void sp_general_front(SpCtx<64>& c, int f, FA F, doub
                     sv[u] = acc;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) if (k + u <= i) F[i + ff * (k + u)] = fv[u] - sv[u];
+                for (int u = 0; u < UF; u++) if (k + u <= i) F[i + ff * (k + u)] = fv[u] - sv[u];
             }
         }
         sync();
     }
+    GPROF(c, LDSF ? SP_FACTOR : SP_LCQP);      // (elimination of a front in LDS / of a front in memory)
     {   // the update block goes onto the stack (its place was fixed by the host: where its children's blocks lay)
-        GD CB = stack + (int)db.gCBoff[f];
+        GD CB = stack + (int)CBoff;
         for (int e = t; e < nb * nb; e += 64) { const int b = e / nb, a = e - b * nb; if (a >= b) CB[a + nb * b] = (double)F[(np + a) + ff * (np + b)]; }
     }
     g_sync();
+    GPROF(c, SP_RHS);
 }
 
 template <class Dd, class Use>
@@ -806,10 +830,30 @@ __device__ __forceinline__ void sp_general_factor(SpCtx<64>& c, GD Lst, GD Kd, d
     double* P = c.win + GEN_LDS_FRONT * GEN_LDS_FRONT;        // panel of a front in LDS (64 x 8) ...
     GD stack = c.GStack(), Fg = c.GFront();
     SPROF(c, SP_VECTORS);
+    // the working set as a bit set in LDS (behind everything a front uses of the window)
+    unsigned* bits = reinterpret_cast<unsigned*>(c.win + GEN_BITS_OFF);
+    const int m = db.m, words = (m + 31) >> 5;
+    const bool haveBits = words <= GEN_BITS_WORDS;
+    if (haveBits) {
+        for (int w = c.gl; w < words; w += 64) {
+            unsigned word = 0u;
+#pragma unroll 8
+            for (int k = 0; k < 32; k++) { const int r = w * 32 + k; if (r < m && use(r)) word |= 1u << k; }
+            bits[w] = word;
+        }
+        wave_sync();
+    }
     for (int f = 0; f < db.gnF; f++) {
-        const int ff = db.gNp[f] + db.gNb[f];
-        if (ff <= GEN_LDS_FRONT) sp_general_front<true>(c, f, Fl, P, Lst, Kd, stack, dprim, ddual, use);
-        else sp_general_front<false>(c, f, Fg, c.win, Lst, Kd, stack, dprim, ddual, use);      // ... or of a front in memory (up to GEN_MAX_FRONT x 8: the whole window)
+        const int* mt = db.gMeta + (size_t)f * GEN_META;
+        const int ff = mt[0] + mt[1];
+        if (haveBits) {
+            auto in = [=](int r) { return ((bits[r >> 5] >> (r & 31)) & 1u) != 0u; };
+            if (ff <= GEN_LDS_FRONT) sp_general_front<true>(c, f, Fl, P, Lst, Kd, stack, dprim, ddual, in);
+            else sp_general_front<false>(c, f, Fg, c.win, Lst, Kd, stack, dprim, ddual, in);      // ... or of a front in memory (up to GEN_MAX_FRONT x 8: the whole window)
+        } else {
+            if (ff <= GEN_LDS_FRONT) sp_general_front<true>(c, f, Fl, P, Lst, Kd, stack, dprim, ddual, use);
+            else sp_general_front<false>(c, f, Fg, c.win, Lst, Kd, stack, dprim, ddual, use);
+        }
     }
     c.bytes += db.by[BY_FACTOR];
     SPROF(c, SP_FACTOR);
@@ -828,9 +872,10 @@ __device__ __forceinline__ void sp_general_sweep(SpCtx<64>& c, GD Lst, GD b)
     constexpr int CHUNK = GEN_LDS_FRONT * GEN_LDS_FRONT + 16 * 64 - GEN_MAX_FRONT;      // doubles left in the window
     for (int q = 0; q < db.gnF; q++) {
         const int f = FWD ? q : db.gnF - 1 - q;
-        const int np = db.gNp[f], nb = db.gNb[f], ff = np + nb, piv0 = db.gPiv0[f];
-        const int* rows = db.gRows + db.gRowPtr[f];
-        GD Lp = Lst + (int)db.gLoff[f];
+        const int* mt = db.gMeta + (size_t)f * GEN_META;
+        const int np = mt[0], nb = mt[1], ff = np + nb, piv0 = mt[2];
+        const int* rows = db.gRows + mt[3];
+        GD Lp = Lst + mt[8];
         for (int i = t; i < ff; i += 64) bl[i] = (double)b[i < np ? piv0 + i : rows[i - np]];
         const int cw = max(1, min(np, CHUNK / ff));
         for (int c0 = FWD ? 0 : ((np - 1) / cw) * cw; FWD ? c0 < np : c0 >= 0; c0 += FWD ? cw : -cw) {
@@ -2369,6 +2414,13 @@ try {
          (d.yout = sp_alloc<double>(h, B * m));
     if (general) {
         std::vector<unsigned> lo(sym.Loff.begin(), sym.Loff.end()), co(sym.CBoff.begin(), sym.CBoff.end());
+        std::vector<int> meta((size_t)sym.nF * GEN_META, 0), cinfo(std::max<size_t>(sym.child.size(), 1) * 4, 0);
+        for (int f = 0; f < sym.nF; f++) {
+            int* mt = meta.data() + (size_t)f * GEN_META;
+            mt[0] = sym.np[f]; mt[1] = sym.nb[f]; mt[2] = sym.piv0[f]; mt[3] = sym.rowPtr[f]; mt[4] = sym.asmPtr[f]; mt[5] = sym.asmPtr[f + 1];
+            mt[6] = sym.childPtr[f]; mt[7] = sym.childPtr[f + 1]; mt[8] = (int)sym.Loff[f]; mt[9] = (int)sym.CBoff[f];
+        }
+        for (size_t ci = 0; ci < sym.child.size(); ci++) { const int ch = sym.child[ci]; cinfo[4 * ci] = sym.nb[ch]; cinfo[4 * ci + 1] = (int)sym.CBoff[ch]; cinfo[4 * ci + 2] = sym.rowPtr[ch]; }
         ok = ok && (d.gPiv0 = sp_alloc<int>(h, sym.piv0.size(), sym.piv0.data())) && (d.gNp = sp_alloc<int>(h, sym.np.size(), sym.np.data())) &&
              (d.gNb = sp_alloc<int>(h, sym.nb.size(), sym.nb.data())) && (d.gRowPtr = sp_alloc<int>(h, sym.rowPtr.size(), sym.rowPtr.data())) &&
              (d.gRows = sp_alloc<int>(h, std::max<size_t>(sym.rows.size(), 1), sym.rows.empty() ? nullptr : sym.rows.data())) &&
@@ -2378,6 +2430,7 @@ try {
              (d.gAsmPtr = sp_alloc<int>(h, sym.asmPtr.size(), sym.asmPtr.data())) && (d.gAsmSrc = sp_alloc<int>(h, sym.asmSrc.size(), sym.asmSrc.data())) &&
              (d.gAsmGate = sp_alloc<int>(h, sym.asmGate.size(), sym.asmGate.data())) && (d.gAsmPos = sp_alloc<int>(h, sym.asmPos.size(), sym.asmPos.data())) &&
              (d.gLoff = sp_alloc<unsigned>(h, lo.size(), lo.data())) && (d.gCBoff = sp_alloc<unsigned>(h, co.size(), co.data())) &&
+             (d.gMeta = sp_alloc<int>(h, meta.size(), meta.data())) && (d.gChildInfo = sp_alloc<int>(h, cinfo.size(), cinfo.data())) &&
              (d.gStack = sp_alloc<double>(h, B * d.gStackSize)) && (d.gFront = sp_alloc<double>(h, B * (size_t)d.gMaxFront * d.gMaxFront));
     }
     {

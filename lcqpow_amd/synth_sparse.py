@@ -75,3 +75,48 @@ def _rowsum(av, xv):
     for k in range(av.shape[1]):
         s = s + av[:, k] * xv[:, k]
     return s
+
+
+# ---- a second sparse workload: a pattern that is neither banded nor bordered (round 6: the general sparse LDL') --------------------------------
+GRID_SEED0 = 0x4C43515000000006
+
+
+def grid_pattern_arrays(g=128, nC=800, nComp=1200):
+    """B sparse LCQPs whose KKT graph is a g x g grid: Q a 5-point stencil, row r of A couples two vertically adjacent cells, complementarity
+    between horizontally adjacent cells (cells (r, 2c), (r, 2c + 1)); which cells carry rows is fixed by the pattern seed, the values differ per
+    instance.  Returns (Q pattern, stacked [A; L; R] pattern, qorder, eorder, info) with info = the cell indices the value generator needs."""
+    n = g * g
+    rng = np.random.Generator(np.random.PCG64(GRID_SEED0))
+    idx = lambda r, c: r * g + c
+    rr, cc = np.divmod(np.arange(n), g)
+    right = np.flatnonzero(cc + 1 < g); down = np.flatnonzero(rr + 1 < g)
+    qi = np.concatenate([np.arange(n), right + 1, right, down + g, down])      # diagonal; (i+1, i), (i, i+1); (i+g, i), (i, i+g)
+    qj = np.concatenate([np.arange(n), right, right + 1, down, down + g])
+    Qp, qorder = _coo_to_csc(n, n, qi, qj)
+    cells = np.array([idx(r, c) for r in range(g) for c in range(0, g - 1, 2)])
+    assert nComp <= len(cells)
+    li = np.sort(rng.choice(cells, nComp, replace=False))                       # L_k = e_{li[k]}, R_k = e_{li[k] + 1}
+    ar = rng.integers(0, g - 1, nC); ac = rng.integers(0, g, nC)
+    a0 = ar * g + ac                                                            # A_k touches a0[k] and a0[k] + g
+    ei = np.concatenate([np.arange(nC), np.arange(nC), nC + np.arange(nComp), nC + nComp + np.arange(nComp)])
+    ej = np.concatenate([a0, a0 + g, li, li + 1])
+    Ep, eorder = _coo_to_csc(nC + 2 * nComp, n, ei, ej)
+    return Qp, Ep, qorder, eorder, dict(g=g, n=n, nC=nC, nComp=nComp, right=right, down=down, li=li, a0=a0)
+
+
+def grid_values(inst, info, orders, seed0=GRID_SEED0):
+    """Values of instance `inst` of the grid workload in the CSC order of grid_pattern_arrays: dict(Qx, g, Ex, lbA, ubA)"""
+    qorder, eorder = orders
+    g, n, nC, nK = info["g"], info["n"], info["nC"], info["nComp"]
+    rng = np.random.Generator(np.random.PCG64(seed0 ^ (inst + 1)))
+    dq = 4.5 + rng.uniform(0, 1, n)
+    offr = -rng.uniform(0.8, 1.2, len(info["right"])); offd = -rng.uniform(0.8, 1.2, len(info["down"]))      # diagonally dominant: positive definite
+    xs = rng.uniform(-1, 1, n)
+    coin = rng.integers(0, 2, nK)
+    xs[info["li"]] = np.where(coin == 0, 0.0, rng.uniform(0, 1, nK))
+    xs[info["li"] + 1] = np.where(coin == 0, rng.uniform(0, 1, nK), 0.0)
+    a1 = rng.uniform(0.5, 1.5, nC); a2 = rng.uniform(-1.5, -0.5, nC)
+    ax = a1 * xs[info["a0"]] + a2 * xs[info["a0"] + g]
+    Qx = np.concatenate([dq, offr, offr, offd, offd])[qorder]
+    Ex = np.concatenate([a1, a2, np.ones(2 * nK)])[eorder]
+    return dict(Qx=Qx, g=rng.uniform(-2, 2, n), Ex=Ex, lbA=ax - rng.uniform(0.1, 1.0, nC), ubA=ax + rng.uniform(0.1, 1.0, nC))

@@ -20,4 +20,10 @@ for g in [int(a) for a in sys.argv[1:]]:
     s = st[0]
     print(f"g {g} n {n} m {nC + 2 * nK}: fronts {sb.fronts()} create {t1 - t0:.2f} s load {t2 - t1:.2f} s run {t3 - t2:.2f} s (device timing {sb.last_timing()}) ret {s['returnValue']} iter {s['iterTotal']} "
           f"factorizations {s['factorizations']} corrections {s['corrections']} trials {s['trials']}", flush=True)
+    import ctypes as C
+    out = np.zeros(8)
+    la.lib().lcqp_hip_sparse_read_profile.argtypes = [C.c_void_p, C.c_void_p]
+    if la.lib().lcqp_hip_sparse_read_profile(sb.h, out.ctypes.data_as(C.c_void_p)) == 0 and out.sum() > 0:      # a -DLCQP_PROFILE build (LCQPOW_HIP_LIBRARY=lcqpow_amd/liblcqpow_hip_prof.so)
+        names = ["sparse products", "status test", "factorisation", "forward sweeps", "backward sweeps", "vector operations", "LCQP level", "rhs of a correction"]
+        print("   profile (100 MHz ticks: %.0f ms): " % (out.sum() / 1e5) + ", ".join(f"{nm} {100 * v / out.sum():.1f} %" for nm, v in zip(names, out)), flush=True)
     sb.close()
