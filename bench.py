@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--no-resident", action="store_true", help="skip the 8192-resident-instances measurement")
     ap.add_argument("--no-sparse", action="store_true", help="skip the sparse_config5 object (BASELINE configs[4]) of the default line")
     ap.add_argument("--sparse-batch", type=int, default=65536, help="instances of the sparse_config5 object")
-    ap.add_argument("--grid-batch", type=int, default=256, help="instances of the grid_128 object inside sparse_config5 (the general sparse LDL'; 0 = skip)")
+    ap.add_argument("--grid-batch", type=int, default=1024, help="instances of the grid_128 object inside sparse_config5 (the general sparse LDL'; 0 = skip)")
     ap.add_argument("--devices", type=str, default=None, help="comma-separated device ids of the N shards (default 0..N-1; under torch.distributed.run: rank r takes entry r). "
                     "A device may appear more than once: `--gpus 2 --devices 0,0` rehearses the N = 2 path -- two shards, aggregation, JSON -- on a one-GPU box")
     args = ap.parse_args()
@@ -328,7 +328,7 @@ def main():
             obj = {"metric": f"LCQPs/sec (batched sparse n={ns},nC={nCs},nComp={nKs}, OSQP-style ADMM KKT + polish)", "value": Bs / dts, "unit": "LCQPs/s",
                    "batch": Bs, "steps": 1, "ms_per_step": 1e3 * dts, "solved": sum(1 for s_ in sts if s_["returnValue"] == 0),
                    "kkt_half_bandwidth": sb.bandwidth(), "lanes_per_instance": sb.lanes(),
-                   "mean_lcqp_iterates": float(np.mean([s_["iterTotal"] for s_ in sts])),
+                   "mean_lcqp_iterates": float(np.mean([s_["iterTotal"] for s_ in sts])), "max_lcqp_iterates": int(max(s_["iterTotal"] for s_ in sts)),
                    "roofline": {"bound": "hbm", "kernel": "k_sparse_setup + k_sparse_sched", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("sparse", Bs, (ns, nCs, nKs)), "algorithmic_bytes_per_launch": sbytes},
                    "data": "synthetic (lcqpow_amd/synth_sparse.py: banded pattern, numpy PCG64 seed0=0x4C43515000000005 ^ instance id)"}
@@ -386,7 +386,10 @@ def main():
                 raise
             big, _ = sparse_object(16384)
             big["note"] = f"batch {args.sparse_batch} does not fit ({type(e).__name__}: {e}); 16384 instead"
-        big["batch_4096"] = {k_: small[k_] for k_ in ("value", "unit", "batch", "ms_per_step", "solved", "mean_lcqp_iterates", "roofline")}
+        big["batch_4096"] = {k_: small[k_] for k_ in ("value", "unit", "batch", "ms_per_step", "solved", "mean_lcqp_iterates", "max_lcqp_iterates", "roofline")}
+        one, _ = sparse_object(1)      # ONE problem alone: the three sequential chains of the band engine are what the stragglers of a batch run at
+        big["single_instance_ms"] = one["ms_per_step"]
+        big["single_instance_lcqp_iterates"] = one["mean_lcqp_iterates"]
         out["sparse_config5"] = big
         if args.cpu_sample > 0:
             try:

@@ -773,7 +773,7 @@ __device__ __forceinline__ void sp_general_front(SpCtx<64>& c, int f, FA F, doub
     for (int j0 = 0; j0 < np; j0 += GEN_JB) {
         const int jb = min(GEN_JB, np - j0), h = ff - j0;
         // the panel of the block: rows j0 .. ff-1, columns j0 .. j0+jb-1 -> P[(i - j0) * JB + c]
-        for (int e = t; e < h * jb; e += 64) { const int cc = e / h, i = e - cc * h; P[i * GEN_JB + cc] = F[(j0 + i) + ff * (j0 + cc)]; }
+        for (int e = t; e < h * GEN_JB; e += 64) { const int cc = e / h, i = e - cc * h; P[i * GEN_JB + cc] = (cc < jb) ? (double)F[(j0 + i) + ff * (j0 + cc)] : 0.0; }
         wave_sync();
         for (int cc = 0; cc < jb; cc++) {      // eliminate inside the panel (columns unscaled: column c holds l_ic d_c)
             const double dinv = 1.0 / P[cc * GEN_JB + cc];
@@ -792,7 +792,7 @@ __device__ __forceinline__ void sp_general_front(SpCtx<64>& c, int f, FA F, doub
             double pi[GEN_JB];
 #pragma unroll
             for (int cc = 0; cc < GEN_JB; cc++) pi[cc] = (cc < jb) ? P[(i - j0) * GEN_JB + cc] * dv[cc] : 0.0;
-            constexpr int UF = LDSF ? 4 : 16;      // entries of F in flight per lane: a front in memory pays a round trip per group
+            constexpr int UF = LDSF ? 8 : 16;      // entries of F in flight per lane: a front in memory pays a round trip per group
             for (int k = k0; k <= i; k += UF) {
                 double fv[UF], sv[UF];
 #pragma unroll
@@ -801,9 +801,11 @@ __device__ __forceinline__ void sp_general_front(SpCtx<64>& c, int f, FA F, doub
                 for (int u = 0; u < UF; u++) {
                     double acc = 0.0;
                     if (k + u <= i) {
-                        const double* pk = P + (k + u - j0) * GEN_JB;
-#pragma unroll
-                        for (int cc = 0; cc < GEN_JB; cc++) if (cc < jb) acc += pi[cc] * pk[cc];
+                        // a row of the panel is eight doubles, 64-byte aligned: four 16-byte LDS reads (the same address in every lane: a broadcast);
+                        // columns beyond jb hold finite values and meet pi = 0
+                        const double2* pk = reinterpret_cast<const double2*>(P + (k + u - j0) * GEN_JB);
+                        const double2 q0 = pk[0], q1 = pk[1], q2 = pk[2], q3 = pk[3];
+                        acc = ((pi[0] * q0.x + pi[1] * q0.y) + (pi[2] * q1.x + pi[3] * q1.y)) + ((pi[4] * q2.x + pi[5] * q2.y) + (pi[6] * q3.x + pi[7] * q3.y));
                     }
                     sv[u] = acc;
                 }
