@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
-KERNEL_SOURCES = ("lcqp_hip.hip", "lcqp_nch.hip", "lcqp_kernels.hpp", "lcqp_launch.hpp", "lcqp_dev.hpp", "lcqp_wg.hpp", "lcqp_sparse.hip")
+KERNEL_SOURCES = ("lcqp_hip.hip", "lcqp_nch.hip", "lcqp_kernels.hpp", "lcqp_launch.hpp", "lcqp_dev.hpp", "lcqp_wg.hpp", "lcqp_sparse.hip", "lcqp_sparse_general.hpp")
 
 
 def shard_range(rank, world, per_rank):

@@ -878,6 +878,41 @@ __device__ __forceinline__ void sp_general_sweep(SpCtx<64>& c, GD Lst, GD b)
         const int np = mt[0], nb = mt[1], ff = np + nb, piv0 = mt[2];
         const int* rows = db.gRows + mt[3];
         GD Lp = Lst + mt[8];
+        if (ff <= 64) {
+            // A front of at most 64 rows (every leaf, every merged separator: most of the pivots): lane t IS row t.  The right-hand side lives in
+            // one register per lane, a pivot's value travels by v_readlane, the panel's column (forward) or row (backward) comes from LDS with an
+            // address that does not depend on the chain -- a pivot step is a broadcast and a fused multiply-add, ~30 clocks, where the version
+            // through LDS (below, kept for larger fronts) paid a read - modify - write round trip of the right-hand side per pivot, ~1000 clocks
+            // with one wavefront per SIMD.  Backward in axpy form too (a finished x_i leaves every earlier row), so no reduction sits in the chain.
+            const int ldp = ff | 1;                                 // odd leading dimension: the row access of the backward sweep is free of bank conflicts
+            double* Pf = c.win;
+            wave_sync();
+            GPROF(c, SP_LCQP);
+            for (int e = t; e < ff * np; e += 64) { const int cc = e / ff, i = e - cc * ff; Pf[i + ldp * cc] = (i > cc) ? (double)Lp[i + ff * cc] : 0.0; }
+            GPROF(c, SP_PRODUCTS);
+            double x = (t < ff) ? (double)b[t < np ? piv0 + t : rows[t - np]] : 0.0;
+            wave_sync();
+            GPROF(c, SP_ASSEMBLE);
+            if (FWD) {
+                for (int j = 0; j < np; j++) {
+                    const double yj = wave_bcast(x, j);
+                    const double lij = (t > j && t < ff) ? Pf[t + ldp * j] : 0.0;
+                    x -= lij * yj;
+                }
+                if (t < ff) b[t < np ? piv0 + t : rows[t - np]] = x;
+            } else {
+                for (int i = ff - 1; i >= 1; i--) {
+                    const double xi = wave_bcast(x, i);
+                    const double lit = (t < i && t < np) ? Pf[i + ldp * t] : 0.0;      // L[i][t]: a row of the panel
+                    x -= lit * xi;
+                }
+                if (t < np) b[piv0 + t] = x;
+            }
+            GPROF(c, SP_VECTORS);
+            g_sync();
+            GPROF(c, SP_RHS);
+            continue;
+        }
         for (int i = t; i < ff; i += 64) bl[i] = (double)b[i < np ? piv0 + i : rows[i - np]];
         const int cw = max(1, min(np, CHUNK / ff));
         for (int c0 = FWD ? 0 : ((np - 1) / cw) * cw; FWD ? c0 < np : c0 >= 0; c0 += FWD ? cw : -cw) {

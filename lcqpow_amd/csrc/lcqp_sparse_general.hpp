@@ -41,7 +41,10 @@ struct Symbolic {
 };
 
 // adj: adjacency lists of the KKT graph on N = n + m nodes (sorted, no self loops).  Q given as both triangles (CSC = CSR), E in CSR.
-inline Symbolic analyze(int n, int m, const std::vector<std::vector<int>>& adj, const int* Qp, const int* Qi, const int* Ep, const int* Ei, int leaf = 32)
+// mergeFront: a front absorbs its LAST child (whose pivots lie right in front of its own) while the merged front stays within this many rows --
+// the small separators at the bottom of the dissection tree then ride in their parents' fronts instead of costing a front of their own
+// (a front costs a fixed ~20 us in a factorisation and ~5 us per sweep whatever its size; 0: no merging)
+inline Symbolic analyze(int n, int m, const std::vector<std::vector<int>>& adj, const int* Qp, const int* Qi, const int* Ep, const int* Ei, int leaf = 32, int mergeFront = 64)
 {
     const int N = n + m;
     Symbolic S;
@@ -135,10 +138,41 @@ inline Symbolic analyze(int n, int m, const std::vector<std::vector<int>>& adj, 
         for (int c : frontChildren[f]) for (int pu : bnd[c]) if (pu >= last) b.push_back(pu);
         std::sort(b.begin(), b.end()); b.erase(std::unique(b.begin(), b.end()), b.end());
     }
-    S.nb.resize(nF); S.rowPtr.assign(nF + 1, 0);
-    for (int f = 0; f < nF; f++) { S.nb[f] = (int)bnd[f].size(); S.rowPtr[f + 1] = S.rowPtr[f] + S.nb[f]; }
-    S.rows.reserve(S.rowPtr[nF]);
-    for (int f = 0; f < nF; f++) for (int p : bnd[f]) S.rows.push_back(p);
+    if (mergeFront > 0) {
+        std::vector<char> dead(nF, 0);
+        for (int f = 0; f < nF; f++) {
+            while (!frontChildren[f].empty()) {
+                const int c = frontChildren[f].back();
+                if (S.piv0[c] + S.np[c] != S.piv0[f]) break;                                   // (the last child in postorder: always adjacent)
+                if (S.np[c] + S.np[f] + (int)bnd[f].size() > mergeFront) break;
+                S.piv0[f] = S.piv0[c]; S.np[f] += S.np[c];
+                frontChildren[f].pop_back();
+                for (int ch : frontChildren[c]) { frontChildren[f].push_back(ch); S.parent[ch] = f; }      // (indices between the other children's and c: still ascending)
+                dead[c] = 1;
+            }
+        }
+        std::vector<int> newId(nF, -1);
+        int live = 0;
+        for (int f = 0; f < nF; f++) if (!dead[f]) newId[f] = live++;
+        std::vector<int> piv0(live), npv(live), par(live);
+        std::vector<std::vector<int>> fc(live), bd(live);
+        for (int f = 0; f < nF; f++) {
+            if (dead[f]) continue;
+            const int g = newId[f];
+            piv0[g] = S.piv0[f]; npv[g] = S.np[f]; par[g] = S.parent[f] >= 0 ? newId[S.parent[f]] : -1;
+            for (int ch : frontChildren[f]) fc[g].push_back(newId[ch]);
+            bd[g].swap(bnd[f]);
+        }
+        S.piv0.swap(piv0); S.np.swap(npv); S.parent.swap(par); frontChildren.swap(fc); bnd.swap(bd);
+        S.nF = live;
+        for (int f = 0; f < live; f++) for (int j = 0; j < S.np[f]; j++) frontOf[S.piv0[f] + j] = f;
+        S.childPtr.assign(live + 1, 0); S.child.clear();
+        for (int f = 0; f < live; f++) { S.childPtr[f + 1] = S.childPtr[f] + (int)frontChildren[f].size(); for (int ch : frontChildren[f]) S.child.push_back(ch); }
+    }
+    S.nb.resize(S.nF); S.rowPtr.assign(S.nF + 1, 0);
+    for (int f = 0; f < S.nF; f++) { S.nb[f] = (int)bnd[f].size(); S.rowPtr[f + 1] = S.rowPtr[f] + S.nb[f]; }
+    S.rows.reserve(S.rowPtr[S.nF]);
+    for (int f = 0; f < S.nF; f++) for (int p : bnd[f]) S.rows.push_back(p);
     // local index of a position in front f
     auto local = [&](int f, int pos) {
         if (pos >= S.piv0[f] && pos < S.piv0[f] + S.np[f]) return pos - S.piv0[f];
@@ -147,14 +181,14 @@ inline Symbolic analyze(int n, int m, const std::vector<std::vector<int>>& adj, 
         return (it != b1 && *it == pos) ? S.np[f] + (int)(it - b0) : -1;
     };
     S.rel.assign(S.rows.size(), -1);
-    for (int f = 0; f < nF; f++) {
+    for (int f = 0; f < S.nF; f++) {
         const int p = S.parent[f];
         if (p < 0) continue;      // (a root has no boundary: nothing comes after the last region)
         for (int a = 0; a < S.nb[f]; a++) S.rel[S.rowPtr[f] + a] = local(p, S.rows[S.rowPtr[f] + a]);
     }
     // assembly lists
     const int nnzQ = Qp[n];
-    std::vector<std::vector<int>> aS(nF), aG(nF), aP(nF);
+    std::vector<std::vector<int>> aS(S.nF), aG(S.nF), aP(S.nF);
     auto put = [&](int pa, int pb, int src, int gate) {
         const int lo = std::min(pa, pb), hi = std::max(pa, pb), f = frontOf[lo], ff = S.np[f] + S.nb[f];
         const int j = lo - S.piv0[f], i = local(f, hi);
@@ -162,13 +196,13 @@ inline Symbolic analyze(int n, int m, const std::vector<std::vector<int>>& adj, 
     };
     for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) { const int pi = S.iperm[i], pj = S.iperm[Qi[k]]; if (pj <= pi) put(pi, pj, k, -1); }     // one of each symmetric pair
     for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) put(S.iperm[n + r], S.iperm[Ei[k]], nnzQ + k, r);
-    S.asmPtr.assign(nF + 1, 0);
-    for (int f = 0; f < nF; f++) S.asmPtr[f + 1] = S.asmPtr[f] + (int)aS[f].size();
-    for (int f = 0; f < nF; f++) { S.asmSrc.insert(S.asmSrc.end(), aS[f].begin(), aS[f].end()); S.asmGate.insert(S.asmGate.end(), aG[f].begin(), aG[f].end()); S.asmPos.insert(S.asmPos.end(), aP[f].begin(), aP[f].end()); }
+    S.asmPtr.assign(S.nF + 1, 0);
+    for (int f = 0; f < S.nF; f++) S.asmPtr[f + 1] = S.asmPtr[f] + (int)aS[f].size();
+    for (int f = 0; f < S.nF; f++) { S.asmSrc.insert(S.asmSrc.end(), aS[f].begin(), aS[f].end()); S.asmGate.insert(S.asmGate.end(), aG[f].begin(), aG[f].end()); S.asmPos.insert(S.asmPos.end(), aP[f].begin(), aP[f].end()); }
     // storage: panels one after the other; the stack of update blocks (a front's block takes the place its children's blocks had)
-    S.Loff.resize(nF); S.CBoff.resize(nF);
+    S.Loff.resize(S.nF); S.CBoff.resize(S.nF);
     long long sp = 0;
-    for (int f = 0; f < nF; f++) {
+    for (int f = 0; f < S.nF; f++) {
         const long long ff = S.np[f] + S.nb[f];
         S.Loff[f] = S.Lsize; S.Lsize += ff * S.np[f];
         S.maxFront = std::max(S.maxFront, (int)ff);

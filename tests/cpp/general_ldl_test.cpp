@@ -76,7 +76,7 @@ static void solve(const Symbolic& S, const Factor& W, std::vector<double>& b)
 
 int main(int argc, char** argv)
 {
-    const int g = argc > 1 ? std::atoi(argv[1]) : 12, leaf = argc > 2 ? std::atoi(argv[2]) : 32;
+    const int g = argc > 1 ? std::atoi(argv[1]) : 12, leaf = argc > 2 ? std::atoi(argv[2]) : 32, mergeFront = argc > 3 ? std::atoi(argv[3]) : 64;
     // a 2-D grid Hessian (5-point stencil), rows of E that couple vertical and horizontal neighbours, a few denser rows
     const int n = g * g;
     std::vector<std::vector<std::pair<int, double>>> Qrows(n), Erows;
@@ -106,7 +106,7 @@ int main(int argc, char** argv)
     for (int i = 0; i < n; i++) for (int k = Qp[i]; k < Qp[i + 1]; k++) if (Qi[k] != i) adj[i].push_back(Qi[k]);
     for (int r = 0; r < m; r++) for (int k = Ep[r]; k < Ep[r + 1]; k++) { adj[n + r].push_back(Ei[k]); adj[Ei[k]].push_back(n + r); }
     for (auto& a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
-    Symbolic S = lcqp_general::analyze(n, m, adj, Qp.data(), Qi.data(), Ep.data(), Ei.data(), leaf);
+    Symbolic S = lcqp_general::analyze(n, m, adj, Qp.data(), Qi.data(), Ep.data(), Ei.data(), leaf, mergeFront);
     int fails = 0;
     // structure checks
     { std::vector<int> seen(N, 0); for (int p = 0; p < N; p++) seen[S.perm[p]]++; for (int v = 0; v < N; v++) if (seen[v] != 1) fails++; }
