@@ -41,10 +41,15 @@ def shard_range(rank, world, per_rank):
     return first, first + per_rank
 
 
-def kernel_source_hash():
-    """sha256 over the kernel sources: identifies the binary a rocprofv3 PMC pass was taken on (profiles/latest_traffic.json)"""
+DENSE_KERNEL_SOURCES = ("lcqp_hip.hip", "lcqp_nch.hip", "lcqp_kernels.hpp", "lcqp_launch.hpp", "lcqp_dev.hpp", "lcqp_wg.hpp")      # what k_lcqp_run and the setup kernels are compiled from
+
+
+def kernel_source_hash(workload=None):
+    """sha256 over the kernel sources: identifies the binary a rocprofv3 PMC pass was taken on (profiles/latest_traffic.json).
+    workload="dense": only the translation units of the dense kernels (the sparse engine is a translation unit of its own: a change there
+    does not touch k_lcqp_run's binary); None / "sparse": every kernel source."""
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in (DENSE_KERNEL_SOURCES if workload == "dense" else KERNEL_SOURCES):
         with open(os.path.join(ROOT, "lcqpow_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -58,7 +63,7 @@ def pmc_traffic(workload, B, shape):
         with open(os.path.join(ROOT, "profiles", "latest_traffic.json")) as f:
             t = json.load(f)
         for e in t.get("entries", [t]):
-            if e.get("source_hash") == kernel_source_hash() and e.get("workload") == [workload, B] + list(shape):
+            if e.get("source_hash") == kernel_source_hash(workload) and e.get("workload") == [workload, B] + list(shape):
                 return float(e["traffic_bytes_guide_recipe"])
     except Exception:
         pass

@@ -786,31 +786,34 @@ __device__ __forceinline__ void sp_general_front(SpCtx<64>& c, int f, FA F, doub
         }
         // the scaled columns are the factor's panel (column-major, ld = ff)
         for (int e = t; e < h * jb; e += 64) { const int cc = e / h, i = e - cc * h; if (i > cc) Lp[(j0 + i) + ff * (j0 + cc)] = P[i * GEN_JB + cc] * dv[cc]; }
-        // rank-jb update of what lies behind the block: row i of a lane, columns k = j0+jb .. i, four entries of F in flight
+        // rank-jb update of what lies behind the block, on the fp64 matrix cores: 16 x 16 tiles over the lower triangle of F[k0.., k0..],
+        // each D = A B with A[i][c] = (l_ic d_c) / d_c ... = P[i][c] dv[c] and B[c][k] = P[k][c] (v_mfma_f64_16x16x4_f64, two per tile: c = 0..3, 4..7).
+        // Operand lane map: A[i = lane & 15][c = lane >> 4], B[c = lane >> 4][k = lane & 15]; result register r of a lane: row (lane >> 4) + 4 r,
+        // column lane & 15 (cdna_hip_programming.md).  A row or column outside the front feeds only results that are not written.
+        // (The VALU version -- a lane per row, eight fused multiply-adds behind four 16-byte LDS reads per entry, half the lanes idle in a
+        // triangle -- was 41 % of a factorisation: profiles/round6/README.md.)
         const int k0 = j0 + jb;
-        for (int i = k0 + t; i < ff; i += 64) {
-            double pi[GEN_JB];
+        {
+            const int lr = t >> 4, lc = t & 15;
+            const double dva = (lr < jb) ? dv[lr] : 0.0, dvb = (lr + 4 < jb) ? dv[lr + 4] : 0.0;
+            const int nt = (ff - k0 + 15) >> 4;
+            for (int ti = 0; ti < nt; ti++) {
+                const int ia = k0 + 16 * ti + lc;
+                const double a0 = (ia < ff && lr < jb) ? P[(ia - j0) * GEN_JB + lr] * dva : 0.0;
+                const double a1 = (ia < ff && lr + 4 < jb) ? P[(ia - j0) * GEN_JB + lr + 4] * dvb : 0.0;
+                for (int tk = 0; tk <= ti; tk++) {
+                    const int kb = k0 + 16 * tk + lc;
+                    const double b0 = (kb < ff && lr < jb) ? P[(kb - j0) * GEN_JB + lr] : 0.0;
+                    const double b1 = (kb < ff && lr + 4 < jb) ? P[(kb - j0) * GEN_JB + lr + 4] : 0.0;
+                    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+                    double fv[4];
 #pragma unroll
-            for (int cc = 0; cc < GEN_JB; cc++) pi[cc] = (cc < jb) ? P[(i - j0) * GEN_JB + cc] * dv[cc] : 0.0;
-            constexpr int UF = LDSF ? 8 : 16;      // entries of F in flight per lane: a front in memory pays a round trip per group
-            for (int k = k0; k <= i; k += UF) {
-                double fv[UF], sv[UF];
+                    for (int r = 0; r < 4; r++) { const int i = k0 + 16 * ti + lr + 4 * r; fv[r] = (i < ff && kb < ff && i >= kb) ? (double)F[i + ff * kb] : 0.0; }
 #pragma unroll
-                for (int u = 0; u < UF; u++) fv[u] = (k + u <= i) ? (double)F[i + ff * (k + u)] : 0.0;
-#pragma unroll
-                for (int u = 0; u < UF; u++) {
-                    double acc = 0.0;
-                    if (k + u <= i) {
-                        // a row of the panel is eight doubles, 64-byte aligned: four 16-byte LDS reads (the same address in every lane: a broadcast);
-                        // columns beyond jb hold finite values and meet pi = 0
-                        const double2* pk = reinterpret_cast<const double2*>(P + (k + u - j0) * GEN_JB);
-                        const double2 q0 = pk[0], q1 = pk[1], q2 = pk[2], q3 = pk[3];
-                        acc = ((pi[0] * q0.x + pi[1] * q0.y) + (pi[2] * q1.x + pi[3] * q1.y)) + ((pi[4] * q2.x + pi[5] * q2.y) + (pi[6] * q3.x + pi[7] * q3.y));
-                    }
-                    sv[u] = acc;
+                    for (int r = 0; r < 4; r++) { const int i = k0 + 16 * ti + lr + 4 * r; if (i < ff && kb < ff && i >= kb) F[i + ff * kb] = fv[r] - acc[r]; }
                 }
-#pragma unroll
-                for (int u = 0; u < UF; u++) if (k + u <= i) F[i + ff * (k + u)] = fv[u] - sv[u];
             }
         }
         sync();
