@@ -772,20 +772,65 @@ __device__ __forceinline__ void sp_general_front(SpCtx<64>& c, int f, FA F, doub
     GD Lp = Lst + (int)Loff;
     for (int j0 = 0; j0 < np; j0 += GEN_JB) {
         const int jb = min(GEN_JB, np - j0), h = ff - j0;
-        // the panel of the block: rows j0 .. ff-1, columns j0 .. j0+jb-1 -> P[(i - j0) * JB + c]
-        for (int e = t; e < h * GEN_JB; e += 64) { const int cc = e / h, i = e - cc * h; P[i * GEN_JB + cc] = (cc < jb) ? (double)F[(j0 + i) + ff * (j0 + cc)] : 0.0; }
-        wave_sync();
-        for (int cc = 0; cc < jb; cc++) {      // eliminate inside the panel (columns unscaled: column c holds l_ic d_c)
-            const double dinv = 1.0 / P[cc * GEN_JB + cc];
-            if (t == 0) { dv[cc] = dinv; Kd[piv0 + j0 + cc] = dinv; }
-            for (int i = cc + 1 + t; i < h; i += 64) {
-                const double li = P[i * GEN_JB + cc] * dinv;
-                for (int c2 = cc + 1; c2 < jb; c2++) if (c2 <= i) P[i * GEN_JB + c2] -= li * P[c2 * GEN_JB + cc];
+        if (h <= 256) {
+            // The panel of the block in REGISTERS: lane t holds rows t, t + 64, t + 128, t + 192 of the panel, eight entries each.  The eight
+            // pivots are eliminated with v_readlane broadcasts (the pivot rows are rows 0 .. 7: lanes 0 .. 7 of the first register set) --
+            // a division and at most seven broadcast + fused multiply-add steps per pivot, ~100 clocks, where the version through LDS below paid a
+            // dependent LDS round trip per step (~2000 clocks per pivot with one wavefront per SIMD: 23 % + 16 % of a factorisation's time).
+            // Same operations on the same values: li = p[cc] / d, p[c2] -= li * P[c2][cc]; rows above the diagonal compute entries nobody reads.
+            constexpr int QP = 4;
+            double p[QP][GEN_JB];
+#pragma unroll
+            for (int q = 0; q < QP; q++)
+#pragma unroll
+                for (int cc = 0; cc < GEN_JB; cc++) { const int i = t + 64 * q; p[q][cc] = (i < h && cc < jb) ? (double)F[(j0 + i) + ff * (j0 + cc)] : 0.0; }
+            double dvr[GEN_JB];
+#pragma unroll
+            for (int cc = 0; cc < GEN_JB; cc++) {
+                dvr[cc] = 0.0;
+                if (cc < jb) {
+                    const double dinv = 1.0 / wave_bcast(p[0][cc], cc);
+                    dvr[cc] = dinv;
+                    if (t == 0) { dv[cc] = dinv; Kd[piv0 + j0 + cc] = dinv; }
+#pragma unroll
+                    for (int c2 = cc + 1; c2 < GEN_JB; c2++) {
+                        if (c2 < jb) {
+                            const double pc = wave_bcast(p[0][cc], c2);      // P[c2][cc], unscaled
+#pragma unroll
+                            for (int q = 0; q < QP; q++) p[q][c2] -= (p[q][cc] * dinv) * pc;
+                        }
+                    }
+                }
+            }
+            // the scaled columns are the factor's panel; the unscaled ones go to LDS for the tiles below
+#pragma unroll
+            for (int q = 0; q < QP; q++) {
+                const int i = t + 64 * q;
+                if (i < h) {
+#pragma unroll
+                    for (int cc = 0; cc < GEN_JB; cc++) {
+                        P[i * GEN_JB + cc] = p[q][cc];
+                        if (cc < jb && i > cc) Lp[(j0 + i) + ff * (j0 + cc)] = p[q][cc] * dvr[cc];
+                    }
+                }
             }
             wave_sync();
+        } else {
+            // the panel of the block: rows j0 .. ff-1, columns j0 .. j0+jb-1 -> P[(i - j0) * JB + c]
+            for (int e = t; e < h * GEN_JB; e += 64) { const int cc = e / h, i = e - cc * h; P[i * GEN_JB + cc] = (cc < jb) ? (double)F[(j0 + i) + ff * (j0 + cc)] : 0.0; }
+            wave_sync();
+            for (int cc = 0; cc < jb; cc++) {      // eliminate inside the panel (columns unscaled: column c holds l_ic d_c)
+                const double dinv = 1.0 / P[cc * GEN_JB + cc];
+                if (t == 0) { dv[cc] = dinv; Kd[piv0 + j0 + cc] = dinv; }
+                for (int i = cc + 1 + t; i < h; i += 64) {
+                    const double li = P[i * GEN_JB + cc] * dinv;
+                    for (int c2 = cc + 1; c2 < jb; c2++) if (c2 <= i) P[i * GEN_JB + c2] -= li * P[c2 * GEN_JB + cc];
+                }
+                wave_sync();
+            }
+            // the scaled columns are the factor's panel (column-major, ld = ff)
+            for (int e = t; e < h * jb; e += 64) { const int cc = e / h, i = e - cc * h; if (i > cc) Lp[(j0 + i) + ff * (j0 + cc)] = P[i * GEN_JB + cc] * dv[cc]; }
         }
-        // the scaled columns are the factor's panel (column-major, ld = ff)
-        for (int e = t; e < h * jb; e += 64) { const int cc = e / h, i = e - cc * h; if (i > cc) Lp[(j0 + i) + ff * (j0 + cc)] = P[i * GEN_JB + cc] * dv[cc]; }
         // rank-jb update of what lies behind the block, on the fp64 matrix cores: 16 x 16 tiles over the lower triangle of F[k0.., k0..],
         // each D = A B with A[i][c] = (l_ic d_c) / d_c ... = P[i][c] dv[c] and B[c][k] = P[k][c] (v_mfma_f64_16x16x4_f64, two per tile: c = 0..3, 4..7).
         // Operand lane map: A[i = lane & 15][c = lane >> 4], B[c = lane >> 4][k = lane & 15]; result register r of a lane: row (lane >> 4) + 4 r,
@@ -890,30 +935,100 @@ __device__ __forceinline__ void sp_general_sweep(SpCtx<64>& c, GD Lst, GD b)
             const int ldp = ff | 1;                                 // odd leading dimension: the row access of the backward sweep is free of bank conflicts
             double* Pf = c.win;
             wave_sync();
-            GPROF(c, SP_LCQP);
-            for (int e = t; e < ff * np; e += 64) { const int cc = e / ff, i = e - cc * ff; Pf[i + ldp * cc] = (i > cc) ? (double)Lp[i + ff * cc] : 0.0; }
-            GPROF(c, SP_PRODUCTS);
+            // forward: lane t reads ITS entry of column j straight from the factor (coalesced; the addresses do not depend on the chain, so the
+            // loads of all columns are in flight together) -- no staging in LDS; backward needs rows of the panel: staged with an odd leading dimension
+#ifdef GEN_STAGE_BACKWARD
+            if (!FWD) for (int e = t; e < ff * np; e += 64) { const int cc = e / ff, i = e - cc * ff; Pf[i + ldp * cc] = (i > cc) ? (double)Lp[i + ff * cc] : 0.0; }
+#endif
             double x = (t < ff) ? (double)b[t < np ? piv0 + t : rows[t - np]] : 0.0;
             wave_sync();
-            GPROF(c, SP_ASSEMBLE);
             if (FWD) {
-                for (int j = 0; j < np; j++) {
-                    const double yj = wave_bcast(x, j);
-                    const double lij = (t > j && t < ff) ? Pf[t + ldp * j] : 0.0;
-                    x -= lij * yj;
+                for (int j0 = 0; j0 < np; j0 += 8) {
+                    double lv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const int j = j0 + u; lv[u] = (j < np && t > j && t < ff) ? (double)Lp[t + ff * j] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const int j = j0 + u; if (j < np) { const double yj = wave_bcast(x, j); x -= lv[u] * yj; } }
                 }
                 if (t < ff) b[t < np ? piv0 + t : rows[t - np]] = x;
             } else {
+#ifdef GEN_STAGE_BACKWARD
                 for (int i = ff - 1; i >= 1; i--) {
                     const double xi = wave_bcast(x, i);
                     const double lit = (t < i && t < np) ? Pf[i + ldp * t] : 0.0;      // L[i][t]: a row of the panel
                     x -= lit * xi;
                 }
+#else
+                // backward: lane t (a pivot) walks down ITS column of the panel, L[i][t] for i = ff-1 .. t+1 -- contiguous per lane (a cache line serves
+                // eight steps), a stride of ff between the lanes; again no address depends on the chain, eight loads in flight (a row-major copy of
+                // the panels for coalesced rows was measured: slower, 3.43 -> 3.59 s, the extra stores cost more than the strides)
+                for (int i0 = ff - 1; i0 >= 1; i0 -= 8) {
+                    double lv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const int i = i0 - u; lv[u] = (i >= 1 && t < i && t < np) ? (double)Lp[i + ff * t] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const int i = i0 - u; if (i >= 1) { const double xi = wave_bcast(x, i); x -= lv[u] * xi; } }
+                }
+#endif
                 if (t < np) b[piv0 + t] = x;
             }
-            GPROF(c, SP_VECTORS);
             g_sync();
-            GPROF(c, SP_RHS);
+            continue;
+        }
+        if (ff <= 256) {
+            // the same for a front of up to 256 rows: lane t holds rows t, t + 64, t + 128, t + 192 in four registers
+            constexpr int QR = 4;
+            double x[QR];
+#pragma unroll
+            for (int q = 0; q < QR; q++) { const int i = t + 64 * q; x[q] = (i < ff) ? (double)b[i < np ? piv0 + i : rows[i - np]] : 0.0; }
+            auto bc = [&](int i) {      // value of row i: a broadcast from the register of lane i & 63 that holds chunk i >> 6 (uniform selection)
+                const int qi = i >> 6, li = i & 63;
+                double v = wave_bcast(x[0], li);
+                if (qi == 1) v = wave_bcast(x[1], li);
+                if (qi == 2) v = wave_bcast(x[2], li);
+                if (qi == 3) v = wave_bcast(x[3], li);
+                return v;
+            };
+            if (FWD) {
+                for (int j0 = 0; j0 < np; j0 += 4) {
+                    double lv[4][QR];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int q = 0; q < QR; q++) { const int j = j0 + u, i = t + 64 * q; lv[u][q] = (j < np && i > j && i < ff) ? (double)Lp[i + ff * j] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int j = j0 + u;
+                        if (j < np) {
+                            const double yj = bc(j);
+#pragma unroll
+                            for (int q = 0; q < QR; q++) x[q] -= lv[u][q] * yj;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < QR; q++) { const int i = t + 64 * q; if (i < ff) b[i < np ? piv0 + i : rows[i - np]] = x[q]; }
+            } else {
+                for (int i0 = ff - 1; i0 >= 1; i0 -= 4) {
+                    double lv[4][QR];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int q = 0; q < QR; q++) { const int i = i0 - u, j = t + 64 * q; lv[u][q] = (i >= 1 && j < i && j < np) ? (double)Lp[i + ff * j] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int i = i0 - u;
+                        if (i >= 1) {
+                            const double xi = bc(i);
+#pragma unroll
+                            for (int q = 0; q < QR; q++) x[q] -= lv[u][q] * xi;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < QR; q++) { const int j = t + 64 * q; if (j < np) b[piv0 + j] = x[q]; }
+            }
+            g_sync();
             continue;
         }
         for (int i = t; i < ff; i += 64) bl[i] = (double)b[i < np ? piv0 + i : rows[i - np]];
