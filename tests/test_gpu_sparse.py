@@ -352,6 +352,65 @@ def test_sparse_general_ldl_on_a_banded_pattern_matches_the_band_engine(hip, ora
     sb.close()
 
 
+@pytest.mark.parametrize("feature", ["perturbed steps", "admm first", "shifted complementarity bounds", "x0 and y0 given"])
+def test_sparse_general_ldl_with_every_option_of_the_arm(hip, oracle, monkeypatch, feature):
+    """The general LDL' sits behind the same two entry points as the band engines (factorise for a working set, solve), so everything else of
+    the arm -- perturbStep (src/LCQProblem.cpp:1353-1362), an ADMM-first cold start (ADMM iterations on the factor of k_sparse_setup), shifted
+    complementarity bounds with finite ubL, a warm start (x0, y0) -- must work through it unchanged: the banded workload sent through the general
+    engine (LCQP_SPARSE_GENERAL=1) against the oracle"""
+    monkeypatch.setenv("LCQP_SPARSE_GENERAL", "1")
+    n, nC, nK, B = 512, 256, 64, 3
+    Qp, Ap = P.sparse_pattern(n, nC, nK)
+    inst = [P.sparse_instance(i, n, nC, nK) for i in range(B)]
+    okw, lkw = dict(perturbStep=0), [dict() for _ in range(B)]
+    if feature == "perturbed steps":
+        okw = dict(perturbStep=1, perturbSeed=7)
+    elif feature == "admm first":
+        okw = dict(perturbStep=0, admmFirst=50)
+    elif feature.startswith("shifted"):
+        lkw = [dict(lbL=np.full(nK, 0.01), lbR=np.full(nK, 0.02), ubL=np.full(nK, 5.0), ubR=np.full(nK, np.inf)) for _ in range(B)]
+    else:
+        lkw = [dict(x0=np.random.default_rng(b).uniform(-0.5, 0.5, n), y0=np.random.default_rng(100 + b).uniform(-0.1, 0.1, nC + 2 * nK)) for b in range(B)]
+    sb = hip.SparseBatchLCQP(B, n, nC, nK, Qp, Ap, opt=hip.default_options(printLevel=0, **okw))
+    assert sb.fronts() > 4
+    stacked = {k: np.stack([q[k] for q in lkw]) for k in lkw[0]}
+    assert sb.load(0, B, np.stack([d["Q"].data for d in inst]), np.stack([d["g"] for d in inst]), np.stack([d["E"].data for d in inst]),
+                   lbA=np.stack([d["lbA"] for d in inst]), ubA=np.stack([d["ubA"] for d in inst]), **stacked) == 0
+    sb.run()
+    x, y, st = sb.solution()
+    tol = 1e-7 if feature == "perturbed steps" else 1e-8
+    for b in range(B):
+        d = inst[b]
+        ro = oracle.sparse_lcqp_solve(n, nC, nK, d["Q"].tocsr(), d["g"], d["E"].tocsr(), lbA=d["lbA"], ubA=d["ubA"], opt=oracle.default_options(**okw), **lkw[b])
+        assert st[b]["returnValue"] == ro["ret"] == 0, (feature, b, st[b], ro["stats"])
+        assert np.abs(x[b] - ro["x"]).max() < tol, (feature, b)
+        if feature == "admm first":
+            assert st[b]["admmIter"] >= 50
+    sb.close()
+
+
+def test_sparse_general_ldl_on_the_circle_example(hip, oracle, monkeypatch):
+    """examples/OptimizeOnCircle.cpp (the reference's own OSQP_SPARSE example; a PSD Hessian with a 5e-12 diagonal, an arrow-shaped KKT matrix) through
+    the general LDL' instead of the bordered band: the coupling row and the shared variables end up in the top separators; the optimum the
+    reference prints (:144), the dense oracle's solution"""
+    import scipy.sparse as sp
+    monkeypatch.setenv("LCQP_SPARSE_GENERAL", "1")
+    d = P.circle(100)
+    n, nC, nK = d["nV"], d["nC"], d["nComp"]
+    Q = sp.csc_matrix(d["Q"]); E = sp.csc_matrix(np.vstack([d["A"], d["L"], d["R"]]))
+    Q.sort_indices(); E.sort_indices()
+    sb = hip.SparseBatchLCQP(1, n, nC, nK, Q, E, opt=hip.default_options(perturbStep=0, printLevel=0))
+    assert sb.fronts() >= 1 and sb.border() == 0
+    one = lambda v: np.asarray(v, dtype=float)[None, :]
+    assert sb.load(0, 1, one(Q.data), one(d["g"]), one(E.data), lbA=one(d["lbA"]), ubA=one(d["ubA"]), x0=one(d["x0"])) == 0
+    sb.run()
+    x, y, st = sb.solution()
+    rd = P.oracle_solve(oracle, d, oracle.default_options(perturbStep=0))
+    assert st[0]["returnValue"] == rd["ret"] == 0
+    assert np.abs(x[0] - rd["x"]).max() < 1e-7 and np.abs(x[0][:2] - [0.1811, -0.9835]).max() < 1e-4
+    sb.close()
+
+
 @pytest.mark.parametrize("n,nC,nK,extra", [(512, 256, 64, 1), (512, 256, 64, 3)])
 def test_sparse_banded_pattern_with_coupling_rows(hip, oracle, n, nC, nK, extra):
     """the banded synthetic pattern plus `extra` coupling rows that touch every variable (a budget constraint over an OCP horizon): band of
