@@ -204,10 +204,13 @@ int lcqp_hip_chol_solve(int batch, int n, const double* K, const double* b, doub
  * (src/LCQProblem.cpp:929-960: no box constraints, nC + 2 nComp duals) on the device -- ADMM on the quasi-definite KKT
  * matrix + active-set polish (the role of SubsolverOSQP, src/SubsolverOSQP.cpp:124-200), CSR/CSC products, band LDL' in a
  * reverse Cuthill-McKee ordering computed here once per pattern.  Pattern arrays are the CSC arrays the reference holds
- * (Q_sparse and the stacked A_sparse = [A; L; R], src/LCQProblem.cpp:629-723; Q full symmetric).  The KKT graph may be a band of
- * half width <= 63 plus at most 16 dense border nodes (rows or variables that touch many others: the arrow of
- * examples/OptimizeOnCircle.cpp).  Returns NULL for any other pattern (lcqp_hip_sparse_last_error() says why): the host layer runs
- * such problems on the dense kernels, which take nV <= 4096.
+ * (Q_sparse and the stacked A_sparse = [A; L; R], src/LCQProblem.cpp:629-723; Q full symmetric).  Three factorisation engines, chosen
+ * here per pattern: a band of half width <= 63; such a band plus at most 16 dense border nodes (rows or variables that touch many
+ * others: the arrow of examples/OptimizeOnCircle.cpp); and, for any other pattern -- as the reference's OSQP arm takes any
+ * (src/SubsolverOSQP.cpp:136-152) --, a general sparse LDL' (nested dissection with dense fronts, one wavefront per instance:
+ * lcqp_sparse_general.hpp; a 2-D grid with 16 384 variables is one).  Returns NULL only when a front of that factorisation would exceed
+ * 576 rows or the factor 2^28 entries (lcqp_hip_sparse_last_error() says so): the host layer runs such a problem on the dense kernels,
+ * which take nV <= 4096.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct lcqp_hip_sparse lcqp_hip_sparse_t;
 lcqp_hip_sparse_t* lcqp_hip_sparse_create(int batch, int nV, int nC, int nComp, const int* Qp, const int* Qi,

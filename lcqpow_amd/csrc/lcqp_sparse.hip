@@ -454,16 +454,19 @@ template <int G, class Pre, class Base> __device__ __forceinline__ double sp_ETy
 }
 // the residual of the stationarity condition in one pass over Q and E' (both indexed by the variable):
 // r1[i] = (-g[i] - (Q x)[i]) - (E'y)[i]; returns max |r1|
-template <int G> __device__ __forceinline__ double sp_residual(SpCtx<G>& c, GD g, GD x, GD y, GD r1, GD qx)
+// r1 = -g - Q x - E'y; returns |r1|_inf and, in `scale`, max_i(|g_i| + |Q x|_i + |E'y|_i): the residual's own rounding floor is 64 eps of that (round 6, as on
+// the dense path: qp_polish in lcqp_dev.hpp)
+template <int G> __device__ __forceinline__ double sp_residual(SpCtx<G>& c, GD g, GD x, GD y, GD r1, GD qx, double& scale)
 {
     SPROF(c, SP_VECTORS);
     sp_ell<G, false>(c.db->ellQ, c.gl, c.Qx(), [&](int j) { return D2{x[j], 0.0}; }, [](int) { return NoPre{}; }, [&](int i, double s, double, NoPre) { qx[i] = s; });
     g_sync();
-    double mx = 0.0;
+    double mx = 0.0, sc = 0.0;
     sp_ell<G, true>(c.db->ellT, c.gl, c.Ex(), [&](int r) { return D2{y[r], 0.0}; }, [&](int i) { return D2{g[i], qx[i]}; },
-              [&](int i, double s, double, D2 pv) { const double v = (-pv.a - pv.b) - s; r1[i] = v; mx = nmax(mx, fabs(v)); });
+              [&](int i, double s, double, D2 pv) { const double v = (-pv.a - pv.b) - s; r1[i] = v; mx = nmax(mx, fabs(v)); sc = fmax(sc, fabs(pv.a) + fabs(pv.b) + fabs(s)); });
     g_sync();
     SPROF(c, SP_PRODUCTS);
+    scale = g_max<G>(sc);
     return g_max<G>(mx);
 }
 // C v = L'(R v) + R'(L v) for two vectors: lx = E v (rows of L: nC .. nC+nComp, of R: nC+nComp ..), then a column gather with
@@ -1399,9 +1402,10 @@ __device__ __forceinline__ int sp_ph_trial(SpCtx<G>& c, SpState& S, GD g)
             else if (v.e > v.hi + ftol) ns = ST_UPPER;
         } else {
             const double bb = (v.s == ST_UPPER) ? v.hi : v.lo;
-            res_eq = nmax(res_eq, fabs(bb - v.e));
+            const bool above = !(fabs(bb - v.e) <= 16.0 * 2.221e-16 * (fabs(bb) + exScale));      // (a NaN counts) a row at the rounding floor of its computed E_r x is not a residual (round 6)
+            if (above) res_eq = nmax(res_eq, fabs(bb - v.e));
             bmax = fmax(bmax, fabs(bb));
-            loose |= (fabs(bb - v.e) > 16.0 * 2.221e-16 * (fabs(bb) + exScale));
+            loose |= above;
             if (v.s == ST_LOWER && v.y > ytol) ns = ST_INACT;
             if (v.s == ST_UPPER && v.y < -ytol) ns = ST_INACT;
         }
@@ -1429,13 +1433,14 @@ __device__ __forceinline__ int sp_ph_trial(SpCtx<G>& c, SpState& S, GD g)
     res_eq = g_max<G>(res_eq);
     bmax = g_max<G>(bmax);
     SPROF(c, SP_ASSEMBLE);      // (profile builds: the status test on its own)
+    double rscale = 0.0;
     if (!have_r1 && (trial == 0 || !changed)) {
-        res_stat = sp_residual<G>(c, g, x, yt, r1, qx);
+        res_stat = sp_residual<G>(c, g, x, yt, r1, qx, rscale);
         c.cSweeps++;
         c.bytes += db.by[BY_SWEEP];
         have_r1 = 1;
     }
-    if (trial > 0 && !changed && res_stat <= o.resTol * gs && res_eq <= o.resTol * (1.0 + bmax)) {
+    if (trial > 0 && !changed && res_stat <= fmax(o.resTol * gs, 64.0 * 2.221e-16 * rscale) && res_eq <= o.resTol * (1.0 + bmax)) {
         if (!(g_any<G>(loose) && S.nrefine < 2 && trial + 1 < o.maxTrials)) return PH_QPEND;      // a verified KKT point
         S.nrefine++;      // ... whose active rows can be held more exactly: one more correction
     }

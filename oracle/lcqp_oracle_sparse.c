@@ -480,9 +480,10 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
                 else if (Ex[r] > q->u[r] + ftol) ns = SP_UPPER;
             } else {
                 const double bb = (s == SP_UPPER) ? q->u[r] : q->l[r];
-                if (fabs(bb - Ex[r]) > res_eq || Ex[r] != Ex[r]) res_eq = fabs(bb - Ex[r]);
+                const int above = !(fabs(bb - Ex[r]) <= 16.0 * 2.221e-16 * (fabs(bb) + exScale));      /* (a NaN counts) a row at the rounding floor of its computed E_r x is not a residual (round 6) */
+                if (above && (fabs(bb - Ex[r]) > res_eq || Ex[r] != Ex[r])) res_eq = fabs(bb - Ex[r]);
                 if (fabs(bb) > bmax) bmax = fabs(bb);
-                if (fabs(bb - Ex[r]) > 16.0 * 2.221e-16 * (fabs(bb) + exScale)) nloose++;
+                if (above) nloose++;
                 if (s == SP_LOWER && y[r] > ytol) ns = SP_INACT;
                 if (s == SP_UPPER && y[r] < -ytol) ns = SP_INACT;
             }
@@ -490,18 +491,21 @@ static int sqp_polish(sqp_t* q, const double* g, double* x, double* y, int* st, 
             if (ns != s) changed++;
             nact += (ns != SP_INACT);
         }
+        double rscale = 0.0;      /* max_i(|g_i| + |Q x|_i + |E'y|_i): 64 eps of it is the residual's own rounding floor (round 6, as in qp_polish of lcqp_oracle.c) */
         if (!have_r1 && (trial == 0 || !changed)) {
             q->c_sweeps++;
             sp_Qx(q, x, r1);
-            for (int i = 0; i < n; i++) r1[i] = -g[i] - r1[i];
+            for (int i = 0; i < n; i++) { b[i] = r1[i]; r1[i] = -g[i] - r1[i]; }      /* b: scratch (the correction's right-hand side is formed later) */
             sp_ETy_sub(q, y, r1);
+            for (int i = 0; i < n; i++) { const double t3 = fabs(g[i]) + fabs(b[i]) + fabs(-g[i] - b[i] - r1[i]); if (t3 > rscale) rscale = t3; }
             have_r1 = 1;
         }
+        const double rtolS = fmax(o->resTol * gs, 64.0 * 2.221e-16 * rscale);
         if (have_r1) for (int i = 0; i < n; i++) if (fabs(r1[i]) > res_stat || r1[i] != r1[i]) res_stat = fabs(r1[i]);      /* a NaN stays (and is never accepted) */
-        if (trial > 0 && !changed && res_stat <= o->resTol * gs && res_eq <= o->resTol * (1.0 + bmax) && nloose > 0 && nrefine < 2 && trial + 1 < o->maxTrials) {
+        if (trial > 0 && !changed && res_stat <= rtolS && res_eq <= o->resTol * (1.0 + bmax) && nloose > 0 && nrefine < 2 && trial + 1 < o->maxTrials) {
             nrefine++;      /* a verified KKT point whose active rows can be held more exactly: one more correction */
         } else
-        if (trial > 0 && !changed && res_stat <= o->resTol * gs && res_eq <= o->resTol * (1.0 + bmax)) {
+        if (trial > 0 && !changed && res_stat <= rtolS && res_eq <= o->resTol * (1.0 + bmax)) {
             memcpy(q->r1_last, r1, sizeof(double) * n); memcpy(q->ex_last, Ex, sizeof(double) * m); memcpy(q->g_last, g, sizeof(double) * n);
             return 1;
         }
