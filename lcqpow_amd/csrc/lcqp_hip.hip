@@ -119,6 +119,7 @@ struct lcqp_hip_batch {
     // the setup has two independent branches (C = L'R + R'L and its compression; L1 -> Et -> M): the short one runs beside the long one
     hipStream_t side;
     hipEvent_t evFork, evJoin;
+    int numCU;
     // two pinned staging slots for loadLCQP: instance k is packed into slot k&1 while slot (k-1)&1 is in flight
     void* stage[2];
     hipEvent_t stageDone[2];
@@ -182,6 +183,8 @@ try {
     h->device = device; h->setupDone = false; h->ran = false; h->anyLoaded = false; h->bytesTotal = 0;
     h->stage[0] = h->stage[1] = nullptr; h->stageBytes = 0;
     h->stream = nullptr; h->ev0 = h->ev1 = h->ev2 = nullptr; h->side = nullptr; h->evFork = h->evJoin = nullptr;
+    h->numCU = 256;
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) h->numCU = cu; }
     DevBatch& d = h->db;
     memset(&d, 0, sizeof(d));
     hipError_t e0 = hipStreamCreate(&h->stream);
@@ -480,9 +483,11 @@ static int launch_setup(lcqp_hip_batch* h)
     const DevBatch& d = h->db;
     hipStream_t on = h->stream;
     const int ntile = d.nblk * (d.nblk + 1) / 2;
+    const int nrb = (d.mEcap + 63) / 64, nb = (d.mMld + 127) / 128, nmt = nb * (nb + 1) / 2;      // k_build_M: 128 x 128 tiles of the lower triangle
     dispatch_db(h, ID_k_prepare, d.B);
     // C and its compressed rows depend on L and R only, the chain L1 -> Et -> M on Q and E: two branches.  The short one goes to the side
-    // stream and fills the machine while k_factor (one workgroup per instance, chains of 64-step diagonal blocks) leaves most of it idle.
+    // stream and runs in the gaps of k_factor (one workgroup per instance, a life of dependent chains).  Measured alternatives, round 6
+    // (profiles/round6/README.md): the side branch beside k_trsm, or beside k_trsm and k_build_M -- both 0.2 ms slower.
     const bool fork = d.nComp > 0;
     if (fork) {
         HIPCHK(hipEventRecord(h->evFork, on));
@@ -491,12 +496,14 @@ static int launch_setup(lcqp_hip_batch* h)
         dispatch_db(h, ID_k_compress_C, d.B, nullptr, 0, 0, 0, h->side);
         HIPCHK(hipEventRecord(h->evJoin, h->side));
     }
-    dispatch_db(h, ID_k_factor, d.B);
-    dispatch_db(h, ID_k_trsm, d.B * ((d.mEcap + 63) / 64));
+    // more than three workgroups per CU (np <= 256: 36 KB of LDS each): the instantiation held to 128 registers, so that four are resident and
+    // the batch needs one round
+    dispatch_db(h, (h->nch <= 2 && d.B > 3 * h->numCU) ? ID_k_factor_full : ID_k_factor, d.B);
+    dispatch_db(h, ID_k_trsm, d.B * nrb);
     // the join sits in front of the last setup kernel, not behind it: an event recorded right after a stream wait carried a late time stamp
     // (the homotopy kernel appeared 2 ms shorter than rocprofv3 and the wall clock say), and the side branch has long finished by then
     if (fork) HIPCHK(hipStreamWaitEvent(on, h->evJoin, 0));
-    { const int nb = (d.mMld + 127) / 128; dispatch_db(h, ID_k_build_M, d.B * (nb * (nb + 1) / 2)); }      // 128 x 128 tiles of the lower triangle
+    dispatch_db(h, ID_k_build_M, d.B * nmt);
     HIPCHK(hipGetLastError());
     h->setupDone = true;
     return 0;

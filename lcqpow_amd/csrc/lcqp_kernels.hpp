@@ -96,7 +96,8 @@ __global__ __launch_bounds__(WG) void k_build_C(DevBatch db)
     LCQP_LDS_N(NCH)
     constexpr int np = 128 * NCH;
     const int ntile = db.nblk * (db.nblk + 1) / 2;
-    const int b = blockIdx.x / ntile, tIdx = blockIdx.x % ntile;
+    const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int b = bid / ntile, tIdx = bid % ntile;
     int I, J;
     tri_tile(tIdx, I, J);
     const double* Lm = db.E + (size_t)b * db.mEcap * np + (size_t)db.nC * np;
@@ -171,10 +172,13 @@ __global__ __launch_bounds__(WG) void k_compress_C(DevBatch db)
 }
 
 // ---- k_factor: the constant factorisation L1 of Q + sp I (L_K of the ADMM fallback is built on demand, qp_build_K) ----
-// (4 instead of 3 workgroups per CU -- __launch_bounds__(WG, 4): the batch in one residency wave -- changes nothing: 5.566 vs 5.567 ms of setup in a
-// same-box A/B; the kernel is bound by its 64-step chains, not by slots)
-template <int NCH>
-__global__ __launch_bounds__(WG) void k_factor(DevBatch db)
+// One workgroup per instance; its life is chains (16 x 16 sub-block factorisations, dependent tiles): ~0.35 ms alone, ~0.7 ms with four per CU.
+// Round 6: profiles/round6/factor_phases*.log -- with 138 registers only three workgroups per CU were resident and the default batch took two
+// rounds (a quarter of the workgroups started 0.6 ms late); the copy F1 = Q + sp I in front of the factorisation was 15 % of a workgroup's life.
+// MINW = 4 holds the kernel to 128 registers: four workgroups per CU, a batch of more than three workgroups per CU in one residency round
+// (-0.12 ms at B = 1024); MINW = 1 (138 registers) is 0.09 ms faster for one workgroup alone -- the launcher picks by the size of the batch.
+template <int NCH, int MINW>
+__global__ __launch_bounds__(WG, MINW) void k_factor(DevBatch db)
 {
     LCQP_LDS_N(NCH)
     constexpr int np = 128 * NCH;
@@ -184,22 +188,25 @@ __global__ __launch_bounds__(WG) void k_factor(DevBatch db)
     __shared__ int sfail;
     int failed = 0;
     double spv = 0.0;
+#ifdef LCQP_FACTOR_PROFILE
+    unsigned long long fpv[16];
+    for (int k = 0; k < 16; k++) fpv[k] = 0;
+    fpv[15] = fpv[14] = clock64();
+    fpv[13] = wall_clock64();
+    unsigned long long* fp = fpv;
+#else
+    unsigned long long* fp = nullptr;
+#endif
     for (int pass = 0; pass < 2; pass++) {
         spv = (pass == 0 ? db.opt.proxSmall : db.opt.proxBig) * scale;
-        for (int e0 = t; e0 < np * np; e0 += 8 * WG) {      // eight loads in flight per thread, then the stores
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { const int e = e0 + u * WG; const int i = e / np, j = e - i * np; v[u] = c.Q[e] + (i == j ? spv : 0.0); }
-#pragma unroll
-            for (int u = 0; u < 8; u++) c.F1[e0 + u * WG] = v[u];
-        }
         if (t == 0) sfail = 0;
         __syncthreads();
+        FPROF(7);
         // D1 keeps every inverted diagonal block (dense lower) for the TRSM that forms Et
         double minpiv = INFINITY;
         {
             // factor block column by block column so each D block lands in its own slot of D1
-            minpiv = wg_chol(c.F1, np, c.nblk, c.n, 0.0, c.D1, nullptr, &sfail, lds, 4096);
+            minpiv = wg_chol(c.F1, np, c.nblk, c.n, 0.0, c.D1, nullptr, &sfail, lds, 4096, fp, c.Q, spv);      // F1 = chol(Q + spv I), Q read in place
         }
         __syncthreads();
         failed = sfail;
@@ -212,17 +219,146 @@ __global__ __launch_bounds__(WG) void k_factor(DevBatch db)
         c.info->kReady = 0;          // L_K (ADMM fallback) is built by the first instance that needs it: qp_build_K
         c.info->rnReady = 0;         // row norms of E for the row screening of the residual sweeps: first sweep
         if (failed) c.info->setupFail = 3;
+#ifdef LCQP_FACTOR_PROFILE
+        fpv[8] = clock64() - fpv[14];      // the whole kernel as this workgroup saw it
+        for (int k = 0; k < 9; k++) db.prof[(size_t)b * 16 + k] = fpv[k];
+        db.prof[(size_t)b * 16 + 9] = wall_clock64();      // 100 MHz, the same counter on every XCD: when did this workgroup end
+        db.prof[(size_t)b * 16 + 10] = fpv[13];            // and start
+#endif
     }
 }
 
 // ---- k_trsm: Et = E L1^-T, 64 rows of E per workgroup ----------------------------------------------
+// Block column J of the result is  Et_J = (E_J - sum_{K<J} Et_K L_JK') D_J'  (D_J: the inverted diagonal block of L1 from k_factor).
+//
+// trsm_rows_resident (np <= 256): the sums of ALL block columns still to come live in registers (wave w: rows 16w..16w+15, 16 doubles per lane
+// and block column), and the block column just finished is the A operand of the products out of a wave-private LDS region -- so E is read
+// once, Et written once, and only the blocks of L1 / D1 stream through the workgroup (two 16-deep panels in LDS, one barrier per panel).
+// Before (rounds 1 - 5, still the form of the larger sizes below): block column J re-read Et_0..J-1 from memory and wrote Et_J twice:
+// 10 GB of traffic per launch of the default workload for 3.2 GB of operands (pmc_fetch_size / pmc_write_size), 1.69 ms at 6 TB/s.
+// Every element is the same chain of v_mfma_f64_16x16x4 (k ascending, four per instruction, from zero), so the bits are the same.
 template <int NCH>
-__global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
+__device__ __forceinline__ void trsm_rows_resident(const DevBatch& db)
+{
+    constexpr int np = 128 * NCH, NB = 2 * NCH, PL = TILE_PL;
+    __shared__ double sA[NWAVE * 1024];      // per wave: 64 k x 16 rows, entry (k, r) at 16 k + (r ^ swz(k)): conflict-free C-layout writes and A-operand reads
+    __shared__ double sB[2][16 * PL];
+    const int nrb = (db.mEcap + 63) / 64;
+    const int bid = xcd_contiguous(blockIdx.x, gridDim.x);      // the row blocks of an instance share L1 and D1: one L2
+    const int b = bid / nrb, rb = bid % nrb;
+    if (64 * rb >= db.info[b].mE) return;
+    const double* E = db.E + (size_t)b * db.mEcap * np + (size_t)(64 * rb) * np;
+    double* Et = db.Et + (size_t)b * db.mEcap * np + (size_t)(64 * rb) * np;
+    const double* F1 = db.F1 + (size_t)b * np * np;
+    const double* D1 = db.D1 + (size_t)b * db.nblk * 4096;
+    const int rows = min(64, db.mEcap - 64 * rb);
+    const int t = tid_here(), lane = t & 63, w = t >> 6, il = lane & 15, kl = lane >> 4;
+    double* A = sA + 1024 * w;
+    auto swz = [](int k) { return ((k >> 1) & 7) << 1; };
+    const int lr = t >> 2, kq = (t & 3) * 4;      // loader of the B panels: row lr of the block, four consecutive k
+    // panel q (16 k) of block `blk` of column J: blk 0 is D_J, blk i > 0 is L_{J+i, J}
+    auto src = [&](int J, int blk, int q) -> const double* {
+        return blk == 0 ? D1 + (size_t)J * 4096 + lr * 64 + 16 * q + kq
+                        : F1 + (size_t)(64 * (J + blk) + lr) * np + 64 * J + 16 * q + kq;
+    };
+    double2 r0, r1;
+    auto fetch = [&](const double* p) { r0 = *reinterpret_cast<const double2*>(p); r1 = *reinterpret_cast<const double2*>(p + 2); };
+    auto commit = [&](int buf) {
+        double* Bs = sB[buf];
+        Bs[(kq + 0) * PL + lr] = r0.x; Bs[(kq + 1) * PL + lr] = r0.y; Bs[(kq + 2) * PL + lr] = r1.x; Bs[(kq + 3) * PL + lr] = r1.y;
+    };
+    // C layout of this wave's 16 x 64 block: x[a][q] is row (lane >> 4) + 4 q, column 16 a + (lane & 15)
+    auto loadE = [&](d4_t (&x)[4], int J) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int li = 16 * w + kl + 4 * q;
+                x[a][q] = (li < rows) ? E[(size_t)li * np + 64 * J + 16 * a + il] : 0.0;
+            }
+    };
+    auto toA = [&](const d4_t (&x)[4]) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int k = 16 * a + il, r = kl + 4 * q; A[16 * k + (r ^ swz(k))] = x[a][q]; }
+    };
+    d4_t acc[NB][4];      // acc[I]: sum_{K<J} Et_K L_IK' of the block columns I > J still to come
+#pragma unroll
+    for (int I = 0; I < NB; I++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) acc[I][a] = d4_t{0.0, 0.0, 0.0, 0.0};
+    d4_t cur[4];
+    fetch(src(0, 0, 0));
+    loadE(cur, 0);
+    commit(0);
+    fetch(src(0, 0, 1));
+    toA(cur);
+    __syncthreads();
+    int pc = 0;
+#pragma unroll
+    for (int J = 0; J < NB; J++) {
+#pragma unroll
+        for (int blk = 0; blk < NB - J; blk++) {
+            if (blk == 0) {
+#pragma unroll
+                for (int a = 0; a < 4; a++) cur[a] = d4_t{0.0, 0.0, 0.0, 0.0};
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const double* Bs = sB[pc & 1];
+#pragma unroll
+                for (int k4 = 0; k4 < 4; k4++) {
+                    const int k = 16 * q + 4 * k4 + kl;
+                    const double av = A[16 * k + (il ^ swz(k))];
+#pragma unroll
+                    for (int a = 0; a < 4; a++) {
+                        const double bv = Bs[(4 * k4 + kl) * PL + 16 * a + il];
+                        if (blk == 0) cur[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, cur[a], 0, 0, 0);
+                        else acc[J + blk][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[J + blk][a], 0, 0, 0);
+                    }
+                }
+                // the successors of this panel in the order of the loops
+                int J1 = J, b1 = blk, q1 = q + 1;
+                if (q1 == 4) { q1 = 0; b1++; if (b1 == NB - J1) { b1 = 0; J1++; } }
+                if (J1 < NB) {
+                    commit((pc + 1) & 1);
+                    int J2 = J1, b2 = b1, q2 = q1 + 1;
+                    if (q2 == 4) { q2 = 0; b2++; if (b2 == NB - J2) { b2 = 0; J2++; } }
+                    if (J2 < NB) fetch(src(J2, b2, q2));
+                }
+                __syncthreads();
+                pc++;
+            }
+            if (blk == 0) {
+                // cur = Et_J: to memory, and in place of E_J - sum as the A operand of the products with the blocks of L1 below D_J
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int li = 16 * w + kl + 4 * q;
+                        if (li < rows) Et[(size_t)li * np + 64 * J + 16 * a + il] = cur[a][q];
+                    }
+                toA(cur);
+                if (J + 1 < NB) loadE(cur, J + 1);      // on its way while the products of this block column run
+            }
+        }
+        if (J + 1 < NB) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) cur[a] = cur[a] - acc[J + 1][a];
+            toA(cur);
+        }
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void trsm_rows_streamed(const DevBatch& db)
 {
     LCQP_LDS_N(NCH)
     constexpr int np = 128 * NCH;
     const int nrb = (db.mEcap + 63) / 64;
-    const int b = blockIdx.x / nrb, rb = blockIdx.x % nrb;
+    const int bid = xcd_contiguous(blockIdx.x, gridDim.x);      // the row blocks of an instance share L1 and D1: one L2
+    const int b = bid / nrb, rb = bid % nrb;
     const InstInfo* info = db.info + b;
     if (64 * rb >= info->mE) return;
     const double* E = db.E + (size_t)b * db.mEcap * np + (size_t)(64 * rb) * np;
@@ -262,6 +398,16 @@ __global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
     }
 }
 
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
+{
+#if !defined(LCQP_TRSM_STREAMED) && !defined(LCQP_TILE_VALU)
+    if constexpr (NCH <= 2) trsm_rows_resident<NCH>(db);
+    else
+#endif
+        trsm_rows_streamed<NCH>(db);
+}
+
 // ---- k_build_M: M = Et Et', every entry of every working-set matrix S_W = Et_W Et_W' (lower triangle; readers take M[max][min]) ----
 // fp64 MFMA, 128 x 128 output tiles (round 3; round 2: 64 x 64 tiles through wg_tile_nt, 35 TFLOP/s): the four waves own the four
 // 64 x 64 quadrants as 4 x 4 blocks of v_mfma_f64_16x16x4_f64, so that one 16-deep panel pair in LDS (k-major, pitch 144 doubles:
@@ -274,7 +420,8 @@ __global__ __launch_bounds__(WG) void k_build_M(DevBatch db)
     constexpr int P = 144;
     __shared__ double As[16 * P], Bs[16 * P];
     const int nb = (db.mMld + 127) / 128, ntile = nb * (nb + 1) / 2;
-    const int b = blockIdx.x / ntile, tIdx = blockIdx.x % ntile;
+    const int bid = xcd_contiguous(blockIdx.x, gridDim.x);      // the 15 tiles of an instance read the same Et (1.3 MB): one L2
+    const int b = bid / ntile, tIdx = bid % ntile;
     int I, J;
     tri_tile(tIdx, I, J);
     const int mE = db.info[b].mE, ld = db.mMld;
@@ -513,7 +660,8 @@ static void launch_impl(int kid, int grid, hipStream_t s, const LaunchArgs& a)
         case ID_k_prepare:    hipLaunchKernelGGL((k_prepare<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_build_C:    hipLaunchKernelGGL((k_build_C<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_compress_C: hipLaunchKernelGGL((k_compress_C<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
-        case ID_k_factor:     hipLaunchKernelGGL((k_factor<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
+        case ID_k_factor:     hipLaunchKernelGGL((k_factor<NCH, 1>), dim3(grid), dim3(WG), 0, s, a.db); break;
+        case ID_k_factor_full: hipLaunchKernelGGL((k_factor<NCH, NCH <= 2 ? 4 : 1>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_trsm:       hipLaunchKernelGGL((k_trsm<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_build_M:    hipLaunchKernelGGL((k_build_M<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_lcqp_run:

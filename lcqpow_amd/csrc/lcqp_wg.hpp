@@ -700,13 +700,23 @@ __device__ __forceinline__ void wg_tile_nt(double (&acc)[4][4], const double* __
 //   tau == 0: plain Cholesky; *info_fail is set when a pivot is not positive.
 // dscr0 + J*dscrStride: 64*64 doubles of global scratch (dense copy of the J-th inverted diagonal block).
 // d0  : nn doubles of global scratch (original diagonal), only used when tau > 0.
+// src0 (tau == 0 only): the matrix to factor is src0 + shift0 I and F is output only -- the first block column reads src0 where it would read
+// F (same values, same operations: the copy F = src0 + shift0 I the callers made before is gone, a pass over the matrix less).
 // Returns the smallest pivot over rows < nreal (uniform).
 // LDS: arena[0..64*65) tile + arena[4160..4224) flags + arena[4224..4496) 16x17 scratch.
 // ---------------------------------------------------------------------------------------------
+// -DLCQP_FACTOR_PROFILE (diagnostic build, tools/micro/factor_phases.py): thread 0 adds the shader clocks between the stamps to fp[0..6]
+#ifdef LCQP_FACTOR_PROFILE
+#define FPROF(k) do { if (fp) { const unsigned long long t_ = clock64(); fp[k] += t_ - fp[15]; fp[15] = t_; } } while (0)
+#else
+#define FPROF(k) do { } while (0)
+#endif
 __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal, double tau, double* dscr0, double* d0,
-                          int* info_fail, Lds lds, int dscrStride)
+                          int* info_fail, Lds lds, int dscrStride, unsigned long long* fp = nullptr,
+                          const double* src0 = nullptr, double shift0 = 0.0)
 {
     const int t = tid_here();
+    (void)fp;
     double* tile = lds.arena;
     double* dl = lds.arena + 64 * TILE_LD;
     // the smallest pivot and the failure flag are kept in LDS (dl[8], dl[9]; thread 0 writes them), not in registers around the loops
@@ -731,11 +741,14 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
         const int t = tid_here();      // per block column: nothing derived from the thread number is carried around the loop
         const int o = 64 * J;
         double* dscr = dscr0 + (size_t)J * dscrStride;
+        const bool first = (J == 0 && src0 != nullptr);      // the trailing matrix is still the input
+        const double* S = first ? src0 : F;
         for (int e = t; e < 64 * 64; e += WG) {
             const int i = e >> 6, j = e & 63;
-            tile[i * TILE_LD + j] = (j <= i) ? F[(size_t)(o + i) * ld + o + j] : 0.0;
+            tile[i * TILE_LD + j] = (j <= i) ? S[(size_t)(o + i) * ld + o + j] + ((first && i == j) ? shift0 : 0.0) : 0.0;
         }
         __syncthreads();
+        FPROF(0);
         // Factor and invert the 64x64 tile in LDS with 16x16 sub-blocks.  Per sub-block column jb:
         //  (1) wave 0, lanes 0..15: row-per-lane Cholesky of the 16x16 diagonal sub-block in registers
         //      (wave-synchronous, v_readlane broadcasts, no barriers), then its inverse, column-per-lane;
@@ -800,6 +813,7 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
                 __builtin_amdgcn_s_setprio(0);
             }
             __syncthreads();
+            FPROF(1);
             const int nrem = 16 * nsub - (c0 + 16);     // (non-padded) rows below the diagonal sub-block
             if (nrem > 0) {
                 // (2) panel: outputs (r, j), r in [c0+16, 64), j in [0,16)
@@ -834,6 +848,7 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
                     }
                 }
                 __syncthreads();
+                FPROF(2);
             }
         }
         // (4) blocked inversion: thread (r, c) of a 16x16 block
@@ -857,6 +872,7 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
                     __syncthreads();
                 }
         }
+        FPROF(3);
         // write D: symmetric fill into F_JJ, dense lower copy into dscr
         for (int e = t; e < 64 * 64; e += WG) {
             const int i = e >> 6, j = e & 63;
@@ -865,10 +881,11 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
             dscr[e] = (j <= i) ? v : 0.0;
         }
         __syncthreads();
+        FPROF(4);
         // panel:  L_IJ = A_IJ * D'   (rows of block I, k over block J)
         for (int I = J + 1; I < nblk; I++) {
             double acc[4][4];
-            wg_tile_nt(acc, F + (size_t)(64 * I) * ld + o, ld, [](int r) { return (long)r; },
+            wg_tile_nt(acc, S + (size_t)(64 * I) * ld + o, ld, [](int r) { return (long)r; },
                        dscr, 64, [](int r) { return (long)r; }, 64, lds, tau > 0.0 ? nreal - 64 * I : 64);
 #pragma unroll
             for (int i = 0; i < 4; i++)
@@ -880,6 +897,7 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
                 }
             __syncthreads();
         }
+        FPROF(5);
         // trailing update:  A_IK -= L_IJ * L_KJ'   for I >= K > J
         for (int I = J + 1; I < nblk; I++)
             for (int Kb = J + 1; Kb <= I; Kb++) {
@@ -892,10 +910,14 @@ __device__ __forceinline__ double wg_chol(double* F, int ld, int nblk, int nreal
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const int gi = 64 * I + tile_li(i, j), gj = 64 * Kb + tile_lj(i, j);
-                        if (I != Kb || gj <= gi) F[(size_t)gi * ld + gj] -= acc[i][j];
+                        if (I != Kb || gj <= gi) {
+                            if (first) F[(size_t)gi * ld + gj] = (S[(size_t)gi * ld + gj] + (gi == gj ? shift0 : 0.0)) - acc[i][j];
+                            else F[(size_t)gi * ld + gj] -= acc[i][j];
+                        }
                     }
                 __syncthreads();
             }
+        FPROF(6);
     }
     __syncthreads();
     const double minpiv = dl[8];
@@ -944,6 +966,18 @@ __device__ __forceinline__ void wg_tile_tn(double (&acc)[4][4], const double* __
         tile_panel(acc, As, Bs);
     }
     __syncthreads();
+}
+
+// Workgroup ids are handed to the 8 XCDs round robin (id % 8 labels the workgroups that share an L2): the tiles of ONE instance read the same
+// operands, so every XCD gets a contiguous range of logical ids (bijective for any grid; cdna_hip_programming.md §5.5 T1).  A speed choice only.
+__device__ __forceinline__ int xcd_contiguous(int bid, int nwg)
+{
+#ifdef LCQP_NO_XCD_REMAP
+    (void)nwg; return bid;
+#else
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+#endif
 }
 
 // lower-triangular tile index -> (I, J), I >= J
