@@ -483,7 +483,7 @@ static int launch_setup(lcqp_hip_batch* h)
     const DevBatch& d = h->db;
     hipStream_t on = h->stream;
     const int ntile = d.nblk * (d.nblk + 1) / 2;
-    const int nrb = (d.mEcap + 63) / 64, nb = (d.mMld + 127) / 128, nmt = nb * (nb + 1) / 2;      // k_build_M: 128 x 128 tiles of the lower triangle
+    const int nrb = (d.mEcap + 63) / 64, nb = (d.mMld + 127) / 128, nmt = nb * (nb + 1);      // k_build_M: 128 x 64 tiles of the lower triangle
     dispatch_db(h, ID_k_prepare, d.B);
     // C and its compressed rows depend on L and R only, the chain L1 -> Et -> M on Q and E: two branches.  The short one goes to the side
     // stream and runs in the gaps of k_factor (one workgroup per instance, a life of dependent chains).  Measured alternatives, round 6

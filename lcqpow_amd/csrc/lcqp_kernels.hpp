@@ -90,11 +90,15 @@ __global__ __launch_bounds__(WG) void k_prepare(DevBatch db)
 }
 
 // ---- k_build_C: C = L'R + R'L (Utilities::MatrixSymmetrizationProduct, src/Utilities.cpp:104-116) ----
+// One 64 x 64 tile of the lower triangle per workgroup.  Both products advance in the same loop (four panels of 16 rows of L and R per step:
+// half the steps, barriers and exposed loads of two products one after the other), and the mirrored tile goes through LDS so that its rows
+// are stored contiguously (rounds 1 - 5: every lane its own 8 bytes at a stride of a row).  Each sum is the same chain as before.
 template <int NCH>
 __global__ __launch_bounds__(WG) void k_build_C(DevBatch db)
 {
-    LCQP_LDS_N(NCH)
-    constexpr int np = 128 * NCH;
+    constexpr int np = 128 * NCH, PL = TILE_PL;
+    __shared__ double sP[4 * 16 * PL];      // panels of L_I, R_I, L_J, R_J; afterwards the tile for the mirrored store (64 x 65)
+    static_assert(4 * 16 * PL >= 64 * 65, "the tile must fit where the panels were");
     const int ntile = db.nblk * (db.nblk + 1) / 2;
     const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
     const int b = bid / ntile, tIdx = bid % ntile;
@@ -103,19 +107,54 @@ __global__ __launch_bounds__(WG) void k_build_C(DevBatch db)
     const double* Lm = db.E + (size_t)b * db.mEcap * np + (size_t)db.nC * np;
     const double* Rm = Lm + (size_t)db.nComp * np;
     double* C = db.C + (size_t)b * np * np;
+    const int nrows = db.nComp;
+    const int t = tid_here(), kk = t >> 4, c4 = (t & 15) * 4;
     double a1[4][4], a2[4][4];
-    auto one = [](int) { return 1.0; };
-    wg_tile_tn(a1, Lm, np, 64 * I, Rm, np, 64 * J, db.nComp, one, lds);
-    wg_tile_tn(a2, Rm, np, 64 * I, Lm, np, 64 * J, db.nComp, one, lds);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) a1[i][j] = a2[i][j] = 0.0;
+    double2 p[4][2];
+    auto fetch = [&](int r) {
+        const double2 z{0.0, 0.0};
+#pragma unroll
+        for (int m = 0; m < 4; m++) p[m][0] = p[m][1] = z;
+        if (r < nrows) {
+            const double* src[4] = {Lm + (size_t)r * np + 64 * I + c4, Rm + (size_t)r * np + 64 * I + c4,
+                                    Lm + (size_t)r * np + 64 * J + c4, Rm + (size_t)r * np + 64 * J + c4};
+#pragma unroll
+            for (int m = 0; m < 4; m++) { p[m][0] = *reinterpret_cast<const double2*>(src[m]); p[m][1] = *reinterpret_cast<const double2*>(src[m] + 2); }
+        }
+    };
+    fetch(kk);
+    for (int k0 = 0; k0 < nrows; k0 += 16) {
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            *reinterpret_cast<double2*>(sP + m * 16 * PL + kk * PL + c4) = p[m][0];
+            *reinterpret_cast<double2*>(sP + m * 16 * PL + kk * PL + c4 + 2) = p[m][1];
+        }
+        __syncthreads();
+        if (k0 + 16 < nrows) fetch(k0 + 16 + kk);
+        tile_panel(a1, sP, sP + 3 * 16 * PL);                    // L_I' R_J
+        tile_panel(a2, sP + 16 * PL, sP + 2 * 16 * PL);          // R_I' L_J
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int gi = 64 * I + tile_li(i, j), gj = 64 * J + tile_lj(i, j);
+            const int li = tile_li(i, j), lj = tile_lj(i, j);
             const double v = a1[i][j] + a2[i][j];
-            C[(size_t)gi * np + gj] = v;
-            C[(size_t)gj * np + gi] = v;
+            C[(size_t)(64 * I + li) * np + 64 * J + lj] = v;
+            if (I != J) sP[li * 65 + lj] = v;
         }
+    if (I == J) return;      // the tile on the diagonal is its own mirror image, entry by entry
+    __syncthreads();
+    for (int e = t; e < 64 * 64; e += WG) {
+        const int r = e >> 6, cidx = e & 63;
+        C[(size_t)(64 * J + r) * np + 64 * I + cidx] = sP[cidx * 65 + r];
+    }
 }
 
 // ---- k_compress_C: C in compressed rows when it is sparse (one-hot L, R give 2 nComp non-zeros) ------------------------------------
@@ -133,10 +172,23 @@ __global__ __launch_bounds__(WG) void k_compress_C(DevBatch db)
     double* cv = db.Cv + (size_t)b * db.capC;
     int* cnt = reinterpret_cast<int*>(lds.arena);        // np row counts, then row starts
     const int n = db.n;
-    for (int r = w; r < np; r += NWAVE) {
-        int k = 0;
-        if (r < n) for (int c0 = 0; c0 < np; c0 += 64) k += __popcll(__ballot(C[(size_t)r * np + c0 + l] != 0.0));
-        if (l == 0) cnt[r] = k;
+    // (up to eight loads of a row, and two rows per wave, are in flight together: a wave that waited for every load by itself made this kernel
+    // 0.49 ms of dependent round trips at B = 1024; np is a multiple of 2 NWAVE)
+    constexpr int NC = (np / 64 < 8) ? np / 64 : 8;
+    for (int r = w; r < np; r += 2 * NWAVE) {
+        const int r2 = r + NWAVE;
+        int k1 = 0, k2 = 0;
+        for (int c0 = 0; c0 < np; c0 += 64 * NC) {
+            double v1[NC], v2[NC];
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                v1[q] = (r < n) ? C[(size_t)r * np + c0 + 64 * q + l] : 0.0;
+                v2[q] = (r2 < n) ? C[(size_t)r2 * np + c0 + 64 * q + l] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < NC; q++) { k1 += __popcll(__ballot(v1[q] != 0.0)); k2 += __popcll(__ballot(v2[q] != 0.0)); }
+        }
+        if (l == 0) { cnt[r] = k1; cnt[r2] = k2; }
     }
     __syncthreads();
     {   // exclusive scan of the np counts: each thread a contiguous chunk
@@ -158,16 +210,25 @@ __global__ __launch_bounds__(WG) void k_compress_C(DevBatch db)
         if (total > db.capC) { if (t == 0) db.info[b].cNnz = -1; return; }
         if (t == 0) { db.info[b].cNnz = total; cp[np] = total; }
     }
-    for (int r = w; r < np; r += NWAVE) {
-        int pos = cnt[r];
-        if (l == 0) cp[r] = pos;
-        if (r < n)
-            for (int c0 = 0; c0 < np; c0 += 64) {
-                const double v = C[(size_t)r * np + c0 + l];
-                const unsigned long long mask = __ballot(v != 0.0);
-                if (v != 0.0) { const int o = pos + __popcll(mask & ((1ULL << l) - 1ULL)); ci[o] = c0 + l; cv[o] = v; }
-                pos += __popcll(mask);
+    for (int r = w; r < np; r += 2 * NWAVE) {
+        const int r2 = r + NWAVE;
+        int pos1 = cnt[r], pos2 = cnt[r2];
+        if (l == 0) { cp[r] = pos1; cp[r2] = pos2; }
+        for (int c0 = 0; c0 < np; c0 += 64 * NC) {
+            double v1[NC], v2[NC];
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                v1[q] = (r < n) ? C[(size_t)r * np + c0 + 64 * q + l] : 0.0;
+                v2[q] = (r2 < n) ? C[(size_t)r2 * np + c0 + 64 * q + l] : 0.0;
             }
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                const unsigned long long m1 = __ballot(v1[q] != 0.0), m2 = __ballot(v2[q] != 0.0), below = (1ULL << l) - 1ULL;
+                if (v1[q] != 0.0) { const int o = pos1 + __popcll(m1 & below); ci[o] = c0 + 64 * q + l; cv[o] = v1[q]; }
+                if (v2[q] != 0.0) { const int o = pos2 + __popcll(m2 & below); ci[o] = c0 + 64 * q + l; cv[o] = v2[q]; }
+                pos1 += __popcll(m1); pos2 += __popcll(m2);
+            }
+        }
     }
 }
 
@@ -398,8 +459,11 @@ __device__ __forceinline__ void trsm_rows_streamed(const DevBatch& db)
     }
 }
 
+#ifndef LCQP_TRSM_WAVES
+#define LCQP_TRSM_WAVES 1      // 207 registers, two waves per SIMD; held to 168 (three waves) the kernel spills 32 registers and the setup is 0.17 ms slower
+#endif
 template <int NCH>
-__global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
+__global__ __launch_bounds__(WG, LCQP_TRSM_WAVES) void k_trsm(DevBatch db)
 {
 #if !defined(LCQP_TRSM_STREAMED) && !defined(LCQP_TILE_VALU)
     if constexpr (NCH <= 2) trsm_rows_resident<NCH>(db);
@@ -409,64 +473,72 @@ __global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
 }
 
 // ---- k_build_M: M = Et Et', every entry of every working-set matrix S_W = Et_W Et_W' (lower triangle; readers take M[max][min]) ----
-// fp64 MFMA, 128 x 128 output tiles (round 3; round 2: 64 x 64 tiles through wg_tile_nt, 35 TFLOP/s): the four waves own the four
-// 64 x 64 quadrants as 4 x 4 blocks of v_mfma_f64_16x16x4_f64, so that one 16-deep panel pair in LDS (k-major, pitch 144 doubles:
-// conflict-free operand reads) feeds 64 MFMAs per wave between two barriers, and every operand read from LDS is used four times.
-// The panels of step k + 16 are fetched into registers while the products of step k run.  Diagonal tiles use one panel for both operands.
+// fp64 MFMA.  Tiles of 128 rows x 64 columns (round 6; rounds 3 - 5: 128 x 128 with a 64 x 64 quadrant per wave -- 128 accumulator registers of
+// 226, two waves per SIMD, the matrix pipe busy 62 % of the time): the four waves own 64 x 32 blocks as 4 x 2 blocks of v_mfma_f64_16x16x4_f64,
+// 64 accumulator registers, so that three to four workgroups share a CU and another wave has products to issue while one waits at a barrier.  One
+// 16-deep panel pair in LDS (k-major, pitches 144 / 80 doubles: conflict-free operand reads); the panels of step k + 16 are fetched into registers
+// while the products of step k run.  Column blocks inside the row block (the tiles on the diagonal) take their operand from the row panel.
+// Every element is the same chain of instructions as before (k ascending, four per instruction, from zero): the bits are the same.
+// Tile t of an instance: row block I (128 rows), column block J (64 columns), J <= 2 I + 1; tiles are numbered row block by row block.
 template <int NCH>
-__global__ __launch_bounds__(WG) void k_build_M(DevBatch db)
+__global__ __launch_bounds__(WG, 4) void k_build_M(DevBatch db)
 {
     constexpr int np = 128 * NCH;
-    constexpr int P = 144;
-    __shared__ double As[16 * P], Bs[16 * P];
-    const int nb = (db.mMld + 127) / 128, ntile = nb * (nb + 1) / 2;
-    const int bid = xcd_contiguous(blockIdx.x, gridDim.x);      // the 15 tiles of an instance read the same Et (1.3 MB): one L2
+    constexpr int PA = 144, PB = 80;
+    __shared__ double As[16 * PA], Bs[16 * PB];
+    const int nb = (db.mMld + 127) / 128, ntile = nb * (nb + 1);
+    const int bid = xcd_contiguous(blockIdx.x, gridDim.x);      // the tiles of an instance read the same Et (1.3 MB): one L2
     const int b = bid / ntile, tIdx = bid % ntile;
-    int I, J;
-    tri_tile(tIdx, I, J);
+    int I = 0;
+    while ((I + 1) * (I + 2) <= tIdx) I++;
+    const int J = tIdx - I * (I + 1);
     const int mE = db.info[b].mE, ld = db.mMld;
-    if (128 * J >= mE) return;       // I >= J: both row blocks beyond the rows in use
+    if (128 * (J >> 1) >= mE || 64 * J >= ld) return;       // a block of 128 columns beyond the rows in use (then the rows are too)
     const double* Et = db.Et + (size_t)b * db.mEcap * np;
     double* M = db.MM + (size_t)b * ld * ld;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, wy = w >> 1, wx = w & 1;
-    const int lr = t >> 1, kh = (t & 1) * 8;      // loader: row lr of the tile, eight consecutive k
-    const bool diag = (I == J);
+    const int lr = t >> 1, kh = (t & 1) * 8;      // loader of the row panel: row lr of the tile, eight consecutive k
+    const int lc = t >> 2, kq = (t & 3) * 4;      // loader of the column panel: row lc of the column block, four consecutive k
+    const bool inside = (J >> 1) == I;            // the column block is part of the row block
     const double* ap = (128 * I + lr < mE) ? Et + (size_t)(128 * I + lr) * np + kh : nullptr;
-    const double* bp = (!diag && 128 * J + lr < mE) ? Et + (size_t)(128 * J + lr) * np + kh : nullptr;
-    d4_t acc[4][4];
+    const double* bp = (!inside && 64 * J + lc < mE) ? Et + (size_t)(64 * J + lc) * np + kq : nullptr;
+    d4_t acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
-    double2 ra[4], rb[4];
+        for (int j = 0; j < 2; j++) acc[i][j] = d4_t{0.0, 0.0, 0.0, 0.0};
+    double2 ra[4], rb[2];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            ra[q] = ap ? *reinterpret_cast<const double2*>(ap + k0 + 2 * q) : double2{0.0, 0.0};
-            rb[q] = bp ? *reinterpret_cast<const double2*>(bp + k0 + 2 * q) : double2{0.0, 0.0};
-        }
+        for (int q = 0; q < 4; q++) ra[q] = ap ? *reinterpret_cast<const double2*>(ap + k0 + 2 * q) : double2{0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 2; q++) rb[q] = bp ? *reinterpret_cast<const double2*>(bp + k0 + 2 * q) : double2{0.0, 0.0};
     };
     fetch(0);
-    const double* Bsrc = diag ? As : Bs;
+    const double* Bsrc = inside ? As + 64 * (J & 1) : Bs;
+    const int PBs = inside ? PA : PB;
     for (int k0 = 0; k0 < np; k0 += 16) {
         __syncthreads();      // the panels of the last step are consumed
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            As[(kh + 2 * q) * P + lr] = ra[q].x; As[(kh + 2 * q + 1) * P + lr] = ra[q].y;
-            if (!diag) { Bs[(kh + 2 * q) * P + lr] = rb[q].x; Bs[(kh + 2 * q + 1) * P + lr] = rb[q].y; }
+        for (int q = 0; q < 4; q++) { As[(kh + 2 * q) * PA + lr] = ra[q].x; As[(kh + 2 * q + 1) * PA + lr] = ra[q].y; }
+        if (!inside) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) { Bs[(kq + 2 * q) * PB + lc] = rb[q].x; Bs[(kq + 2 * q + 1) * PB + lc] = rb[q].y; }
         }
         __syncthreads();
         if (k0 + 16 < np) fetch(k0 + 16);
 #pragma unroll
         for (int k4 = 0; k4 < 4; k4++) {
-            const int ko = (4 * k4 + (lane >> 4)) * P + (lane & 15);
-            double av[4], bv[4];
+            const int kk = 4 * k4 + (lane >> 4), il = lane & 15;
+            double av[4], bv[2];
 #pragma unroll
-            for (int i = 0; i < 4; i++) { av[i] = As[ko + 64 * wy + 16 * i]; bv[i] = Bsrc[ko + 64 * wx + 16 * i]; }
+            for (int i = 0; i < 4; i++) av[i] = As[kk * PA + 64 * wy + 16 * i + il];
+#pragma unroll
+            for (int j = 0; j < 2; j++) bv[j] = Bsrc[kk * PBs + 32 * wx + 16 * j + il];
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
     }
     // block (i, j), accumulator register q: row 16 i + (lane >> 4) + 4 q, column 16 j + (lane & 15)   (C/D layout of the f64 MFMA)
@@ -477,8 +549,8 @@ __global__ __launch_bounds__(WG) void k_build_M(DevBatch db)
             const int gi = 128 * I + 64 * wy + 16 * i + (lane >> 4) + 4 * q;
             if (gi >= ld) continue;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int gj = 128 * J + 64 * wx + 16 * j + (lane & 15);
+            for (int j = 0; j < 2; j++) {
+                const int gj = 64 * J + 32 * wx + 16 * j + (lane & 15);
                 if (gj < ld) M[(size_t)gi * ld + gj] = acc[i][j][q];
             }
         }
