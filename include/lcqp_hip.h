@@ -139,6 +139,12 @@ int  lcqp_hip_batch_setup(lcqp_hip_batch_t* b);
 /* LCQProblem::runSolver for all instances, src/LCQProblem.cpp:444-560.  Asynchronous on the batch
  * stream; includes setup if it has not run since the last load. */
 int  lcqp_hip_batch_run(lcqp_hip_batch_t* b);
+/* Hint of a caller that keeps several batch objects in flight (BatchPipeline): the setup of this object will run beside the homotopy
+ * kernel of another one.  The library then launches the setup kernels that fit into the registers and LDS ONE finished instance frees on
+ * a compute unit (the streamed form of Et = E L1^-T instead of the register-resident one), so that the setup starts in the gaps of the
+ * other launch instead of behind it (+10 % through a two-deep pipeline at B = 1024, profiles/round6/setup/pipelined_variants.log).  The
+ * results are the same bits either way; the default (0) is the faster setup of a batch that runs alone. */
+int  lcqp_hip_batch_set_overlapped(lcqp_hip_batch_t* b, int overlapped);
 int  lcqp_hip_batch_synchronize(lcqp_hip_batch_t* b);
 /* time of the last run measured with HIP events on the batch stream, ms: setup_ms = the setup kernels, solve_ms = the homotopy launch */
 int  lcqp_hip_batch_last_timing(lcqp_hip_batch_t* b, float* setup_ms, float* solve_ms);

@@ -84,6 +84,7 @@ def lib():
         L.lcqp_hip_batch_create.argtypes = [C.c_int] * 6
         L.lcqp_hip_batch_destroy.argtypes = [C.c_void_p]
         L.lcqp_hip_batch_set_options.argtypes = [C.c_void_p, C.POINTER(Options)]
+        L.lcqp_hip_batch_set_overlapped.argtypes = [C.c_void_p, C.c_int]
         L.lcqp_hip_batch_load.argtypes = [C.c_void_p, C.c_int, C.c_int] + [c_double_p] * 15
         L.lcqp_hip_batch_generate_synthetic.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
         L.lcqp_hip_batch_read_problem.argtypes = [C.c_void_p, C.c_int] + [c_double_p] * 7
@@ -216,6 +217,7 @@ def solve_mixed(problems, opt=None, device=0):
     flying = None
     for (nV, nC, nComp, box), members in buckets.items():
         bt = BatchLCQP(len(members), nV, nC, nComp, with_box=box, device=device, opt=opt)
+        if len(buckets) > 1: bt.set_overlapped(True)      # its setup runs beside the homotopy of the bucket launched before it
         failed = False
         for s_, i in enumerate(members):
             d = problems[i]
@@ -254,6 +256,8 @@ class BatchPipeline:
                           "call of the process, or set GPU_MAX_HW_QUEUES", RuntimeWarning, stacklevel=2)
         self.owned = over is None
         self.slots = list(over) if over is not None else [BatchLCQP(batch, nV, nC, nComp, with_box=with_box, device=device, opt=opt) for _ in range(depth)]
+        if len(self.slots) > 1:
+            for bt in self.slots: bt.set_overlapped(True)      # the setup of one slot runs beside the homotopy of another
         self.state = [0] * len(self.slots)          # 0 free, 1 in flight, 2 finished
         self.order = []
 
@@ -288,6 +292,9 @@ class BatchPipeline:
         if self.owned:
             for s in self.slots:
                 s.close()
+        elif len(self.slots) > 1:
+            for s in self.slots:
+                s.set_overlapped(False)      # the caller's objects run alone again
 
 
 class BatchLCQP:
@@ -304,6 +311,10 @@ class BatchLCQP:
 
     def set_options(self, opt):
         _check(lib().lcqp_hip_batch_set_options(self.h, C.byref(opt)), "set_options")
+
+    def set_overlapped(self, overlapped=True):
+        """lcqp_hip_batch_set_overlapped: this object's setup runs beside another object's homotopy kernel (BatchPipeline sets it)."""
+        _check(lib().lcqp_hip_batch_set_overlapped(self.h, 1 if overlapped else 0), "set_overlapped")
 
     def load(self, first, count, Q, g, L, R, lbL=None, ubL=None, lbR=None, ubR=None, A=None, lbA=None, ubA=None,
              lb=None, ub=None, x0=None, y0=None):

@@ -21,6 +21,8 @@ class BatchLCQProblem {
 
     bool ok() const { return h != nullptr; }
     ReturnValue setOptions(const Options& o) { return (ReturnValue)lcqp_hip_batch_set_options(h, &o.getHIPOptions()); }
+    // the setup of this object runs beside another object's homotopy kernel (BatchPipeline sets it): see lcqp_hip_batch_set_overlapped
+    ReturnValue setOverlapped(bool overlapped) { return (ReturnValue)lcqp_hip_batch_set_overlapped(h, overlapped ? 1 : 0); }
     // instance-by-instance load with the argument list of LCQProblem::loadLCQP
     ReturnValue loadLCQP(int instance, const double* Q, const double* g, const double* L, const double* R,
                          const double* lbL = 0, const double* ubL = 0, const double* lbR = 0, const double* ubR = 0,
@@ -88,7 +90,10 @@ class BatchPipeline {
   public:
     BatchPipeline(int depth, int batch, int nV, int nC, int nComp, bool withBoxBounds = false, int device = 0)
     {
-        for (int k = 0; k < depth; ++k) { slots.push_back(new BatchLCQProblem(batch, nV, nC, nComp, withBoxBounds, device)); state.push_back(0); }
+        for (int k = 0; k < depth; ++k) {
+            slots.push_back(new BatchLCQProblem(batch, nV, nC, nComp, withBoxBounds, device)); state.push_back(0);
+            if (depth > 1 && slots.back()->ok()) slots.back()->setOverlapped(true);
+        }
     }
     ~BatchPipeline() { for (size_t k = 0; k < slots.size(); ++k) delete slots[k]; }
     BatchPipeline(const BatchPipeline&) = delete;
@@ -178,6 +183,7 @@ class MixedBatchLCQProblem {
             b.batch = new BatchLCQProblem((int)b.members.size(), b.nV, b.nC, b.nComp, b.box, device_);
             ReturnValue rc = b.batch->ok() ? SUCCESSFUL_RETURN : LCQPOBJECT_NOT_SETUP;
             if (rc == SUCCESSFUL_RETURN && haveOptions) rc = b.batch->setOptions(options);
+            if (rc == SUCCESSFUL_RETURN && buckets.size() > 1) rc = b.batch->setOverlapped(true);      // beside the bucket launched before it
             for (size_t s = 0; s < b.members.size() && rc == SUCCESSFUL_RETURN; ++s) {
                 const Problem& p = problems[b.members[s]];
                 rc = b.batch->loadLCQP((int)s, p.Q, p.g, p.L, p.R, p.lbL, p.ubL, p.lbR, p.ubR, p.A, p.lbA, p.ubA, p.lb, p.ub, p.x0, p.y0);

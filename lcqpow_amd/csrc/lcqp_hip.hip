@@ -120,6 +120,7 @@ struct lcqp_hip_batch {
     hipStream_t side;
     hipEvent_t evFork, evJoin;
     int numCU;
+    bool overlapped;      // lcqp_hip_batch_set_overlapped
     // two pinned staging slots for loadLCQP: instance k is packed into slot k&1 while slot (k-1)&1 is in flight
     void* stage[2];
     hipEvent_t stageDone[2];
@@ -183,7 +184,7 @@ try {
     h->device = device; h->setupDone = false; h->ran = false; h->anyLoaded = false; h->bytesTotal = 0;
     h->stage[0] = h->stage[1] = nullptr; h->stageBytes = 0;
     h->stream = nullptr; h->ev0 = h->ev1 = h->ev2 = nullptr; h->side = nullptr; h->evFork = h->evJoin = nullptr;
-    h->numCU = 256;
+    h->numCU = 256; h->overlapped = false;
     { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) h->numCU = cu; }
     DevBatch& d = h->db;
     memset(&d, 0, sizeof(d));
@@ -499,13 +500,20 @@ static int launch_setup(lcqp_hip_batch* h)
     // more than three workgroups per CU (np <= 256: 36 KB of LDS each): the instantiation held to 128 registers, so that four are resident and
     // the batch needs one round
     dispatch_db(h, (h->nch <= 2 && d.B > 3 * h->numCU) ? ID_k_factor_full : ID_k_factor, d.B);
-    dispatch_db(h, ID_k_trsm, d.B * nrb);
+    dispatch_db(h, h->overlapped ? ID_k_trsm_streamed : ID_k_trsm, d.B * nrb);
     // the join sits in front of the last setup kernel, not behind it: an event recorded right after a stream wait carried a late time stamp
     // (the homotopy kernel appeared 2 ms shorter than rocprofv3 and the wall clock say), and the side branch has long finished by then
     if (fork) HIPCHK(hipStreamWaitEvent(on, h->evJoin, 0));
     dispatch_db(h, ID_k_build_M, d.B * nmt);
     HIPCHK(hipGetLastError());
     h->setupDone = true;
+    return 0;
+}
+
+extern "C" int lcqp_hip_batch_set_overlapped(lcqp_hip_batch_t* h, int overlapped)
+{
+    if (!h) return LCQP_LCQPOBJECT_NOT_SETUP;
+    h->overlapped = overlapped != 0;
     return 0;
 }
 

@@ -459,18 +459,21 @@ __device__ __forceinline__ void trsm_rows_streamed(const DevBatch& db)
     }
 }
 
-#ifndef LCQP_TRSM_WAVES
-#define LCQP_TRSM_WAVES 1      // 207 registers, two waves per SIMD; held to 168 (three waves) the kernel spills 32 registers and the setup is 0.17 ms slower
-#endif
+// 207 registers, two waves per SIMD (held to 168 -- three waves -- the kernel spills 32 registers and the setup is 0.17 ms slower)
 template <int NCH>
-__global__ __launch_bounds__(WG, LCQP_TRSM_WAVES) void k_trsm(DevBatch db)
+__global__ __launch_bounds__(WG) void k_trsm(DevBatch db)
 {
-#if !defined(LCQP_TRSM_STREAMED) && !defined(LCQP_TILE_VALU)
+#ifndef LCQP_TILE_VALU
     if constexpr (NCH <= 2) trsm_rows_resident<NCH>(db);
     else
 #endif
         trsm_rows_streamed<NCH>(db);
 }
+
+// the streamed form for every size: 52 registers and 36 KB of LDS, a workgroup fits where ONE instance of k_lcqp_run has finished
+// (lcqp_hip_batch_set_overlapped)
+template <int NCH>
+__global__ __launch_bounds__(WG) void k_trsm_streamed(DevBatch db) { trsm_rows_streamed<NCH>(db); }
 
 // ---- k_build_M: M = Et Et', every entry of every working-set matrix S_W = Et_W Et_W' (lower triangle; readers take M[max][min]) ----
 // fp64 MFMA.  Tiles of 128 rows x 64 columns (round 6; rounds 3 - 5: 128 x 128 with a 64 x 64 quadrant per wave -- 128 accumulator registers of
@@ -735,6 +738,7 @@ static void launch_impl(int kid, int grid, hipStream_t s, const LaunchArgs& a)
         case ID_k_factor:     hipLaunchKernelGGL((k_factor<NCH, 1>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_factor_full: hipLaunchKernelGGL((k_factor<NCH, NCH <= 2 ? 4 : 1>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_trsm:       hipLaunchKernelGGL((k_trsm<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
+        case ID_k_trsm_streamed: hipLaunchKernelGGL((k_trsm_streamed<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_build_M:    hipLaunchKernelGGL((k_build_M<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_lcqp_run:
 #ifndef LCQP_NO_LDS_ROWS      // experiment switch: the row state in global memory for every size

@@ -5,7 +5,7 @@
 
 namespace lcqp {
 
-enum KernelId { ID_k_prepare, ID_k_build_C, ID_k_compress_C, ID_k_factor, ID_k_factor_full, ID_k_trsm, ID_k_build_M, ID_k_lcqp_run, ID_k_qp_solve,
+enum KernelId { ID_k_prepare, ID_k_build_C, ID_k_compress_C, ID_k_factor, ID_k_factor_full, ID_k_trsm, ID_k_trsm_streamed, ID_k_build_M, ID_k_lcqp_run, ID_k_qp_solve,
                 ID_k_synth_fill, ID_k_synth_Q, ID_k_util_symv, ID_k_util_rows, ID_k_util_rows_list };
 
 struct LaunchArgs {

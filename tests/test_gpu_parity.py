@@ -388,6 +388,30 @@ def test_lcqp_synthetic_vs_oracle(hip, oracle, B, n, nC, nComp):
     bt.close()
 
 
+@pytest.mark.parametrize("B,n,nC,nComp", [(5, 256, 512, 64), (3, 200, 330, 37), (1040, 128, 96, 32)])
+def test_setup_kernel_choices_give_the_same_bits(hip, B, n, nC, nComp):
+    """lcqp_hip_batch_set_overlapped (the streamed form of Et = E inv(L1)' for a setup beside another batch's homotopy) and the instantiation of
+    k_factor for batches of more than three workgroups per CU (B = 1040) are speed choices: every element is the same chain of operations"""
+    res = []
+    for overlapped in (False, True):
+        bt = hip.BatchLCQP(B, n, nC, nComp, opt=hip.default_options(perturbStep=0))
+        bt.set_overlapped(overlapped)
+        bt.generate_synthetic(0)
+        bt.run()
+        res.append(bt.solution())
+        bt.close()
+    small = hip.BatchLCQP(2, n, nC, nComp, opt=hip.default_options(perturbStep=0))      # instances 0, 1 through the kernels of a small batch
+    small.generate_synthetic(0)
+    small.run()
+    xs, ys, sts = small.solution()
+    small.close()
+    (x0, y0, st0), (x1, y1, st1) = res
+    assert np.array_equal(x0, x1) and np.array_equal(y0, y1)
+    assert [s["iterTotal"] for s in st0] == [s["iterTotal"] for s in st1]
+    assert np.array_equal(x0[:2], xs) and np.array_equal(y0[:2], ys)
+    assert all(s["returnValue"] == 0 for s in st0)
+
+
 def test_lcqp_synthetic_golden(hip):
     bt = hip.BatchLCQP(4, 256, 512, 64, opt=hip.default_options(perturbStep=0))
     bt.generate_synthetic(0)
