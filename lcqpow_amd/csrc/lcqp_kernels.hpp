@@ -94,7 +94,7 @@ __global__ __launch_bounds__(WG) void k_prepare(DevBatch db)
 // half the steps, barriers and exposed loads of two products one after the other), and the mirrored tile goes through LDS so that its rows
 // are stored contiguously (rounds 1 - 5: every lane its own 8 bytes at a stride of a row).  Each sum is the same chain as before.
 template <int NCH>
-__global__ __launch_bounds__(WG) void k_build_C(DevBatch db)
+__global__ __launch_bounds__(WG, 4) void k_build_C(DevBatch db)      // 128 registers: a workgroup fits where one instance of k_lcqp_run has finished
 {
     constexpr int np = 128 * NCH, PL = TILE_PL;
     __shared__ double sP[4 * 16 * PL];      // panels of L_I, R_I, L_J, R_J; afterwards the tile for the mirrored store (64 x 65)
