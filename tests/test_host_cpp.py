@@ -71,3 +71,32 @@ def test_example_programs():
         assert r.returncode == 0 and "128/128 LCQPs solved" in r.stdout, r.stdout + r.stderr
         outs.append(float(r.stdout.split("checksum")[1].split(",")[0]))
     assert abs(outs[0] - outs[1]) <= 1e-10 * abs(outs[0]), outs      # the sum over shards is taken in another order
+
+
+@pytest.mark.gpu
+def test_reference_example_programs(tmp_path):
+    """examples/optimize_on_circle.cpp and examples/solve_lcqp_from_file.cpp: the other two programs of the reference's examples/ directory
+    (OptimizeOnCircle.cpp, solve_lcqp_from_file.cpp) written against this backend's LCQProblem"""
+    import re
+    import numpy as np
+    import problems as P
+    import __graft_entry__ as g
+    g.build_examples()
+    bindir = os.path.join(ROOT, "examples", "bin")
+    for args in (["100"], ["100", "dense"], ["400"]):
+        r = subprocess.run([os.path.join(bindir, "optimize_on_circle")] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        m = re.search(r"xOpt = \[ ([-0-9.e]+), ([-0-9.e]+) \]; \|xOpt\| = ([0-9.]+)", r.stdout)
+        x = (float(m.group(1)), float(m.group(2)))
+        # the two local minimisers the reference's program accepts (examples/OptimizeOnCircle.cpp:144-145), on the polygon around the circle
+        assert min(abs(x[0] - 0.1811) + abs(x[1] + 0.9835), abs(x[0] - 0.9764) + abs(x[1] + 0.2183)) < 2e-3, r.stdout
+        assert abs(float(m.group(3)) - 1.0) < 2e-3
+    z = np.load(os.path.join(P.GOLDEN, "example_data.npz"))
+    for k in z.files:
+        with open(tmp_path / (k + ".txt"), "w") as f:
+            for v in np.ravel(z[k]):
+                f.write("Inf\n" if v == np.inf else "-Inf\n" if v == -np.inf else repr(float(v)) + "\n")
+    r = subprocess.run([os.path.join(bindir, "solve_lcqp_from_file"), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "nV = 151, nC = 50, nComp = 100" in r.stdout and "xOpt =" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([os.path.join(bindir, "solve_lcqp_from_file"), str(tmp_path / "nothing")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1
