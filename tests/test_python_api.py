@@ -452,3 +452,27 @@ def test_python_sparse_pattern_that_is_neither_banded_nor_bordered_runs_on_the_g
     Lx, Rx = d["L"] @ x, d["R"] @ x
     assert abs(Lx @ Rx) < 1e3 * 2.221e-16 and Lx.min() > -1e-9 and Rx.min() > -1e-9
     assert np.abs(d["Q"] @ x + d["g"] - d["E"].T @ y).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_python_example_scripts(tmp_path):
+    """examples/optimize_on_circle.py (dense, sparse, stored steps) and examples/solve_lcqp_from_file.py run as programs"""
+    import re
+    import subprocess
+    import sys
+    ex = os.path.join(ROOT, "examples")
+    for extra in ([], ["--sparse"], ["--store-steps"]):
+        r = subprocess.run([sys.executable, os.path.join(ex, "optimize_on_circle.py"), "100"] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        m = re.search(r"xOpt = \[([-0-9.]+), ([-0-9.]+)\], \|xOpt\| = ([0-9.]+)", r.stdout)
+        x = (float(m.group(1)), float(m.group(2)))
+        assert min(abs(x[0] - 0.1811) + abs(x[1] + 0.9835), abs(x[0] - 0.9764) + abs(x[1] + 0.2183)) < 2e-3, r.stdout
+        if extra == ["--store-steps"]:
+            assert "per iterate: complementarity" in r.stdout
+    z = np.load(os.path.join(P.GOLDEN, "example_data.npz"))
+    for k in z.files:
+        with open(tmp_path / (k + ".txt"), "w") as f:
+            for v in np.ravel(z[k]):
+                f.write("Inf\n" if v == np.inf else "-Inf\n" if v == -np.inf else repr(float(v)) + "\n")
+    r = subprocess.run([sys.executable, os.path.join(ex, "solve_lcqp_from_file.py"), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "nV = 151, nC = 50, nComp = 100" in r.stdout and "xOpt = " in r.stdout, r.stdout + r.stderr
