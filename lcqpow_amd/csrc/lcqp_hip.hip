@@ -154,10 +154,32 @@ static void lcqp_dispatch(int nch, int kid, int grid, hipStream_t s, const Launc
     }
 #endif
 }
+// the second build of the persistent kernels (256 registers): np <= 256 and at most three workgroups per CU
+static bool lcqp_dispatch_few(int nch, int kid, int grid, hipStream_t s, const LaunchArgs& a)
+{
+#ifdef LCQP_ONLY_NCH
+#if LCQP_ONLY_NCH <= 2
+    (void)nch;
+    LCQP_CAT(lcqp_launch_few_, LCQP_ONLY_NCH)(kid, grid, s, a);
+    return true;
+#else
+    (void)nch; (void)kid; (void)grid; (void)s; (void)a;
+    return false;
+#endif
+#else
+    if (nch == 1) lcqp_launch_few_1(kid, grid, s, a);
+    else if (nch == 2) lcqp_launch_few_2(kid, grid, s, a);
+    else return false;
+    return true;
+#endif
+}
+
 static void dispatch_db(lcqp_hip_batch* h, int kid, int grid, const int* list = nullptr, int initial = 0, uint64_t seed0 = 0, uint64_t first = 0, hipStream_t on = nullptr)
 {
     LaunchArgs a;
     a.db = h->db; a.list = list; a.initial = initial; a.seed0 = seed0; a.first = first;
+    if ((kid == ID_k_lcqp_run || kid == ID_k_qp_solve) && h->nch <= 2 && h->db.B <= 3 * h->numCU && !h->overlapped
+        && lcqp_dispatch_few(h->nch, kid, grid, on ? on : h->stream, a)) return;
     lcqp_dispatch(h->nch, kid, grid, on ? on : h->stream, a);
 }
 

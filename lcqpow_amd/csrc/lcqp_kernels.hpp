@@ -563,8 +563,18 @@ __global__ __launch_bounds__(WG, 4) void k_build_M(DevBatch db)
 #ifndef LCQP_MINWAVES
 #define LCQP_MINWAVES 4      // waves per SIMD the register allocation is held to (4 workgroups per CU)
 #endif
+// A second build of the two persistent kernels for batches of at most three workgroups per CU (lcqp_nch.hip with -DLCQP_TU_FEW: LCQP_VARIANT 1,
+// LCQP_MINWAVES 2): 256 registers instead of 128 -- 8.0 -> 7.3 ms for one LCQP alone, 11.3 -> 10.3 at B = 16, 13.5 -> 12.3 at B = 128,
+// 14.4 -> 13.2 at B = 256, 21.7 -> 20.7 at B = 768 (two workgroups per CU resident, the rest behind them), the same bits; from B = 896 on four
+// resident workgroups per CU win (28.6 against 31.9 ms at B = 1024).  profiles/round6/latency/.  (Eight rows in flight per wave instead of
+// four would take another 1 - 4 % off the small batches, but the compiler then contracts the dot products of the sweeps into other fused
+// multiply-adds: 1e-16 of difference and other iterate counts -- an instance must not depend on the size of the batch it is solved in.)
+// V only gives the instantiations of the two builds different names.
+#ifndef LCQP_VARIANT
+#define LCQP_VARIANT 0
+#endif
 // LR: the row state of the subsolver lives in LDS (np <= 256 and at most LDS_ROWS_MAX rows of E; lcqp_wg.hpp)
-template <int NCH, bool LR>
+template <int NCH, bool LR, int V>
 __global__ __launch_bounds__(WG, LCQP_MINWAVES) void k_lcqp_run(DevBatch db)
 {
     LCQP_LDS_N(NCH)
@@ -574,8 +584,8 @@ __global__ __launch_bounds__(WG, LCQP_MINWAVES) void k_lcqp_run(DevBatch db)
 }
 
 // ---- one QP per workgroup with the SubsolverBase semantics ----------------------------------------
-template <int NCH>
-__global__ __launch_bounds__(WG, 4) void k_qp_solve(DevBatch db, int initial)
+template <int NCH, int V>
+__global__ __launch_bounds__(WG, LCQP_MINWAVES) void k_qp_solve(DevBatch db, int initial)
 {
     LCQP_LDS_N(NCH)
     Ctx<NCH> c = make_ctx<NCH>(db, blockIdx.x, lds);
@@ -729,6 +739,29 @@ __global__ __launch_bounds__(WG) void k_util_rows_list(int m, int nlist, const d
 
 // ---- launcher of this translation unit's instantiation (declared in lcqp_launch.hpp) -----------------------------------------
 template <int NCH>
+static void launch_run(int grid, hipStream_t s, const LaunchArgs& a)
+{
+#ifndef LCQP_NO_LDS_ROWS      // experiment switch: the row state in global memory for every size
+    if constexpr (NCH <= 2) {
+        // the row state sits behind the routines' scratch (arena[0, LDS_ROWS_OFF)): the sweeps need 6 np doubles there, the triangular solves
+        // 5 np, the widest pass over the inverse factor 4 capS, the rotations 3 capS
+        static_assert(6 * 128 * NCH <= LDS_ROWS_OFF, "k_lcqp_run<NCH, true>: the sweeps' scratch must end below the row state");
+        if (a.db.mEcap <= LDS_ROWS_MAX && 4 * a.db.capS <= LDS_ROWS_OFF) { hipLaunchKernelGGL((k_lcqp_run<NCH, true, LCQP_VARIANT>), dim3(grid), dim3(WG), 0, s, a.db); return; }
+    }
+#endif
+    hipLaunchKernelGGL((k_lcqp_run<NCH, false, LCQP_VARIANT>), dim3(grid), dim3(WG), 0, s, a.db);
+}
+
+#ifdef LCQP_TU_FEW
+// the translation unit of the second build holds the two persistent kernels only
+template <int NCH>
+static void launch_impl(int kid, int grid, hipStream_t s, const LaunchArgs& a)
+{
+    if (kid == ID_k_lcqp_run) launch_run<NCH>(grid, s, a);
+    else if (kid == ID_k_qp_solve) hipLaunchKernelGGL((k_qp_solve<NCH, LCQP_VARIANT>), dim3(grid), dim3(WG), 0, s, a.db, a.initial);
+}
+#else
+template <int NCH>
 static void launch_impl(int kid, int grid, hipStream_t s, const LaunchArgs& a)
 {
     switch (kid) {
@@ -740,17 +773,8 @@ static void launch_impl(int kid, int grid, hipStream_t s, const LaunchArgs& a)
         case ID_k_trsm:       hipLaunchKernelGGL((k_trsm<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_trsm_streamed: hipLaunchKernelGGL((k_trsm_streamed<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_build_M:    hipLaunchKernelGGL((k_build_M<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
-        case ID_k_lcqp_run:
-#ifndef LCQP_NO_LDS_ROWS      // experiment switch: the row state in global memory for every size
-            if constexpr (NCH <= 2) {
-                // the row state sits behind the routines' scratch (arena[0, LDS_ROWS_OFF)): the sweeps need 6 np doubles there, the triangular solves
-                // 5 np, the widest pass over the inverse factor 4 capS, the rotations 3 capS
-                static_assert(6 * 128 * NCH <= LDS_ROWS_OFF, "k_lcqp_run<NCH, true>: the sweeps' scratch must end below the row state");
-                if (a.db.mEcap <= LDS_ROWS_MAX && 4 * a.db.capS <= LDS_ROWS_OFF) { hipLaunchKernelGGL((k_lcqp_run<NCH, true>), dim3(grid), dim3(WG), 0, s, a.db); break; }
-            }
-#endif
-            hipLaunchKernelGGL((k_lcqp_run<NCH, false>), dim3(grid), dim3(WG), 0, s, a.db); break;
-        case ID_k_qp_solve:   hipLaunchKernelGGL((k_qp_solve<NCH>), dim3(grid), dim3(WG), 0, s, a.db, a.initial); break;
+        case ID_k_lcqp_run:   launch_run<NCH>(grid, s, a); break;
+        case ID_k_qp_solve:   hipLaunchKernelGGL((k_qp_solve<NCH, LCQP_VARIANT>), dim3(grid), dim3(WG), 0, s, a.db, a.initial); break;
         case ID_k_synth_fill: hipLaunchKernelGGL((k_synth_fill<NCH>), dim3(grid), dim3(WG), 0, s, a.db, a.seed0, a.first); break;
         case ID_k_synth_Q:    hipLaunchKernelGGL((k_synth_Q<NCH>), dim3(grid), dim3(WG), 0, s, a.db); break;
         case ID_k_util_symv:  hipLaunchKernelGGL((k_util_symv<NCH>), dim3(grid), dim3(WG), 0, s, a.n, a.alpha, a.A, a.b, a.c, a.d); break;
@@ -759,3 +783,4 @@ static void launch_impl(int kid, int grid, hipStream_t s, const LaunchArgs& a)
         default: break;
     }
 }
+#endif

@@ -8,5 +8,10 @@
 #define LCQP_CAT(a, b) LCQP_CAT2(a, b)
 
 namespace lcqp {
+#ifdef LCQP_TU_FEW      // the second build of the persistent kernels (batches of at most three workgroups per CU; lcqp_kernels.hpp): with
+                        // -DLCQP_VARIANT=1 -DLCQP_MINWAVES=2
+void LCQP_CAT(lcqp_launch_few_, LCQP_TU_NCH)(int kid, int grid, hipStream_t s, const LaunchArgs& a) { launch_impl<LCQP_TU_NCH>(kid, grid, s, a); }
+#else
 void LCQP_CAT(lcqp_launch_, LCQP_TU_NCH)(int kid, int grid, hipStream_t s, const LaunchArgs& a) { launch_impl<LCQP_TU_NCH>(kid, grid, s, a); }
+#endif
 }
