@@ -154,11 +154,11 @@ static void lcqp_dispatch(int nch, int kid, int grid, hipStream_t s, const Launc
     }
 #endif
 }
-// the second build of the persistent kernels (256 registers): np <= 256 and at most three workgroups per CU
+// the second build of the persistent kernels (256 registers): np <= 512 (36 KB of LDS per workgroup) and at most three workgroups per CU
 static bool lcqp_dispatch_few(int nch, int kid, int grid, hipStream_t s, const LaunchArgs& a)
 {
 #ifdef LCQP_ONLY_NCH
-#if LCQP_ONLY_NCH <= 2
+#if LCQP_ONLY_NCH <= 4
     (void)nch;
     LCQP_CAT(lcqp_launch_few_, LCQP_ONLY_NCH)(kid, grid, s, a);
     return true;
@@ -169,6 +169,8 @@ static bool lcqp_dispatch_few(int nch, int kid, int grid, hipStream_t s, const L
 #else
     if (nch == 1) lcqp_launch_few_1(kid, grid, s, a);
     else if (nch == 2) lcqp_launch_few_2(kid, grid, s, a);
+    else if (nch == 3) lcqp_launch_few_3(kid, grid, s, a);
+    else if (nch == 4) lcqp_launch_few_4(kid, grid, s, a);
     else return false;
     return true;
 #endif
@@ -178,7 +180,7 @@ static void dispatch_db(lcqp_hip_batch* h, int kid, int grid, const int* list = 
 {
     LaunchArgs a;
     a.db = h->db; a.list = list; a.initial = initial; a.seed0 = seed0; a.first = first;
-    if ((kid == ID_k_lcqp_run || kid == ID_k_qp_solve) && h->nch <= 2 && h->db.B <= 3 * h->numCU && !h->overlapped
+    if ((kid == ID_k_lcqp_run || kid == ID_k_qp_solve) && h->nch <= 4 && h->db.B <= 3 * h->numCU && !h->overlapped
         && lcqp_dispatch_few(h->nch, kid, grid, on ? on : h->stream, a)) return;
     lcqp_dispatch(h->nch, kid, grid, on ? on : h->stream, a);
 }

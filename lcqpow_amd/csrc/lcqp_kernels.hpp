@@ -563,7 +563,7 @@ __global__ __launch_bounds__(WG, 4) void k_build_M(DevBatch db)
 #ifndef LCQP_MINWAVES
 #define LCQP_MINWAVES 4      // waves per SIMD the register allocation is held to (4 workgroups per CU)
 #endif
-// A second build of the two persistent kernels for batches of at most three workgroups per CU (lcqp_nch.hip with -DLCQP_TU_FEW: LCQP_VARIANT 1,
+// A second build of the two persistent kernels for batches of at most three workgroups per CU, np <= 512 (lcqp_nch.hip with -DLCQP_TU_FEW: LCQP_VARIANT 1,
 // LCQP_MINWAVES 2): 256 registers instead of 128 -- 8.0 -> 7.3 ms for one LCQP alone, 11.3 -> 10.3 at B = 16, 13.5 -> 12.3 at B = 128,
 // 14.4 -> 13.2 at B = 256, 21.7 -> 20.7 at B = 768 (two workgroups per CU resident, the rest behind them), the same bits; from B = 896 on four
 // resident workgroups per CU win (28.6 against 31.9 ms at B = 1024).  profiles/round6/latency/.  (Eight rows in flight per wave instead of

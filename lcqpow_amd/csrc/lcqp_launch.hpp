@@ -28,8 +28,10 @@ void lcqp_launch_4(int kid, int grid, hipStream_t s, const LaunchArgs& a);
 void lcqp_launch_8(int kid, int grid, hipStream_t s, const LaunchArgs& a);
 void lcqp_launch_16(int kid, int grid, hipStream_t s, const LaunchArgs& a);
 void lcqp_launch_32(int kid, int grid, hipStream_t s, const LaunchArgs& a);
-// k_lcqp_run and k_qp_solve for batches of at most three workgroups per CU (lcqp_nch.hip with -DLCQP_TU_FEW), np <= 256
+// k_lcqp_run and k_qp_solve for batches of at most three workgroups per CU (lcqp_nch.hip with -DLCQP_TU_FEW), np <= 512
 void lcqp_launch_few_1(int kid, int grid, hipStream_t s, const LaunchArgs& a);
 void lcqp_launch_few_2(int kid, int grid, hipStream_t s, const LaunchArgs& a);
+void lcqp_launch_few_3(int kid, int grid, hipStream_t s, const LaunchArgs& a);
+void lcqp_launch_few_4(int kid, int grid, hipStream_t s, const LaunchArgs& a);
 
 }  // namespace lcqp

@@ -388,10 +388,12 @@ def test_lcqp_synthetic_vs_oracle(hip, oracle, B, n, nC, nComp):
     bt.close()
 
 
-@pytest.mark.parametrize("B,n,nC,nComp", [(5, 256, 512, 64), (3, 200, 330, 37), (1040, 128, 96, 32)])
+@pytest.mark.parametrize("B,n,nC,nComp", [(5, 256, 512, 64), (3, 200, 330, 37), (1040, 128, 96, 32), (800, 300, 96, 40)])
 def test_setup_kernel_choices_give_the_same_bits(hip, B, n, nC, nComp):
     """lcqp_hip_batch_set_overlapped (the streamed form of Et = E inv(L1)' for a setup beside another batch's homotopy) and the instantiation of
-    k_factor for batches of more than three workgroups per CU (B = 1040) are speed choices: every element is the same chain of operations"""
+    k_factor for batches of more than three workgroups per CU (B = 1040) are speed choices: every element is the same chain of operations.  So is
+    the 256-register build of k_lcqp_run that batches of at most three workgroups per CU run (np <= 512): instances 0, 1 solved in a batch of 2
+    and in the larger batch (B = 1040 and B = 800 are beyond three per CU on a 256-CU device) are the same bits"""
     res = []
     for overlapped in (False, True):
         bt = hip.BatchLCQP(B, n, nC, nComp, opt=hip.default_options(perturbStep=0))
